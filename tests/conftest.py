@@ -1,0 +1,32 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def fdn():
+    """The product package (directory name starts with a digit, so import by string)."""
+    return importlib.import_module("4dflownet_amd")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    return importlib.import_module("oracle.flownet_oracle")
+
+
+def has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
