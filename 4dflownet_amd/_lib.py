@@ -1,0 +1,62 @@
+"""ctypes binding of lib4dflow_hip.so (include/fdn.h).  There is NO fallback: if the library is missing or a
+call fails, an exception is raised."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib4dflow_hip.so")
+
+c_fp = ctypes.c_void_p      # device pointer to float
+c_i = ctypes.c_int
+c_i64 = ctypes.c_int64
+c_f = ctypes.c_float
+c_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/fdn.h one to one
+SIGNATURES = {
+    "fdn_version": (c_i, []),
+    "fdn_last_error": (ctypes.c_char_p, []),
+    "fdn_input_features": (c_i, [c_fp] * 8 + [c_i64, c_fp]),
+    "fdn_pack_conv64_weights": (c_i, [c_fp, c_fp, c_fp, c_fp]),
+    "fdn_conv3d_fwd": (c_i, [c_fp] * 7 + [c_i] * 10 + [c_f, c_fp]),
+    "fdn_conv3d_dgrad": (c_i, [c_fp] * 4 + [c_i] * 9 + [c_fp]),
+    "fdn_fold_halo": (c_i, [c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_f, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "fdn_conv1x1_dgrad": (c_i, [c_fp] * 6 + [c_i64, c_fp]),
+    "fdn_conv3d_wgrad_workspace_bytes": (c_sz, [c_i] * 7),
+    "fdn_conv3d_wgrad": (c_i, [c_fp] * 6 + [c_sz] + [c_i] * 9 + [c_fp]),
+    "fdn_upsample_trilinear_fwd": (c_i, [c_fp, c_fp] + [c_i] * 6 + [c_fp]),
+    "fdn_upsample_trilinear_bwd": (c_i, [c_fp, c_fp, c_i, c_f, c_fp] + [c_i] * 6 + [c_fp]),
+    "fdn_loss_metrics": (c_i, [c_fp] * 8 + [c_i, c_i64, c_fp]),
+    "fdn_l2_sumsq": (c_i, [c_fp, c_fp, c_i64, c_fp, c_fp]),
+    "fdn_adam_step": (c_i, [c_fp] * 5 + [c_i64] + [c_f] * 5 + [c_fp]),
+}
+
+
+class FdnError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and attach the prototypes.  Raises FdnError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FdnError("lib4dflow_hip.so is not built (%s).  Run `python __graft_entry__.py` or "
+                       "`python 4dflownet_amd/build.py`; there is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if an export is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().fdn_last_error()
+        raise FdnError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else "?"))

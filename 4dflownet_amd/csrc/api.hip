@@ -1,0 +1,124 @@
+// extern "C" boundary of lib4dflow_hip.so: argument validation, shape dispatch, error reporting.
+// See include/fdn.h for the contract and the reference call sites each entry point replaces.
+#include <stdarg.h>
+#include <stdio.h>
+#include "fdn_common.h"
+
+static thread_local char g_err[512] = "";
+
+void fdn_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int fdn_version(void) { return 100; }
+extern "C" const char* fdn_last_error(void) { return g_err; }
+
+// small-channel kernels (small_convs.hip)
+int fdn_conv_cin3_fwd_launch(const float* x, const float* w, const float* bias, float* y, int N, int D, int H, int W,
+                             int act, float alpha, hipStream_t s);
+int fdn_conv_cout1_fwd_launch(const float* x, const float* w, const float* bias, float* y, int N, int D, int H, int W,
+                              int ldy, int y_coff, int act, float alpha, hipStream_t s);
+int fdn_conv1x1_fwd_launch(const float* xa, const float* xb, const float* w, const float* bias, float* y, int64_t nvox,
+                           int act, float alpha, hipStream_t s);
+int fdn_conv_cout1_dgrad_launch(const float* dz, const float* w, float* dxpad, int N, int D, int H, int W, int lddz,
+                                int dz_coff, hipStream_t s);
+int fdn_wgrad_cin3_launch(const float* x, const float* dz, float* dw, void* ws, size_t ws_bytes, int N, int D, int H,
+                          int W, hipStream_t s);
+int fdn_wgrad_cout1_launch(const float* x, const float* dz, float* dw, void* ws, size_t ws_bytes, int N, int D, int H,
+                           int W, int lddz, int dz_coff, hipStream_t s);
+int fdn_wgrad_1x1_launch(const float* xa, const float* xb, const float* dz, float* dw, void* ws, size_t ws_bytes,
+                         int64_t nvox, hipStream_t s);
+int fdn_bias_grad_launch(const float* dz, float* db, void* ws, size_t ws_bytes, int64_t nvox, int C, int lddz,
+                         int dz_coff, hipStream_t s);
+size_t fdn_small_wgrad_workspace_bytes(int Cin, int Cout, int K);
+
+extern "C" int fdn_conv3d_fwd(const float* x, const float* x2, const float* w, const float* wpack, const float* bias,
+                              const float* residual, float* y, int N, int D, int H, int W, int Cin, int Cout, int K,
+                              int ldy, int y_coff, int act, float alpha, void* stream) {
+    FDN_REQUIRE(x && y, "fdn_conv3d_fwd: x/y is NULL");
+    FDN_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "fdn_conv3d_fwd: bad dims N=%d D=%d H=%d W=%d", N, D, H, W);
+    FDN_REQUIRE(act >= FDN_ACT_NONE && act <= FDN_ACT_LEAKY, "fdn_conv3d_fwd: bad act %d", act);
+    hipStream_t s = (hipStream_t)stream;
+    if (Cin == 64 && Cout == 64 && K == 3) {
+        FDN_REQUIRE(wpack, "fdn_conv3d_fwd: the 64->64 MFMA path needs wpack (fdn_pack_conv64_weights)");
+        FDN_REQUIRE(ldy == 64 && y_coff == 0, "fdn_conv3d_fwd: 64->64 path writes dense rows (ldy=64,y_coff=0)");
+        FDN_REQUIRE(D <= 1022 && H <= 1022 && W <= 1022, "fdn_conv3d_fwd: dims too large");
+        return fdn_conv64_launch(x, wpack, bias, residual, y, N, D, H, W, D, H, W, 0, 0, act, alpha, s);
+    }
+    FDN_REQUIRE(residual == nullptr, "fdn_conv3d_fwd: residual only on the 64->64 path");
+    if (Cin == 3 && Cout == 64 && K == 3) {
+        FDN_REQUIRE(w && ldy == 64 && y_coff == 0, "fdn_conv3d_fwd(3->64): needs w, dense output");
+        return fdn_conv_cin3_fwd_launch(x, w, bias, y, N, D, H, W, act, alpha, s);
+    }
+    if (Cin == 64 && Cout == 1 && K == 3) {
+        FDN_REQUIRE(w && ldy >= 1 && y_coff >= 0 && y_coff < ldy, "fdn_conv3d_fwd(64->1): bad w/ldy/y_coff");
+        return fdn_conv_cout1_fwd_launch(x, w, bias, y, N, D, H, W, ldy, y_coff, act, alpha, s);
+    }
+    if (Cin == 128 && Cout == 64 && K == 1) {
+        FDN_REQUIRE(w && x2 && ldy == 64 && y_coff == 0, "fdn_conv3d_fwd(1x1 128->64): needs w, x2, dense output");
+        return fdn_conv1x1_fwd_launch(x, x2, w, bias, y, (int64_t)N * D * H * W, act, alpha, s);
+    }
+    fdn_set_error("fdn_conv3d_fwd: unsupported (Cin=%d,Cout=%d,K=%d)", Cin, Cout, K);
+    return FDN_ERR_UNSUPPORTED;
+}
+
+extern "C" int fdn_conv3d_dgrad(const float* dz, const float* w, const float* wpack, float* dxpad, int N, int D,
+                                int H, int W, int Cin, int Cout, int K, int lddz, int dz_coff, void* stream) {
+    FDN_REQUIRE(dz && dxpad, "fdn_conv3d_dgrad: dz/dxpad is NULL");
+    FDN_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "fdn_conv3d_dgrad: bad dims");
+    hipStream_t s = (hipStream_t)stream;
+    if (Cin == 64 && Cout == 64 && K == 3) {
+        FDN_REQUIRE(wpack, "fdn_conv3d_dgrad: the 64->64 MFMA path needs wpack = wp_dgrad");
+        FDN_REQUIRE(lddz == 64 && dz_coff == 0, "fdn_conv3d_dgrad: 64->64 path reads dense rows");
+        FDN_REQUIRE(D <= 1020 && H <= 1020 && W <= 1020, "fdn_conv3d_dgrad: dims too large");
+        return fdn_conv64_launch(dz, wpack, nullptr, nullptr, dxpad, N, D, H, W, D + 2, H + 2, W + 2, -1, 1,
+                                 FDN_ACT_NONE, 0.f, s);
+    }
+    if (Cin == 64 && Cout == 1 && K == 3) {
+        FDN_REQUIRE(w, "fdn_conv3d_dgrad(64->1): needs w");
+        return fdn_conv_cout1_dgrad_launch(dz, w, dxpad, N, D, H, W, lddz, dz_coff, s);
+    }
+    fdn_set_error("fdn_conv3d_dgrad: unsupported (Cin=%d,Cout=%d,K=%d)", Cin, Cout, K);
+    return FDN_ERR_UNSUPPORTED;
+}
+
+extern "C" size_t fdn_conv3d_wgrad_workspace_bytes(int N, int D, int H, int W, int Cin, int Cout, int K) {
+    if (Cin == 64 && Cout == 64 && K == 3) return fdn_wgrad64_workspace_bytes(N, D, H, W);
+    return fdn_small_wgrad_workspace_bytes(Cin, Cout, K);
+}
+
+extern "C" int fdn_conv3d_wgrad(const float* x, const float* x2, const float* dz, float* dw, float* dbias,
+                                void* workspace, size_t workspace_bytes, int N, int D, int H, int W, int Cin, int Cout,
+                                int K, int lddz, int dz_coff, void* stream) {
+    FDN_REQUIRE(x && dz && dw, "fdn_conv3d_wgrad: x/dz/dw is NULL");
+    FDN_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "fdn_conv3d_wgrad: bad dims");
+    const size_t need = fdn_conv3d_wgrad_workspace_bytes(N, D, H, W, Cin, Cout, K);
+    if (workspace_bytes < need || (need && !workspace)) {
+        fdn_set_error("fdn_conv3d_wgrad: workspace %zu < %zu bytes", workspace_bytes, need);
+        return FDN_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t nvox = (int64_t)N * D * H * W;
+    int rc;
+    if (Cin == 64 && Cout == 64 && K == 3) {
+        FDN_REQUIRE(lddz == 64 && dz_coff == 0, "fdn_conv3d_wgrad: 64->64 path reads dense dz rows");
+        rc = fdn_wgrad64_launch(x, dz, dw, workspace, workspace_bytes, N, D, H, W, s);
+    } else if (Cin == 3 && Cout == 64 && K == 3) {
+        FDN_REQUIRE(lddz == 64 && dz_coff == 0, "fdn_conv3d_wgrad(3->64): dense dz rows");
+        rc = fdn_wgrad_cin3_launch(x, dz, dw, workspace, workspace_bytes, N, D, H, W, s);
+    } else if (Cin == 64 && Cout == 1 && K == 3) {
+        rc = fdn_wgrad_cout1_launch(x, dz, dw, workspace, workspace_bytes, N, D, H, W, lddz, dz_coff, s);
+    } else if (Cin == 128 && Cout == 64 && K == 1) {
+        FDN_REQUIRE(x2 && lddz == 64 && dz_coff == 0, "fdn_conv3d_wgrad(1x1): needs x2, dense dz rows");
+        rc = fdn_wgrad_1x1_launch(x, x2, dz, dw, workspace, workspace_bytes, nvox, s);
+    } else {
+        fdn_set_error("fdn_conv3d_wgrad: unsupported (Cin=%d,Cout=%d,K=%d)", Cin, Cout, K);
+        return FDN_ERR_UNSUPPORTED;
+    }
+    if (rc != FDN_OK) return rc;
+    if (dbias) return fdn_bias_grad_launch(dz, dbias, workspace, workspace_bytes, nvox, Cout, lddz, dz_coff, s);
+    return FDN_OK;
+}

@@ -1,0 +1,367 @@
+// HBM-bound pieces of the train step: input features, halo fold (MirrorPadGrad) fused with gradient fan-in and
+// activation gradient, trilinear upsample fwd/bwd, masked-MSE loss + relative-error metric + dPred, L2 sum, Adam.
+// All of them stream 16-B vectors with 16 lanes per 256-B channel row.
+#include "fdn_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// src/Network/SR4DFlowNet.py:10-15
+// ---------------------------------------------------------------------------------------------
+__global__ void input_features_kernel(const float* __restrict__ u, const float* __restrict__ v, const float* __restrict__ w,
+                                      const float* __restrict__ mu, const float* __restrict__ mv,
+                                      const float* __restrict__ mw, float* __restrict__ phase, float* __restrict__ pc,
+                                      int64_t nvox) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvox; i += (int64_t)gridDim.x * blockDim.x) {
+        const float a = u[i], b = v[i], c = w[i];
+        const float speed = sqrtf(a * a + b * b + c * c);
+        const float ma = mu[i], mb = mv[i], mc = mw[i];
+        const float mag = sqrtf(ma * ma + mb * mb + mc * mc);
+        phase[i * 3 + 0] = a; phase[i * 3 + 1] = b; phase[i * 3 + 2] = c;
+        pc[i * 3 + 0] = mag * speed; pc[i * 3 + 1] = mag; pc[i * 3 + 2] = speed;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fold: adjoint of the SYMMETRIC p=1 pad (MirrorPadGrad) + fan-in of up to 3 padded gradients + skip + act'
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fold_halo_kernel(const float* __restrict__ s0, const float* __restrict__ s1,
+                                                         const float* __restrict__ s2, int nsrc,
+                                                         const float* __restrict__ skip, const float* __restrict__ yprev,
+                                                         int act, float alpha, float* __restrict__ out, int N, int D, int H,
+                                                         int W, int C4) {
+    const int64_t total = (int64_t)N * D * H * W * C4;
+    const int PH = H + 2, PW = W + 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        int64_t v = i / C4;
+        const int w = (int)(v % W); v /= W;
+        const int h = (int)(v % H); v /= H;
+        const int d = (int)(v % D);
+        const int n = (int)(v / D);
+        // padded indices that clamp onto (d,h,w): p = i+1, plus 0 when i==0, plus dim+1 when i==dim-1
+        int pd[3], ph[3], pw[3];
+        int nd = 0, nh = 0, nw = 0;
+        pd[nd++] = d + 1; if (d == 0) pd[nd++] = 0; if (d == D - 1) pd[nd++] = D + 1;
+        ph[nh++] = h + 1; if (h == 0) ph[nh++] = 0; if (h == H - 1) ph[nh++] = H + 1;
+        pw[nw++] = w + 1; if (w == 0) pw[nw++] = 0; if (w == W - 1) pw[nw++] = W + 1;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < nd; ++a)
+            for (int b = 0; b < nh; ++b)
+                for (int c = 0; c < nw; ++c) {
+                    const int64_t off = (((((int64_t)n * (D + 2) + pd[a]) * PH + ph[b]) * PW + pw[c]) * C4 + c4);
+                    acc += ((const f32x4*)s0)[off];
+                    if (nsrc > 1) acc += ((const f32x4*)s1)[off];
+                    if (nsrc > 2) acc += ((const f32x4*)s2)[off];
+                }
+        if (skip) acc += ((const f32x4*)skip)[i];
+        if (yprev) {
+            const f32x4 y = ((const f32x4*)yprev)[i];
+            acc.x *= fdn_act_grad(y.x, act, alpha); acc.y *= fdn_act_grad(y.y, act, alpha);
+            acc.z *= fdn_act_grad(y.z, act, alpha); acc.w *= fdn_act_grad(y.w, act, alpha);
+        }
+        ((f32x4*)out)[i] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// upsample3d (src/Network/SR4DFlowNet.py:53-90): trilinear, align_corners=True.
+// coefficient rule of tf resize_bilinear(align_corners): in = out * scale (fp32), scale = (n-1)/(nR-1).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lerp_coeff(int o, float scale, int n, int& lo, int& hi, float& f) {
+    const float src = (float)o * scale;
+    const float fl = floorf(src);
+    lo = (int)fl;
+    hi = min(lo + 1, n - 1);
+    f = src - fl;
+}
+
+__global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int D,
+                                                            int H, int W, int C4, int R, float sd, float sh, float sw) {
+    const int OD = D * R, OH = H * R, OW = W * R;
+    const int64_t total = (int64_t)N * OD * OH * OW * C4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        int64_t v = i / C4;
+        const int ow = (int)(v % OW); v /= OW;
+        const int oh = (int)(v % OH); v /= OH;
+        const int od = (int)(v % OD);
+        const int n = (int)(v / OD);
+        int d0, d1, h0, h1, w0, w1;
+        float fd, fh, fw;
+        lerp_coeff(od, sd, D, d0, d1, fd);
+        lerp_coeff(oh, sh, H, h0, h1, fh);
+        lerp_coeff(ow, sw, W, w0, w1, fw);
+        const f32x4* xb = (const f32x4*)x + (int64_t)n * D * H * W * C4 + c4;
+#define XAT(dd, hh, ww) xb[(((int64_t)(dd)*H + (hh)) * W + (ww)) * C4]
+        // innermost (z) first, then y, then x -- the order of the reference's two resize passes
+        const f32x4 a00 = XAT(d0, h0, w0), a01 = XAT(d0, h0, w1), a10 = XAT(d0, h1, w0), a11 = XAT(d0, h1, w1);
+        const f32x4 b00 = XAT(d1, h0, w0), b01 = XAT(d1, h0, w1), b10 = XAT(d1, h1, w0), b11 = XAT(d1, h1, w1);
+#undef XAT
+        const f32x4 a0 = a00 + (a01 - a00) * fw, a1 = a10 + (a11 - a10) * fw;
+        const f32x4 b0 = b00 + (b01 - b00) * fw, b1 = b10 + (b11 - b10) * fw;
+        const f32x4 a = a0 + (a1 - a0) * fh, b = b0 + (b1 - b0) * fh;
+        ((f32x4*)y)[i] = a + (b - a) * fd;
+    }
+}
+
+// weight of output index o on input index i along one axis (0 if o does not touch i)
+__device__ __forceinline__ float axis_weight(int o, int i, float scale, int n) {
+    int lo, hi;
+    float f;
+    lerp_coeff(o, scale, n, lo, hi, f);
+    float wgt = 0.f;
+    if (lo == i) wgt += 1.f - f;
+    if (hi == i) wgt += f;
+    return wgt;
+}
+
+// candidate output range [o0,o1] that can touch input i: o*scale in (i-1, i+1)
+__device__ __forceinline__ void axis_range(int i, float inv_scale, int m, int& o0, int& o1) {
+    o0 = max(0, (int)floorf((float)(i - 1) * inv_scale) - 1);
+    o1 = min(m - 1, (int)ceilf((float)(i + 1) * inv_scale) + 1);
+}
+
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ yprev,
+                                                            int act, float alpha, float* __restrict__ dx, int N, int D,
+                                                            int H, int W, int C4, int R, float sd, float sh, float sw) {
+    const int OD = D * R, OH = H * R, OW = W * R;
+    const int64_t total = (int64_t)N * D * H * W * C4;
+    const float isd = sd > 0.f ? 1.f / sd : 0.f, ish = sh > 0.f ? 1.f / sh : 0.f, isw = sw > 0.f ? 1.f / sw : 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        int64_t v = i / C4;
+        const int w = (int)(v % W); v /= W;
+        const int h = (int)(v % H); v /= H;
+        const int d = (int)(v % D);
+        const int n = (int)(v / D);
+        int od0, od1, oh0, oh1, ow0, ow1;
+        axis_range(d, isd, OD, od0, od1);
+        axis_range(h, ish, OH, oh0, oh1);
+        axis_range(w, isw, OW, ow0, ow1);
+        if (sd == 0.f) { od0 = 0; od1 = OD - 1; }
+        if (sh == 0.f) { oh0 = 0; oh1 = OH - 1; }
+        if (sw == 0.f) { ow0 = 0; ow1 = OW - 1; }
+        const f32x4* gb = (const f32x4*)dy + (int64_t)n * OD * OH * OW * C4 + c4;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int od = od0; od <= od1; ++od) {
+            const float wd = axis_weight(od, d, sd, D);
+            if (wd == 0.f) continue;
+            f32x4 accd = {0.f, 0.f, 0.f, 0.f};
+            for (int oh = oh0; oh <= oh1; ++oh) {
+                const float wh = axis_weight(oh, h, sh, H);
+                if (wh == 0.f) continue;
+                f32x4 acch = {0.f, 0.f, 0.f, 0.f};
+                for (int ow = ow0; ow <= ow1; ++ow) {
+                    const float ww = axis_weight(ow, w, sw, W);
+                    if (ww == 0.f) continue;
+                    acch += gb[(((int64_t)od * OH + oh) * OW + ow) * C4] * ww;
+                }
+                accd += acch * wh;
+            }
+            acc += accd * wd;
+        }
+        if (yprev) {
+            const f32x4 y = ((const f32x4*)yprev)[i];
+            acc.x *= fdn_act_grad(y.x, act, alpha); acc.y *= fdn_act_grad(y.y, act, alpha);
+            acc.z *= fdn_act_grad(y.z, act, alpha); acc.w *= fdn_act_grad(y.w, act, alpha);
+        }
+        ((f32x4*)dx)[i] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// loss / metric: TrainerController.py:84-127,152-156 ; loss_utils.py:64-103
+// scratch layout per sample: [0]=sum mask [1]=sum nonfluid [2]=sum mse*mask [3]=sum mse*nf [4]=sum rel
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int wv = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[wv] = v;
+    __syncthreads();
+    float s = 0.f;
+    if (threadIdx.x == 0)
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) s += red[k];
+    return s;   // valid in thread 0
+}
+
+__global__ __launch_bounds__(256) void mask_sums_kernel(const float* __restrict__ mask, float* __restrict__ scratch, int64_t V) {
+    __shared__ float red[4];
+    const int n = blockIdx.y;
+    float sm = 0.f, snf = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (int64_t)gridDim.x * blockDim.x) {
+        const float m = mask[(int64_t)n * V + i];
+        sm += m;
+        snf += m < 0.5f ? 1.f : 0.f;
+    }
+    const float a = block_sum(sm, red);
+    const float b = block_sum(snf, red);
+    if (threadIdx.x == 0) { atomicAdd(&scratch[n * 8 + 0], a); atomicAdd(&scratch[n * 8 + 1], b); }
+}
+
+__global__ __launch_bounds__(256) void loss_main_kernel(const float* __restrict__ pred, const float* __restrict__ uh,
+                                                         const float* __restrict__ vh, const float* __restrict__ wh,
+                                                         const float* __restrict__ mask, float* __restrict__ scratch,
+                                                         float* __restrict__ dpred, int64_t V) {
+    __shared__ float red[4];
+    const int n = blockIdx.y;
+    const float inv_f = 1.f / (scratch[n * 8 + 0] + 1.f);
+    const float inv_nf = 1.f / (scratch[n * 8 + 1] + 1.f);
+    float sf = 0.f, snf = 0.f, srel = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t g = (int64_t)n * V + i;
+        const float tu = uh[g], tv = vh[g], tw = wh[g];
+        const float du = pred[g * 3] - tu, dv = pred[g * 3 + 1] - tv, dw = pred[g * 3 + 2] - tw;
+        const float m = mask[g];
+        const float nf = m < 0.5f ? 1.f : 0.f;
+        const float mse = du * du + dv * dv + dw * dw;
+        sf += mse * m;
+        snf += mse * nf;
+        // relative error (loss_utils.py:64-103); rintf == round-half-to-even == tf.round
+        const float diff = sqrtf(mse);
+        const float actual = sqrtf(tu * tu + tv * tv + tw * tw);
+        float rel = diff / (actual + 1e-5f);
+        rel = fminf(fmaxf(rel, 0.f), 1.f);
+        float corr = actual != 0.f ? rel : diff;
+        corr = rintf(corr * 1e4f) / 1e4f;
+        if (m == 1.0f) srel += corr;
+        if (dpred) {
+            const float wgt = 2.f * (m * inv_f + nf * inv_nf);
+            dpred[g * 3] = du * wgt; dpred[g * 3 + 1] = dv * wgt; dpred[g * 3 + 2] = dw * wgt;
+        }
+    }
+    const float a = block_sum(sf, red);
+    const float b = block_sum(snf, red);
+    const float c = block_sum(srel, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(&scratch[n * 8 + 2], a);
+        atomicAdd(&scratch[n * 8 + 3], b);
+        atomicAdd(&scratch[n * 8 + 4], c);
+    }
+}
+
+__global__ void loss_finalize_kernel(const float* __restrict__ scratch, float* __restrict__ out, int N) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float sm = scratch[n * 8 + 0], snf = scratch[n * 8 + 1];
+    out[n * 4 + 0] = scratch[n * 8 + 2] / (sm + 1.f) + scratch[n * 8 + 3] / (snf + 1.f);
+    out[n * 4 + 1] = scratch[n * 8 + 4] / (sm + 1.f) * 100.f;
+    out[n * 4 + 2] = sm;
+    out[n * 4 + 3] = snf;
+}
+
+__global__ __launch_bounds__(256) void l2_sumsq_kernel(const float* __restrict__ w, const uint8_t* __restrict__ isk,
+                                                        int64_t n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        if (isk[i]) s += w[i] * w[i];
+    const float a = block_sum(s, red);
+    if (threadIdx.x == 0) atomicAdd(out, a);
+}
+
+__global__ void adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            const uint8_t* __restrict__ isk, int64_t n, float lr_t, float b1, float b2, float eps,
+                            float l2s) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float wi = w[i];
+        float gi = g[i];
+        if (isk[i]) gi += l2s * wi;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        w[i] = wi - lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+int grid_for(int64_t items, int cap = 4096) {
+    int64_t b = (items + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (int)b;
+}
+
+float axis_scale(int n, int R) {
+    const int m = n * R;
+    return m > 1 ? (float)(n - 1) / (float)(m - 1) : 0.f;
+}
+
+}  // namespace
+
+extern "C" int fdn_input_features(const float* u, const float* v, const float* w, const float* mu, const float* mv,
+                                  const float* mw, float* phase, float* pc, int64_t nvox, void* stream) {
+    FDN_REQUIRE(u && v && w && mu && mv && mw && phase && pc && nvox > 0, "fdn_input_features: NULL argument or nvox<=0");
+    hipLaunchKernelGGL(input_features_kernel, dim3(grid_for(nvox)), dim3(256), 0, (hipStream_t)stream, u, v, w, mu, mv, mw,
+                       phase, pc, nvox);
+    FDN_CHECK_LAUNCH("input_features_kernel");
+    return FDN_OK;
+}
+
+extern "C" int fdn_fold_halo(const float* dxpad0, const float* dxpad1, const float* dxpad2, int nsrc, const float* skip,
+                             const float* y_prev, int act, float alpha, float* dz_prev, int N, int D, int H, int W, int C,
+                             void* stream) {
+    FDN_REQUIRE(dxpad0 && dz_prev, "fdn_fold_halo: NULL argument");
+    FDN_REQUIRE(nsrc >= 1 && nsrc <= 3 && (nsrc < 2 || dxpad1) && (nsrc < 3 || dxpad2), "fdn_fold_halo: bad nsrc %d", nsrc);
+    FDN_REQUIRE(C % 4 == 0 && N > 0 && D > 0 && H > 0 && W > 0, "fdn_fold_halo: bad dims (C must be a multiple of 4)");
+    const int64_t total = (int64_t)N * D * H * W * (C / 4);
+    hipLaunchKernelGGL(fold_halo_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, dxpad0, dxpad1,
+                       dxpad2, nsrc, skip, y_prev, act, alpha, dz_prev, N, D, H, W, C / 4);
+    FDN_CHECK_LAUNCH("fold_halo_kernel");
+    return FDN_OK;
+}
+
+extern "C" int fdn_upsample_trilinear_fwd(const float* x, float* y, int N, int D, int H, int W, int C, int R, void* stream) {
+    FDN_REQUIRE(x && y && C % 4 == 0 && R >= 1 && N > 0 && D > 0 && H > 0 && W > 0, "fdn_upsample_trilinear_fwd: bad argument");
+    const int64_t total = (int64_t)N * D * R * H * R * W * R * (C / 4);
+    hipLaunchKernelGGL(upsample_fwd_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, x, y, N, D, H, W,
+                       C / 4, R, axis_scale(D, R), axis_scale(H, R), axis_scale(W, R));
+    FDN_CHECK_LAUNCH("upsample_fwd_kernel");
+    return FDN_OK;
+}
+
+extern "C" int fdn_upsample_trilinear_bwd(const float* dy, const float* y_prev, int act, float alpha, float* dx, int N, int D,
+                                          int H, int W, int C, int R, void* stream) {
+    FDN_REQUIRE(dy && dx && C % 4 == 0 && R >= 1 && N > 0 && D > 0 && H > 0 && W > 0, "fdn_upsample_trilinear_bwd: bad argument");
+    const int64_t total = (int64_t)N * D * H * W * (C / 4);
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, dy, y_prev, act,
+                       alpha, dx, N, D, H, W, C / 4, R, axis_scale(D, R), axis_scale(H, R), axis_scale(W, R));
+    FDN_CHECK_LAUNCH("upsample_bwd_kernel");
+    return FDN_OK;
+}
+
+extern "C" int fdn_loss_metrics(const float* pred, const float* uh, const float* vh, const float* wh, const float* mask,
+                                float* out, float* dpred, float* scratch, int N, int64_t V, void* stream) {
+    FDN_REQUIRE(pred && uh && vh && wh && mask && out && scratch && N > 0 && V > 0, "fdn_loss_metrics: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(scratch, 0, (size_t)N * 8 * sizeof(float), s);
+    if (e != hipSuccess) { fdn_set_error("fdn_loss_metrics: memset: %s", hipGetErrorString(e)); return FDN_ERR_HIP; }
+    const int gx = grid_for(V, 256);
+    hipLaunchKernelGGL(mask_sums_kernel, dim3(gx, N), dim3(256), 0, s, mask, scratch, V);
+    FDN_CHECK_LAUNCH("mask_sums_kernel");
+    hipLaunchKernelGGL(loss_main_kernel, dim3(gx, N), dim3(256), 0, s, pred, uh, vh, wh, mask, scratch, dpred, V);
+    FDN_CHECK_LAUNCH("loss_main_kernel");
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3((N + 63) / 64), dim3(64), 0, s, (const float*)scratch, out, N);
+    FDN_CHECK_LAUNCH("loss_finalize_kernel");
+    return FDN_OK;
+}
+
+extern "C" int fdn_l2_sumsq(const float* w, const uint8_t* is_kernel, int64_t n, float* out, void* stream) {
+    FDN_REQUIRE(w && is_kernel && out && n > 0, "fdn_l2_sumsq: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float), s);
+    if (e != hipSuccess) { fdn_set_error("fdn_l2_sumsq: memset: %s", hipGetErrorString(e)); return FDN_ERR_HIP; }
+    hipLaunchKernelGGL(l2_sumsq_kernel, dim3(grid_for(n, 512)), dim3(256), 0, s, w, is_kernel, n, out);
+    FDN_CHECK_LAUNCH("l2_sumsq_kernel");
+    return FDN_OK;
+}
+
+extern "C" int fdn_adam_step(float* w, const float* g, float* m, float* v, const uint8_t* is_kernel, int64_t n, float lr_t,
+                             float b1, float b2, float eps, float l2_grad_scale, void* stream) {
+    FDN_REQUIRE(w && g && m && v && is_kernel && n > 0, "fdn_adam_step: bad argument");
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, (hipStream_t)stream, w, g, m, v, is_kernel, n,
+                       lr_t, b1, b2, eps, l2_grad_scale);
+    FDN_CHECK_LAUNCH("adam_kernel");
+    return FDN_OK;
+}

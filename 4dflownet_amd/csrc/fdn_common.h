@@ -1,0 +1,58 @@
+// Shared helpers for the lib4dflow_hip.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "fdn.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+void fdn_set_error(const char* fmt, ...);
+
+#define FDN_CHECK_LAUNCH(name)                                                         \
+    do {                                                                               \
+        hipError_t e_ = hipGetLastError();                                             \
+        if (e_ != hipSuccess) {                                                        \
+            fdn_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));      \
+            return FDN_ERR_HIP;                                                        \
+        }                                                                              \
+    } while (0)
+
+#define FDN_REQUIRE(cond, ...)                                                         \
+    do {                                                                               \
+        if (!(cond)) {                                                                 \
+            fdn_set_error(__VA_ARGS__);                                                \
+            return FDN_ERR_BAD_ARG;                                                    \
+        }                                                                              \
+    } while (0)
+
+// floor(r/d) for 0 <= r < 1024 and 1 <= d <= 1024, with magic = ceil(2^20/d).
+__host__ __device__ inline unsigned fdn_magic20(unsigned d) { return ((1u << 20) + d - 1) / d; }
+__device__ __forceinline__ int fdn_div20(int r, unsigned magic) { return (int)(((unsigned)r * magic) >> 20); }
+
+__device__ __forceinline__ float fdn_act(float z, int act, float alpha) {
+    if (act == FDN_ACT_RELU) return z > 0.f ? z : 0.f;
+    if (act == FDN_ACT_LEAKY) return z > 0.f ? z : alpha * z;
+    return z;
+}
+// act'(z) recovered from the stored output y = act(z)  (y > 0 <=> z > 0 for relu / leaky-relu)
+__device__ __forceinline__ float fdn_act_grad(float y, int act, float alpha) {
+    if (act == FDN_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+    if (act == FDN_ACT_LEAKY) return y > 0.f ? 1.f : alpha;
+    return 1.f;
+}
+
+// Tile planner shared by host code of the MFMA kernels: choose (td,th,tw) with td*th*tw <= max_vox and
+// halo rows <= max_rows minimising the number of workgroup-rounds over `ncu` CUs.
+struct FdnTile { int td, th, tw, ntd, nth, ntw; };
+FdnTile fdn_plan_tile(int N, int OD, int OH, int OW, int max_vox, int max_halo_rows, int halo_d);
+
+// entry points implemented in the per-kernel translation units
+int fdn_conv64_launch(const float* x, const float* wpack, const float* bias, const float* residual, float* y,
+                      int N, int ID, int IH, int IW, int OD, int OH, int OW, int off, int zero_mode, int act,
+                      float alpha, hipStream_t s);
+int fdn_wgrad64_launch(const float* x, const float* dz, float* dw, void* ws, size_t ws_bytes, int N, int D, int H,
+                       int W, hipStream_t s);
+size_t fdn_wgrad64_workspace_bytes(int N, int D, int H, int W);

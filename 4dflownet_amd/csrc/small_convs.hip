@@ -1,0 +1,506 @@
+// The thin layers of SR4DFlowNet (src/Network/SR4DFlowNet.py:17,20,24,40,43,46) -- 3->64 and 64->1 3x3x3 convs and
+// the 1x1x1 128->64 fuse conv -- forward, input-gradient and weight-gradient.  Together they are <0.6 % of the
+// network's FLOPs and are HBM/L2-bound, so they are plain coalesced VALU kernels (no MFMA reshaping):
+// 256-B channel rows are always read/written by 16 lanes x 16 B or 64 lanes x 4 B.
+#include "fdn_common.h"
+
+namespace {
+
+__device__ __forceinline__ int clampi(int v, int hi) { return min(max(v, 0), hi); }
+
+// -------------------------------------------------------------------------------------------------
+// forward 3 -> 64, k=3.  Block = 64 voxels x 4 cout-groups of 16; weights (81 x 64) in LDS.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_cin3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ y,
+                                                             int N, int D, int H, int W, int act, float alpha) {
+    __shared__ __attribute__((aligned(16))) float ws[81 * 64];
+    for (int i = threadIdx.x; i < 81 * 64; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const int64_t nvox = (int64_t)N * D * H * W;
+    const int64_t v = (int64_t)blockIdx.x * 64 + (threadIdx.x >> 2);
+    if (v >= nvox) return;
+    const int q = threadIdx.x & 3;
+    int r = (int)(v % ((int64_t)D * H * W));
+    const int64_t nb = v - r;
+    const int d = r / (H * W); r -= d * H * W;
+    const int h = r / W;
+    const int wv = r - h * W;
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = bias ? bias[q * 16 + j] : 0.f;
+    for (int a = 0; a < 3; ++a) {
+        const int qd = clampi(d + a - 1, D - 1);
+        for (int b = 0; b < 3; ++b) {
+            const int qh = clampi(h + b - 1, H - 1);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int qw = clampi(wv + c - 1, W - 1);
+                const float* xp = x + (nb + ((int64_t)qd * H + qh) * W + qw) * 3;
+                const float x0 = xp[0], x1 = xp[1], x2 = xp[2];
+                const float* wp = ws + ((a * 3 + b) * 3 + c) * 192 + q * 16;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[j] += x0 * wp[j] + x1 * wp[64 + j] + x2 * wp[128 + j];
+            }
+        }
+    }
+    float* yp = y + v * 64 + q * 16;
+#pragma unroll
+    for (int j = 0; j < 16; j += 4) {
+        f32x4 o = {fdn_act(acc[j], act, alpha), fdn_act(acc[j + 1], act, alpha), fdn_act(acc[j + 2], act, alpha),
+                   fdn_act(acc[j + 3], act, alpha)};
+        *(f32x4*)(yp + j) = o;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// forward 64 -> 1, k=3.  16 lanes per voxel (4 channels each), 27 coalesced row reads, 16-lane reduce.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_cout1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ y,
+                                                              int N, int D, int H, int W, int ldy, int y_coff, int act,
+                                                              float alpha) {
+    __shared__ __attribute__((aligned(16))) float ws[27 * 64];
+    for (int i = threadIdx.x; i < 27 * 64; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const int64_t nvox = (int64_t)N * D * H * W;
+    const int c4 = threadIdx.x & 15;
+    for (int64_t v = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); v < nvox; v += (int64_t)gridDim.x * 16) {
+        int r = (int)(v % ((int64_t)D * H * W));
+        const int64_t nb = v - r;
+        const int d = r / (H * W); r -= d * H * W;
+        const int h = r / W;
+        const int wv = r - h * W;
+        float s = 0.f;
+        for (int a = 0; a < 3; ++a) {
+            const int qd = clampi(d + a - 1, D - 1);
+            for (int b = 0; b < 3; ++b) {
+                const int qh = clampi(h + b - 1, H - 1);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int qw = clampi(wv + c - 1, W - 1);
+                    const f32x4 xv = *(const f32x4*)(x + (nb + ((int64_t)qd * H + qh) * W + qw) * 64 + c4 * 4);
+                    const f32x4 wt = *(const f32x4*)(ws + ((a * 3 + b) * 3 + c) * 64 + c4 * 4);
+                    s += xv.x * wt.x + xv.y * wt.y + xv.z * wt.z + xv.w * wt.w;
+                }
+            }
+        }
+        s += __shfl_xor(s, 8, 16);
+        s += __shfl_xor(s, 4, 16);
+        s += __shfl_xor(s, 2, 16);
+        s += __shfl_xor(s, 1, 16);
+        if (c4 == 0) y[v * ldy + y_coff] = fdn_act(s + (bias ? bias[0] : 0.f), act, alpha);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// forward 1x1x1 (64 + 64) -> 64.  Thread = (voxel, 16 couts); weights (128 x 64) in LDS.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv1x1_fwd_kernel(const float* __restrict__ xa, const float* __restrict__ xb,
+                                                           const float* __restrict__ w, const float* __restrict__ bias,
+                                                           float* __restrict__ y, int64_t nvox, int act, float alpha) {
+    __shared__ __attribute__((aligned(16))) float ws[128 * 64];
+    for (int i = threadIdx.x; i < 128 * 64; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const int q = threadIdx.x & 3;
+    for (int64_t v = (int64_t)blockIdx.x * 64 + (threadIdx.x >> 2); v < nvox; v += (int64_t)gridDim.x * 64) {
+        float acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = bias ? bias[q * 16 + j] : 0.f;
+#pragma unroll 1
+        for (int src = 0; src < 2; ++src) {
+            const float* xp = (src ? xb : xa) + v * 64;
+            const float* wsrc = ws + src * 64 * 64 + q * 16;
+#pragma unroll 4
+            for (int k4 = 0; k4 < 16; ++k4) {
+                const f32x4 xv = *(const f32x4*)(xp + k4 * 4);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const float xs = xv[kk];
+                    const float* wr = wsrc + (k4 * 4 + kk) * 64;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) acc[j] += xs * wr[j];
+                }
+            }
+        }
+        float* yp = y + v * 64 + q * 16;
+#pragma unroll
+        for (int j = 0; j < 16; j += 4) {
+            f32x4 o = {fdn_act(acc[j], act, alpha), fdn_act(acc[j + 1], act, alpha), fdn_act(acc[j + 2], act, alpha),
+                       fdn_act(acc[j + 3], act, alpha)};
+            *(f32x4*)(yp + j) = o;
+        }
+    }
+}
+
+// 1x1 backward w.r.t. inputs, fused with the ReLU masks of the two producers.
+// thread = (voxel, 16 of the 128 input channels); Wt[co][ci] in LDS.
+__global__ __launch_bounds__(256) void conv1x1_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ w,
+                                                             const float* __restrict__ ya, const float* __restrict__ yb,
+                                                             float* __restrict__ dxa, float* __restrict__ dxb, int64_t nvox) {
+    __shared__ __attribute__((aligned(16))) float wt[64 * 128];
+    for (int i = threadIdx.x; i < 128 * 64; i += 256) {
+        const int ci = i >> 6, co = i & 63;
+        wt[co * 128 + ci] = w[i];
+    }
+    __syncthreads();
+    const int q = threadIdx.x & 7;        // 16-channel group of the 128 inputs
+    for (int64_t v = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3); v < nvox; v += (int64_t)gridDim.x * 32) {
+        float acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+        const float* dp = dz + v * 64;
+#pragma unroll 4
+        for (int k4 = 0; k4 < 16; ++k4) {
+            const f32x4 dv = *(const f32x4*)(dp + k4 * 4);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const float ds = dv[kk];
+                const float* wr = wt + (k4 * 4 + kk) * 128 + q * 16;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[j] += ds * wr[j];
+            }
+        }
+        const int half = q >> 2;
+        const int cofs = (q & 3) * 16;
+        const float* yp = (half ? yb : ya) + v * 64 + cofs;
+        float* op = (half ? dxb : dxa) + v * 64 + cofs;
+#pragma unroll
+        for (int j = 0; j < 16; j += 4) {
+            const f32x4 yv = *(const f32x4*)(yp + j);
+            f32x4 o = {yv.x > 0.f ? acc[j] : 0.f, yv.y > 0.f ? acc[j + 1] : 0.f, yv.z > 0.f ? acc[j + 2] : 0.f,
+                       yv.w > 0.f ? acc[j + 3] : 0.f};
+            *(f32x4*)(op + j) = o;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// dgrad of 64 -> 1 (k=3) onto the padded grid: dxpad[P][ci] = sum_u w[-u][ci] * dz[P+u]  (zero outside).
+// One wave per padded position at a time, lanes = ci; the 27 dz scalars are wave-uniform.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_cout1_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ w,
+                                                                float* __restrict__ dxpad, int N, int D, int H, int W,
+                                                                int lddz, int dz_coff) {
+    const int lane = threadIdx.x & 63;
+    float wr[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) wr[t] = w[t * 64 + lane];
+    const int PD = D + 2, PH = H + 2, PW = W + 2;
+    const int64_t npos = (int64_t)N * PD * PH * PW;
+    const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t pos = wave_id; pos < npos; pos += nwaves) {
+        int r = (int)(pos % ((int64_t)PD * PH * PW));
+        const int n = (int)(pos / ((int64_t)PD * PH * PW));
+        const int pd = r / (PH * PW); r -= pd * PH * PW;
+        const int ph = r / PW;
+        const int pw = r - ph * PW;
+        float s = 0.f;
+        // padded index p <-> position P = p-1; contributing output voxel o = P - (t-1) = p - t, t = tap index
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int od = pd - a;
+            if ((unsigned)od >= (unsigned)D) continue;
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const int oh = ph - b;
+                if ((unsigned)oh >= (unsigned)H) continue;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int ow = pw - c;
+                    if ((unsigned)ow >= (unsigned)W) continue;
+                    const float g = dz[(((int64_t)n * D + od) * H + oh) * W * lddz + (int64_t)ow * lddz + dz_coff];
+                    s += wr[(a * 3 + b) * 3 + c] * g;
+                }
+            }
+        }
+        dxpad[pos * 64 + lane] = s;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// weight gradients of the thin layers: per-block partials in workspace, then reduce_partials.
+// -------------------------------------------------------------------------------------------------
+// 3 -> 64: one wave owns the full (81 x 64) output (lane = cout, 81 accumulators), waves take voxels round-robin.
+__global__ __launch_bounds__(256) void wgrad_cin3_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+                                                          float* __restrict__ partial, int N, int D, int H, int W) {
+    __shared__ float red[81 * 64];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    float acc[81];
+#pragma unroll
+    for (int t = 0; t < 81; ++t) acc[t] = 0.f;
+    const int64_t nvox = (int64_t)N * D * H * W;
+    const int64_t wave_id = (int64_t)blockIdx.x * 4 + wv;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t v = wave_id; v < nvox; v += nwaves) {
+        int r = (int)(v % ((int64_t)D * H * W));
+        const int64_t nb = v - r;
+        const int d = r / (H * W); r -= d * H * W;
+        const int h = r / W;
+        const int w0 = r - h * W;
+        const float g = dz[v * 64 + lane];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int qd = clampi(d + a - 1, D - 1);
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const int qh = clampi(h + b - 1, H - 1);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int qw = clampi(w0 + c - 1, W - 1);
+                    const float* xp = x + (nb + ((int64_t)qd * H + qh) * W + qw) * 3;
+                    const int t = ((a * 3 + b) * 3 + c) * 3;
+                    acc[t] += xp[0] * g;
+                    acc[t + 1] += xp[1] * g;
+                    acc[t + 2] += xp[2] * g;
+                }
+            }
+        }
+    }
+    for (int ph = 0; ph < 4; ++ph) {       // waves fold their accumulators into LDS one after another
+        if (wv == ph) {
+#pragma unroll
+            for (int t = 0; t < 81; ++t) {
+                if (ph == 0) red[t * 64 + lane] = acc[t];
+                else red[t * 64 + lane] += acc[t];
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < 81 * 64; i += 256) partial[(size_t)blockIdx.x * (81 * 64) + i] = red[i];
+}
+
+// 64 -> 1: iterate over PADDED input positions so each x row is read once; lane = ci, 27 accumulators.
+__global__ __launch_bounds__(256) void wgrad_cout1_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+                                                           float* __restrict__ partial, int N, int D, int H, int W,
+                                                           int lddz, int dz_coff) {
+    __shared__ float red[4][27 * 64];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    float acc[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc[t] = 0.f;
+    const int PD = D + 2, PH = H + 2, PW = W + 2;
+    const int64_t npos = (int64_t)N * PD * PH * PW;
+    const int64_t wave_id = (int64_t)blockIdx.x * 4 + wv;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t pos = wave_id; pos < npos; pos += nwaves) {
+        int r = (int)(pos % ((int64_t)PD * PH * PW));
+        const int n = (int)(pos / ((int64_t)PD * PH * PW));
+        const int pd = r / (PH * PW); r -= pd * PH * PW;
+        const int ph = r / PW;
+        const int pw = r - ph * PW;
+        const int qd = clampi(pd - 1, D - 1), qh = clampi(ph - 1, H - 1), qw = clampi(pw - 1, W - 1);
+        const float xv = x[((((int64_t)n * D + qd) * H + qh) * W + qw) * 64 + lane];
+        // padded position p is tap t's input of output voxel o = p - t
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int od = pd - a;
+            if ((unsigned)od >= (unsigned)D) continue;
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const int oh = ph - b;
+                if ((unsigned)oh >= (unsigned)H) continue;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int ow = pw - c;
+                    if ((unsigned)ow >= (unsigned)W) continue;
+                    const float g = dz[(((int64_t)n * D + od) * H + oh) * W * lddz + (int64_t)ow * lddz + dz_coff];
+                    acc[(a * 3 + b) * 3 + c] += xv * g;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 27; ++t) red[wv][t * 64 + lane] = acc[t];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 27 * 64; i += 256)
+        partial[(size_t)blockIdx.x * (27 * 64) + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+}
+
+// 1x1 (64+64) -> 64: thread owns ci = tid>>1 and 32 couts; voxel chunks staged through LDS.
+__global__ __launch_bounds__(256) void wgrad_1x1_kernel(const float* __restrict__ xa, const float* __restrict__ xb,
+                                                         const float* __restrict__ dz, float* __restrict__ partial,
+                                                         int64_t nvox) {
+    constexpr int CH = 32;   // voxels per chunk
+    __shared__ __attribute__((aligned(16))) float xs[CH * 128];
+    __shared__ __attribute__((aligned(16))) float zs[CH * 64];
+    const int ci = threadIdx.x >> 1;
+    const int ch = threadIdx.x & 1;
+    float acc[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) acc[j] = 0.f;
+    for (int64_t v0 = (int64_t)blockIdx.x * CH; v0 < nvox; v0 += (int64_t)gridDim.x * CH) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < CH * 32; i += 256) {      // float4 units: 16 from xa + 16 from xb per voxel
+            const int vv = i >> 5, c4 = i & 31;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (v0 + vv < nvox) val = *(const f32x4*)((c4 < 16 ? xa : xb) + (v0 + vv) * 64 + (c4 & 15) * 4);
+            *(f32x4*)(xs + vv * 128 + c4 * 4) = val;
+        }
+        for (int i = threadIdx.x; i < CH * 16; i += 256) {
+            const int vv = i >> 4, c4 = i & 15;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (v0 + vv < nvox) val = *(const f32x4*)(dz + (v0 + vv) * 64 + c4 * 4);
+            *(f32x4*)(zs + vv * 64 + c4 * 4) = val;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int vv = 0; vv < CH; ++vv) {
+            const float xv = xs[vv * 128 + ci];
+            const float* zr = zs + vv * 64 + ch * 32;
+#pragma unroll
+            for (int j = 0; j < 32; j += 4) {
+                const f32x4 g = *(const f32x4*)(zr + j);
+                acc[j] += xv * g.x; acc[j + 1] += xv * g.y; acc[j + 2] += xv * g.z; acc[j + 3] += xv * g.w;
+            }
+        }
+    }
+    float* out = partial + (size_t)blockIdx.x * (128 * 64) + ci * 64 + ch * 32;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) out[j] = acc[j];
+}
+
+// bias gradient: db[c] = sum_v dz[v*ld + coff + c]
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dz, float* __restrict__ partial,
+                                                         int64_t nvox, int C, int lddz, int dz_coff) {
+    __shared__ float red[256];
+    float s = 0.f;
+    if (C == 64) {
+        const int c = threadIdx.x & 63;
+        for (int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); v < nvox; v += (int64_t)gridDim.x * 4)
+            s += dz[v * lddz + dz_coff + c];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (threadIdx.x < 64)
+            partial[(size_t)blockIdx.x * 64 + c] = (red[c] + red[64 + c]) + (red[128 + c] + red[192 + c]);
+    } else {   // C == 1
+        for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvox; v += (int64_t)gridDim.x * 256)
+            s += dz[v * lddz + dz_coff];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+    }
+}
+
+__global__ void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int nparts, int nelem) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nelem) return;
+    float s0 = 0.f, s1 = 0.f;
+    int p = 0;
+    for (; p + 2 <= nparts; p += 2) {
+        s0 += partial[(size_t)p * nelem + e];
+        s1 += partial[(size_t)(p + 1) * nelem + e];
+    }
+    if (p < nparts) s0 += partial[(size_t)p * nelem + e];
+    out[e] = s0 + s1;
+}
+
+constexpr int kSmallBlocks = 512;   // partial-sum blocks of the thin-layer wgrad / bias kernels
+
+int reduce_partials(const float* partial, float* out, int nparts, int nelem, hipStream_t s) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((nelem + 255) / 256), dim3(256), 0, s, partial, out, nparts, nelem);
+    FDN_CHECK_LAUNCH("reduce_partials_kernel");
+    return FDN_OK;
+}
+
+int nblocks_for(int64_t items, int per_block, int cap) {
+    int64_t b = (items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (int)b;
+}
+
+}  // namespace
+
+size_t fdn_small_wgrad_workspace_bytes(int Cin, int Cout, int K) {
+    size_t elems = (size_t)K * K * K * Cin * Cout;
+    if (elems < 64) elems = 64;
+    return (size_t)kSmallBlocks * elems * sizeof(float);
+}
+
+int fdn_conv_cin3_fwd_launch(const float* x, const float* w, const float* bias, float* y, int N, int D, int H, int W,
+                             int act, float alpha, hipStream_t s) {
+    const int64_t nvox = (int64_t)N * D * H * W;
+    hipLaunchKernelGGL(conv_cin3_fwd_kernel, dim3((unsigned)((nvox + 63) / 64)), dim3(256), 0, s, x, w, bias, y, N, D, H,
+                       W, act, alpha);
+    FDN_CHECK_LAUNCH("conv_cin3_fwd_kernel");
+    return FDN_OK;
+}
+
+int fdn_conv_cout1_fwd_launch(const float* x, const float* w, const float* bias, float* y, int N, int D, int H, int W,
+                              int ldy, int y_coff, int act, float alpha, hipStream_t s) {
+    const int64_t nvox = (int64_t)N * D * H * W;
+    hipLaunchKernelGGL(conv_cout1_fwd_kernel, dim3(nblocks_for(nvox, 16, 8192)), dim3(256), 0, s, x, w, bias, y, N, D, H,
+                       W, ldy, y_coff, act, alpha);
+    FDN_CHECK_LAUNCH("conv_cout1_fwd_kernel");
+    return FDN_OK;
+}
+
+int fdn_conv1x1_fwd_launch(const float* xa, const float* xb, const float* w, const float* bias, float* y, int64_t nvox,
+                           int act, float alpha, hipStream_t s) {
+    hipLaunchKernelGGL(conv1x1_fwd_kernel, dim3(nblocks_for(nvox, 64, 2048)), dim3(256), 0, s, xa, xb, w, bias, y, nvox,
+                       act, alpha);
+    FDN_CHECK_LAUNCH("conv1x1_fwd_kernel");
+    return FDN_OK;
+}
+
+extern "C" int fdn_conv1x1_dgrad(const float* dz, const float* w, const float* ya, const float* yb, float* dxa,
+                                 float* dxb, int64_t nvox, void* stream) {
+    FDN_REQUIRE(dz && w && ya && yb && dxa && dxb && nvox > 0, "fdn_conv1x1_dgrad: NULL argument or nvox<=0");
+    hipLaunchKernelGGL(conv1x1_dgrad_kernel, dim3(nblocks_for(nvox, 32, 2048)), dim3(256), 0, (hipStream_t)stream, dz, w,
+                       ya, yb, dxa, dxb, nvox);
+    FDN_CHECK_LAUNCH("conv1x1_dgrad_kernel");
+    return FDN_OK;
+}
+
+int fdn_conv_cout1_dgrad_launch(const float* dz, const float* w, float* dxpad, int N, int D, int H, int W, int lddz,
+                                int dz_coff, hipStream_t s) {
+    const int64_t npos = (int64_t)N * (D + 2) * (H + 2) * (W + 2);
+    hipLaunchKernelGGL(conv_cout1_dgrad_kernel, dim3(nblocks_for(npos, 4 * 16, 4096)), dim3(256), 0, s, dz, w, dxpad, N,
+                       D, H, W, lddz, dz_coff);
+    FDN_CHECK_LAUNCH("conv_cout1_dgrad_kernel");
+    return FDN_OK;
+}
+
+int fdn_wgrad_cin3_launch(const float* x, const float* dz, float* dw, void* ws, size_t, int N, int D, int H, int W,
+                          hipStream_t s) {
+    const int64_t nvox = (int64_t)N * D * H * W;
+    const int nb = nblocks_for(nvox, 4 * 32, kSmallBlocks);
+    hipLaunchKernelGGL(wgrad_cin3_kernel, dim3(nb), dim3(256), 0, s, x, dz, (float*)ws, N, D, H, W);
+    FDN_CHECK_LAUNCH("wgrad_cin3_kernel");
+    return reduce_partials((const float*)ws, dw, nb, 81 * 64, s);
+}
+
+int fdn_wgrad_cout1_launch(const float* x, const float* dz, float* dw, void* ws, size_t, int N, int D, int H, int W,
+                           int lddz, int dz_coff, hipStream_t s) {
+    const int64_t npos = (int64_t)N * (D + 2) * (H + 2) * (W + 2);
+    const int nb = nblocks_for(npos, 4 * 64, kSmallBlocks);
+    hipLaunchKernelGGL(wgrad_cout1_kernel, dim3(nb), dim3(256), 0, s, x, dz, (float*)ws, N, D, H, W, lddz, dz_coff);
+    FDN_CHECK_LAUNCH("wgrad_cout1_kernel");
+    return reduce_partials((const float*)ws, dw, nb, 27 * 64, s);
+}
+
+int fdn_wgrad_1x1_launch(const float* xa, const float* xb, const float* dz, float* dw, void* ws, size_t, int64_t nvox,
+                         hipStream_t s) {
+    const int nb = nblocks_for(nvox, 32 * 4, kSmallBlocks);
+    hipLaunchKernelGGL(wgrad_1x1_kernel, dim3(nb), dim3(256), 0, s, xa, xb, dz, (float*)ws, nvox);
+    FDN_CHECK_LAUNCH("wgrad_1x1_kernel");
+    return reduce_partials((const float*)ws, dw, nb, 128 * 64, s);
+}
+
+int fdn_bias_grad_launch(const float* dz, float* db, void* ws, size_t ws_bytes, int64_t nvox, int C, int lddz,
+                         int dz_coff, hipStream_t s) {
+    if (C != 64 && C != 1) { fdn_set_error("bias_grad: unsupported C=%d", C); return FDN_ERR_UNSUPPORTED; }
+    const int nb = nblocks_for(nvox, C == 64 ? 4 * 64 : 256 * 16, kSmallBlocks);
+    if (ws_bytes < (size_t)nb * C * sizeof(float)) { fdn_set_error("bias_grad: workspace too small"); return FDN_ERR_WORKSPACE; }
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(nb), dim3(256), 0, s, dz, (float*)ws, nvox, C, lddz, dz_coff);
+    FDN_CHECK_LAUNCH("bias_grad_kernel");
+    return reduce_partials((const float*)ws, db, nb, C, s);
+}

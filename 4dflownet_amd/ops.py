@@ -1,0 +1,180 @@
+"""Operator layer: torch tensors (containers only) -> raw pointers -> lib4dflow_hip.so.
+
+Every function launches asynchronously on torch's current HIP stream and returns its output tensor(s).
+Tensors must be fp32, contiguous and on a ROCm device; anything else raises (no CPU path)."""
+import torch
+
+from . import _lib
+from ._lib import FdnError, check
+
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+LEAKY_ALPHA = 0.2
+
+
+def _p(t, name="tensor", allow_none=False):
+    if t is None:
+        if allow_none:
+            return None
+        raise FdnError("%s is None" % name)
+    if not t.is_cuda:
+        raise FdnError("%s must live on the GPU; the HIP path has no CPU fallback" % name)
+    if t.dtype != torch.float32 and t.dtype != torch.uint8:
+        raise FdnError("%s must be float32 (got %s)" % (name, t.dtype))
+    if not t.is_contiguous():
+        raise FdnError("%s must be contiguous" % name)
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def input_features(u, v, w, mu, mv, mw, phase=None, pc=None):
+    shp = u.shape[:-1] if u.shape[-1] == 1 else u.shape
+    nvox = u.numel()
+    if phase is None:
+        phase = torch.empty(tuple(shp) + (3,), device=u.device, dtype=torch.float32)
+    if pc is None:
+        pc = torch.empty(tuple(shp) + (3,), device=u.device, dtype=torch.float32)
+    check(_lib.load().fdn_input_features(_p(u), _p(v), _p(w), _p(mu), _p(mv), _p(mw), _p(phase), _p(pc), nvox, _stream()),
+          "fdn_input_features")
+    return phase, pc
+
+
+def pack_conv64_weights(w, wp_fwd=None, wp_dgrad=None, want_dgrad=True):
+    if tuple(w.shape) != (3, 3, 3, 64, 64):
+        raise FdnError("pack_conv64_weights: expected (3,3,3,64,64), got %s" % (tuple(w.shape),))
+    if wp_fwd is None:
+        wp_fwd = torch.empty(27 * 64 * 64, device=w.device, dtype=torch.float32)
+    if wp_dgrad is None and want_dgrad:
+        wp_dgrad = torch.empty(27 * 64 * 64, device=w.device, dtype=torch.float32)
+    check(_lib.load().fdn_pack_conv64_weights(_p(w), _p(wp_fwd), _p(wp_dgrad, allow_none=True), _stream()),
+          "fdn_pack_conv64_weights")
+    return wp_fwd, wp_dgrad
+
+
+def conv3d_fwd(x, w, bias=None, act=ACT_NONE, alpha=LEAKY_ALPHA, residual=None, x2=None, wpack=None, out=None,
+               ldy=None, y_coff=0):
+    """x (N,D,H,W,Cin[/2 if x2]); w Keras layout (K,K,K,Cin,Cout)."""
+    N, D, H, W = x.shape[:4]
+    K, Cin, Cout = w.shape[0], w.shape[3], w.shape[4]
+    if out is None:
+        out = torch.empty((N, D, H, W, Cout), device=x.device, dtype=torch.float32)
+        ldy = Cout
+    elif ldy is None:
+        ldy = out.shape[-1]
+    if Cin == 64 and Cout == 64 and K == 3 and wpack is None:
+        wpack, _ = pack_conv64_weights(w, want_dgrad=False)
+    check(_lib.load().fdn_conv3d_fwd(_p(x, "x"), _p(x2, allow_none=True), _p(w, "w"), _p(wpack, allow_none=True),
+                                     _p(bias, allow_none=True), _p(residual, allow_none=True), _p(out, "out"),
+                                     N, D, H, W, Cin, Cout, K, ldy, y_coff, act, float(alpha), _stream()),
+          "fdn_conv3d_fwd")
+    return out
+
+
+def conv3d_dgrad(dz, w, wpack_dgrad=None, out=None, lddz=None, dz_coff=0, spatial=None):
+    """Returns the gradient on the PADDED input grid (N,D+2,H+2,W+2,Cin) for K=3."""
+    K, Cin, Cout = w.shape[0], w.shape[3], w.shape[4]
+    N, D, H, W = dz.shape[:4] if spatial is None else spatial
+    if lddz is None:
+        lddz = dz.shape[-1]
+    if out is None:
+        out = torch.empty((N, D + 2, H + 2, W + 2, Cin), device=dz.device, dtype=torch.float32)
+    if Cin == 64 and Cout == 64 and K == 3 and wpack_dgrad is None:
+        _, wpack_dgrad = pack_conv64_weights(w)
+    check(_lib.load().fdn_conv3d_dgrad(_p(dz, "dz"), _p(w, "w"), _p(wpack_dgrad, allow_none=True), _p(out, "dxpad"),
+                                       N, D, H, W, Cin, Cout, K, lddz, dz_coff, _stream()), "fdn_conv3d_dgrad")
+    return out
+
+
+def fold_halo(dxpads, skip=None, y_prev=None, act=ACT_NONE, alpha=LEAKY_ALPHA, out=None):
+    """dxpads: 1..3 tensors (N,D+2,H+2,W+2,C).  Returns (N,D,H,W,C)."""
+    p0 = dxpads[0]
+    N, D, H, W, C = p0.shape[0], p0.shape[1] - 2, p0.shape[2] - 2, p0.shape[3] - 2, p0.shape[4]
+    if out is None:
+        out = torch.empty((N, D, H, W, C), device=p0.device, dtype=torch.float32)
+    ptrs = [_p(t) for t in dxpads] + [None] * (3 - len(dxpads))
+    check(_lib.load().fdn_fold_halo(ptrs[0], ptrs[1], ptrs[2], len(dxpads), _p(skip, allow_none=True),
+                                    _p(y_prev, allow_none=True), act, float(alpha), _p(out), N, D, H, W, C, _stream()),
+          "fdn_fold_halo")
+    return out
+
+
+def conv1x1_dgrad(dz, w, ya, yb, dxa=None, dxb=None):
+    nvox = dz.numel() // 64
+    if dxa is None:
+        dxa = torch.empty_like(ya)
+    if dxb is None:
+        dxb = torch.empty_like(yb)
+    check(_lib.load().fdn_conv1x1_dgrad(_p(dz), _p(w), _p(ya), _p(yb), _p(dxa), _p(dxb), nvox, _stream()),
+          "fdn_conv1x1_dgrad")
+    return dxa, dxb
+
+
+def wgrad_workspace_bytes(N, D, H, W, Cin, Cout, K):
+    return int(_lib.load().fdn_conv3d_wgrad_workspace_bytes(N, D, H, W, Cin, Cout, K))
+
+
+def conv3d_wgrad(x, dz, K, Cin, Cout, x2=None, want_bias=False, dw=None, dbias=None, workspace=None, lddz=None,
+                 dz_coff=0):
+    N, D, H, W = x.shape[:4]
+    if lddz is None:
+        lddz = dz.shape[-1]
+    if dw is None:
+        dw = torch.empty((K, K, K, Cin, Cout), device=x.device, dtype=torch.float32)
+    if want_bias and dbias is None:
+        dbias = torch.empty((Cout,), device=x.device, dtype=torch.float32)
+    need = wgrad_workspace_bytes(N, D, H, W, Cin, Cout, K)
+    if workspace is None:
+        workspace = torch.empty((need + 3) // 4, device=x.device, dtype=torch.float32)
+    check(_lib.load().fdn_conv3d_wgrad(_p(x, "x"), _p(x2, allow_none=True), _p(dz, "dz"), _p(dw, "dw"),
+                                       _p(dbias, allow_none=True), _p(workspace, "workspace"),
+                                       workspace.numel() * workspace.element_size(), N, D, H, W, Cin, Cout, K, lddz,
+                                       dz_coff, _stream()), "fdn_conv3d_wgrad")
+    return dw, dbias
+
+
+def upsample_trilinear_fwd(x, R, out=None):
+    N, D, H, W, C = x.shape
+    if out is None:
+        out = torch.empty((N, D * R, H * R, W * R, C), device=x.device, dtype=torch.float32)
+    check(_lib.load().fdn_upsample_trilinear_fwd(_p(x), _p(out), N, D, H, W, C, R, _stream()), "fdn_upsample_trilinear_fwd")
+    return out
+
+
+def upsample_trilinear_bwd(dy, R, y_prev=None, act=ACT_NONE, alpha=LEAKY_ALPHA, out=None):
+    N, OD, OH, OW, C = dy.shape
+    D, H, W = OD // R, OH // R, OW // R
+    if out is None:
+        out = torch.empty((N, D, H, W, C), device=dy.device, dtype=torch.float32)
+    check(_lib.load().fdn_upsample_trilinear_bwd(_p(dy), _p(y_prev, allow_none=True), act, float(alpha), _p(out), N, D, H, W,
+                                                 C, R, _stream()), "fdn_upsample_trilinear_bwd")
+    return out
+
+
+def loss_metrics(pred, uh, vh, wh, mask, want_grad=True, out=None, dpred=None, scratch=None):
+    """Returns out (N,4) = [mse-loss, rel-err %, sum mask, sum nonfluid] and dpred (N,...,3) or None."""
+    N = pred.shape[0]
+    V = pred.numel() // (3 * N)
+    if out is None:
+        out = torch.empty((N, 4), device=pred.device, dtype=torch.float32)
+    if scratch is None:
+        scratch = torch.empty((N * 8,), device=pred.device, dtype=torch.float32)
+    if want_grad and dpred is None:
+        dpred = torch.empty_like(pred)
+    check(_lib.load().fdn_loss_metrics(_p(pred), _p(uh), _p(vh), _p(wh), _p(mask), _p(out),
+                                       _p(dpred, allow_none=True) if want_grad else None, _p(scratch), N, V, _stream()),
+          "fdn_loss_metrics")
+    return out, (dpred if want_grad else None)
+
+
+def l2_sumsq(w_flat, is_kernel, out=None):
+    if out is None:
+        out = torch.empty((1,), device=w_flat.device, dtype=torch.float32)
+    check(_lib.load().fdn_l2_sumsq(_p(w_flat), _p(is_kernel), w_flat.numel(), _p(out), _stream()), "fdn_l2_sumsq")
+    return out
+
+
+def adam_step(w, g, m, v, is_kernel, lr_t, b1, b2, eps, l2_grad_scale):
+    check(_lib.load().fdn_adam_step(_p(w), _p(g), _p(m), _p(v), _p(is_kernel), w.numel(), float(lr_t), float(b1), float(b2),
+                                    float(eps), float(l2_grad_scale), _stream()), "fdn_adam_step")

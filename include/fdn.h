@@ -1,0 +1,109 @@
+/* lib4dflow_hip.so -- C-ABI of the MI355X-native 4DFlowNet hot path.
+ *
+ * The reference (EdwardFerdian/4DFlowNet) has no FFI: it calls TensorFlow/Keras ops from Python.
+ * Each entry point below replaces the TF op(s) the reference invokes implicitly at the cited
+ * file:line (paths relative to the reference root).  Conventions:
+ *   - every pointer is a DEVICE pointer to fp32 data owned by the caller (torch tensors);
+ *     the library allocates nothing and keeps no global mutable state;
+ *   - tensors are NDHWC, channel innermost; conv kernels are Keras layout (kd,kh,kw,Cin,Cout);
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - return value: FDN_OK or a negative error code; fdn_last_error() gives a message
+ *     (thread-local).  No exceptions cross the boundary.
+ */
+#ifndef FDN_H
+#define FDN_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FDN_OK 0
+#define FDN_ERR_BAD_ARG (-1)
+#define FDN_ERR_UNSUPPORTED (-2)
+#define FDN_ERR_HIP (-3)
+#define FDN_ERR_WORKSPACE (-4)
+
+#define FDN_ACT_NONE 0
+#define FDN_ACT_RELU 1  /* Conv3D(activation='relu')            src/Network/SR4DFlowNet.py:17-25,39,42,45 */
+#define FDN_ACT_LEAKY 2 /* tf.keras.layers.LeakyReLU(alpha=0.2) src/Network/SR4DFlowNet.py:113,118 */
+
+int fdn_version(void);
+const char* fdn_last_error(void);
+
+/* speed/mag/pcmr + the two channel concats.  src/Network/SR4DFlowNet.py:10-15.
+ * u..mw: (nvox) each; phase, pc: (nvox,3). */
+int fdn_input_features(const float* u, const float* v, const float* w, const float* mu, const float* mv,
+                       const float* mw, float* phase, float* pc, int64_t nvox, void* stream);
+
+/* Re-layout one 3x3x3 64->64 Keras kernel (27,64,64) into the MFMA operand streams used by
+ * fdn_conv3d_fwd (wp_fwd) and fdn_conv3d_dgrad (wp_dgrad: taps flipped, Cin/Cout swapped).
+ * Each output is 27*64*64 floats.  Either output may be NULL. */
+int fdn_pack_conv64_weights(const float* w, float* wp_fwd, float* wp_dgrad, void* stream);
+
+/* y = act(conv3d(sym_pad(x), w) + bias + residual).
+ * Replaces tf.pad(SYMMETRIC,p=(K-1)/2) + Conv3D(valid) + BiasAdd + activation, and the
+ * resnet_block add + LeakyReLU when `residual` is given.  src/Network/SR4DFlowNet.py:93-120.
+ * Supported (Cin,Cout,K): (64,64,3) [MFMA path; needs wpack from fdn_pack_conv64_weights],
+ * (3,64,3), (64,1,3), (128,64,1) [x = first 64 input channels, x2 = last 64: the concat at
+ * SR4DFlowNet.py:23 is never materialised].  x2, wpack, bias, residual may be NULL where unused.
+ * Output rows are written at y[voxel*ldy + y_coff + c] (ldy=Cout,y_coff=0 for a dense tensor;
+ * the three 64->1 heads write straight into the (N,V,3) prediction: SR4DFlowNet.py:49). */
+int fdn_conv3d_fwd(const float* x, const float* x2, const float* w, const float* wpack, const float* bias,
+                   const float* residual, float* y, int N, int D, int H, int W, int Cin, int Cout, int K,
+                   int ldy, int y_coff, int act, float alpha, void* stream);
+
+/* Gradient w.r.t. the PADDED conv input (Conv3DBackpropInputV2): dxpad (N,D+2,H+2,W+2,Cin) for K=3.
+ * dz rows are read at dz[voxel*lddz + dz_coff + c].  Fold the halo with fdn_fold_halo.
+ * Supported (Cin,Cout,K): (64,64,3) [needs wpack = wp_dgrad], (64,1,3). */
+int fdn_conv3d_dgrad(const float* dz, const float* w, const float* wpack, float* dxpad, int N, int D, int H,
+                     int W, int Cin, int Cout, int K, int lddz, int dz_coff, void* stream);
+
+/* MirrorPadGrad + gradient fan-in + activation gradient in one pass:
+ * dz_prev[i] = (sum_s sum_{P: clamp(P)=i} dxpad_s[P] + skip[i]) * act'(y_prev[i]).
+ * nsrc in 1..3; skip, y_prev may be NULL (act' = 1). */
+int fdn_fold_halo(const float* dxpad0, const float* dxpad1, const float* dxpad2, int nsrc, const float* skip,
+                  const float* y_prev, int act, float alpha, float* dz_prev, int N, int D, int H, int W,
+                  int C, void* stream);
+
+/* 1x1x1 128->64 conv backward w.r.t. its two 64-channel inputs, fused with their ReLU masks:
+ * dxa = (dz . W[0:64,:]^T) * (ya>0), dxb = (dz . W[64:128,:]^T) * (yb>0).  SR4DFlowNet.py:23-24. */
+int fdn_conv1x1_dgrad(const float* dz, const float* w, const float* ya, const float* yb, float* dxa,
+                      float* dxb, int64_t nvox, void* stream);
+
+/* dW (K,K,K,Cin,Cout) = Conv3DBackpropFilterV2(sym_pad(x), dz); dbias (Cout) = BiasAddGrad(dz) if
+ * dbias != NULL.  Same (Cin,Cout,K) support and x/x2 convention as fdn_conv3d_fwd.
+ * workspace: caller-owned scratch of at least fdn_conv3d_wgrad_workspace_bytes(...). */
+size_t fdn_conv3d_wgrad_workspace_bytes(int N, int D, int H, int W, int Cin, int Cout, int K);
+int fdn_conv3d_wgrad(const float* x, const float* x2, const float* dz, float* dw, float* dbias,
+                     void* workspace, size_t workspace_bytes, int N, int D, int H, int W, int Cin, int Cout,
+                     int K, int lddz, int dz_coff, void* stream);
+
+/* upsample3d: trilinear, align_corners=True, integer factor R.  src/Network/SR4DFlowNet.py:53-90.
+ * fwd: x (N,D,H,W,C) -> y (N,DR,HR,WR,C).
+ * bwd: dx = U^T dy, optionally * act'(y_prev) with y_prev (N,D,H,W,C). */
+int fdn_upsample_trilinear_fwd(const float* x, float* y, int N, int D, int H, int W, int C, int R, void* stream);
+int fdn_upsample_trilinear_bwd(const float* dy, const float* y_prev, int act, float alpha, float* dx, int N,
+                               int D, int H, int W, int C, int R, void* stream);
+
+/* Loss + metric + dPred in one call.  src/Network/TrainerController.py:84-127,143-156,
+ * src/Network/loss_utils.py:64-103.
+ * pred (N,V,3); uh,vh,wh (N,V); mask (N,V).  out (N,4) = {mse loss, rel-error %, sum(mask), sum(nonfluid)}.
+ * dpred (N,V,3) = d(sum_b loss_b)/dpred, or NULL (test_step).  scratch: N*8 floats. */
+int fdn_loss_metrics(const float* pred, const float* uh, const float* vh, const float* wh, const float* mask,
+                     float* out, float* dpred, float* scratch, int N, int64_t V, void* stream);
+
+/* sum of squares of the kernel (non-bias) parameters: the l2(5e-7) regulariser value is 5e-7 * out[0].
+ * src/Network/TrainerController.py:129-141.  is_kernel: one byte per parameter. */
+int fdn_l2_sumsq(const float* w, const uint8_t* is_kernel, int64_t n, float* out, void* stream);
+
+/* Keras Adam on one flat buffer, with the L2-regulariser gradient folded in:
+ * g' = g + l2_grad_scale * w (kernels only); m,v EMA; w -= lr_t * m / (sqrt(v) + eps).
+ * lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is computed by the caller.  TrainerController.py:73,225. */
+int fdn_adam_step(float* w, const float* g, float* m, float* v, const uint8_t* is_kernel, int64_t n,
+                  float lr_t, float b1, float b2, float eps, float l2_grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

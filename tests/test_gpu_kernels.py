@@ -1,0 +1,191 @@
+"""Parity of every HIP entry point against the CPU oracle, called through the C-ABI (ctypes) on a real MI355X.
+Tolerance: north_star asks <= 1e-3 relative fp32; the kernels are exact-fp32 FMA chains, so we check 2e-5
+of the output scale (max |ref|)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import flownet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 2e-5
+
+
+def dev(a):
+    return torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device="cuda")
+
+
+def close(got, ref, tol=RTOL, name=""):
+    got = got.detach().cpu().numpy().astype(np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    scale = max(np.abs(ref).max(), 1e-30)
+    err = np.abs(got - ref).max() / scale
+    assert err <= tol, "%s: max err %.3e of scale %.3e" % (name, err, scale)
+
+
+@pytest.fixture(scope="module")
+def ops(fdn):
+    return fdn.ops
+
+
+SHAPES = [(2, 8, 8, 8), (1, 5, 7, 9), (1, 10, 12, 16), (3, 4, 4, 2)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("mt", [0, 1, 2])
+def test_conv64_fwd(ops, fdn, shape, mt):
+    rng = np.random.default_rng(1)
+    N, D, H, W = shape
+    x = rng.normal(size=(N, D, H, W, 64)).astype(np.float32)
+    w = (rng.normal(size=(3, 3, 3, 64, 64)) * 0.05).astype(np.float32)
+    b = rng.normal(size=64).astype(np.float32)
+    res = rng.normal(size=(N, D, H, W, 64)).astype(np.float32)
+    fdn._lib.load().fdn_debug_set_conv64_mt(mt)
+    try:
+        for act, bias, r in [(O.ACT_RELU, b, None), (O.ACT_LEAKY, None, res), (O.ACT_NONE, None, None)]:
+            ref = O.conv3d_fwd(x.astype(np.float64), w.astype(np.float64), None if bias is None else bias.astype(np.float64),
+                               act, 0.2, None if r is None else r.astype(np.float64))
+            got = ops.conv3d_fwd(dev(x), dev(w), None if bias is None else dev(bias), act, 0.2,
+                                 None if r is None else dev(r))
+            close(got, ref, name="conv64 fwd act=%d" % act)
+    finally:
+        fdn._lib.load().fdn_debug_set_conv64_mt(0)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_conv64_dgrad_and_fold(ops, shape):
+    rng = np.random.default_rng(2)
+    N, D, H, W = shape
+    dz = rng.normal(size=(N, D, H, W, 64)).astype(np.float32)
+    w = (rng.normal(size=(3, 3, 3, 64, 64)) * 0.05).astype(np.float32)
+    y = rng.normal(size=(N, D, H, W, 64)).astype(np.float32)
+    skip = rng.normal(size=(N, D, H, W, 64)).astype(np.float32)
+    dx = O.conv3d_dgrad(dz.astype(np.float64), w.astype(np.float64), (N, D, H, W, 64))
+    pad = ops.conv3d_dgrad(dev(dz), dev(w))
+    close(ops.fold_halo([pad]), dx, name="dgrad+fold")
+    ref = O.act_bwd_from_output(dx + skip, y, O.ACT_LEAKY)
+    close(ops.fold_halo([pad], dev(skip), dev(y), O.ACT_LEAKY, 0.2), ref, name="fold skip+leaky")
+    ref3 = O.act_bwd_from_output(3 * dx, y, O.ACT_RELU)
+    close(ops.fold_halo([pad, pad, pad], None, dev(y), O.ACT_RELU), ref3, name="fold 3 src+relu")
+
+
+@pytest.mark.parametrize("shape", SHAPES + [(2, 16, 16, 16)])
+def test_conv64_wgrad(ops, shape):
+    rng = np.random.default_rng(3)
+    N, D, H, W = shape
+    x = rng.normal(size=(N, D, H, W, 64)).astype(np.float32)
+    dz = rng.normal(size=(N, D, H, W, 64)).astype(np.float32)
+    ref = O.conv3d_wgrad(x.astype(np.float64), dz.astype(np.float64), 3)
+    dw, db = ops.conv3d_wgrad(dev(x), dev(dz), 3, 64, 64, want_bias=True)
+    close(dw, ref, name="wgrad64")
+    close(db, O.bias_grad(dz.astype(np.float64)), name="bias grad 64")
+
+
+@pytest.mark.parametrize("shape", [(2, 6, 6, 6), (1, 5, 7, 9)])
+def test_thin_layers(ops, shape):
+    rng = np.random.default_rng(4)
+    N, D, H, W = shape
+    f64 = lambda a: a.astype(np.float64)
+    # 3 -> 64
+    x3 = rng.normal(size=(N, D, H, W, 3)).astype(np.float32)
+    w3 = (rng.normal(size=(3, 3, 3, 3, 64)) * 0.2).astype(np.float32)
+    b = rng.normal(size=64).astype(np.float32)
+    close(ops.conv3d_fwd(dev(x3), dev(w3), dev(b), O.ACT_RELU), O.conv3d_fwd(f64(x3), f64(w3), f64(b), O.ACT_RELU), name="3->64 fwd")
+    dz = rng.normal(size=(N, D, H, W, 64)).astype(np.float32)
+    dw, db = ops.conv3d_wgrad(dev(x3), dev(dz), 3, 3, 64, want_bias=True)
+    close(dw, O.conv3d_wgrad(f64(x3), f64(dz), 3), name="3->64 wgrad")
+    close(db, O.bias_grad(f64(dz)), name="3->64 bias grad")
+    # 64 -> 1 writing into channel 1 of an (N,V,3) tensor
+    x = rng.normal(size=(N, D, H, W, 64)).astype(np.float32)
+    w1 = (rng.normal(size=(3, 3, 3, 64, 1)) * 0.1).astype(np.float32)
+    b1 = rng.normal(size=1).astype(np.float32)
+    out = torch.zeros((N, D, H, W, 3), device="cuda")
+    ops.conv3d_fwd(dev(x), dev(w1), dev(b1), O.ACT_NONE, out=out, ldy=3, y_coff=1)
+    ref = np.zeros((N, D, H, W, 3)); ref[..., 1:2] = O.conv3d_fwd(f64(x), f64(w1), f64(b1))
+    close(out, ref, name="64->1 fwd")
+    dpred = rng.normal(size=(N, D, H, W, 3)).astype(np.float32)
+    dzo = f64(dpred[..., 1:2])
+    pad = ops.conv3d_dgrad(dev(dpred), dev(w1), lddz=3, dz_coff=1)
+    close(ops.fold_halo([pad]), O.conv3d_dgrad(dzo, f64(w1), x.shape), name="64->1 dgrad")
+    dw, db = ops.conv3d_wgrad(dev(x), dev(dpred), 3, 64, 1, want_bias=True, lddz=3, dz_coff=1)
+    close(dw, O.conv3d_wgrad(f64(x), dzo, 3), name="64->1 wgrad")
+    close(db, O.bias_grad(dzo), name="64->1 bias grad")
+    # 1x1x1 (64+64) -> 64
+    xa = rng.normal(size=(N, D, H, W, 64)).astype(np.float32)
+    xb = rng.normal(size=(N, D, H, W, 64)).astype(np.float32)
+    wk = (rng.normal(size=(1, 1, 1, 128, 64)) * 0.1).astype(np.float32)
+    cat = np.concatenate([xa, xb], -1)
+    close(ops.conv3d_fwd(dev(xa), dev(wk), dev(b), O.ACT_RELU, x2=dev(xb)), O.conv3d_fwd(f64(cat), f64(wk), f64(b), O.ACT_RELU), name="1x1 fwd")
+    dcat = O.conv3d_dgrad(f64(dz), f64(wk), cat.shape)
+    da, dbb = ops.conv1x1_dgrad(dev(dz), dev(wk), dev(xa), dev(xb))
+    close(da, dcat[..., :64] * (xa > 0), name="1x1 dgrad a")
+    close(dbb, dcat[..., 64:] * (xb > 0), name="1x1 dgrad b")
+    dw, db = ops.conv3d_wgrad(dev(xa), dev(dz), 1, 128, 64, x2=dev(xb), want_bias=True)
+    close(dw, O.conv3d_wgrad(f64(cat), f64(dz), 1), name="1x1 wgrad")
+
+
+@pytest.mark.parametrize("R", [2, 3, 4])
+def test_upsample(ops, R):
+    rng = np.random.default_rng(5)
+    x = rng.normal(size=(2, 5, 4, 6, 64)).astype(np.float32)
+    ref = O.upsample_trilinear_fwd(x.astype(np.float64), R, f32_coeffs=True)
+    close(ops.upsample_trilinear_fwd(dev(x), R), ref, name="upsample fwd")
+    # against exact (float64-coefficient) trilinear the fp32 coefficient rule differs by ~1e-6
+    close(ops.upsample_trilinear_fwd(dev(x), R), O.upsample_trilinear_fwd(x.astype(np.float64), R), tol=1e-5, name="upsample fwd exact")
+    dy = rng.normal(size=ref.shape).astype(np.float32)
+    y = rng.normal(size=x.shape).astype(np.float32)
+    refb = O.upsample_trilinear_bwd(dy.astype(np.float64), x.shape[1:4], R, f32_coeffs=True)
+    close(ops.upsample_trilinear_bwd(dev(dy), R), refb, name="upsample bwd")
+    close(ops.upsample_trilinear_bwd(dev(dy), R, dev(y), O.ACT_LEAKY, 0.2), O.act_bwd_from_output(refb, y, O.ACT_LEAKY), name="upsample bwd+mask")
+
+
+def test_input_features_loss_metric(ops):
+    B, P, R = 2, 6, 2
+    batch = O.synthetic_batch(B, P, R, seed=11)
+    u, v, w, mu, mv, mw, uh, vh, wh, venc, mask = batch
+    ph, pc = ops.input_features(*[dev(a) for a in batch[:6]])
+    rph, rpc = O.input_features(*[a.astype(np.float64) for a in batch[:6]])
+    close(ph, rph, name="phase"); close(pc, rpc, name="pc")
+    rng = np.random.default_rng(12)
+    H = P * R
+    pred = rng.uniform(-0.5, 0.5, size=(B, H, H, H, 3)).astype(np.float32)
+    # exercise the metric's branches: exact zeros in target and exact hits
+    uh[0, 0, 0, :4] = 0; vh[0, 0, 0, :4] = 0; wh[0, 0, 0, :4] = 0; mask[0, 0, 0, :4] = 1
+    hires = np.concatenate([uh, vh, wh], -1).astype(np.float64)
+    loss, dpred = O.masked_mse_loss_fwd_bwd(pred.astype(np.float64), hires, mask.astype(np.float64))
+    rel = O.relative_error(pred.astype(np.float32), hires.astype(np.float32), mask)
+    out, dp = ops.loss_metrics(dev(pred), dev(uh), dev(vh), dev(wh), dev(mask))
+    close(out[:, 0], loss, tol=1e-5, name="loss")
+    close(out[:, 1], rel, tol=2e-3, name="rel err (rounding to 1e-4 steps)")
+    close(out[:, 2], mask.sum((1, 2, 3)), name="sum mask")
+    close(dp, dpred, name="dpred")
+    out2, none = ops.loss_metrics(dev(pred), dev(uh), dev(vh), dev(wh), dev(mask), want_grad=False)
+    assert none is None
+    close(out2[:, 0], loss, tol=1e-5, name="loss (no grad)")
+
+
+def test_adam_and_l2(ops):
+    rng = np.random.default_rng(13)
+    n = 10007
+    w = rng.normal(size=n).astype(np.float32); g = rng.normal(size=n).astype(np.float32)
+    isk = (rng.uniform(size=n) < 0.8)
+    m = np.zeros(n); v = np.zeros(n); wr = w.astype(np.float64).copy()
+    dw, dm, dv, dk = dev(w), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda"), torch.tensor(isk.astype(np.uint8), device="cuda")
+    close(ops.l2_sumsq(dw, dk), [float((w[isk].astype(np.float64) ** 2).sum())], tol=1e-5, name="l2 sumsq")
+    l2s = 8 * 2 * O.L2_LAMBDA
+    for t in range(1, 4):
+        lr_t = 1e-3 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        O.adam_step_tf(wr, g.astype(np.float64) + l2s * wr * isk, m, v, t, 1e-3)
+        ops.adam_step(dw, dev(g), dm, dv, dk, lr_t, 0.9, 0.999, 1e-7, l2s)
+    close(dw, wr, tol=1e-5, name="adam w"); close(dm, m, tol=1e-5, name="adam m"); close(dv, v, tol=1e-5, name="adam v")
+
+
+def test_errors_are_loud(ops, fdn):
+    x = torch.zeros((1, 4, 4, 4, 5), device="cuda")
+    w = torch.zeros((3, 3, 3, 5, 7), device="cuda")
+    with pytest.raises(fdn.FdnError):
+        ops.conv3d_fwd(x, w)                        # unsupported shape
+    with pytest.raises(fdn.FdnError):
+        ops.conv3d_fwd(torch.zeros((1, 4, 4, 4, 64)), torch.zeros((3, 3, 3, 64, 64)))   # CPU tensors: no fallback
