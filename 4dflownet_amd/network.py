@@ -1,0 +1,321 @@
+"""Host-side mirror of src/Network/SR4DFlowNet.py: the network graph, expressed as a fixed schedule of calls
+into lib4dflow_hip.so.  Same names and argument meaning as the reference (SR4DFlowNet(res_increase)
+.build_network(u, v, w, u_mag, v_mag, w_mag, low_resblock, hi_resblock, channel_nr)); the returned model is
+callable on 6 arrays (B,P,P,P,1), has .predict(list), .trainable_variables, .save / .load_weights, and adds
+.backward(dpred) (what tape.gradient does in TrainerController.py:223).
+
+Parameters live in ONE flat fp32 device buffer in Keras trainable_variables order (kernel, bias per layer in
+creation order conv3d, conv3d_1, ... conv3d_35), gradients in a second flat buffer of the same layout, so the
+data-parallel all-reduce and the Adam step are one call each."""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import FdnError
+
+ACT_NONE, ACT_RELU, ACT_LEAKY = ops.ACT_NONE, ops.ACT_RELU, ops.ACT_LEAKY
+
+
+class Input:
+    """Placeholder with the role of tf.keras.layers.Input(shape=..., name=...) (TrainerController.py:38-44)."""
+
+    def __init__(self, shape, name=None):
+        self.shape = (None,) + tuple(shape)
+        self.name = name
+
+
+def layer_specs(low_resblock=8, hi_resblock=4):
+    """[(name, K, Cin, Cout, use_bias)] in Keras creation order (SR4DFlowNet.py:17-46)."""
+    specs = []
+
+    def add(k, cin, cout, bias):
+        i = len(specs)
+        specs.append(("conv3d" if i == 0 else "conv3d_%d" % i, k, cin, cout, bias))
+
+    add(3, 3, 64, True); add(3, 64, 64, True)        # pc path        :17-18
+    add(3, 3, 64, True); add(3, 64, 64, True)        # phase path     :20-21
+    add(1, 128, 64, True); add(3, 64, 64, True)      # concat fuse    :24-25
+    for _ in range(low_resblock + hi_resblock):      # ResBlocks      :29-30,35-36 (no bias)
+        add(3, 64, 64, False); add(3, 64, 64, False)
+    for _ in range(3):                               # u,v,w heads    :39-46
+        add(3, 64, 64, True); add(3, 64, 1, True)
+    return specs
+
+
+class _Layer:
+    __slots__ = ("name", "k", "cin", "cout", "w", "b", "gw", "gb", "wp_f", "wp_d", "w_off", "b_off")
+
+
+class _T:
+    """An activation tensor + the activation of the op that produced it (needed to form act'(y) in backward)."""
+    __slots__ = ("t", "act")
+
+    def __init__(self, t, act):
+        self.t = t
+        self.act = act
+
+
+class FlowNetModel:
+    def __init__(self, res_increase, low_resblock=8, hi_resblock=4, device=None, seed=0):
+        if not torch.cuda.is_available():
+            raise FdnError("FlowNetModel needs a ROCm GPU: the hot path is HIP-only (no CPU fallback)")
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        self.res_increase = int(res_increase)
+        self.low_resblock = int(low_resblock)
+        self.hi_resblock = int(hi_resblock)
+        self.specs = layer_specs(low_resblock, hi_resblock)
+        n = sum(k ** 3 * ci * co + (co if ub else 0) for _, k, ci, co, ub in self.specs)
+        self.n_params = n
+        self.flat_w = torch.zeros(n, device=self.device, dtype=torch.float32)
+        self.flat_g = torch.zeros(n, device=self.device, dtype=torch.float32)
+        is_kernel = np.zeros(n, dtype=np.uint8)
+        self.layers = []
+        off = 0
+        n64 = sum(1 for _, k, ci, co, _ in self.specs if (k, ci, co) == (3, 64, 64))
+        self._packs = torch.empty((n64, 2, 27 * 64 * 64), device=self.device, dtype=torch.float32)
+        i64 = 0
+        for name, k, ci, co, ub in self.specs:
+            L = _Layer()
+            L.name, L.k, L.cin, L.cout = name, k, ci, co
+            sz = k ** 3 * ci * co
+            L.w_off = off
+            L.w = self.flat_w[off:off + sz].view(k, k, k, ci, co)
+            L.gw = self.flat_g[off:off + sz].view(k, k, k, ci, co)
+            is_kernel[off:off + sz] = 1
+            off += sz
+            if ub:
+                L.b_off = off
+                L.b = self.flat_w[off:off + co]
+                L.gb = self.flat_g[off:off + co]
+                off += co
+            else:
+                L.b_off = -1
+                L.b = L.gb = None
+            if (k, ci, co) == (3, 64, 64):
+                L.wp_f, L.wp_d = self._packs[i64, 0], self._packs[i64, 1]
+                i64 += 1
+            else:
+                L.wp_f = L.wp_d = None
+            self.layers.append(L)
+        assert off == n
+        self.is_kernel = torch.tensor(is_kernel, device=self.device)
+        self._ws = None
+        self._cache = None
+        self.glorot_uniform_init(seed)
+
+    # ------------------------------------------------------------------ parameters
+    def glorot_uniform_init(self, seed=0):
+        """Keras default for kernel_initializer=None: GlorotUniform, zero bias (SR4DFlowNet.py:104).
+        Drawn with numpy default_rng(seed) layer by layer in creation order."""
+        rng = np.random.default_rng(seed)
+        flat = np.zeros(self.n_params, dtype=np.float32)
+        for L in self.layers:
+            fan_in, fan_out = L.k ** 3 * L.cin, L.k ** 3 * L.cout
+            limit = math.sqrt(6.0 / (fan_in + fan_out))
+            wv = rng.uniform(-limit, limit, size=(L.k, L.k, L.k, L.cin, L.cout)).astype(np.float32)
+            flat[L.w_off:L.w_off + wv.size] = wv.reshape(-1)
+        self.flat_w.copy_(torch.from_numpy(flat))
+        self.weights_changed()
+
+    def weights_changed(self):
+        """Re-derive the MFMA operand streams after any parameter update (Adam step, load_weights)."""
+        for L in self.layers:
+            if L.wp_f is not None:
+                ops.pack_conv64_weights(L.w, L.wp_f, L.wp_d)
+
+    @property
+    def trainable_variables(self):
+        out = []
+        for L in self.layers:
+            out.append(L.w)
+            if L.b is not None:
+                out.append(L.b)
+        return out
+
+    def get_weights(self):
+        return [t.detach().cpu().numpy().copy() for t in self.trainable_variables]
+
+    def set_weights(self, arrays):
+        tv = self.trainable_variables
+        if len(arrays) != len(tv):
+            raise ValueError("set_weights: expected %d arrays, got %d" % (len(tv), len(arrays)))
+        for t, a in zip(tv, arrays):
+            a = np.asarray(a, dtype=np.float32)
+            if tuple(a.shape) != tuple(t.shape):
+                raise ValueError("set_weights: shape mismatch %s vs %s" % (a.shape, tuple(t.shape)))
+            t.copy_(torch.from_numpy(np.ascontiguousarray(a)))
+        self.weights_changed()
+
+    def save(self, path):
+        from . import weights_io
+        weights_io.save_model_weights(self, path)
+
+    def load_weights(self, path):
+        from . import weights_io
+        weights_io.load_model_weights(self, path)
+
+    # ------------------------------------------------------------------ forward
+    def _to_dev(self, a):
+        if isinstance(a, torch.Tensor):
+            t = a.to(device=self.device, dtype=torch.float32)
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float32))).to(self.device)
+        return t.contiguous()
+
+    def _conv(self, x, L, act, residual=None, x2=None, out=None, ldy=None, y_coff=0):
+        return ops.conv3d_fwd(x, L.w, L.b, act, ops.LEAKY_ALPHA, residual, x2, L.wp_f, out, ldy, y_coff)
+
+    def forward(self, inputs, training=False):
+        """inputs: [u, v, w, u_mag, v_mag, w_mag], each (B,P,P,P,1) or (B,P,P,P).  Returns a device tensor
+        (B,PR,PR,PR,3).  With training=True every activation backward needs is kept in self._cache."""
+        u, v, w, mu, mv, mw = [self._to_dev(a) for a in inputs]
+        if u.dim() == 5:
+            B, D, H, W = u.shape[:4]
+        else:
+            B, D, H, W = u.shape
+        R = self.res_increase
+        Ls = self.layers
+        phase = torch.empty((B, D, H, W, 3), device=self.device)
+        pc = torch.empty((B, D, H, W, 3), device=self.device)
+        ops.input_features(u, v, w, mu, mv, mw, phase, pc)
+        a0 = self._conv(pc, Ls[0], ACT_RELU)
+        a1 = self._conv(a0, Ls[1], ACT_RELU)
+        p0 = self._conv(phase, Ls[2], ACT_RELU)
+        p1 = self._conv(p0, Ls[3], ACT_RELU)
+        c0 = self._conv(p1, Ls[4], ACT_RELU, x2=a1)          # concat [phase, pc] never materialised (:23)
+        c1 = self._conv(c0, Ls[5], ACT_RELU)
+        rb = _T(c1, ACT_RELU)
+        blocks = []
+        up = None
+        li = 6
+        nb = self.low_resblock + self.hi_resblock
+        for i in range(nb + 1):
+            if i == self.low_resblock and R > 1:
+                up_out = _T(ops.upsample_trilinear_fwd(rb.t, R), ACT_NONE)
+                up = (rb, up_out)
+                rb = up_out
+            if i == nb:
+                break
+            h = self._conv(rb.t, Ls[li], ACT_LEAKY)
+            out = self._conv(h, Ls[li + 1], ACT_LEAKY, residual=rb.t)
+            blocks.append((rb, h, out))
+            rb = _T(out, ACT_LEAKY)
+            li += 2
+        pred = torch.empty(tuple(rb.t.shape[:4]) + (3,), device=self.device)
+        heads = []
+        for hidx in range(3):
+            g = self._conv(rb.t, Ls[li], ACT_RELU)
+            self._conv(g, Ls[li + 1], ACT_NONE, out=pred, ldy=3, y_coff=hidx)
+            heads.append(g)
+            li += 2
+        if training:
+            self._cache = dict(phase=phase, pc=pc, a0=a0, a1=a1, p0=p0, p1=p1, c0=c0, c1=c1, blocks=blocks, up=up,
+                               rb=rb, heads=heads)
+        return pred
+
+    __call__ = forward
+
+    def predict(self, inputs, batch_size=None):
+        """Keras Model.predict: numpy in, numpy out (predictor.py:87)."""
+        n = len(inputs[0])
+        bs = n if not batch_size else batch_size
+        outs = []
+        for s in range(0, n, bs):
+            outs.append(self.forward([a[s:s + bs] for a in inputs]).cpu().numpy())
+        return np.concatenate(outs, axis=0)
+
+    # ------------------------------------------------------------------ backward
+    def _workspace(self, nbytes):
+        if self._ws is None or self._ws.numel() * 4 < nbytes:
+            self._ws = torch.empty((nbytes + 3) // 4, device=self.device, dtype=torch.float32)
+        return self._ws
+
+    def _wgrad(self, x, dz, L, x2=None, lddz=None, dz_coff=0):
+        N, D, H, W = x.shape[:4]
+        ws = self._workspace(ops.wgrad_workspace_bytes(N, D, H, W, L.cin, L.cout, L.k))
+        ops.conv3d_wgrad(x, dz, L.k, L.cin, L.cout, x2=x2, dw=L.gw, dbias=L.gb, workspace=ws, lddz=lddz, dz_coff=dz_coff)
+
+    def backward(self, dpred):
+        """Fill self.flat_g with d(sum_b loss_b)/d(params) given dpred (B,PR,PR,PR,3); L2 is NOT included here
+        (it is folded into the Adam kernel).  Consumes the cache of the last forward(training=True)."""
+        c = self._cache
+        if c is None:
+            raise FdnError("backward() without forward(training=True)")
+        self._cache = None
+        Ls = self.layers
+        R = self.res_increase
+        rb = c["rb"]
+        li = len(Ls) - 6
+        pads = []
+        for hidx in range(3):
+            L1, L2 = Ls[li], Ls[li + 1]
+            g = c["heads"][hidx]
+            self._wgrad(g, dpred, L2, lddz=3, dz_coff=hidx)
+            pad1 = ops.conv3d_dgrad(dpred, L2.w, lddz=3, dz_coff=hidx, spatial=tuple(g.shape[:4]))
+            dz_g = ops.fold_halo([pad1], None, g, ACT_RELU)
+            del pad1
+            self._wgrad(rb.t, dz_g, L1)
+            pads.append(ops.conv3d_dgrad(dz_g, L1.w, L1.wp_d))
+            del dz_g
+            li += 2
+        c["heads"] = None
+        # gradient w.r.t. rb, times act'(rb) of its producer
+        dz = ops.fold_halo(pads, None, rb.t if rb.act != ACT_NONE else None, rb.act)
+        del pads
+        li = len(Ls) - 6
+        nb = self.low_resblock + self.hi_resblock
+        up = c["up"]
+        for i in range(nb, -1, -1):
+            if up is not None and i == self.low_resblock:
+                # dz currently holds d(up_out) (linear producer): pull it through the upsample
+                up_in = up[0]
+                dz = ops.upsample_trilinear_bwd(dz, R, up_in.t if up_in.act != ACT_NONE else None, up_in.act)
+            if i == 0:
+                break
+            x, h, out = c["blocks"][i - 1]
+            c["blocks"][i - 1] = None
+            li -= 2
+            La, Lb = Ls[li], Ls[li + 1]
+            self._wgrad(h, dz, Lb)
+            pad = ops.conv3d_dgrad(dz, Lb.w, Lb.wp_d)
+            dz_h = ops.fold_halo([pad], None, h, ACT_LEAKY)
+            del pad
+            self._wgrad(x.t, dz_h, La)
+            pad = ops.conv3d_dgrad(dz_h, La.w, La.wp_d)
+            del dz_h
+            dz = ops.fold_halo([pad], dz, x.t if x.act != ACT_NONE else None, x.act)
+            del pad
+        assert li == 6
+        # dz == dz_c1
+        self._wgrad(c["c0"], dz, Ls[5])
+        pad = ops.conv3d_dgrad(dz, Ls[5].w, Ls[5].wp_d)
+        dz_c0 = ops.fold_halo([pad], None, c["c0"], ACT_RELU)
+        self._wgrad(c["p1"], dz_c0, Ls[4], x2=c["a1"])
+        dz_p1, dz_a1 = ops.conv1x1_dgrad(dz_c0, Ls[4].w, c["p1"], c["a1"])
+        for (first, second, src, dzz) in ((Ls[2], Ls[3], "p", dz_p1), (Ls[0], Ls[1], "a", dz_a1)):
+            x0 = c[src + "0"]
+            self._wgrad(x0, dzz, second)
+            pad = ops.conv3d_dgrad(dzz, second.w, second.wp_d)
+            dz0 = ops.fold_halo([pad], None, x0, ACT_RELU)
+            self._wgrad(c["phase"] if src == "p" else c["pc"], dz0, first)
+        return self.flat_g
+
+
+class SR4DFlowNet:
+    """Same constructor / build_network signature as the reference (SR4DFlowNet.py:4-7).  The six leading
+    arguments are placeholders there (Keras Inputs); here they are accepted and only used to sanity-check
+    the patch shape.  channel_nr is forced to 64 exactly like SR4DFlowNet.py:8."""
+
+    def __init__(self, res_increase):
+        self.res_increase = res_increase
+
+    def build_network(self, u, v, w, u_mag, v_mag, w_mag, low_resblock=8, hi_resblock=4, channel_nr=64, device=None,
+                      seed=0):
+        channel_nr = 64   # noqa: F841  (the reference overwrites the argument)
+        for t in (u, v, w, u_mag, v_mag, w_mag):
+            shp = getattr(t, "shape", None)
+            if shp is not None and len(shp) == 5 and shp[-1] != 1:
+                raise ValueError("inputs must have a single channel, got shape %s" % (tuple(shp),))
+        return FlowNetModel(self.res_increase, low_resblock, hi_resblock, device=device, seed=seed)

@@ -1,0 +1,286 @@
+"""Host-side mirror of src/Network/TrainerController.py: same constructor, same methods
+(init_model_dir, restore_model, train_network, train_step, test_step, save_best_model, quicksave), same loss.csv
+columns; the arithmetic runs in lib4dflow_hip.so.
+
+Differences that are deliberate and documented in DESIGN.md:
+  * no TensorBoard event files (TensorFlow is not a dependency); loss.csv carries the same scalars;
+  * metrics accumulate on the device and are only synchronised when .result() is read, so a training loop that
+    does not print every step never stalls the GPU (the reference forces a sync per step, :290);
+  * with torch.distributed initialised, train_step sum-all-reduces the flat gradient over RCCL before Adam."""
+import datetime
+import os
+import pickle
+import shutil
+import time
+
+import numpy as np
+import torch
+
+from . import ops, parallel
+from .network import Input, SR4DFlowNet
+
+L2_LAMBDA = 5e-7                      # SR4DFlowNet.py:99
+ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-7   # tf.keras.optimizers.Adam defaults (TrainerController.py:73)
+
+
+class Mean:
+    """tf.keras.metrics.Mean: running mean over every element ever passed to update_state."""
+
+    def __init__(self, name, device):
+        self.name = name
+        self.device = device
+        self.reset_states()
+
+    def reset_states(self):
+        self._total = torch.zeros((), device=self.device, dtype=torch.float64)
+        self._count = 0
+
+    def update_state(self, values):
+        if isinstance(values, torch.Tensor):
+            self._total += values.sum().to(torch.float64)
+            self._count += values.numel()
+        else:
+            self._total += float(values)
+            self._count += 1
+
+    def result(self):
+        return float(self._total.item()) / self._count if self._count else 0.0
+
+
+class _Optimizer:
+    """Keras-Adam state on one flat buffer.  `weights` mirrors optimizer.weights = [iterations, m..., v...]."""
+
+    def __init__(self, model, lr):
+        self.lr = float(lr)
+        self.iterations = 0
+        self.m = torch.zeros_like(model.flat_w)
+        self.v = torch.zeros_like(model.flat_w)
+
+    def lr_t(self):
+        t = self.iterations
+        return self.lr * np.sqrt(1.0 - ADAM_B2 ** t) / (1.0 - ADAM_B1 ** t)
+
+
+class TrainerController:
+    def __init__(self, patch_size, res_increase, initial_learning_rate=1e-4, quicksave_enable=True,
+                 network_name='4DFlowNet', low_resblock=8, hi_resblock=4, device=None, seed=0):
+        self.div_weight = 0            # divergence loss is dead code in the reference (TrainerController.py:23,121)
+        self.non_fluid_weight = 1
+        self.res_increase = res_increase
+        self.patch_size = patch_size
+        self.QUICKSAVE_ENABLED = quicksave_enable
+        self.network_name = network_name
+
+        input_shape = (patch_size, patch_size, patch_size, 1)
+        u, v, w = Input(input_shape, 'u'), Input(input_shape, 'v'), Input(input_shape, 'w')
+        u_mag, v_mag, w_mag = Input(input_shape, 'u_mag'), Input(input_shape, 'v_mag'), Input(input_shape, 'w_mag')
+        net = SR4DFlowNet(res_increase)
+        self.model = net.build_network(u, v, w, u_mag, v_mag, w_mag, low_resblock, hi_resblock, device=device, seed=seed)
+        self.device = self.model.device
+
+        names = ['train_loss', 'val_loss', 'train_accuracy', 'val_accuracy', 'train_mse', 'val_mse', 'train_div',
+                 'val_div', 'l2_reg_loss']
+        self.loss_metrics = dict((n, Mean(n, self.device)) for n in names)
+        self.accuracy_metric = 'val_loss'
+        self.learning_rate = initial_learning_rate
+        self.optimizer = _Optimizer(self.model, initial_learning_rate)
+        self._l2_buf = torch.zeros(1, device=self.device)
+        self.unique_model_name = network_name
+        self.model_dir = None
+
+    # ------------------------------------------------------------------ steps
+    def _unpack(self, data_pairs):
+        arrs = [self.model._to_dev(a) for a in data_pairs]
+        u, v, w, u_mag, v_mag, w_mag, u_hr, v_hr, w_hr, venc, mask = arrs
+        return (u, v, w, u_mag, v_mag, w_mag), (u_hr, v_hr, w_hr), venc, mask
+
+    def calculate_regularizer_loss(self):
+        """5e-7 * sum(kernel^2) as a 0-d device tensor (TrainerController.py:129-141)."""
+        ops.l2_sumsq(self.model.flat_w, self.model.is_kernel, self._l2_buf)
+        return self._l2_buf[0] * L2_LAMBDA
+
+    def calculate_and_update_metrics(self, hires, predictions, mask, metric_set, want_grad):
+        out, dpred = ops.loss_metrics(predictions, hires[0], hires[1], hires[2], mask, want_grad=want_grad)
+        mse, rel_error = out[:, 0], out[:, 1]
+        loss = mse
+        if metric_set == 'train':
+            l2 = self.calculate_regularizer_loss()
+            self.loss_metrics['l2_reg_loss'].update_state(l2.reshape(1))
+            loss = mse + l2
+        self.loss_metrics['%s_loss' % metric_set].update_state(loss)
+        self.loss_metrics['%s_mse' % metric_set].update_state(mse)
+        self.loss_metrics['%s_div' % metric_set].update_state(0.0)
+        self.loss_metrics['%s_accuracy' % metric_set].update_state(rel_error)
+        return loss, dpred
+
+    def train_step(self, data_pairs):
+        """TrainerController.py:209-225: forward, loss (+L2), gradient of sum_b loss_b, Adam."""
+        inputs, hires, venc, mask = self._unpack(data_pairs)
+        B = inputs[0].shape[0]
+        m = self.model
+        if B > 0:
+            pred = m.forward(inputs, training=True)
+            loss, dpred = self.calculate_and_update_metrics(hires, pred, mask, 'train', True)
+            m.backward(dpred)
+        else:                                   # ragged tail on this rank: contribute a zero gradient
+            m.flat_g.zero_()
+            loss = None
+        Bg = B
+        if parallel.world_size() > 1:
+            parallel.allreduce_sum_(m.flat_g)
+            Bg = parallel.global_batch_size(B, self.device)
+        opt = self.optimizer
+        opt.iterations += 1
+        # L2 regulariser gradient: the (B,) loss vector carries the scalar L2 term B times (:249) -> B * 2*lambda*w
+        ops.adam_step(m.flat_w, m.flat_g, opt.m, opt.v, m.is_kernel, opt.lr_t(), ADAM_B1, ADAM_B2, ADAM_EPS,
+                      Bg * 2.0 * L2_LAMBDA)
+        m.weights_changed()
+        return loss
+
+    def test_step(self, data_pairs):
+        """TrainerController.py:227-239: forward + metrics, no L2, no update."""
+        inputs, hires, venc, mask = self._unpack(data_pairs)
+        pred = self.model.forward(inputs, training=False)
+        self.calculate_and_update_metrics(hires, pred, mask, 'val', False)
+        return pred
+
+    def reset_metrics(self):
+        for k in self.loss_metrics:
+            self.loss_metrics[k].reset_states()
+
+    # ------------------------------------------------------------------ directories / logging
+    def init_model_dir(self, base_dir="../models"):
+        timestamp = datetime.datetime.now().strftime("%Y%m%d-%H%M")
+        self.unique_model_name = '%s_%s' % (self.network_name, timestamp)
+        self.model_dir = "%s/%s" % (base_dir, self.unique_model_name)
+        self.model_path = "%s/%s" % (self.model_dir, self.network_name)
+        if parallel.rank() == 0:
+            os.makedirs(self.model_dir, exist_ok=True)
+            self._prepare_logfile_and_summary()
+
+    def _log(self, msg):
+        with open(self.logfile, 'a') as f:
+            f.write(msg)
+
+    def _prepare_logfile_and_summary(self):
+        self.logfile = self.model_dir + '/loss.csv'
+        self._log('Network: %s\n' % self.network_name)
+        self._log('Initial learning rate: %s\n' % self.learning_rate)
+        self._log('Accuracy metric: %s\n' % self.accuracy_metric)
+        self._log('Divergence weight: %s\n' % self.div_weight)
+        stat_names = ','.join(self.loss_metrics.keys())
+        self._log('epoch, %s, learning rate, elapsed (sec), best_model, benchmark_err, benchmark_rel_err, '
+                  'benchmark_mse, benchmark_divloss\n' % stat_names)
+        # source backup like TrainerController.py:196-206 (our package instead of ./Network)
+        here = os.path.dirname(os.path.abspath(__file__))
+        dest = os.path.join(self.model_dir, "backup_source")
+        os.makedirs(dest, exist_ok=True)
+        for fname in os.listdir(here):
+            if fname.endswith(".py"):
+                shutil.copy2(os.path.join(here, fname), os.path.join(dest, fname))
+
+    # ------------------------------------------------------------------ training loop
+    def train_network(self, trainset, valset, n_epoch, testset=None, verbose=True):
+        """TrainerController.py:263-343.  trainset/valset: iterables of 11-tuples (PatchHandler3D datasets)."""
+        if self.model_dir is None:
+            self.init_model_dir()
+        is0 = parallel.rank() == 0
+        if is0:
+            print("==================== TRAINING =================")
+            print('Learning rate %.7f' % self.optimizer.lr)
+            print("Start training at %s - %s\n" % (time.ctime(), self.unique_model_name))
+        start_time = time.time()
+        previous_loss = np.inf
+        total_batch_train = len(trainset) if hasattr(trainset, "__len__") else -1
+        total_batch_val = len(valset) if hasattr(valset, "__len__") else -1
+        for epoch in range(n_epoch):
+            self.reset_metrics()
+            start_loop = time.time()
+            for i, data_pairs in enumerate(trainset):
+                self.train_step(data_pairs)
+                if verbose and is0:
+                    print("\rEpoch %d Train batch %d/%d | loss: %.5f (%.1f %%) - %.1f secs" % (
+                        epoch + 1, i + 1, total_batch_train, self.loss_metrics['train_loss'].result(),
+                        self.loss_metrics['train_accuracy'].result(), time.time() - start_loop), end='')
+            for i, data_pairs in enumerate(valset):
+                self.test_step(data_pairs)
+                if verbose and is0:
+                    print("\rEpoch %d Validation batch %d/%d | loss: %.5f (%.1f %%) - %.1f secs" % (
+                        epoch + 1, i + 1, total_batch_val, self.loss_metrics['val_loss'].result(),
+                        self.loss_metrics['val_accuracy'].result(), time.time() - start_loop), end='')
+            res = dict((k, v.result()) for k, v in self.loss_metrics.items())
+            message = "\rEpoch %d Train loss: %.5f (%.1f %%), Val loss: %.5f (%.1f %%) - %.1f secs" % (
+                epoch + 1, res['train_loss'], res['train_accuracy'], res['val_loss'], res['val_accuracy'],
+                time.time() - start_loop)
+            loss_str = ','.join('%.5f' % res[k] for k in self.loss_metrics)
+            log_line = "%d,%s,%.6f,%.1f" % (epoch + 1, loss_str, self.optimizer.lr, time.time() - start_loop)
+            if res[self.accuracy_metric] < previous_loss:
+                if is0:
+                    self.save_best_model()
+                previous_loss = res[self.accuracy_metric]
+                message += ' **'
+                log_line += ',**'
+                if self.QUICKSAVE_ENABLED and testset is not None and is0:
+                    ql, qa, qm, qd = self.quicksave(testset, epoch + 1)
+                    message += ' Benchmark loss: %.5f (%.1f %%)' % (np.mean(ql), np.mean(qa))
+                    log_line += ', %.7f, %.2f%%, %.7f, %.7f' % (np.mean(ql), np.mean(qa), np.mean(qm), np.mean(qd))
+            if is0:
+                print(message)
+                self._log(log_line + "\n")
+        if is0:
+            el = time.time() - start_time
+            hrs, mins = el // 3600, (el % 3600) // 60
+            msg = "\nTraining %s completed! - name: %s" % (self.network_name, self.unique_model_name)
+            msg += "\nTotal training time: %d hrs %d mins %d secs." % (hrs, mins, int(el - hrs * 3600 - mins * 60))
+            msg += "\nFinished at %s\n==================== END TRAINING =================" % time.ctime()
+            self._log(msg)
+            print(msg)
+
+    # ------------------------------------------------------------------ checkpoints
+    def save_best_model(self):
+        """TrainerController.py:347-363: '<dir>/<name>-best.h5' + optimizer.pkl = [iterations, m..., v...]."""
+        self.model.save('%s-best.h5' % self.model_path)
+        tv = self.model.trainable_variables
+        sizes = [t.numel() for t in tv]
+        shapes = [tuple(t.shape) for t in tv]
+        m = [a.reshape(s) for a, s in zip(np.split(self.optimizer.m.cpu().numpy(), np.cumsum(sizes)[:-1]), shapes)]
+        v = [a.reshape(s) for a, s in zip(np.split(self.optimizer.v.cpu().numpy(), np.cumsum(sizes)[:-1]), shapes)]
+        weight_values = [np.int64(self.optimizer.iterations)] + m + v
+        with open('%s/optimizer.pkl' % self.model_dir, 'wb') as f:
+            pickle.dump(weight_values, f)
+
+    def restore_model(self, old_model_dir, old_model_file):
+        """TrainerController.py:365-394."""
+        with open("%s/optimizer.pkl" % old_model_dir, 'rb') as f:
+            opt_weights = pickle.load(f)
+        n = len(self.model.trainable_variables)
+        if len(opt_weights) != 1 + 2 * n:
+            raise ValueError("optimizer.pkl holds %d arrays, expected %d" % (len(opt_weights), 1 + 2 * n))
+        self.optimizer.iterations = int(opt_weights[0])
+        flat = lambda arrs: torch.from_numpy(np.concatenate([np.asarray(a, np.float32).reshape(-1) for a in arrs]))
+        self.optimizer.m.copy_(flat(opt_weights[1:1 + n]))
+        self.optimizer.v.copy_(flat(opt_weights[1 + n:]))
+        self.model.load_weights("%s/%s" % (old_model_dir, old_model_file))
+
+    def quicksave(self, testset, epoch_nr):
+        """TrainerController.py:415-454: predict the first benchmark batch, append to quicksave_<name>.h5."""
+        from . import h5io
+        for data_pairs in testset:
+            inputs, hires, venc, mask = self._unpack(data_pairs)
+            preds_t = self.model.forward(inputs)
+            out, _ = ops.loss_metrics(preds_t, hires[0], hires[1], hires[2], mask, want_grad=False)
+            break
+        out = out.cpu().numpy()
+        preds = preds_t.cpu().numpy()
+        path = os.path.join(self.model_dir, "quicksave_%s.h5" % self.network_name)
+        sv = lambda name, arr: h5io.append_dataset(path, name, np.asarray(arr), compression='gzip')
+        sv("epoch", np.asarray([epoch_nr]))
+        pe = np.expand_dims(preds, 0)
+        sv("u", pe[..., 0]); sv("v", pe[..., 1]); sv("w", pe[..., 2])
+        if epoch_nr == 1:
+            cpu = lambda t: t.cpu().numpy()
+            sv("lr_u", cpu(inputs[0])); sv("lr_v", cpu(inputs[1])); sv("lr_w", cpu(inputs[2]))
+            sv("hr_u", np.squeeze(cpu(hires[0]), -1)); sv("hr_v", np.squeeze(cpu(hires[1]), -1))
+            sv("hr_w", np.squeeze(cpu(hires[2]), -1))
+            sv("venc", cpu(venc)); sv("mask", cpu(mask))
+        return out[:, 0], out[:, 1], out[:, 0], np.zeros_like(out[:, 0])
