@@ -1,0 +1,196 @@
+"""Data side of the path, API-compatible with the reference:
+
+  PatchHandler3D  (src/Network/PatchHandler3D.py)  CSV rows + HDF5 volumes -> batches of 11-tuples
+  ImageDataset    (src/utils/ImageDataset.py)      one inference volume, normalised
+  load_indexes    (src/trainer.py:5-10)            patch-index CSV -> (N,10) unicode array
+
+Unlike the reference (two h5py.File opens + gzip chunk decodes PER SAMPLE, PatchHandler3D.py:122,133), every
+volume is decoded once and cached; a sample is then pure slicing.  Outputs are bit-identical to the reference's
+loader (pinned by tests/golden/reference_golden.json)."""
+import os
+
+import numpy as np
+
+from . import h5io, parallel
+
+
+def load_indexes(index_file):
+    """np.genfromtxt(..., delimiter=',', skip_header=True, dtype='unicode')  (trainer.py:9)."""
+    return np.genfromtxt(index_file, delimiter=',', skip_header=True, dtype='unicode')
+
+
+# (plane, k) -> (source component of each output component, sign of each output component) for PHASE images.
+# Magnitude images use the same permutation with all signs +1.  Derived from the behaviour of
+# rotate90 / rotate180_3d (PatchHandler3D.py:166-274): e.g. plane 1, 90 deg: v <- w, w <- -v.
+_ROT = {
+    (1, 1): ((0, 2, 1), (1, 1, -1)), (1, 3): ((0, 2, 1), (1, -1, 1)), (1, 2): ((0, 1, 2), (1, -1, -1)),
+    (2, 1): ((2, 1, 0), (-1, 1, 1)), (2, 3): ((2, 1, 0), (1, 1, -1)), (2, 2): ((0, 1, 2), (-1, 1, -1)),
+    (3, 1): ((1, 0, 2), (-1, 1, 1)), (3, 3): ((1, 0, 2), (1, -1, 1)), (3, 2): ((0, 1, 2), (-1, -1, 1)),
+}
+_AXES = {1: (0, 1), 2: (0, 2), 3: (1, 2)}
+
+
+def rotate_vector_field(comps, rotation_idx, plane_nr, is_phase_image):
+    """apply_rotation (PatchHandler3D.py:97-108): swap/sign the components, then np.rot90 each."""
+    key = (plane_nr, rotation_idx)
+    if key not in _ROT:
+        return tuple(comps)
+    perm, sign = _ROT[key]
+    out = []
+    for i in range(3):
+        c = comps[perm[i]]
+        if is_phase_image and sign[i] < 0:
+            c = c * np.float32(-1)
+        out.append(np.rot90(c, k=rotation_idx, axes=_AXES[plane_nr]))
+    return tuple(out)
+
+
+def rotate_object(img, rotation_idx, plane_nr):
+    """PatchHandler3D.rotate_object (:83-95)."""
+    if plane_nr not in _AXES:
+        return img
+    return np.rot90(img, k=rotation_idx, axes=_AXES[plane_nr])
+
+
+class _VolumeCache:
+    """Decoded HDF5 datasets, keyed by (path, dataset name)."""
+
+    def __init__(self):
+        self._d = {}
+
+    def get(self, path, name):
+        key = (path, name)
+        if key not in self._d:
+            with h5io.open_read(path) as f:
+                obj = f.get(name)
+                self._d[key] = None if obj is None else np.asarray(obj[...] if hasattr(obj, "id") else obj.read())
+        return self._d[key]
+
+
+class _BatchedDataset:
+    """What initialize_dataset returns: iterable of batched 11-tuples; reshuffled on every pass
+    (ds.shuffle(len).map(load).batch(bs).prefetch(bs), PatchHandler3D.py:25-36)."""
+
+    def __init__(self, handler, indexes, shuffle, seed, shard):
+        self.h = handler
+        self.indexes = np.atleast_2d(indexes)
+        self.sampler = parallel.ShardedIndexSampler(len(self.indexes), handler.batch_size, shuffle, seed,
+                                                    rank_=shard[0], world=shard[1])
+
+    def __len__(self):
+        return len(self.sampler)
+
+    def __iter__(self):
+        for rows in self.sampler:
+            samples = [self.h.load_patches_from_index_file(self.indexes[r]) for r in rows]
+            if not samples:
+                P, H = self.h.patch_size, self.h.patch_size * self.h.res_increase
+                z = lambda *s: np.zeros(s, np.float32)
+                yield tuple([z(0, P, P, P, 1)] * 6 + [z(0, H, H, H, 1)] * 3 + [z(0), z(0, H, H, H)])
+                continue
+            yield tuple(np.stack([s[i] for s in samples], axis=0) for i in range(11))
+
+
+class PatchHandler3D:
+    def __init__(self, data_dir, patch_size, res_increase, batch_size, mask_threshold=0.6):
+        self.patch_size = patch_size
+        self.res_increase = res_increase
+        self.batch_size = batch_size
+        self.mask_threshold = mask_threshold
+        self.data_directory = data_dir
+        self.hr_colnames = ['u', 'v', 'w']
+        self.lr_colnames = ['u', 'v', 'w']
+        self.venc_colnames = ['venc_u', 'venc_v', 'venc_w']
+        self.mag_colnames = ['mag_u', 'mag_v', 'mag_w']
+        self.mask_colname = 'mask'
+        self._cache = _VolumeCache()
+
+    def initialize_dataset(self, indexes, shuffle, n_parallel=None, seed=0, shard=None):
+        """indexes: (N,10) array from load_indexes.  n_parallel is accepted for compatibility (slicing from the
+        in-memory cache needs no worker pool).  shard=(rank, world) splits every global batch across ranks;
+        default: the current torch.distributed rank/world (single process -> no sharding)."""
+        print("Total dataset:", len(np.atleast_2d(indexes)), 'shuffle', shuffle)
+        if shard is None:
+            shard = (parallel.rank(), parallel.world_size())
+        return _BatchedDataset(self, indexes, shuffle, seed, shard)
+
+    @staticmethod
+    def _cell(c):
+        if hasattr(c, "numpy"):
+            c = c.numpy()
+        if isinstance(c, bytes):
+            c = c.decode()
+        return c
+
+    def load_patches_from_index_file(self, indexes):
+        """One CSV row [source,target,index,start_x,start_y,start_z,rotate,rotation_plane,rotation_degree_idx,
+        coverage] -> (u,v,w, mag_u,mag_v,mag_w, u_hr,v_hr,w_hr)[...,None], venc (), mask (PR,PR,PR).
+        PatchHandler3D.py:49-81."""
+        row = [self._cell(c) for c in indexes]
+        lr_path = '{}/{}'.format(self.data_directory, row[0])
+        hr_path = '{}/{}'.format(self.data_directory, row[1])
+        idx = int(row[2])
+        x0, y0, z0 = int(row[3]), int(row[4]), int(row[5])
+        is_rotate, plane, rot_idx = int(row[6]), int(row[7]), int(row[8])
+        P, R = self.patch_size, self.res_increase
+        H = P * R
+        lr_sl = np.index_exp[idx, x0:x0 + P, y0:y0 + P, z0:z0 + P]
+        hr_sl = np.index_exp[idx, x0 * R:x0 * R + H, y0 * R:y0 * R + H, z0 * R:z0 * R + H]
+        mask_sl = np.index_exp[0, x0 * R:x0 * R + H, y0 * R:y0 * R + H, z0 * R:z0 * R + H]   # one mask per file (:129)
+
+        vol = self._cache.get
+        hires = np.asarray([vol(hr_path, n)[hr_sl] for n in self.hr_colnames])
+        mask = (vol(hr_path, self.mask_colname)[mask_sl] >= self.mask_threshold) * 1.
+        lowres = np.asarray([vol(lr_path, n)[lr_sl] for n in self.lr_colnames])
+        mags = np.asarray([vol(lr_path, n)[lr_sl] for n in self.mag_colnames])
+        venc = np.max([vol(lr_path, n)[idx] for n in self.venc_colnames])
+        hires = hires / venc                      # :152-154
+        lowres = lowres / venc
+        mags = mags / 4095.
+        lr = tuple(lowres[i].astype('float32') for i in range(3))
+        hr = tuple(hires[i].astype('float32') for i in range(3))
+        mg = tuple(mags[i].astype('float32') for i in range(3))
+        mask = mask.astype('float32')
+        if is_rotate > 0:                          # :71-75
+            lr = rotate_vector_field(lr, rot_idx, plane, True)
+            hr = rotate_vector_field(hr, rot_idx, plane, True)
+            mg = rotate_vector_field(mg, rot_idx, plane, False)
+            mask = rotate_object(mask, rot_idx, plane)
+        ex = lambda a: np.ascontiguousarray(a)[..., None]
+        return (ex(lr[0]), ex(lr[1]), ex(lr[2]), ex(mg[0]), ex(mg[1]), ex(mg[2]), ex(hr[0]), ex(hr[1]), ex(hr[2]),
+                venc.astype('float32'), np.ascontiguousarray(mask))
+
+
+class ImageDataset:
+    """src/utils/ImageDataset.py: one row of an inference file, velocities / venc, magnitudes / 4095."""
+
+    def __init__(self):
+        self.velocity_colnames = ['u', 'v', 'w']
+        self.venc_colnames = ['venc_u', 'venc_v', 'venc_w']
+        self.mag_colnames = ['mag_u', 'mag_v', 'mag_w']
+        self.dx_colname = 'dx'
+
+    def get_dataset_len(self, filepath):
+        with h5io.open_read(filepath) as hl:
+            return hl[self.velocity_colnames[0]].shape[0]
+
+    def load_vectorfield(self, filepath, idx):
+        with h5io.open_read(filepath) as hl:
+            rd = lambda n: np.asarray(hl[n][...] if hasattr(hl[n], "id") else hl[n].read())
+            dx = rd(self.dx_colname)[idx] if self.dx_colname in hl else None
+            vel = np.asarray([rd(n)[idx] for n in self.velocity_colnames])
+            mag = np.asarray([rd(n)[idx] for n in self.mag_colnames])
+            venc = np.max([rd(n)[idx] for n in self.venc_colnames])
+        vel = vel / venc
+        mag = mag / 4095.
+        self.u, self.v, self.w = (vel[i].astype('float32') for i in range(3))
+        self.mag_u, self.mag_v, self.mag_w = (mag[i].astype('float32') for i in range(3))
+        self.venc = venc.astype('float32')
+        self.velocity_per_px = self.venc / 2048          # ImageDataset.py:31
+        self.dx = dx
+
+    def postprocess_result(self, results, zerofy=True):
+        results = results * self.venc
+        if zerofy:
+            results[np.abs(results) < self.velocity_per_px] = 0
+        return results

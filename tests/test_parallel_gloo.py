@@ -1,0 +1,78 @@
+"""Data-parallel path on CPU with gloo, world_size 2: the flat-gradient SUM all-reduce reproduces the
+single-process gradient of the global batch, shards are disjoint, ragged tails are handled."""
+import importlib
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import flownet_oracle as O
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    parallel = importlib.import_module("4dflownet_amd.parallel")
+    r, w, lr = parallel.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world) and parallel.rank() == rank and parallel.world_size() == world
+    P, R, LB, HB = 4, 2, 1, 1
+    params = O.init_params(0, LB, HB, np.float64)
+    full = O.synthetic_batch(4, P, R, seed=5, dtype=np.float64)
+    sampler = parallel.ShardedIndexSampler(4, 2, shuffle=False)
+    rows = next(iter(sampler))
+    mine = tuple(a[rows] for a in full)
+    out = O.loss_and_grads(params, mine, R, LB, HB)
+    # the product folds L2 in after the all-reduce with the GLOBAL batch; emulate: strip the local L2 part first
+    g = O.flatten(out["grads"]) - len(rows) * 2 * O.L2_LAMBDA * O.flatten([{"w": p["w"], "b": None if p["b"] is None else 0 * p["b"]} for p in params])
+    flat = torch.from_numpy(g.copy())
+    parallel.allreduce_sum_(flat)
+    Bg = parallel.global_batch_size(len(rows))
+    # ragged tail: 5 rows, batch 2 x 2 ranks -> global batches of 4 and 1; rank 1's last slice is empty
+    s2 = parallel.ShardedIndexSampler(5, 2, shuffle=True, seed=1)
+    sizes = [len(x) for x in s2]
+    parallel.barrier()
+    q.put((rank, rows.tolist(), flat.numpy(), Bg, sizes))
+    dist.destroy_process_group()
+
+
+def test_dp2_sum_allreduce_equals_global_batch_gradient():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == [0, 1] and res[1][1] == [2, 3]                  # disjoint shards of the global batch
+    assert np.array_equal(res[0][2], res[1][2])                          # every rank holds the same reduced gradient
+    assert res[0][3] == 4 and res[1][3] == 4
+    assert res[0][4] == [2, 1] and res[1][4] == [2, 0]
+    # single-process reference: gradient of sum_b loss_b over the whole batch of 4, without the L2 term
+    P, R, LB, HB = 4, 2, 1, 1
+    params = O.init_params(0, LB, HB, np.float64)
+    full = O.synthetic_batch(4, P, R, seed=5, dtype=np.float64)
+    out = O.loss_and_grads(params, full, R, LB, HB)
+    gref = O.flatten(out["grads"]) - 4 * 2 * O.L2_LAMBDA * O.flatten([{"w": p["w"], "b": None if p["b"] is None else 0 * p["b"]} for p in params])
+    np.testing.assert_allclose(res[0][2], gref, rtol=1e-9, atol=1e-12)
+
+
+def test_sampler_covers_everything_once_per_epoch():
+    parallel = importlib.import_module("4dflownet_amd.parallel")
+    seen = []
+    for r in range(4):
+        s = parallel.ShardedIndexSampler(50, 3, shuffle=True, seed=7, rank_=r, world=4)
+        assert len(s) == 5
+        for rows in s:
+            seen.extend(rows.tolist())
+    assert sorted(seen) == list(range(50))
