@@ -1,0 +1,82 @@
+"""Loader -> TrainerController.train_network -> checkpoint -> predictor on the reference's example data (GPU)."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import flownet_oracle as O
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+DATA = os.path.join(HERE, "golden", "data")
+
+data = importlib.import_module("4dflownet_amd.data")
+trainer = importlib.import_module("4dflownet_amd.trainer")
+predictor = importlib.import_module("4dflownet_amd.predictor")
+h5io = importlib.import_module("4dflownet_amd.h5io")
+
+
+def test_cfg1_train_network_checkpoint_restore_and_quicksave(tmp_path):
+    """BASELINE cfg1 (patch 16, res 1, batch 2, 2 LR + 1 HR blocks) on data/train.csv rows: plumbing end to end."""
+    P, R, B, LB, HB = 16, 1, 2, 2, 1
+    idx = data.load_indexes(os.path.join(DATA, "train.csv"))[:6]
+    val = data.load_indexes(os.path.join(DATA, "validate.csv"))[:4]
+    bench = data.load_indexes(os.path.join(DATA, "benchmark.csv"))[:2]
+    mk = lambda rows, sh: data.PatchHandler3D(DATA, P, R, B, 0.6).initialize_dataset(rows, shuffle=sh, shard=(0, 1))
+    tc = trainer.TrainerController(P, R, initial_learning_rate=2e-4, quicksave_enable=True, network_name="t4d",
+                                   low_resblock=LB, hi_resblock=HB)
+    tc.init_model_dir(base_dir=str(tmp_path / "models"))
+    tc.train_network(mk(idx, True), mk(val, True), n_epoch=2, testset=mk(bench, False), verbose=False)
+    md = tc.model_dir
+    lines = open(os.path.join(md, "loss.csv")).read().splitlines()
+    header = [l for l in lines if l.startswith("epoch")][0]
+    assert "train_loss,val_loss,train_accuracy,val_accuracy,train_mse,val_mse,train_div,val_div,l2_reg_loss" in header
+    rows = [l for l in lines if l[:2] in ("1,", "2,")]
+    assert len(rows) == 2 and rows[0].split(",")[-5 if "%" in rows[0] else -1] is not None
+    assert os.path.exists(os.path.join(md, "t4d-best.h5")) and os.path.exists(os.path.join(md, "optimizer.pkl"))
+    q = h5io.read_all(os.path.join(md, "quicksave_t4d.h5"))
+    assert q["u"].shape[1:] == (2, 16, 16, 16) and q["lr_u"].shape == (2, 16, 16, 16, 1) and q["mask"].shape == (2, 16, 16, 16)
+    # the first step of a fresh controller equals the oracle on the same loader batch
+    tc2 = trainer.TrainerController(P, R, initial_learning_rate=2e-4, quicksave_enable=False, low_resblock=LB, hi_resblock=HB)
+    batch = next(iter(mk(idx, False)))
+    params = O.init_params(0, LB, HB, np.float64)
+    ref = O.loss_and_grads(params, tuple(np.asarray(a, np.float64) for a in batch), R, LB, HB)
+    loss = tc2.train_step(batch)
+    assert np.abs(loss.cpu().numpy() - ref["loss"]).max() / np.abs(ref["loss"]).max() < 1e-4
+    # restore: weights + Adam slots come back exactly
+    tc3 = trainer.TrainerController(P, R, initial_learning_rate=2e-4, quicksave_enable=False, low_resblock=LB, hi_resblock=HB, seed=9)
+    tc3.restore_model(md, "t4d-best.h5")
+    best = h5io.read_keras_weights(os.path.join(md, "t4d-best.h5"))
+    assert np.array_equal(tc3.model.layers[7].w.cpu().numpy(), best["conv3d_7"][0])
+    assert tc3.optimizer.iterations > 0 and float(tc3.optimizer.v.abs().sum()) > 0
+
+
+def test_predictor_end_to_end_on_example_volume(tmp_path):
+    """predictor.py at its defaults (patch 24, res 2, batch 8) on data/example_data.h5: 12 patches -> (84,76,72)."""
+    net = predictor.prepare_network(24, 2, 2, 1)
+    wpath = str(tmp_path / "w.h5")
+    net.save(wpath)
+    net2 = predictor.prepare_network(24, 2, 2, 1)
+    net2.glorot_uniform_init(seed=123)
+    net2.load_weights(wpath)
+    assert torch.equal(net.flat_w, net2.flat_w)
+    out = str(tmp_path / "result" / "example_result.h5")
+    vols = predictor.predict_file(net2, os.path.join(DATA, "example_data.h5"), out, 24, 2, batch_size=8, verbose=False)
+    back = h5io.read_all(out)
+    assert back["u"].shape == (1, 84, 76, 72) and back["u"].dtype == np.float32 and back["dx"].shape == (1, 3)
+    np.testing.assert_allclose(back["dx"], [[1.1875 / 2] * 3])
+    assert np.array_equal(back["w"], vols[0][2].astype(np.float32))
+    # one patch against the oracle forward
+    ds = data.ImageDataset(); ds.load_vectorfield(os.path.join(DATA, "example_data.h5"), 0)
+    pg = importlib.import_module("4dflownet_amd.tiler").PatchGenerator(24, 2)
+    vel, mag = pg.patchify(ds)
+    ins = [v[5:6] for v in vel] + [m[5:6] for m in mag]
+    params = O.init_params(0, 2, 1, np.float64)
+    ref, _ = O.network_forward(params, tuple(np.asarray(a, np.float64) for a in ins), 2, 2, 1, f32_coeffs=True)
+    got = net.predict(ins)
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-4
+    # small velocities are zeroed: nothing in (0, venc/2048)
+    nz = np.abs(back["u"][back["u"] != 0])
+    assert nz.size == 0 or nz.min() >= float(ds.velocity_per_px)
