@@ -85,6 +85,26 @@ extern "C" int fdn_conv3d_dgrad(const float* dz, const float* w, const float* wp
     return FDN_ERR_UNSUPPORTED;
 }
 
+extern "C" int fdn_conv3d_dgrad_fused(const float* dz, const float* wpack, float* dxpad, const float* skip,
+                                      const float* y_prev, int act, float alpha, float* dz_prev, int N, int D, int H,
+                                      int W, void* stream) {
+    FDN_REQUIRE(dz && wpack && dxpad && dz_prev, "fdn_conv3d_dgrad_fused: NULL argument");
+    FDN_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && D <= 1020 && H <= 1020 && W <= 1020, "fdn_conv3d_dgrad_fused: bad dims");
+    FDN_REQUIRE(act >= FDN_ACT_NONE && act <= FDN_ACT_LEAKY, "fdn_conv3d_dgrad_fused: bad act %d", act);
+    return fdn_conv64_launch_ex(dz, wpack, nullptr, nullptr, dxpad, skip, y_prev, dz_prev, N, D, H, W, D + 2, H + 2, W + 2,
+                                -1, 1, act, alpha, (hipStream_t)stream);
+}
+
+extern "C" int fdn_fold_halo_border(const float* dxpad0, const float* dxpad1, const float* dxpad2, int nsrc,
+                                    const float* skip, const float* y_prev, int act, float alpha, float* dz_prev, int N,
+                                    int D, int H, int W, void* stream) {
+    FDN_REQUIRE(dxpad0 && dz_prev, "fdn_fold_halo_border: NULL argument");
+    FDN_REQUIRE(nsrc >= 1 && nsrc <= 3 && (nsrc < 2 || dxpad1) && (nsrc < 3 || dxpad2), "fdn_fold_halo_border: bad nsrc %d", nsrc);
+    FDN_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "fdn_fold_halo_border: bad dims");
+    return fdn_fold_halo_border_launch(dxpad0, dxpad1, dxpad2, nsrc, skip, y_prev, act, alpha, dz_prev, N, D, H, W,
+                                       (hipStream_t)stream);
+}
+
 extern "C" size_t fdn_conv3d_wgrad_workspace_bytes(int N, int D, int H, int W, int Cin, int Cout, int K) {
     if (Cin == 64 && Cout == 64 && K == 3) return fdn_wgrad64_workspace_bytes(N, D, H, W);
     return fdn_small_wgrad_workspace_bytes(Cin, Cout, K);

@@ -2,25 +2,33 @@
 //
 // Replaces tf.pad(SYMMETRIC) + Conv3D(valid) + BiasAdd + ReLU/LeakyReLU (+ the resnet_block add)
 // of src/Network/SR4DFlowNet.py:93-120, and -- in "zero" boundary mode on the padded output grid --
-// Conv3DBackpropInputV2 of the same layers.
+// Conv3DBackpropInputV2 of the same layers (+ MirrorPadGrad for interior voxels, see the epilogue).
 //
-// Work decomposition (one workgroup = 4 waves = one output box tile of up to 128*MT voxels x 64 cout):
-//   M = output voxels of the tile, N = 64 cout, K = 27 taps x 64 cin.
-//   * The input box + 1-voxel halo is staged ONCE per cin-half into LDS (128 B per voxel row,
-//     16-B chunks XOR-swizzled by row so the A-fragment ds_read_b128 spreads over all banks);
-//     the boundary rule (edge clamp for forward == SYMMETRIC p=1, zero for dgrad) is applied while
-//     staging, so the K loop is branch-free.
-//   * Every wave owns 32*MT voxel rows x all 64 cout: MT x 2 accumulators of 32x32 (16 VGPRs each).
+// Work decomposition: M = output voxels of a box tile, N = 64 cout, K = 27 taps x 64 cin.
+//   * One workgroup (4 waves) per box tile.  The tile's input box + 1-voxel halo is staged in CS slices of
+//     64/CS input channels into LDS (256/CS bytes per voxel row, 16-B chunks XOR-swizzled by row so the A-fragment
+//     ds_read_b128 spreads over all banks).  The boundary rule (edge clamp for forward == SYMMETRIC p=1, zero for
+//     dgrad) is applied while staging, so the K loop is branch-free.
+//   * Latency hiding is by OCCUPANCY, not by software pipelining: the kernel is kept under 128 VGPRs and
+//     (with CS=4) under ~40 KB of LDS so 4 workgroups share a CU (4 waves per SIMD); while one stages or stores,
+//     the others keep the matrix pipe busy.  Measured on MI355X: a persistent, register-prefetching variant of this
+//     kernel (2 waves/SIMD, 256 VGPRs) was slower -- see DESIGN.md.
+//   * Wave layouts <MT,NW>:  <2,1>: tile 256 voxels, wave = 64 voxels x 64 cout;  <1,1>: 128 voxels, wave =
+//     32 x 64;  <1,2>: 64 voxels, wave = 32 voxels x 32 cout (fine load balance on small grids).
+//     Accumulators: MT x (2/NW) tiles of 32x32 (16 VGPRs each).
 //   * A fragments: one ds_read_b128 per (M-tile, 8 cin) -- lane (i,kh) gets cin 8g+4kh+{0..3} of voxel i;
-//     MFMA step s contracts the cin pair {8g+s, 8g+4+s}.  The K order is a permutation of cin, matched
-//     by the packed weight stream, so no data movement is needed to form fragments.
-//   * B fragments (weights) are NOT staged: the packed stream [half][tap][g][kh][cout][s] is read
-//     straight from L1/L2 with one global_load_dwordx4 per (N-tile, 8 cin) and software-prefetched one
-//     tap ahead.  442 KB of weights are shared by every workgroup on the chip, so they stay cache-resident.
-//   * 2 workgroups per CU (<= 80 KB LDS, <= 256 VGPRs): one stages while the other issues MFMAs.
-//   fp32 MFMA rate is 64 cyc / instruction / SIMD: per tap a wave issues 16*MT*2 MFMAs against
-//   4*MT LDS reads and 8 global loads, so the matrix pipe is the only busy resource by construction.
+//     MFMA step s contracts the cin pair {8g+s, 8g+4+s}.  The K order is a permutation of cin, matched by the
+//     packed weight stream, so no data movement is needed to form fragments.
+//   * B fragments (weights) are NOT staged: the packed stream [cin/32][tap][g][kh][cout][s] is read straight from
+//     L1/L2 with one global_load_dwordx4 per (N-tile, 8 cin).  442 KB of weights are shared by every workgroup
+//     on the chip, so they stay cache-resident.
+//   fp32 MFMA rate is 64 cyc / instruction / SIMD: per 8 cin a wave issues 4*MT*(2/NW) MFMAs against MT LDS reads and
+//   2/NW global loads, so the matrix pipe is the only busy resource by construction.
 #include "fdn_common.h"
+
+// test/bench hooks (set through fdn_debug_* entry points; not part of include/fdn.h)
+static int fdn_conv64_force_layout = 0;   // 0 = auto, 1..6 = index into the variant table below
+static int fdn_conv64_dbg = 0;            // ablation bits, see Conv64Args::dbg
 
 struct Conv64Args {
     const float* x;
@@ -28,6 +36,10 @@ struct Conv64Args {
     const float* bias;
     const float* res;
     float* y;
+    // fused fold (dgrad mode only): interior voxels are finished in the epilogue
+    const float* fskip;     // gradient to add (N,ID,IH,IW,64) or null
+    const float* fy;        // producer output for act' or null
+    float* fout;            // dz_prev (N,ID,IH,IW,64) or null (= plain padded-grid dgrad)
     int N, ID, IH, IW, OD, OH, OW;
     int off, zero_mode;
     int td, th, tw, ntd, nth, ntw;
@@ -36,18 +48,39 @@ struct Conv64Args {
     unsigned mg_hhhw, mg_hw;    // magic divisors for halo-row decomposition
     int act;
     float alpha;
+    int dbg;                    // ablation bits (bench only): 1 = B stream stride 0, 4 = no staging loads, 8 = no epilogue
 };
 
-template <int MT>
-__global__ __launch_bounds__(256, 2) void conv64_mfma_kernel(Conv64Args p) {
+template <int MT, int NW, int CS>
+struct Conv64Cfg {
+    static constexpr int WM = 4 / NW;                 // wave rows
+    static constexpr int NT = 2 / NW;                 // 32-wide cout tiles per wave
+    static constexpr int MCAP = WM * MT * 32;         // voxels per tile
+    static constexpr int ROWB = 256 / CS;             // bytes per staged voxel row
+    static constexpr int CH = ROWB / 16;              // 16-B chunks per row
+    static constexpr int KG = 8 / CS;                 // k-groups (8 cin) per staged slice
+    // workgroups per CU the variant is sized for (VGPR cap via launch bounds, LDS via MAXROWS)
+    static constexpr int WG_PER_CU = MT == 2 ? (CS == 4 ? 4 : 2) : (NW == 1 ? (CS == 4 ? 5 : 3) : (CS == 4 ? 6 : 4));
+    static constexpr int MAXROWS = ((160 * 1024 / WG_PER_CU) - MCAP * 4 - 256) / ROWB > 1000
+                                       ? 1000 : ((160 * 1024 / WG_PER_CU) - MCAP * 4 - 256) / ROWB;
+    static constexpr int LDS_BYTES = MAXROWS * ROWB + MCAP * 4;
+};
+
+template <int MT, int NW, int CS>
+__global__ __launch_bounds__(256, (Conv64Cfg<MT, NW, CS>::WG_PER_CU > 8 ? 8 : Conv64Cfg<MT, NW, CS>::WG_PER_CU))
+void conv64_mfma_kernel(Conv64Args p) {
+    using C = Conv64Cfg<MT, NW, CS>;
+    constexpr int NT = C::NT, ROWB = C::ROWB, CH = C::CH, KG = C::KG;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* goff = (int*)(smem + p.rows * 128);
+    int* mtab = (int*)(smem + p.rows * ROWB);          // output voxel index of each tile row's output voxel, -1 if unused
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int li = lane & 31;
     const int kh = lane >> 5;
+    const int wave_m = wave % C::WM;
+    const int wave_n = wave / C::WM;
 
     // ---- which tile ----
     const int tiles_per_n = p.ntd * p.nth * p.ntw;
@@ -57,68 +90,77 @@ __global__ __launch_bounds__(256, 2) void conv64_mfma_kernel(Conv64Args p) {
     const int tdi = b / (p.nth * p.ntw);
     b -= tdi * (p.nth * p.ntw);
     const int thi = b / p.ntw;
-    const int twi = b - thi * p.ntw;
-    const int p0d = tdi * p.td, p0h = thi * p.th, p0w = twi * p.tw;
+    const int p0d = tdi * p.td, p0h = thi * p.th, p0w = (b - thi * p.ntw) * p.tw;
 
     const int nv = p.td * p.th * p.tw;
     const int thtw = p.th * p.tw;
 
-    // ---- output voxel offsets of the tile's M rows (read back in the epilogue) ----
-    for (int m = tid; m < 128 * MT; m += 256) {
+    // ---- output voxel of each tile row: padded-grid voxel index (bit 31 clear), or -1 ----
+    for (int m = tid; m < C::MCAP; m += 256) {
         int g = -1;
         if (m < nv) {
             const int md = m / thtw;
             const int r2 = m - md * thtw;
             const int mh = r2 / p.tw;
-            const int mw = r2 - mh * p.tw;
-            const int pd = p0d + md, ph = p0h + mh, pw = p0w + mw;
-            if (pd < p.OD && ph < p.OH && pw < p.OW) g = ((n * p.OD + pd) * p.OH + ph) * p.OW + pw;
+            const int pd = p0d + md, ph = p0h + mh, pw = p0w + (r2 - mh * p.tw);
+            if (pd < p.OD && ph < p.OH && pw < p.OW) {
+                g = ((n * p.OD + pd) * p.OH + ph) * p.OW + pw;
+                if (p.fout) {
+                    // fused fold: rows strictly inside the input volume are redirected to dz_prev (tag bit 30)
+                    const int id = pd - 1, ih = ph - 1, iw = pw - 1;
+                    if (id >= 1 && id <= p.ID - 2 && ih >= 1 && ih <= p.IH - 2 && iw >= 1 && iw <= p.IW - 2)
+                        g = (((n * p.ID + id) * p.IH + ih) * p.IW + iw) | (1 << 30);
+                }
+            }
         }
-        goff[m] = g;
+        mtab[m] = g;
     }
 
     // ---- this lane's A rows (LDS halo row of voxel m at tap (0,0,0)) ----
     int row0[MT];
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
-        int m = (wave * MT + mi) * 32 + li;
+        int m = (wave_m * MT + mi) * 32 + li;
         m = m < nv ? m : nv - 1;
         const int md = m / thtw;
         const int r2 = m - md * thtw;
         const int mh = r2 / p.tw;
-        const int mw = r2 - mh * p.tw;
-        row0[mi] = (md * p.hh + mh) * p.hw + mw;
+        row0[mi] = (md * p.hh + mh) * p.hw + (r2 - mh * p.tw);
     }
 
-    f32x16 acc[MT][2];
+    f32x16 acc[MT][NT];
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-        for (int nn = 0; nn < 2; ++nn)
+        for (int nn = 0; nn < NT; ++nn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][nn][r] = 0.f;
 
-    const int chunk = tid & 7;
-    const int rsub = tid >> 3;
+    const int chunk = tid % CH;
+    const int rsub = tid / CH;
+    constexpr int RPP = 256 / CH;                      // rows staged per pass
+    const int rows_eff = (p.dbg & 4) ? 0 : p.rows;
+    const int bstride = (p.dbg & 1) ? 0 : 128;
     const size_t in_n = (size_t)n * p.ID * p.IH * p.IW;
+    const int q0d = p0d - 1 + p.off, q0h = p0h - 1 + p.off, q0w = p0w - 1 + p.off;
 
-    for (int half = 0; half < 2; ++half) {
-        if (half) __syncthreads();  // everyone finished reading the previous half
-        // ---- stage input box + halo, cin [32*half, 32*half+32) ----
-        const float* xh = p.x + half * 32 + chunk * 4;
-        constexpr int U = 5;
-        for (int r0 = 0; r0 < p.rows; r0 += 32 * U) {
+#pragma unroll 1
+    for (int sl = 0; sl < CS; ++sl) {
+        if (sl) __syncthreads();  // everyone finished reading the previous slice
+        // ---- stage input box + halo, cin [sl*64/CS, (sl+1)*64/CS) ----
+        const float* xh = p.x + sl * (64 / CS) + chunk * 4;
+        constexpr int U = 4;
+        for (int r0 = 0; r0 < rows_eff; r0 += RPP * U) {
             f32x4 v[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int r = r0 + u * 32 + rsub;
+                const int r = r0 + u * RPP + rsub;
                 v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (r < p.rows) {
+                if (r < rows_eff) {
                     const int zd = fdn_div20(r, p.mg_hhhw);
                     const int r2 = r - zd * p.hh * p.hw;
                     const int zh = fdn_div20(r2, p.mg_hw);
-                    const int zw = r2 - zh * p.hw;
-                    int qd = p0d + zd - 1 + p.off, qh = p0h + zh - 1 + p.off, qw = p0w + zw - 1 + p.off;
+                    int qd = q0d + zd, qh = q0h + zh, qw = q0w + (r2 - zh * p.hw);
                     bool ok = true;
                     if (p.zero_mode) {
                         ok = (unsigned)qd < (unsigned)p.ID && (unsigned)qh < (unsigned)p.IH && (unsigned)qw < (unsigned)p.IW;
@@ -132,75 +174,163 @@ __global__ __launch_bounds__(256, 2) void conv64_mfma_kernel(Conv64Args p) {
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int r = r0 + u * 32 + rsub;
-                if (r < p.rows) *(f32x4*)(smem + r * 128 + ((chunk ^ ((r >> 1) & 7)) << 4)) = v[u];
+                const int r = r0 + u * RPP + rsub;
+                if (r < rows_eff) *(f32x4*)(smem + r * ROWB + ((chunk ^ ((r / CS) & (CH - 1))) << 4)) = v[u];
             }
         }
         __syncthreads();
 
-        // ---- K loop over 27 taps x 32 cin ----
-        const f32x4* bp = (const f32x4*)p.wp + (size_t)half * (27 * 4 * 128) + kh * 64 + li;
-        f32x4 bcur[4][2], bnxt[4][2];
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int nn = 0; nn < 2; ++nn) bcur[g][nn] = bp[g * 128 + nn * 32];
-
+        // ---- K loop over 27 taps x KG k-groups of this slice ----
+        // stream index of (slice, tap, local k-group gl): half = cin/32, g = k-group within the half
+        const int half = (sl * KG) >> 2, g0 = (sl * KG) & 3;
+        const f32x4* bp = (const f32x4*)p.wp + ((size_t)half * 27 * 4 + g0) * 128 + kh * 64 + wave_n * (NT * 32) + li;
         int ta = 0, tb = 0, tc = 0;
 #pragma unroll 1
         for (int tap = 0; tap < 27; ++tap) {
-            const int tnext = tap < 26 ? tap + 1 : 26;
+            f32x4 bv[KG][NT];
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
+            for (int g = 0; g < KG; ++g)
 #pragma unroll
-                for (int nn = 0; nn < 2; ++nn) bnxt[g][nn] = bp[(tnext * 4 + g) * 128 + nn * 32];
-
+                for (int nn = 0; nn < NT; ++nn) bv[g][nn] = bp[(tap * 4 + g) * bstride + nn * 32];
             const int tapoff = (ta * p.hh + tb) * p.hw + tc;
-            f32x4 av[MT][4];
+            f32x4 av[MT][KG];
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi) {
                 const int row = row0[mi] + tapoff;
-                const int sw = (row >> 1) & 7;
-                const char* base = smem + row * 128;
+                const int sw = (row / CS) & (CH - 1);
+                const char* base = smem + row * ROWB;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) av[mi][g] = *(const f32x4*)(base + (((g * 2 + kh) ^ sw) << 4));
+                for (int g = 0; g < KG; ++g) av[mi][g] = *(const f32x4*)(base + (((g * 2 + kh) ^ sw) << 4));
             }
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
+            for (int g = 0; g < KG; ++g)
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
                     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-                        for (int nn = 0; nn < 2; ++nn)
-                            acc[mi][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][g][s], bcur[g][nn][s], acc[mi][nn], 0, 0, 0);
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int nn = 0; nn < 2; ++nn) bcur[g][nn] = bnxt[g][nn];
+                        for (int nn = 0; nn < NT; ++nn)
+                            acc[mi][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][g][s], bv[g][nn][s], acc[mi][nn], 0, 0, 0);
             if (++tc == 3) { tc = 0; if (++tb == 3) { tb = 0; ++ta; } }
         }
     }
+    if (p.dbg & 8) return;
 
-    // ---- epilogue: bias + residual + activation, 128-B row segments per half-wave ----
-    float bv[2] = {0.f, 0.f};
-    if (p.bias) { bv[0] = p.bias[li]; bv[1] = p.bias[32 + li]; }
+    // ---- epilogue: 128-B row segments per half-wave.  Branch-free activation: act(z) = z > 0 ? z : slope*z with
+    // slope 1 (none) / 0 (relu) / alpha (leaky); rows handled 4 at a time so residual / mask loads overlap. ----
+    const float slope = p.act == FDN_ACT_RELU ? 0.f : (p.act == FDN_ACT_LEAKY ? p.alpha : 1.f);
+    const int cofs = wave_n * (NT * 32) + li;
+    float bvs[NT];
+#pragma unroll
+    for (int nn = 0; nn < NT; ++nn) bvs[nn] = p.bias ? p.bias[cofs + nn * 32] : 0.f;
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int mrow = (wave * MT + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            const int g = goff[mrow];
-            if (g >= 0) {
-                const size_t o = (size_t)g * 64 + li;
+        for (int rq = 0; rq < 4; ++rq) {
+            int g[4];
 #pragma unroll
-                for (int nn = 0; nn < 2; ++nn) {
-                    float z = acc[mi][nn][r] + bv[nn];
-                    if (p.res) z += p.res[o + nn * 32];
-                    p.y[o + nn * 32] = fdn_act(z, p.act, p.alpha);
+            for (int j = 0; j < 4; ++j) g[j] = mtab[(wave_m * MT + mi) * 32 + j + 8 * rq + 4 * kh];
+            if (p.fout) {
+                // dgrad with fused fold: tagged rows (voxels strictly inside the volume, exactly one contribution)
+                // are finished here into dz_prev; everything else goes to the padded scratch for the border fold.
+                float sk[4][NT], ym[4][NT];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool inner = g[j] >= 0 && (g[j] & (1 << 30));
+                    const size_t o = (size_t)(inner ? (g[j] & ~(1 << 30)) : 0) * 64 + cofs;
+#pragma unroll
+                    for (int nn = 0; nn < NT; ++nn) {
+                        sk[j][nn] = p.fskip ? p.fskip[o + nn * 32] : 0.f;
+                        ym[j][nn] = p.fy ? p.fy[o + nn * 32] : 1.f;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (g[j] < 0) continue;
+                    const bool inner = g[j] & (1 << 30);
+                    const size_t o = (size_t)(g[j] & ~(1 << 30)) * 64 + cofs;
+#pragma unroll
+                    for (int nn = 0; nn < NT; ++nn) {
+                        const float a = acc[mi][nn][rq * 4 + j];
+                        if (inner) p.fout[o + nn * 32] = (a + sk[j][nn]) * (ym[j][nn] > 0.f ? 1.f : slope);
+                        else p.y[o + nn * 32] = a;
+                    }
+                }
+            } else {
+                float rv[4][NT];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const size_t o = (size_t)(g[j] >= 0 ? g[j] : 0) * 64 + cofs;
+#pragma unroll
+                    for (int nn = 0; nn < NT; ++nn) rv[j][nn] = p.res ? p.res[o + nn * 32] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (g[j] < 0) continue;
+                    const size_t o = (size_t)g[j] * 64 + cofs;
+#pragma unroll
+                    for (int nn = 0; nn < NT; ++nn) {
+                        const float z = acc[mi][nn][rq * 4 + j] + bvs[nn] + rv[j][nn];
+                        p.y[o + nn * 32] = z > 0.f ? z : slope * z;
+                    }
                 }
             }
         }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// border fold: finishes the voxels on the volume surface after fused-fold dgrad launches.
+//   dz_prev[i] = (sum_s sum_{P: clamp(P)=i} dxpad_s[P] + skip[i]) * act'(y[i])   for i with some i_d in {0, D-1}
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fold_halo_border_kernel(const float* __restrict__ s0, const float* __restrict__ s1,
+                                                                const float* __restrict__ s2, int nsrc,
+                                                                const float* __restrict__ skip, const float* __restrict__ yprev,
+                                                                int act, float alpha, float* __restrict__ out, int N, int D,
+                                                                int H, int W) {
+    // surface voxels enumerated as: two full d-faces, then two h-faces without the d-faces, then two w-faces without both
+    const int ID = D > 2 ? D - 2 : 0, IH = H > 2 ? H - 2 : 0;
+    const int nd_faces = (D > 1 ? 2 : 1) * H * W;
+    const int nh_faces = ID * (H > 1 ? 2 : 1) * W;
+    const int nw_faces = ID * IH * (W > 1 ? 2 : 1);
+    const int per_n = nd_faces + nh_faces + nw_faces;
+    const int64_t total = (int64_t)N * per_n * 16;
+    const int PH = H + 2, PW = W + 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i & 15);
+        int s = (int)((i >> 4) % per_n);
+        const int n = (int)((i >> 4) / per_n);
+        int d, h, w;
+        if (s < nd_faces) {
+            d = (s / (H * W)) ? D - 1 : 0; s %= H * W; h = s / W; w = s % W;
+        } else if ((s -= nd_faces) < nh_faces) {
+            const int f = s / (ID * W); s %= ID * W; h = f ? H - 1 : 0; d = 1 + s / W; w = s % W;
+        } else {
+            s -= nh_faces;
+            const int f = s / (ID * IH); s %= ID * IH; w = f ? W - 1 : 0; d = 1 + s / IH; h = 1 + s % IH;
+        }
+        int pd[3], ph[3], pw[3];
+        int nd = 0, nh = 0, nw = 0;
+        pd[nd++] = d + 1; if (d == 0) pd[nd++] = 0; if (d == D - 1) pd[nd++] = D + 1;
+        ph[nh++] = h + 1; if (h == 0) ph[nh++] = 0; if (h == H - 1) ph[nh++] = H + 1;
+        pw[nw++] = w + 1; if (w == 0) pw[nw++] = 0; if (w == W - 1) pw[nw++] = W + 1;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < nd; ++a)
+            for (int b = 0; b < nh; ++b)
+                for (int c = 0; c < nw; ++c) {
+                    const int64_t off = (((((int64_t)n * (D + 2) + pd[a]) * PH + ph[b]) * PW + pw[c]) * 16 + c4);
+                    acc += ((const f32x4*)s0)[off];
+                    if (nsrc > 1) acc += ((const f32x4*)s1)[off];
+                    if (nsrc > 2) acc += ((const f32x4*)s2)[off];
+                }
+        const int64_t o = ((((int64_t)n * D + d) * H + h) * W + w) * 16 + c4;
+        if (skip) acc += ((const f32x4*)skip)[o];
+        if (yprev) {
+            const f32x4 y = ((const f32x4*)yprev)[o];
+            acc.x *= fdn_act_grad(y.x, act, alpha); acc.y *= fdn_act_grad(y.y, act, alpha);
+            acc.z *= fdn_act_grad(y.z, act, alpha); acc.w *= fdn_act_grad(y.w, act, alpha);
+        }
+        ((f32x4*)out)[o] = acc;
     }
 }
 
@@ -235,70 +365,116 @@ extern "C" int fdn_pack_conv64_weights(const float* w, float* wp_fwd, float* wp_
 // --------------------------------------------------------------------------------------------
 // host side: tile planning + launch
 // --------------------------------------------------------------------------------------------
-FdnTile fdn_plan_tile(int N, int OD, int OH, int OW, int max_vox, int max_halo_rows, int halo) {
-    FdnTile best = {1, 1, 2, OD, OH, (OW + 1) / 2};
-    double best_cost = 1e30;
-    for (int td = 1; td <= OD && td <= max_vox; ++td)
-        for (int th = 1; th <= OH && td * th <= max_vox; ++th)
-            for (int tw = 1; tw <= OW && td * th * tw <= max_vox; ++tw) {
-                const int rows = (td + halo) * (th + 2) * (tw + 2);
-                if (rows > max_halo_rows) continue;
-                const int ntd = (OD + td - 1) / td, nth = (OH + th - 1) / th, ntw = (OW + tw - 1) / tw;
-                const double tiles = (double)N * ntd * nth * ntw;
-                // per-tile cost: the M rows are always fully issued; staging adds a little per halo row
-                const double per_tile = max_vox + 0.12 * rows;
-                const double rounds = tiles <= 256 ? 1.0 : tiles / 256.0;   // balance over 256 CUs
-                const double cost = (tiles <= 256 ? 1.0 : (double)((long long)((tiles + 255) / 256))) * per_tile * 0.5 +
-                                    rounds * per_tile * 0.5;
-                if (cost < best_cost) { best_cost = cost; best = {td, th, tw, ntd, nth, ntw}; }
+namespace {
+
+struct Plan { FdnTile t; double cost; };
+
+// estimated time of a launch in units of "one M row through all 27x64 K steps on one CU"
+double plan_cost(const FdnTile& t, int N, int mcap, int cs) {
+    const double tiles = (double)N * t.ntd * t.nth * t.ntw;
+    const double rows = (double)(t.td + 2) * (t.th + 2) * (t.tw + 2);
+    const double per_tile = mcap + 0.02 * rows + 3.0 * cs + 4.0;     // MFMA work + staging + barriers + epilogue
+    const double per_cu_max = (double)((long long)((tiles + 255) / 256));
+    const double per_cu_avg = tiles / 256.0;
+    return (0.75 * per_cu_max + 0.25 * per_cu_avg) * per_tile;
+}
+
+Plan best_plan(int N, int OD, int OH, int OW, int mcap, int max_rows, int cs) {
+    Plan best{{1, 1, 2, OD, OH, (OW + 1) / 2}, 1e30};
+    for (int td = 1; td <= OD && td <= mcap; ++td)
+        for (int th = 1; th <= OH && td * th <= mcap; ++th)
+            for (int tw = 1; tw <= OW && td * th * tw <= mcap; ++tw) {
+                if ((td + 2) * (th + 2) * (tw + 2) > max_rows) continue;
+                FdnTile t{td, th, tw, (OD + td - 1) / td, (OH + th - 1) / th, (OW + tw - 1) / tw};
+                const double c = plan_cost(t, N, mcap, cs);
+                if (c < best.cost) best = {t, c};
             }
     return best;
 }
 
-template <int MT>
-static int launch_conv64(Conv64Args& a, const FdnTile& t, hipStream_t s) {
+template <int MT, int NW, int CS>
+Plan plan_for(int N, int OD, int OH, int OW) {
+    using C = Conv64Cfg<MT, NW, CS>;
+    return best_plan(N, OD, OH, OW, C::MCAP, C::MAXROWS, CS);
+}
+
+template <int MT, int NW, int CS>
+int launch_conv64(Conv64Args& a, const FdnTile& t, hipStream_t s) {
+    using C = Conv64Cfg<MT, NW, CS>;
     a.td = t.td; a.th = t.th; a.tw = t.tw; a.ntd = t.ntd; a.nth = t.nth; a.ntw = t.ntw;
     a.hh = t.th + 2; a.hw = t.tw + 2;
     a.rows = (t.td + 2) * a.hh * a.hw;
     a.mg_hhhw = fdn_magic20(a.hh * a.hw);
     a.mg_hw = fdn_magic20(a.hw);
-    const size_t lds = (size_t)a.rows * 128 + 128 * MT * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv64_mfma_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
+        hipError_t e = hipFuncSetAttribute((const void*)conv64_mfma_kernel<MT, NW, CS>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) { fdn_set_error("conv64: hipFuncSetAttribute: %s", hipGetErrorString(e)); return FDN_ERR_HIP; }
         attr_set = true;
     }
     const long long grid = (long long)a.N * t.ntd * t.nth * t.ntw;
-    hipLaunchKernelGGL(conv64_mfma_kernel<MT>, dim3((unsigned)grid), dim3(256), lds, s, a);
+    const size_t lds = (size_t)a.rows * C::ROWB + C::MCAP * 4;
+    hipLaunchKernelGGL((conv64_mfma_kernel<MT, NW, CS>), dim3((unsigned)grid), dim3(256), lds, s, a);
     FDN_CHECK_LAUNCH("conv64_mfma_kernel");
     return FDN_OK;
 }
 
-static double tile_cost(const FdnTile& t, int N, int mcap) {
-    const double tiles = (double)N * t.ntd * t.nth * t.ntw;
-    const double per_tile = mcap + 0.12 * (t.td + 2) * (t.th + 2) * (t.tw + 2);
-    const double rounds_hi = (double)((long long)((tiles + 255) / 256));
-    const double rounds = tiles <= 256 ? 1.0 : tiles / 256.0;
-    return (0.5 * rounds_hi + 0.5 * rounds) * per_tile;
+}  // namespace
+
+FdnTile fdn_plan_tile(int N, int OD, int OH, int OW, int max_vox, int max_halo_rows, int) {
+    return best_plan(N, OD, OH, OW, max_vox, max_halo_rows, 2).t;
 }
 
-int fdn_conv64_force_mt = 0;   // test/bench hook: 0 = auto, 1 or 2 = force the M-tile count per wave
+int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, const float* residual, float* y,
+                         const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
+                         int OW, int off, int zero_mode, int act, float alpha, hipStream_t s) {
+    Conv64Args a;
+    a.x = x; a.wp = wpack; a.bias = bias; a.res = residual; a.y = y;
+    a.fskip = fskip; a.fy = fy; a.fout = fout;
+    a.N = N; a.ID = ID; a.IH = IH; a.IW = IW; a.OD = OD; a.OH = OH; a.OW = OW;
+    a.off = off; a.zero_mode = zero_mode; a.act = act; a.alpha = alpha; a.dbg = fdn_conv64_dbg;
+    // variant table: 1:<2,1,2> 2:<2,1,4> 3:<1,1,2> 4:<1,1,4> 5:<1,2,2> 6:<1,2,4>
+    const Plan pl[7] = {Plan{{}, 1e30}, plan_for<2, 1, 2>(N, OD, OH, OW), plan_for<2, 1, 4>(N, OD, OH, OW),
+                        plan_for<1, 1, 2>(N, OD, OH, OW), plan_for<1, 1, 4>(N, OD, OH, OW),
+                        plan_for<1, 2, 2>(N, OD, OH, OW), plan_for<1, 2, 4>(N, OD, OH, OW)};
+    int v = fdn_conv64_force_layout;
+    if (v < 1 || v > 6) {
+        v = 2;                                                   // auto: among the measured-good variants
+        if (pl[6].cost < pl[v].cost) v = 6;
+        if (pl[4].cost < pl[v].cost) v = 4;
+    }
+    switch (v) {
+        case 1: return launch_conv64<2, 1, 2>(a, pl[1].t, s);
+        case 2: return launch_conv64<2, 1, 4>(a, pl[2].t, s);
+        case 3: return launch_conv64<1, 1, 2>(a, pl[3].t, s);
+        case 4: return launch_conv64<1, 1, 4>(a, pl[4].t, s);
+        case 5: return launch_conv64<1, 2, 2>(a, pl[5].t, s);
+        default: return launch_conv64<1, 2, 4>(a, pl[6].t, s);
+    }
+}
 
 int fdn_conv64_launch(const float* x, const float* wpack, const float* bias, const float* residual, float* y, int N,
                       int ID, int IH, int IW, int OD, int OH, int OW, int off, int zero_mode, int act, float alpha,
                       hipStream_t s) {
-    Conv64Args a;
-    a.x = x; a.wp = wpack; a.bias = bias; a.res = residual; a.y = y;
-    a.N = N; a.ID = ID; a.IH = IH; a.IW = IW; a.OD = OD; a.OH = OH; a.OW = OW;
-    a.off = off; a.zero_mode = zero_mode; a.act = act; a.alpha = alpha;
-    // <= 80 KB of LDS per workgroup so two fit a CU: 128 B per halo row + the row table
-    const int max_rows = (81920 - 1024) / 128;
-    const FdnTile t2 = fdn_plan_tile(N, OD, OH, OW, 256, max_rows, 2);
-    const FdnTile t1 = fdn_plan_tile(N, OD, OH, OW, 128, max_rows, 2);
-    int mt = tile_cost(t1, N, 128) < tile_cost(t2, N, 256) ? 1 : 2;
-    if (fdn_conv64_force_mt == 1 || fdn_conv64_force_mt == 2) mt = fdn_conv64_force_mt;
-    return mt == 1 ? launch_conv64<1>(a, t1, s) : launch_conv64<2>(a, t2, s);
+    return fdn_conv64_launch_ex(x, wpack, bias, residual, y, nullptr, nullptr, nullptr, N, ID, IH, IW, OD, OH, OW, off,
+                                zero_mode, act, alpha, s);
 }
 
-extern "C" int fdn_debug_set_conv64_mt(int mt) { fdn_conv64_force_mt = mt; return FDN_OK; }
+int fdn_fold_halo_border_launch(const float* s0, const float* s1, const float* s2, int nsrc, const float* skip,
+                                const float* yprev, int act, float alpha, float* out, int N, int D, int H, int W,
+                                hipStream_t s) {
+    const int ID = D > 2 ? D - 2 : 0, IH = H > 2 ? H - 2 : 0;
+    const int64_t per_n = (int64_t)(D > 1 ? 2 : 1) * H * W + (int64_t)ID * (H > 1 ? 2 : 1) * W + (int64_t)ID * IH * (W > 1 ? 2 : 1);
+    const int64_t total = (int64_t)N * per_n * 16;
+    int64_t nb = (total + 255) / 256;
+    if (nb < 1) nb = 1;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(fold_halo_border_kernel, dim3((unsigned)nb), dim3(256), 0, s, s0, s1, s2, nsrc, skip, yprev, act, alpha,
+                       out, N, D, H, W);
+    FDN_CHECK_LAUNCH("fold_halo_border_kernel");
+    return FDN_OK;
+}
+
+extern "C" int fdn_debug_set_conv64_mt(int layout) { fdn_conv64_force_layout = layout; return FDN_OK; }
+extern "C" int fdn_debug_set_conv64_dbg(int bits) { fdn_conv64_dbg = bits; return FDN_OK; }

@@ -53,6 +53,12 @@ FdnTile fdn_plan_tile(int N, int OD, int OH, int OW, int max_vox, int max_halo_r
 int fdn_conv64_launch(const float* x, const float* wpack, const float* bias, const float* residual, float* y,
                       int N, int ID, int IH, int IW, int OD, int OH, int OW, int off, int zero_mode, int act,
                       float alpha, hipStream_t s);
+int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, const float* residual, float* y,
+                         const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
+                         int OW, int off, int zero_mode, int act, float alpha, hipStream_t s);
+int fdn_fold_halo_border_launch(const float* s0, const float* s1, const float* s2, int nsrc, const float* skip,
+                                const float* yprev, int act, float alpha, float* out, int N, int D, int H, int W,
+                                hipStream_t s);
 int fdn_wgrad64_launch(const float* x, const float* dz, float* dw, void* ws, size_t ws_bytes, int N, int D, int H,
                        int W, hipStream_t s);
 size_t fdn_wgrad64_workspace_bytes(int N, int D, int H, int W);

@@ -272,52 +272,129 @@ __global__ __launch_bounds__(256) void wgrad_cin3_kernel(const float* __restrict
     for (int i = threadIdx.x; i < 81 * 64; i += 256) partial[(size_t)blockIdx.x * (81 * 64) + i] = red[i];
 }
 
-// 64 -> 1: iterate over PADDED input positions so each x row is read once; lane = ci, 27 accumulators.
+// 64 -> 1: iterate over rows of PADDED input positions so each x row is read once.  Thread = (position slot g,
+// 4 channels q); the 9 dz rows a padded (d,h) row can touch are staged in LDS (zero-padded), 27 float4 accumulators.
 __global__ __launch_bounds__(256) void wgrad_cout1_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                            float* __restrict__ partial, int N, int D, int H, int W,
                                                            int lddz, int dz_coff) {
-    __shared__ float red[4][27 * 64];
-    const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
-    float acc[27];
-#pragma unroll
-    for (int t = 0; t < 27; ++t) acc[t] = 0.f;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int ZW = W + 4;                       // z[k][j] = dz[od_k][oh_k][j-2], zero outside
+    float* z = sm;                              // 9 * ZW
+    float* red = sm + ((9 * ZW + 3) & ~3);      // 4 waves * 27 * 64
+    const int q = threadIdx.x & 15, g = threadIdx.x >> 4;
     const int PD = D + 2, PH = H + 2, PW = W + 2;
-    const int64_t npos = (int64_t)N * PD * PH * PW;
-    const int64_t wave_id = (int64_t)blockIdx.x * 4 + wv;
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
-    for (int64_t pos = wave_id; pos < npos; pos += nwaves) {
-        int r = (int)(pos % ((int64_t)PD * PH * PW));
-        const int n = (int)(pos / ((int64_t)PD * PH * PW));
-        const int pd = r / (PH * PW); r -= pd * PH * PW;
-        const int ph = r / PW;
-        const int pw = r - ph * PW;
-        const int qd = clampi(pd - 1, D - 1), qh = clampi(ph - 1, H - 1), qw = clampi(pw - 1, W - 1);
-        const float xv = x[((((int64_t)n * D + qd) * H + qh) * W + qw) * 64 + lane];
-        // padded position p is tap t's input of output voxel o = p - t
+    f32x4 acc[27];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const int od = pd - a;
-            if ((unsigned)od >= (unsigned)D) continue;
+    for (int t = 0; t < 27; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nrows = N * PD * PH;
+    for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const int n = row / (PD * PH);
+        const int r2 = row - n * (PD * PH);
+        const int pd = r2 / PH, ph = r2 - (r2 / PH) * PH;
+        __syncthreads();
+        for (int i = threadIdx.x; i < 9 * ZW; i += 256) {
+            const int k = i / ZW, j = i - k * ZW;
+            const int od = pd - k / 3, oh = ph - k % 3, ow = j - 2;      // padded p is tap t's input of output o = p - t
+            float v = 0.f;
+            if ((unsigned)od < (unsigned)D && (unsigned)oh < (unsigned)H && (unsigned)ow < (unsigned)W)
+                v = dz[((((int64_t)n * D + od) * H + oh) * W + ow) * lddz + dz_coff];
+            z[i] = v;
+        }
+        __syncthreads();
+        const int qd = clampi(pd - 1, D - 1), qh = clampi(ph - 1, H - 1);
+        const float* xrow = x + (((int64_t)n * D + qd) * H + qh) * W * 64 + q * 4;
+        for (int pw = g; pw < PW; pw += 16) {
+            const f32x4 xv = *(const f32x4*)(xrow + (int64_t)clampi(pw - 1, W - 1) * 64);
 #pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                const int oh = ph - b;
-                if ((unsigned)oh >= (unsigned)H) continue;
+            for (int k = 0; k < 9; ++k)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const int ow = pw - c;
-                    if ((unsigned)ow >= (unsigned)W) continue;
-                    const float g = dz[(((int64_t)n * D + od) * H + oh) * W * lddz + (int64_t)ow * lddz + dz_coff];
-                    acc[(a * 3 + b) * 3 + c] += xv * g;
-                }
-            }
+                for (int c = 0; c < 3; ++c) acc[k * 3 + c] += xv * z[k * ZW + pw - c + 2];
         }
     }
+    // fold the 4 position slots of a wave (lane bits 4,5), then the 4 waves through LDS
+    const int wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int t = 0; t < 27; ++t) red[wv][t * 64 + lane] = acc[t];
+    for (int t = 0; t < 27; ++t) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = acc[t][e];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            acc[t][e] = v;
+        }
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) < 16) {
+#pragma unroll
+        for (int t = 0; t < 27; ++t) *(f32x4*)(red + (wv * 27 + t) * 64 + q * 4) = acc[t];
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < 27 * 64; i += 256)
-        partial[(size_t)blockIdx.x * (27 * 64) + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+        partial[(size_t)blockIdx.x * (27 * 64) + i] = (red[i] + red[27 * 64 + i]) + (red[2 * 27 * 64 + i] + red[3 * 27 * 64 + i]);
+}
+
+// dgrad of 64 -> 1 (k=3) FUSED with the halo fold and the producer's activation gradient:
+//   dz_prev[i][c] = act'(y[i][c]) * sum over the <=27 (output voxel o, tap t) pairs with clamp(o + t - 1) == i of w[t][c]*dz[o].
+// Per dimension a voxel i always has exactly the pairs {(o,a): clamp(o+a-1)=i}, at most 3 of them.
+__device__ __forceinline__ int pairs_of(int i, int n, int* o, int* a) {
+    int cnt = 0;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {            // candidate padded positions: i+1 always, 0 if i==0, n+1 if i==n-1
+#pragma unroll
+        for (int which = 0; which < 3; ++which) {
+            const int p = which == 0 ? i + 1 : (which == 1 ? 0 : n + 1);
+            if ((which == 1 && i != 0) || (which == 2 && i != n - 1)) continue;
+            const int oo = p - t;
+            if ((unsigned)oo < (unsigned)n) { o[cnt] = oo; a[cnt] = t; ++cnt; }
+        }
+    }
+    return cnt;   // <= 3 by construction
+}
+
+__global__ __launch_bounds__(256) void conv_cout1_dgrad_folded_kernel(const float* __restrict__ dz, const float* __restrict__ w,
+                                                                       const float* __restrict__ yprev, int act, float alpha,
+                                                                       float* __restrict__ out, int N, int D, int H, int W,
+                                                                       int lddz, int dz_coff) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* wl = sm;                 // 27 * 64 weights
+    float* z = sm + 27 * 64;        // 9 rows * W
+    int* meta = (int*)(z + 9 * W);  // [0]=number of (d,h) pairs, then tap base (a*3+b)*3 per row
+    for (int i = threadIdx.x; i < 27 * 64; i += 256) wl[i] = w[i];
+    const int q = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int nrows = N * D * H;
+    for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const int n = row / (D * H);
+        const int r2 = row - n * (D * H);
+        const int d = r2 / H, h = r2 - (r2 / H) * H;
+        int od[4], ta[4], oh[4], tb[4];
+        const int nd = pairs_of(d, D, od, ta), nh = pairs_of(h, H, oh, tb);
+        __syncthreads();
+        if (threadIdx.x == 0) meta[0] = nd * nh;
+        if (threadIdx.x < nd * nh) meta[1 + threadIdx.x] = (ta[threadIdx.x / nh] * 3 + tb[threadIdx.x % nh]) * 3;
+        for (int i = threadIdx.x; i < nd * nh * W; i += 256) {
+            const int k = i / W, ow = i - k * W;
+            z[i] = dz[((((int64_t)n * D + od[k / nh]) * H + oh[k % nh]) * W + ow) * lddz + dz_coff];
+        }
+        __syncthreads();
+        const int nk = meta[0];
+        for (int wv = g; wv < W; wv += 16) {
+            int ow[4], tc[4];
+            const int nw = pairs_of(wv, W, ow, tc);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < nk; ++k) {
+                const int tbase = meta[1 + k];
+                for (int c = 0; c < nw; ++c)
+                    acc += *(const f32x4*)(wl + (tbase + tc[c]) * 64 + q * 4) * z[k * W + ow[c]];
+            }
+            const int64_t o = ((((int64_t)n * D + d) * H + h) * W + wv) * 64 + q * 4;
+            if (yprev) {
+                const f32x4 y = *(const f32x4*)(yprev + o);
+                acc.x *= fdn_act_grad(y.x, act, alpha); acc.y *= fdn_act_grad(y.y, act, alpha);
+                acc.z *= fdn_act_grad(y.z, act, alpha); acc.w *= fdn_act_grad(y.w, act, alpha);
+            }
+            *(f32x4*)(out + o) = acc;
+        }
+    }
 }
 
 // 1x1 (64+64) -> 64: thread owns ci = tid>>1 and 32 couts; voxel chunks staged through LDS.
@@ -480,11 +557,25 @@ int fdn_wgrad_cin3_launch(const float* x, const float* dz, float* dw, void* ws, 
 
 int fdn_wgrad_cout1_launch(const float* x, const float* dz, float* dw, void* ws, size_t, int N, int D, int H, int W,
                            int lddz, int dz_coff, hipStream_t s) {
-    const int64_t npos = (int64_t)N * (D + 2) * (H + 2) * (W + 2);
-    const int nb = nblocks_for(npos, 4 * 64, kSmallBlocks);
-    hipLaunchKernelGGL(wgrad_cout1_kernel, dim3(nb), dim3(256), 0, s, x, dz, (float*)ws, N, D, H, W, lddz, dz_coff);
+    const int nrows = N * (D + 2) * (H + 2);
+    const int nb = nrows < kSmallBlocks ? nrows : kSmallBlocks;
+    const size_t lds = (size_t)(((9 * (W + 4) + 3) & ~3) + 4 * 27 * 64) * sizeof(float);
+    hipLaunchKernelGGL(wgrad_cout1_kernel, dim3(nb), dim3(256), lds, s, x, dz, (float*)ws, N, D, H, W, lddz, dz_coff);
     FDN_CHECK_LAUNCH("wgrad_cout1_kernel");
     return reduce_partials((const float*)ws, dw, nb, 27 * 64, s);
+}
+
+extern "C" int fdn_conv_cout1_dgrad_folded(const float* dz, const float* w, const float* y_prev, int act, float alpha,
+                                           float* dz_prev, int N, int D, int H, int W, int lddz, int dz_coff, void* stream) {
+    FDN_REQUIRE(dz && w && dz_prev && N > 0 && D > 0 && H > 0 && W > 0, "fdn_conv_cout1_dgrad_folded: bad argument");
+    FDN_REQUIRE(W <= 4096, "fdn_conv_cout1_dgrad_folded: W too large for the row stage");
+    const int nrows = N * D * H;
+    const int nb = nrows < 4096 ? nrows : 4096;
+    const size_t lds = (size_t)(27 * 64 + 9 * W + 16) * sizeof(float);
+    hipLaunchKernelGGL(conv_cout1_dgrad_folded_kernel, dim3(nb), dim3(256), lds, (hipStream_t)stream, dz, w, y_prev, act,
+                       alpha, dz_prev, N, D, H, W, lddz, dz_coff);
+    FDN_CHECK_LAUNCH("conv_cout1_dgrad_folded_kernel");
+    return FDN_OK;
 }
 
 int fdn_wgrad_1x1_launch(const float* xa, const float* xb, const float* dz, float* dw, void* ws, size_t, int64_t nvox,

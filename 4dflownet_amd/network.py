@@ -237,6 +237,19 @@ class FlowNetModel:
         ws = self._workspace(ops.wgrad_workspace_bytes(N, D, H, W, L.cin, L.cout, L.k))
         ops.conv3d_wgrad(x, dz, L.k, L.cin, L.cout, x2=x2, dw=L.gw, dbias=L.gb, workspace=ws, lddz=lddz, dz_coff=dz_coff)
 
+    def _pad_like(self, t):
+        N, D, H, W, C = t.shape
+        return torch.empty((N, D + 2, H + 2, W + 2, C), device=t.device, dtype=torch.float32)
+
+    def _dgrad_fold(self, dz, L, skip, y_prev, act):
+        """dz_prev = (MirrorPadGrad(Conv3DBackpropInput(dz)) + skip) * act'(y_prev) for a 64->64 layer: interior voxels
+        are finished by the conv epilogue, the surface by one small border kernel."""
+        out = torch.empty_like(dz)
+        pad = self._pad_like(dz)
+        ops.conv3d_dgrad_fused(dz, L.wp_d, pad, out, skip=skip, y_prev=y_prev, act=act)
+        ops.fold_halo_border([pad], out, skip, y_prev, act)
+        return out
+
     def backward(self, dpred):
         """Fill self.flat_g with d(sum_b loss_b)/d(params) given dpred (B,PR,PR,PR,3); L2 is NOT included here
         (it is folded into the Adam kernel).  Consumes the cache of the last forward(training=True)."""
@@ -248,30 +261,38 @@ class FlowNetModel:
         R = self.res_increase
         rb = c["rb"]
         li = len(Ls) - 6
+        def act_of(t):                     # (tensor for act', act) of a producer; linear producers need no mask
+            return (t.t if t.act != ACT_NONE else None), t.act
+
+        # three heads fan into rb: chain the interior accumulation through `dz` (skip aliases the output),
+        # apply act'(rb) on the last one, then one border fold over the three padded scratches
+        dz = torch.empty_like(rb.t)
         pads = []
         for hidx in range(3):
             L1, L2 = Ls[li], Ls[li + 1]
             g = c["heads"][hidx]
+            c["heads"][hidx] = None
             self._wgrad(g, dpred, L2, lddz=3, dz_coff=hidx)
-            pad1 = ops.conv3d_dgrad(dpred, L2.w, lddz=3, dz_coff=hidx, spatial=tuple(g.shape[:4]))
-            dz_g = ops.fold_halo([pad1], None, g, ACT_RELU)
-            del pad1
+            dz_g = ops.conv_cout1_dgrad_folded(dpred, L2.w, tuple(g.shape[:4]), g, ACT_RELU, lddz=3, dz_coff=hidx)
+            del g
             self._wgrad(rb.t, dz_g, L1)
-            pads.append(ops.conv3d_dgrad(dz_g, L1.w, L1.wp_d))
+            pad = self._pad_like(rb.t)
+            y_m, a_m = act_of(rb) if hidx == 2 else (None, ACT_NONE)
+            ops.conv3d_dgrad_fused(dz_g, L1.wp_d, pad, dz, skip=dz if hidx > 0 else None, y_prev=y_m, act=a_m)
+            pads.append(pad)
             del dz_g
             li += 2
-        c["heads"] = None
-        # gradient w.r.t. rb, times act'(rb) of its producer
-        dz = ops.fold_halo(pads, None, rb.t if rb.act != ACT_NONE else None, rb.act)
-        del pads
+        y_m, a_m = act_of(rb)
+        ops.fold_halo_border(pads, dz, None, y_m, a_m)
+        del pads, pad
         li = len(Ls) - 6
         nb = self.low_resblock + self.hi_resblock
         up = c["up"]
         for i in range(nb, -1, -1):
             if up is not None and i == self.low_resblock:
                 # dz currently holds d(up_out) (linear producer): pull it through the upsample
-                up_in = up[0]
-                dz = ops.upsample_trilinear_bwd(dz, R, up_in.t if up_in.act != ACT_NONE else None, up_in.act)
+                y_m, a_m = act_of(up[0])
+                dz = ops.upsample_trilinear_bwd(dz, R, y_m, a_m)
             if i == 0:
                 break
             x, h, out = c["blocks"][i - 1]
@@ -279,26 +300,21 @@ class FlowNetModel:
             li -= 2
             La, Lb = Ls[li], Ls[li + 1]
             self._wgrad(h, dz, Lb)
-            pad = ops.conv3d_dgrad(dz, Lb.w, Lb.wp_d)
-            dz_h = ops.fold_halo([pad], None, h, ACT_LEAKY)
-            del pad
+            dz_h = self._dgrad_fold(dz, Lb, None, h, ACT_LEAKY)
             self._wgrad(x.t, dz_h, La)
-            pad = ops.conv3d_dgrad(dz_h, La.w, La.wp_d)
+            y_m, a_m = act_of(x)
+            dz = self._dgrad_fold(dz_h, La, dz, y_m, a_m)
             del dz_h
-            dz = ops.fold_halo([pad], dz, x.t if x.act != ACT_NONE else None, x.act)
-            del pad
         assert li == 6
         # dz == dz_c1
         self._wgrad(c["c0"], dz, Ls[5])
-        pad = ops.conv3d_dgrad(dz, Ls[5].w, Ls[5].wp_d)
-        dz_c0 = ops.fold_halo([pad], None, c["c0"], ACT_RELU)
+        dz_c0 = self._dgrad_fold(dz, Ls[5], None, c["c0"], ACT_RELU)
         self._wgrad(c["p1"], dz_c0, Ls[4], x2=c["a1"])
         dz_p1, dz_a1 = ops.conv1x1_dgrad(dz_c0, Ls[4].w, c["p1"], c["a1"])
         for (first, second, src, dzz) in ((Ls[2], Ls[3], "p", dz_p1), (Ls[0], Ls[1], "a", dz_a1)):
             x0 = c[src + "0"]
             self._wgrad(x0, dzz, second)
-            pad = ops.conv3d_dgrad(dzz, second.w, second.wp_d)
-            dz0 = ops.fold_halo([pad], None, x0, ACT_RELU)
+            dz0 = self._dgrad_fold(dzz, second, None, x0, ACT_RELU)
             self._wgrad(c["phase"] if src == "p" else c["pc"], dz0, first)
         return self.flat_g
 

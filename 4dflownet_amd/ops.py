@@ -87,6 +87,16 @@ def conv3d_dgrad(dz, w, wpack_dgrad=None, out=None, lddz=None, dz_coff=0, spatia
     return out
 
 
+def conv_cout1_dgrad_folded(dz, w, spatial, y_prev=None, act=ACT_NONE, alpha=LEAKY_ALPHA, lddz=1, dz_coff=0, out=None):
+    """64->1 head dgrad + halo fold + act'(y_prev) in one kernel.  Returns (N,D,H,W,64)."""
+    N, D, H, W = spatial
+    if out is None:
+        out = torch.empty((N, D, H, W, 64), device=dz.device, dtype=torch.float32)
+    check(_lib.load().fdn_conv_cout1_dgrad_folded(_p(dz, "dz"), _p(w, "w"), _p(y_prev, allow_none=True), act, float(alpha),
+                                                  _p(out), N, D, H, W, lddz, dz_coff, _stream()), "fdn_conv_cout1_dgrad_folded")
+    return out
+
+
 def fold_halo(dxpads, skip=None, y_prev=None, act=ACT_NONE, alpha=LEAKY_ALPHA, out=None):
     """dxpads: 1..3 tensors (N,D+2,H+2,W+2,C).  Returns (N,D,H,W,C)."""
     p0 = dxpads[0]
@@ -97,6 +107,25 @@ def fold_halo(dxpads, skip=None, y_prev=None, act=ACT_NONE, alpha=LEAKY_ALPHA, o
     check(_lib.load().fdn_fold_halo(ptrs[0], ptrs[1], ptrs[2], len(dxpads), _p(skip, allow_none=True),
                                     _p(y_prev, allow_none=True), act, float(alpha), _p(out), N, D, H, W, C, _stream()),
           "fdn_fold_halo")
+    return out
+
+
+def conv3d_dgrad_fused(dz, wpack_dgrad, dxpad, out, skip=None, y_prev=None, act=ACT_NONE, alpha=LEAKY_ALPHA):
+    """64->64 dgrad; interior voxels of `out` are finished in the conv epilogue (skip may alias out), the rest lands
+    in the padded scratch `dxpad` for fold_halo_border."""
+    N, D, H, W = dz.shape[:4]
+    check(_lib.load().fdn_conv3d_dgrad_fused(_p(dz, "dz"), _p(wpack_dgrad, "wpack"), _p(dxpad, "dxpad"),
+                                             _p(skip, allow_none=True), _p(y_prev, allow_none=True), act, float(alpha),
+                                             _p(out, "out"), N, D, H, W, _stream()), "fdn_conv3d_dgrad_fused")
+    return out
+
+
+def fold_halo_border(dxpads, out, skip=None, y_prev=None, act=ACT_NONE, alpha=LEAKY_ALPHA):
+    N, D, H, W = out.shape[:4]
+    ptrs = [_p(t) for t in dxpads] + [None] * (3 - len(dxpads))
+    check(_lib.load().fdn_fold_halo_border(ptrs[0], ptrs[1], ptrs[2], len(dxpads), _p(skip, allow_none=True),
+                                           _p(y_prev, allow_none=True), act, float(alpha), _p(out), N, D, H, W, _stream()),
+          "fdn_fold_halo_border")
     return out
 
 

@@ -59,12 +59,29 @@ int fdn_conv3d_fwd(const float* x, const float* x2, const float* w, const float*
 int fdn_conv3d_dgrad(const float* dz, const float* w, const float* wpack, float* dxpad, int N, int D, int H,
                      int W, int Cin, int Cout, int K, int lddz, int dz_coff, void* stream);
 
+/* The 64->1 head conv's input gradient with the halo fold and the producer's activation gradient fused
+ * (no padded intermediate): dz_prev[i] = act'(y_prev[i]) * sum_{(o,t): clamp(o+t-1)=i} w[t] * dz[o].
+ * dz rows at dz[voxel*lddz + dz_coff]; y_prev may be NULL.  SR4DFlowNet.py:40,43,46 under tape.gradient. */
+int fdn_conv_cout1_dgrad_folded(const float* dz, const float* w, const float* y_prev, int act, float alpha,
+                                float* dz_prev, int N, int D, int H, int W, int lddz, int dz_coff, void* stream);
+
 /* MirrorPadGrad + gradient fan-in + activation gradient in one pass:
  * dz_prev[i] = (sum_s sum_{P: clamp(P)=i} dxpad_s[P] + skip[i]) * act'(y_prev[i]).
  * nsrc in 1..3; skip, y_prev may be NULL (act' = 1). */
 int fdn_fold_halo(const float* dxpad0, const float* dxpad1, const float* dxpad2, int nsrc, const float* skip,
                   const float* y_prev, int act, float alpha, float* dz_prev, int N, int D, int H, int W,
                   int C, void* stream);
+
+/* 64->64 dgrad with MirrorPadGrad fused for the voxels strictly inside the volume (each receives exactly one
+ * contribution): there  dz_prev[i] = (dgrad[i] + skip[i]) * act'(y_prev[i])  is written by the conv epilogue;
+ * every other padded position is written to dxpad (N,D+2,H+2,W+2,64) and finished by fdn_fold_halo_border,
+ * which applies the same formula on the surface voxels with up to 3 padded sources.  skip may alias dz_prev
+ * (gradient fan-in over several consumers: call with y_prev=NULL for all but the last).  wpack = wp_dgrad. */
+int fdn_conv3d_dgrad_fused(const float* dz, const float* wpack, float* dxpad, const float* skip, const float* y_prev,
+                           int act, float alpha, float* dz_prev, int N, int D, int H, int W, void* stream);
+int fdn_fold_halo_border(const float* dxpad0, const float* dxpad1, const float* dxpad2, int nsrc, const float* skip,
+                         const float* y_prev, int act, float alpha, float* dz_prev, int N, int D, int H, int W,
+                         void* stream);
 
 /* 1x1x1 128->64 conv backward w.r.t. its two 64-channel inputs, fused with their ReLU masks:
  * dxa = (dz . W[0:64,:]^T) * (ya>0), dxb = (dz . W[64:128,:]^T) * (yb>0).  SR4DFlowNet.py:23-24. */

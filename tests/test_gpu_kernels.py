@@ -34,7 +34,7 @@ SHAPES = [(2, 8, 8, 8), (1, 5, 7, 9), (1, 10, 12, 16), (3, 4, 4, 2)]
 
 
 @pytest.mark.parametrize("shape", SHAPES)
-@pytest.mark.parametrize("mt", [0, 1, 2])
+@pytest.mark.parametrize("mt", [0, 1, 2, 3, 4, 5, 6])   # 0 = planner, 1..6 = forced <MT,NW,CS> variant
 def test_conv64_fwd(ops, fdn, shape, mt):
     rng = np.random.default_rng(1)
     N, D, H, W = shape
@@ -71,6 +71,37 @@ def test_conv64_dgrad_and_fold(ops, shape):
     close(ops.fold_halo([pad, pad, pad], None, dev(y), O.ACT_RELU), ref3, name="fold 3 src+relu")
 
 
+@pytest.mark.parametrize("shape", SHAPES + [(1, 1, 1, 1), (1, 2, 3, 1)])
+@pytest.mark.parametrize("layout", [0, 1, 2, 3, 4, 5, 6])
+def test_conv64_dgrad_fused_fold(ops, fdn, shape, layout):
+    """dgrad with the interior fold in the conv epilogue + border kernel == oracle dgrad (+ skip, * act')."""
+    rng = np.random.default_rng(6)
+    N, D, H, W = shape
+    dz = rng.normal(size=(N, D, H, W, 64)).astype(np.float32)
+    w = (rng.normal(size=(3, 3, 3, 64, 64)) * 0.05).astype(np.float32)
+    y = rng.normal(size=(N, D, H, W, 64)).astype(np.float32)
+    skip = rng.normal(size=(N, D, H, W, 64)).astype(np.float32)
+    dx = O.conv3d_dgrad(dz.astype(np.float64), w.astype(np.float64), (N, D, H, W, 64))
+    _, wd = ops.pack_conv64_weights(dev(w))
+    fdn._lib.load().fdn_debug_set_conv64_mt(layout)
+    try:
+        pad = torch.full((N, D + 2, H + 2, W + 2, 64), float("nan"), device="cuda")
+        out = torch.full((N, D, H, W, 64), float("nan"), device="cuda")
+        ops.conv3d_dgrad_fused(dev(dz), wd, pad, out, skip=dev(skip), y_prev=dev(y), act=O.ACT_LEAKY)
+        ops.fold_halo_border([pad], out, dev(skip), dev(y), O.ACT_LEAKY)
+        close(out, O.act_bwd_from_output(dx + skip, y, O.ACT_LEAKY), name="fused dgrad+border")
+        # fan-in of three consumers chained through the output buffer (skip aliases out), mask on the last
+        acc = torch.full((N, D, H, W, 64), float("nan"), device="cuda")
+        pads = [torch.empty_like(pad) for _ in range(3)]
+        for k in range(3):
+            ops.conv3d_dgrad_fused(dev(dz * (k + 1)), wd, pads[k], acc, skip=acc if k else None,
+                                   y_prev=dev(y) if k == 2 else None, act=O.ACT_RELU if k == 2 else O.ACT_NONE)
+        ops.fold_halo_border(pads, acc, None, dev(y), O.ACT_RELU)
+        close(acc, O.act_bwd_from_output(6 * dx, y, O.ACT_RELU), name="fused fan-in of 3")
+    finally:
+        fdn._lib.load().fdn_debug_set_conv64_mt(0)
+
+
 @pytest.mark.parametrize("shape", SHAPES + [(2, 16, 16, 16)])
 def test_conv64_wgrad(ops, shape):
     rng = np.random.default_rng(3)
@@ -83,7 +114,7 @@ def test_conv64_wgrad(ops, shape):
     close(db, O.bias_grad(dz.astype(np.float64)), name="bias grad 64")
 
 
-@pytest.mark.parametrize("shape", [(2, 6, 6, 6), (1, 5, 7, 9)])
+@pytest.mark.parametrize("shape", [(2, 6, 6, 6), (1, 5, 7, 9), (1, 1, 2, 3)])
 def test_thin_layers(ops, shape):
     rng = np.random.default_rng(4)
     N, D, H, W = shape
@@ -109,6 +140,11 @@ def test_thin_layers(ops, shape):
     dzo = f64(dpred[..., 1:2])
     pad = ops.conv3d_dgrad(dev(dpred), dev(w1), lddz=3, dz_coff=1)
     close(ops.fold_halo([pad]), O.conv3d_dgrad(dzo, f64(w1), x.shape), name="64->1 dgrad")
+    ymask = rng.normal(size=(N, D, H, W, 64)).astype(np.float32)
+    close(ops.conv_cout1_dgrad_folded(dev(dpred), dev(w1), (N, D, H, W), dev(ymask), O.ACT_RELU, lddz=3, dz_coff=1),
+          O.conv3d_dgrad(dzo, f64(w1), x.shape) * (ymask > 0), name="64->1 dgrad folded+relu")
+    close(ops.conv_cout1_dgrad_folded(dev(dpred), dev(w1), (N, D, H, W), lddz=3, dz_coff=1),
+          O.conv3d_dgrad(dzo, f64(w1), x.shape), name="64->1 dgrad folded")
     dw, db = ops.conv3d_wgrad(dev(x), dev(dpred), 3, 64, 1, want_bias=True, lddz=3, dz_coff=1)
     close(dw, O.conv3d_wgrad(f64(x), dzo, 3), name="64->1 wgrad")
     close(db, O.bias_grad(dzo), name="64->1 bias grad")

@@ -1,6 +1,6 @@
 """Micro-benchmark of the MFMA kernels at the cfg2 shapes (run on the GPU box):
-    python tools/bench_kernels.py [--n 8] [--iters 20]
-Prints one line per kernel/shape: ms, TFLOP/s (algorithmic FLOPs), fraction of the 157.3 TF fp32-MFMA peak."""
+    python tools/bench_kernels.py [--n 8] [--iters 20] [--ablate]
+Prints one line per kernel/shape/variant: ms, TFLOP/s (algorithmic FLOPs), fraction of the 157.3 TF fp32-MFMA peak."""
 import argparse
 import importlib
 import os
@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 fdn = importlib.import_module("4dflownet_amd")
 ops = fdn.ops
 PEAK = 157.3
+VARIANTS = {0: "auto", 1: "<2,1,cs2>", 2: "<2,1,cs4>", 3: "<1,1,cs2>", 4: "<1,1,cs4>", 5: "<1,2,cs2>", 6: "<1,2,cs4>"}
 
 
 def timeit(fn, iters, warmup=3):
@@ -33,6 +34,7 @@ def main():
     ap.add_argument("--n", type=int, default=8)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--sizes", type=int, nargs="*", default=[24, 48])
+    ap.add_argument("--ablate", action="store_true")
     args = ap.parse_args()
     torch.manual_seed(0)
     lib = fdn._lib.load()
@@ -44,22 +46,28 @@ def main():
         wf, wd = ops.pack_conv64_weights(w)
         y = torch.empty_like(x)
         pad = torch.empty((N, P + 2, P + 2, P + 2, 64), device="cuda")
+        dxo = torch.empty_like(x)
         flop = 2.0 * 27 * 64 * 64 * N * P ** 3
-        for mt in (1, 2, 0):
-            lib.fdn_debug_set_conv64_mt(mt)
-            ms = timeit(lambda: ops.conv3d_fwd(x, w, None, ops.ACT_RELU, wpack=wf, out=y), args.iters)
-            print("conv64 fwd   N=%d P=%d mt=%d : %8.3f ms  %7.2f TF  %5.1f %% of peak" % (N, P, mt, ms, flop / ms * 1e-9, flop / ms * 1e-9 / PEAK * 100))
-            ms = timeit(lambda: ops.conv3d_dgrad(dz, w, wd, out=pad), args.iters)
-            print("conv64 dgrad N=%d P=%d mt=%d : %8.3f ms  %7.2f TF  %5.1f %% of peak (algorithmic flops)" % (N, P, mt, ms, flop / ms * 1e-9, flop / ms * 1e-9 / PEAK * 100))
+        rep = lambda name, ms: print("%-34s N=%d P=%d : %8.3f ms  %7.2f TF  %5.1f %% of peak" % (name, N, P, ms, flop / ms * 1e-9, flop / ms * 1e-9 / PEAK * 100))
+        for v in (1, 2, 3, 4, 5, 6, 0):
+            lib.fdn_debug_set_conv64_mt(v)
+            rep("conv64 fwd %s" % VARIANTS[v], timeit(lambda: ops.conv3d_fwd(x, w, None, ops.ACT_RELU, wpack=wf, out=y), args.iters))
+            rep("conv64 fwd+res+leaky %s" % VARIANTS[v], timeit(lambda: ops.conv3d_fwd(x, w, None, ops.ACT_LEAKY, 0.2, dz, wpack=wf, out=y), args.iters))
+            rep("conv64 dgrad(pad) %s" % VARIANTS[v], timeit(lambda: ops.conv3d_dgrad(dz, w, wd, out=pad), args.iters))
+            rep("conv64 dgrad fused+border %s" % VARIANTS[v], timeit(lambda: (ops.conv3d_dgrad_fused(dz, wd, pad, dxo, skip=x, y_prev=y, act=ops.ACT_LEAKY), ops.fold_halo_border([pad], dxo, x, y, ops.ACT_LEAKY)), args.iters))
+            if args.ablate and v in (1, 2, 4):
+                for dbg, name in ((1, "B stride 0"), (4, "no staging loads"), (8, "no epilogue"), (13, "all three")):
+                    lib.fdn_debug_set_conv64_dbg(dbg)
+                    rep("   ablation %s" % name, timeit(lambda: ops.conv3d_fwd(x, w, None, ops.ACT_RELU, wpack=wf, out=y), args.iters))
+                lib.fdn_debug_set_conv64_dbg(0)
         lib.fdn_debug_set_conv64_mt(0)
         ws = torch.empty(ops.wgrad_workspace_bytes(N, P, P, P, 64, 64, 3) // 4 + 1, device="cuda")
         dw = torch.empty_like(w)
-        ms = timeit(lambda: ops.conv3d_wgrad(x, dz, 3, 64, 64, dw=dw, workspace=ws), args.iters)
-        print("conv64 wgrad N=%d P=%d      : %8.3f ms  %7.2f TF  %5.1f %% of peak" % (N, P, ms, flop / ms * 1e-9, flop / ms * 1e-9 / PEAK * 100))
-        dxo = torch.empty_like(x)
+        rep("conv64 wgrad", timeit(lambda: ops.conv3d_wgrad(x, dz, 3, 64, 64, dw=dw, workspace=ws), args.iters))
         ms = timeit(lambda: ops.fold_halo([pad], x, y, ops.ACT_LEAKY, 0.2, out=dxo), args.iters)
-        gb = (pad.numel() + 3 * x.numel()) * 4 / 1e9
-        print("fold_halo    N=%d P=%d      : %8.3f ms  %7.1f GB/s" % (N, P, ms, gb / ms * 1e3))
+        print("fold_halo (full)  N=%d P=%d : %8.3f ms  %7.1f GB/s" % (N, P, ms, (pad.numel() + 3 * x.numel()) * 4 / 1e9 / ms * 1e3))
+        ms = timeit(lambda: ops.fold_halo_border([pad], dxo, x, y, ops.ACT_LEAKY), args.iters)
+        print("fold_halo_border  N=%d P=%d : %8.3f ms" % (N, P, ms))
 
 
 if __name__ == "__main__":
