@@ -25,31 +25,11 @@
 //   fp32 MFMA rate is 64 cyc / instruction / SIMD: per 8 cin a wave issues 4*MT*(2/NW) MFMAs against MT LDS reads and
 //   2/NW global loads, so the matrix pipe is the only busy resource by construction.
 #include "fdn_common.h"
+#include "conv64_args.h"
 
 // test/bench hooks (set through fdn_debug_* entry points; not part of include/fdn.h)
 static int fdn_conv64_force_layout = 0;   // 0 = auto, 1..6 = index into the variant table below
 static int fdn_conv64_dbg = 0;            // ablation bits, see Conv64Args::dbg
-
-struct Conv64Args {
-    const float* x;
-    const float* wp;
-    const float* bias;
-    const float* res;
-    float* y;
-    // fused fold (dgrad mode only): interior voxels are finished in the epilogue
-    const float* fskip;     // gradient to add (N,ID,IH,IW,64) or null
-    const float* fy;        // producer output for act' or null
-    float* fout;            // dz_prev (N,ID,IH,IW,64) or null (= plain padded-grid dgrad)
-    int N, ID, IH, IW, OD, OH, OW;
-    int off, zero_mode;
-    int td, th, tw, ntd, nth, ntw;
-    int hh, hw;                 // halo dims th+2, tw+2 (hd = td+2)
-    int rows;                   // hd*hh*hw
-    unsigned mg_hhhw, mg_hw;    // magic divisors for halo-row decomposition
-    int act;
-    float alpha;
-    int dbg;                    // ablation bits (bench only): 1 = B stream stride 0, 4 = no staging loads, 8 = no epilogue
-};
 
 template <int MT, int NW, int CS>
 struct Conv64Cfg {
@@ -149,7 +129,9 @@ void conv64_mfma_kernel(Conv64Args p) {
         if (sl) __syncthreads();  // everyone finished reading the previous slice
         // ---- stage input box + halo, cin [sl*64/CS, (sl+1)*64/CS) ----
         const float* xh = p.x + sl * (64 / CS) + chunk * 4;
-        constexpr int U = 4;
+        // loads per thread issued before the first LDS write: the whole slice (one memory round trip) when the variant runs
+        // at 2 workgroups per CU (256-VGPR budget), 4 otherwise
+        constexpr int U = C::WG_PER_CU <= 2 ? (C::MAXROWS + RPP - 1) / RPP : 4;
         for (int r0 = 0; r0 < rows_eff; r0 += RPP * U) {
             f32x4 v[U];
 #pragma unroll
@@ -217,60 +199,82 @@ void conv64_mfma_kernel(Conv64Args p) {
     if (p.dbg & 8) return;
 
     // ---- epilogue: 128-B row segments per half-wave.  Branch-free activation: act(z) = z > 0 ? z : slope*z with
-    // slope 1 (none) / 0 (relu) / alpha (leaky); rows handled 4 at a time so residual / mask loads overlap. ----
+    // slope 1 (none) / 0 (relu) / alpha (leaky).  Rows are handled RB at a time; the uniform "is there a residual / skip /
+    // mask tensor" tests sit OUTSIDE the per-row loops so each batch's loads are issued back to back (one latency). ----
     const float slope = p.act == FDN_ACT_RELU ? 0.f : (p.act == FDN_ACT_LEAKY ? p.alpha : 1.f);
     const int cofs = wave_n * (NT * 32) + li;
+    constexpr int RB = C::WG_PER_CU <= 2 ? 16 : (C::WG_PER_CU == 3 ? 8 : 4);    // batch size by VGPR budget
     float bvs[NT];
 #pragma unroll
-    for (int nn = 0; nn < NT; ++nn) bvs[nn] = p.bias ? p.bias[cofs + nn * 32] : 0.f;
+    for (int nn = 0; nn < NT; ++nn) bvs[nn] = 0.f;
+    if (p.bias) {
+#pragma unroll
+        for (int nn = 0; nn < NT; ++nn) bvs[nn] = p.bias[cofs + nn * 32];
+    }
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-            int g[4];
+        for (int r0 = 0; r0 < 16; r0 += RB) {
+            int g[RB];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) g[j] = mtab[(wave_m * MT + mi) * 32 + j + 8 * rq + 4 * kh];
+            for (int j = 0; j < RB; ++j) g[j] = mtab[(wave_m * MT + mi) * 32 + ((r0 + j) & 3) + 8 * ((r0 + j) >> 2) + 4 * kh];
             if (p.fout) {
                 // dgrad with fused fold: tagged rows (voxels strictly inside the volume, exactly one contribution)
                 // are finished here into dz_prev; everything else goes to the padded scratch for the border fold.
-                float sk[4][NT], ym[4][NT];
+                float sk[RB][NT], ym[RB][NT];
+                size_t oi[RB];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < RB; ++j) {
                     const bool inner = g[j] >= 0 && (g[j] & (1 << 30));
-                    const size_t o = (size_t)(inner ? (g[j] & ~(1 << 30)) : 0) * 64 + cofs;
+                    oi[j] = (size_t)(inner ? (g[j] & ~(1 << 30)) : 0) * 64 + cofs;
 #pragma unroll
-                    for (int nn = 0; nn < NT; ++nn) {
-                        sk[j][nn] = p.fskip ? p.fskip[o + nn * 32] : 0.f;
-                        ym[j][nn] = p.fy ? p.fy[o + nn * 32] : 1.f;
-                    }
+                    for (int nn = 0; nn < NT; ++nn) { sk[j][nn] = 0.f; ym[j][nn] = 1.f; }
+                }
+                if (p.fskip) {
+#pragma unroll
+                    for (int j = 0; j < RB; ++j)
+#pragma unroll
+                        for (int nn = 0; nn < NT; ++nn) sk[j][nn] = p.fskip[oi[j] + nn * 32];
+                }
+                if (p.fy) {
+#pragma unroll
+                    for (int j = 0; j < RB; ++j)
+#pragma unroll
+                        for (int nn = 0; nn < NT; ++nn) ym[j][nn] = p.fy[oi[j] + nn * 32];
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < RB; ++j) {
                     if (g[j] < 0) continue;
                     const bool inner = g[j] & (1 << 30);
                     const size_t o = (size_t)(g[j] & ~(1 << 30)) * 64 + cofs;
 #pragma unroll
                     for (int nn = 0; nn < NT; ++nn) {
-                        const float a = acc[mi][nn][rq * 4 + j];
+                        const float a = acc[mi][nn][r0 + j];
                         if (inner) p.fout[o + nn * 32] = (a + sk[j][nn]) * (ym[j][nn] > 0.f ? 1.f : slope);
                         else p.y[o + nn * 32] = a;
                     }
                 }
             } else {
-                float rv[4][NT];
+                float rv[RB][NT];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const size_t o = (size_t)(g[j] >= 0 ? g[j] : 0) * 64 + cofs;
+                for (int j = 0; j < RB; ++j)
 #pragma unroll
-                    for (int nn = 0; nn < NT; ++nn) rv[j][nn] = p.res ? p.res[o + nn * 32] : 0.f;
+                    for (int nn = 0; nn < NT; ++nn) rv[j][nn] = 0.f;
+                if (p.res) {
+#pragma unroll
+                    for (int j = 0; j < RB; ++j) {
+                        const size_t o = (size_t)(g[j] >= 0 ? g[j] : 0) * 64 + cofs;
+#pragma unroll
+                        for (int nn = 0; nn < NT; ++nn) rv[j][nn] = p.res[o + nn * 32];
+                    }
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < RB; ++j) {
                     if (g[j] < 0) continue;
                     const size_t o = (size_t)g[j] * 64 + cofs;
 #pragma unroll
                     for (int nn = 0; nn < NT; ++nn) {
-                        const float z = acc[mi][nn][rq * 4 + j] + bvs[nn] + rv[j][nn];
+                        const float z = acc[mi][nn][r0 + j] + bvs[nn] + rv[j][nn];
                         p.y[o + nn * 32] = z > 0.f ? z : slope * z;
                     }
                 }
@@ -440,9 +444,12 @@ int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, 
                         plan_for<1, 2, 2>(N, OD, OH, OW), plan_for<1, 2, 4>(N, OD, OH, OW)};
     int v = fdn_conv64_force_layout;
     if (v < 1 || v > 6) {
-        v = 2;                                                   // auto: among the measured-good variants
-        if (pl[6].cost < pl[v].cost) v = 6;
-        if (pl[4].cost < pl[v].cost) v = 4;
+        // auto: cheapest of the variants that measured best on MI355X (tools/bench_kernels.py): <2,1,cs2> on large grids
+        // (48^3/50^3: 122 / 107 TF), <1,2,cs2> or <2,1,cs4> on 24^3, <1,1,cs2> on 26^3
+        v = 1;
+        if (pl[2].cost < pl[v].cost) v = 2;
+        if (pl[3].cost < pl[v].cost) v = 3;
+        if (pl[5].cost < pl[v].cost) v = 5;
     }
     switch (v) {
         case 1: return launch_conv64<2, 1, 2>(a, pl[1].t, s);

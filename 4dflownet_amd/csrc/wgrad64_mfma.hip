@@ -52,65 +52,62 @@ __global__ __launch_bounds__(256, 2) void wgrad64_mfma_kernel(Wgrad64Args p) {
     const int c16 = tid & 15;   // 16-B chunk within a 256-B row
     const int rsub = tid >> 4;  // 0..15
 
-    for (int tile = split; tile < p.ntiles; tile += p.S) {
+    // Tile staging is software-pipelined through registers: the K loop below reads only LDS (no vector-memory waits), so
+    // the global loads of tile t+1 issued before it stay in flight under tile t's MFMAs and are written to LDS afterwards.
+    constexpr int XP = (XROWS + 15) / 16, ZP = (ZROWS + 15) / 16;     // float4 per thread for the x rows / dz rows
+    f32x4 xv[XP], zv[ZP];
+    auto prefetch = [&](int tile) {
         int b = tile;
         const int n = b / tiles_per_n;
         b -= n * tiles_per_n;
         const int tdi = b / (p.nth * p.ntw);
         b -= tdi * (p.nth * p.ntw);
         const int thi = b / p.ntw;
-        const int twi = b - thi * p.ntw;
-        const int p0d = tdi * TD, p0h = thi * TH, p0w = twi * TW;
+        const int p0d = tdi * TD, p0h = thi * TH, p0w = (b - thi * p.ntw) * TW;
         const size_t vox_n = (size_t)n * p.D * p.H * p.W;
-
-        __syncthreads();   // previous tile fully consumed
-        // ---- stage x rows (clamped) ----
-        for (int r0 = 0; r0 < XROWS; r0 += 64) {
-            f32x4 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int r = r0 + u * 16 + rsub;
-                if (r < XROWS) {
-                    const int zd = r / (XH * XW);
-                    const int r2 = r - zd * (XH * XW);
-                    const int zh = r2 / XW;
-                    const int zw = r2 - zh * XW;
-                    const int qd = min(max(p0d + zd + a - 1, 0), p.D - 1);
-                    const int qh = min(max(p0h + zh - 1, 0), p.H - 1);
-                    const int qw = min(max(p0w + zw - 1, 0), p.W - 1);
-                    v[u] = *(const f32x4*)(p.x + (vox_n + ((size_t)qd * p.H + qh) * p.W + qw) * 64 + c16 * 4);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int r = r0 + u * 16 + rsub;
-                if (r < XROWS) *(f32x4*)(xs + r * 256 + c16 * 16) = v[u];
+        for (int u = 0; u < XP; ++u) {          // x rows, edge clamp applied here
+            const int r = u * 16 + rsub;
+            xv[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (r < XROWS) {
+                const int zd = r / (XH * XW);
+                const int r2 = r - zd * (XH * XW);
+                const int zh = r2 / XW;
+                const int qd = min(max(p0d + zd + a - 1, 0), p.D - 1);
+                const int qh = min(max(p0h + zh - 1, 0), p.H - 1);
+                const int qw = min(max(p0w + (r2 - zh * XW) - 1, 0), p.W - 1);
+                xv[u] = *(const f32x4*)(p.x + (vox_n + ((size_t)qd * p.H + qh) * p.W + qw) * 64 + c16 * 4);
             }
         }
-        // ---- stage dz rows (zero outside the volume) ----
-        for (int r0 = 0; r0 < ZROWS; r0 += 64) {
-            f32x4 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int r = r0 + u * 16 + rsub;
-                v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (r < ZROWS) {
-                    const int zd = r / (TH * TW);
-                    const int r2 = r - zd * (TH * TW);
-                    const int zh = r2 / TW;
-                    const int zw = r2 - zh * TW;
-                    const int qd = p0d + zd, qh = p0h + zh, qw = p0w + zw;
-                    if (qd < p.D && qh < p.H && qw < p.W)
-                        v[u] = *(const f32x4*)(p.dz + (vox_n + ((size_t)qd * p.H + qh) * p.W + qw) * 64 + c16 * 4);
-                }
+        for (int u = 0; u < ZP; ++u) {          // dz rows, zero outside the volume
+            const int r = u * 16 + rsub;
+            zv[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (r < ZROWS) {
+                const int zd = r / (TH * TW);
+                const int r2 = r - zd * (TH * TW);
+                const int zh = r2 / TW;
+                const int qd = p0d + zd, qh = p0h + zh, qw = p0w + (r2 - zh * TW);
+                if (qd < p.D && qh < p.H && qw < p.W)
+                    zv[u] = *(const f32x4*)(p.dz + (vox_n + ((size_t)qd * p.H + qh) * p.W + qw) * 64 + c16 * 4);
             }
+        }
+    };
+    if (split < p.ntiles) prefetch(split);
+    for (int tile = split; tile < p.ntiles; tile += p.S) {
+        __syncthreads();   // previous tile fully consumed
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int r = r0 + u * 16 + rsub;
-                if (r < ZROWS) *(f32x4*)(zs + r * 256 + c16 * 16) = v[u];
-            }
+        for (int u = 0; u < XP; ++u) {
+            const int r = u * 16 + rsub;
+            if (r < XROWS) *(f32x4*)(xs + r * 256 + c16 * 16) = xv[u];
+        }
+#pragma unroll
+        for (int u = 0; u < ZP; ++u) {
+            const int r = u * 16 + rsub;
+            if (r < ZROWS) *(f32x4*)(zs + r * 256 + c16 * 16) = zv[u];
         }
         __syncthreads();
+        if (tile + p.S < p.ntiles) prefetch(tile + p.S);
 
         // ---- contract over the tile's voxels, two per MFMA (lane half kh picks the voxel of the pair) ----
         const char* xa = xs + (mq * 32 + li) * 4 + kh * 256;
