@@ -263,7 +263,8 @@ __global__ __launch_bounds__(256) void l2_sumsq_kernel(const float* __restrict__
 
 __global__ void adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             const uint8_t* __restrict__ isk, int64_t n, float lr_t, float b1, float b2, float eps,
-                            float l2s) {
+                            float l2s_host, const float* __restrict__ l2s_dev) {
+    const float l2s = l2s_dev ? l2s_host * l2s_dev[0] : l2s_host;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float wi = w[i];
         float gi = g[i];
@@ -358,10 +359,10 @@ extern "C" int fdn_l2_sumsq(const float* w, const uint8_t* is_kernel, int64_t n,
 }
 
 extern "C" int fdn_adam_step(float* w, const float* g, float* m, float* v, const uint8_t* is_kernel, int64_t n, float lr_t,
-                             float b1, float b2, float eps, float l2_grad_scale, void* stream) {
+                             float b1, float b2, float eps, float l2_grad_scale, const float* l2_scale_dev, void* stream) {
     FDN_REQUIRE(w && g && m && v && is_kernel && n > 0, "fdn_adam_step: bad argument");
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, (hipStream_t)stream, w, g, m, v, is_kernel, n,
-                       lr_t, b1, b2, eps, l2_grad_scale);
+                       lr_t, b1, b2, eps, l2_grad_scale, l2_scale_dev);
     FDN_CHECK_LAUNCH("adam_kernel");
     return FDN_OK;
 }

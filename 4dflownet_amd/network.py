@@ -69,7 +69,10 @@ class FlowNetModel:
         n = sum(k ** 3 * ci * co + (co if ub else 0) for _, k, ci, co, ub in self.specs)
         self.n_params = n
         self.flat_w = torch.zeros(n, device=self.device, dtype=torch.float32)
-        self.flat_g = torch.zeros(n, device=self.device, dtype=torch.float32)
+        # gradient buffer + one trailing slot that carries the per-rank batch size through the data-parallel all-reduce
+        self.flat_g_ext = torch.zeros(n + 1, device=self.device, dtype=torch.float32)
+        self.flat_g = self.flat_g_ext[:n]
+        self.batch_slot = self.flat_g_ext[n:n + 1]
         is_kernel = np.zeros(n, dtype=np.uint8)
         self.layers = []
         off = 0

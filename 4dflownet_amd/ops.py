@@ -204,6 +204,7 @@ def l2_sumsq(w_flat, is_kernel, out=None):
     return out
 
 
-def adam_step(w, g, m, v, is_kernel, lr_t, b1, b2, eps, l2_grad_scale):
+def adam_step(w, g, m, v, is_kernel, lr_t, b1, b2, eps, l2_grad_scale, l2_scale_dev=None):
     check(_lib.load().fdn_adam_step(_p(w), _p(g), _p(m), _p(v), _p(is_kernel), w.numel(), float(lr_t), float(b1), float(b2),
-                                    float(eps), float(l2_grad_scale), _stream()), "fdn_adam_step")
+                                    float(eps), float(l2_grad_scale), _p(l2_scale_dev, allow_none=True), _stream()),
+          "fdn_adam_step")

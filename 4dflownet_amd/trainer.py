@@ -125,15 +125,16 @@ class TrainerController:
         else:                                   # ragged tail on this rank: contribute a zero gradient
             m.flat_g.zero_()
             loss = None
-        Bg = B
+        # The trailing slot of the gradient buffer carries this rank's batch size; after the SUM all-reduce it holds the
+        # global batch size, which the Adam kernel reads on the device -- no host synchronisation per step.
+        m.batch_slot.fill_(float(B))
         if parallel.world_size() > 1:
-            parallel.allreduce_sum_(m.flat_g)
-            Bg = parallel.global_batch_size(B, self.device)
+            parallel.allreduce_sum_(m.flat_g_ext)
         opt = self.optimizer
         opt.iterations += 1
-        # L2 regulariser gradient: the (B,) loss vector carries the scalar L2 term B times (:249) -> B * 2*lambda*w
+        # L2 regulariser gradient: the (B,) loss vector carries the scalar L2 term B times (:249) -> B_global * 2*lambda*w
         ops.adam_step(m.flat_w, m.flat_g, opt.m, opt.v, m.is_kernel, opt.lr_t(), ADAM_B1, ADAM_B2, ADAM_EPS,
-                      Bg * 2.0 * L2_LAMBDA)
+                      2.0 * L2_LAMBDA, m.batch_slot)
         m.weights_changed()
         return loss
 

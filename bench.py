@@ -78,6 +78,19 @@ class ConvTimer:
         return n, total_ms / n, total_flop / n
 
 
+def pmc_traffic_bytes():
+    """HBM bytes per conv64 launch from the committed rocprofv3 PMC passes (profiles/r1_pmc_traffic.json, produced by
+    tools/pmc_traffic.py from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command, read side doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  Launch-weighted over the conv64 variants; None if the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    rows = [(v["launches"], v["hbm_bytes_per_launch"]) for k, v in d.items() if "conv64_mfma_kernel" in k]
+    n = sum(r[0] for r in rows)
+    return sum(r[0] * r[1] for r in rows) / n if n else None
+
+
 def cpu_baseline(P, R, LB, HB):
     """Time the CPU oracle (numpy float32 restatement of the same train step) on ONE patch: forward + loss +
     backward + Adam at the benchmark's network configuration.  Returns the cpu_baseline object."""
@@ -165,7 +178,9 @@ def main():
                                % (P, R, B, LB, HB), "global_batch": B * world, "parallelism": "dp%d" % world},
         "roofline": {"bound": "mfma", "kernel": "conv64_mfma_kernel (3x3x3 64->64 fwd + dgrad launches)",
                      "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic_bytes(),
+                     "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_pmc_traffic.json)",
+                     "algorithmic_bytes_per_launch": avg_flop / FLOP_PER_VOXEL_CONV64 * 512.0 + 442368.0,
                      "launches_timed": n_launch, "avg_launch_ms": avg_ms, "avg_launch_gflop": avg_flop / 1e9},
         "train_step_tflops": args.steps * B * world / dt * 986.5e9 / 1e12,
     }

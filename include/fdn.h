@@ -116,9 +116,12 @@ int fdn_l2_sumsq(const float* w, const uint8_t* is_kernel, int64_t n, float* out
 
 /* Keras Adam on one flat buffer, with the L2-regulariser gradient folded in:
  * g' = g + l2_grad_scale * w (kernels only); m,v EMA; w -= lr_t * m / (sqrt(v) + eps).
- * lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is computed by the caller.  TrainerController.py:73,225. */
+ * lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is computed by the caller.  If l2_scale_dev != NULL the scale is
+ * l2_grad_scale * l2_scale_dev[0], read on the device (data-parallel: the global batch size rides in the
+ * all-reduced gradient buffer, so no host synchronisation is needed).  TrainerController.py:73,225. */
 int fdn_adam_step(float* w, const float* g, float* m, float* v, const uint8_t* is_kernel, int64_t n,
-                  float lr_t, float b1, float b2, float eps, float l2_grad_scale, void* stream);
+                  float lr_t, float b1, float b2, float eps, float l2_grad_scale, const float* l2_scale_dev,
+                  void* stream);
 
 #ifdef __cplusplus
 }

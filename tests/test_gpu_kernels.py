@@ -214,7 +214,10 @@ def test_adam_and_l2(ops):
     for t in range(1, 4):
         lr_t = 1e-3 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
         O.adam_step_tf(wr, g.astype(np.float64) + l2s * wr * isk, m, v, t, 1e-3)
-        ops.adam_step(dw, dev(g), dm, dv, dk, lr_t, 0.9, 0.999, 1e-7, l2s)
+        if t == 2:      # the device-side scale (global batch carried through the all-reduce) is equivalent
+            ops.adam_step(dw, dev(g), dm, dv, dk, lr_t, 0.9, 0.999, 1e-7, 2 * O.L2_LAMBDA, torch.tensor([8.0], device="cuda"))
+        else:
+            ops.adam_step(dw, dev(g), dm, dv, dk, lr_t, 0.9, 0.999, 1e-7, l2s)
     # (1-b2) evaluated in fp32 (as Keras does for fp32 variables) is off by 1.3e-5 relative from the float64 oracle
     close(dw, wr, tol=5e-5, name="adam w"); close(dm, m, tol=1e-5, name="adam m"); close(dv, v, tol=5e-5, name="adam v")
 
