@@ -466,23 +466,34 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
     }
 }
 
-__global__ void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int nparts, int nelem) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= nelem) return;
-    float s0 = 0.f, s1 = 0.f;
-    int p = 0;
-    for (; p + 2 <= nparts; p += 2) {
-        s0 += partial[(size_t)p * nelem + e];
-        s1 += partial[(size_t)(p + 1) * nelem + e];
+// out[e] = sum_p partial[p][e].  Block = 32 elements x 8 part-lanes: the nparts-long chain is split 8 ways (and unrolled
+// 4x) so the reduction is not one long dependent latency chain per element; 128-B coalesced reads per part.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                               int nparts, int nelem) {
+    __shared__ float red[8][32];
+    const int ei = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + ei;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (e < nelem) {
+        int p = pl;
+        for (; p + 24 < nparts; p += 32) {
+            s0 += partial[(size_t)p * nelem + e];
+            s1 += partial[(size_t)(p + 8) * nelem + e];
+            s2 += partial[(size_t)(p + 16) * nelem + e];
+            s3 += partial[(size_t)(p + 24) * nelem + e];
+        }
+        for (; p < nparts; p += 8) s0 += partial[(size_t)p * nelem + e];
     }
-    if (p < nparts) s0 += partial[(size_t)p * nelem + e];
-    out[e] = s0 + s1;
+    red[pl][ei] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (pl == 0 && e < nelem)
+        out[e] = ((red[0][ei] + red[1][ei]) + (red[2][ei] + red[3][ei])) + ((red[4][ei] + red[5][ei]) + (red[6][ei] + red[7][ei]));
 }
 
 constexpr int kSmallBlocks = 512;   // partial-sum blocks of the thin-layer wgrad / bias kernels
 
 int reduce_partials(const float* partial, float* out, int nparts, int nelem, hipStream_t s) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((nelem + 255) / 256), dim3(256), 0, s, partial, out, nparts, nelem);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((nelem + 31) / 32), dim3(256), 0, s, partial, out, nparts, nelem);
     FDN_CHECK_LAUNCH("reduce_partials_kernel");
     return FDN_OK;
 }

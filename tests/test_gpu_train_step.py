@@ -139,6 +139,37 @@ def test_test_step_and_predict(fdn):
     assert torch.equal(w_before, tc.model.flat_w)          # test_step never updates
 
 
+def test_full_size_cfg2_patch_matches_oracle(fdn):
+    """BASELINE cfg2 network (patch 24, res x2, 8 LR + 4 HR ResBlocks, Glorot init as in bench.py) on ONE synthetic patch:
+    prediction, loss and every layer's gradient against the float32 CPU oracle (one ~1 TFLOP CPU train step, 20-60 s).
+    north_star tolerance: 1e-3 relative fp32."""
+    P, R, LB, HB = 24, 2, 8, 4
+    trainer_mod = __import__("importlib").import_module("4dflownet_amd.trainer")
+    tc = trainer_mod.TrainerController(P, R, initial_learning_rate=1e-4, quicksave_enable=False, low_resblock=LB,
+                                       hi_resblock=HB, seed=0)
+    params = O.init_params(0, LB, HB, np.float32)
+    batch = O.synthetic_batch(1, P, R, seed=1234)
+    ref = O.loss_and_grads(params, batch, R, LB, HB, f32_coeffs=True)
+    inputs, hires, venc, mask = tc._unpack(batch)
+    pred = tc.model.forward(inputs, training=True)
+    out, dpred = fdn.ops.loss_metrics(pred, hires[0], hires[1], hires[2], mask)
+    g = tc.model.backward(dpred).cpu().numpy().astype(np.float64)
+    assert rel_err(pred.cpu().numpy(), ref["pred"]) < 1e-3
+    assert rel_err(out[:, 0].cpu().numpy(), ref["mse"]) < 1e-3
+    assert abs(float(out[0, 1]) - float(ref["rel_err"][0])) < 0.5          # metric in percent, 1e-4 rounding steps
+    isk = tc.model.is_kernel.cpu().numpy().astype(np.float64)
+    g_total = g + 2 * O.L2_LAMBDA * tc.model.flat_w.cpu().numpy().astype(np.float64) * isk
+    gref = O.flatten(ref["grads"]).astype(np.float64)
+    worst = 0.0
+    for L in tc.model.layers:
+        sl = slice(L.w_off, L.w_off + L.w.numel())
+        worst = max(worst, rel_err(g_total[sl], gref[sl]))
+    assert worst < 1e-3, worst
+    # cosine of the whole 3.3 M-element gradient
+    cos = float(g_total @ gref / (np.linalg.norm(g_total) * np.linalg.norm(gref)))
+    assert cos > 1 - 1e-6
+
+
 def test_linearity_of_conv_at_full_size(fdn):
     """Size-independent property at the BASELINE shape (8,24^3,64): conv(ax+by) == a conv(x) + b conv(y)."""
     ops = fdn.ops
