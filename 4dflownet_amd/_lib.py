@@ -30,6 +30,7 @@ SIGNATURES = {
     "fdn_upsample_trilinear_fwd": (c_i, [c_fp, c_fp] + [c_i] * 6 + [c_fp]),
     "fdn_upsample_trilinear_bwd": (c_i, [c_fp, c_fp, c_i, c_f, c_fp] + [c_i] * 6 + [c_fp]),
     "fdn_loss_metrics": (c_i, [c_fp] * 8 + [c_i, c_i64, c_fp]),
+    "fdn_gather_patches": (c_i, [c_fp, c_fp, c_i, c_i, c_fp]),
     "fdn_l2_sumsq": (c_i, [c_fp, c_fp, c_i64, c_fp, c_fp]),
     "fdn_adam_step": (c_i, [c_fp] * 5 + [c_i64] + [c_f] * 5 + [c_fp, c_fp]),
 }

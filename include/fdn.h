@@ -110,6 +110,14 @@ int fdn_upsample_trilinear_bwd(const float* dy, const float* y_prev, int act, fl
 int fdn_loss_metrics(const float* pred, const float* uh, const float* vh, const float* wh, const float* mask,
                      float* out, float* dpred, float* scratch, int N, int64_t V, void* stream);
 
+/* On-device input pipeline: the per-sample slicing / np.rot90 / sign / normalisation / mask threshold of
+ * PatchHandler3D.load_patches_from_index_file (src/Network/PatchHandler3D.py:49-160) as one gather per output
+ * tensor.  desc: B device-resident descriptors of 56 bytes each
+ *   { const float* src (T,X,Y,Z volume); int32 X,Y,Z,t, x0,y0,z0, plane (0 none,1:(0,1),2:(0,2),3:(1,2)), k (rot90 count),
+ *     mode (0: out = sign*(v/div), 1: out = v >= div ? 1 : 0); float sign, div }
+ * out: (B,S,S,S) patches, S = patch edge. */
+int fdn_gather_patches(const void* desc, float* out, int B, int S, void* stream);
+
 /* sum of squares of the kernel (non-bias) parameters: the l2(5e-7) regulariser value is 5e-7 * out[0].
  * src/Network/TrainerController.py:129-141.  is_kernel: one byte per parameter. */
 int fdn_l2_sumsq(const float* w, const uint8_t* is_kernel, int64_t n, float* out, void* stream);
