@@ -139,6 +139,22 @@ def test_test_step_and_predict(fdn):
     assert torch.equal(w_before, tc.model.flat_w)          # test_step never updates
 
 
+def test_wgrad_side_stream_gives_identical_gradients(fdn):
+    """overlap_wgrad=True runs the weight-gradient launches on a second HIP stream; same kernels, same order within each
+    layer, so the gradient buffer must be bit-identical to the single-stream schedule."""
+    tc, _ = make(fdn, 8, 2, 2, 1, seed=3)
+    batch = O.synthetic_batch(2, 8, 2, seed=9)
+    grads = []
+    for ov in (False, True, True):
+        tc.model.overlap_wgrad = ov
+        inputs, hires, venc, mask = tc._unpack(batch)
+        pred = tc.model.forward(inputs, training=True)
+        out, dpred = fdn.ops.loss_metrics(pred, hires[0], hires[1], hires[2], mask)
+        grads.append(tc.model.backward(dpred).clone())
+        torch.cuda.synchronize()
+    assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
+
+
 def test_full_size_cfg2_patch_matches_oracle(fdn):
     """BASELINE cfg2 network (patch 24, res x2, 8 LR + 4 HR ResBlocks, Glorot init as in bench.py) on ONE synthetic patch:
     prediction, loss and every layer's gradient against the float32 CPU oracle (one ~1 TFLOP CPU train step, 20-60 s).
