@@ -30,6 +30,7 @@
 // test/bench hooks (set through fdn_debug_* entry points; not part of include/fdn.h)
 static int fdn_conv64_force_layout = 0;   // 0 = auto, 1..6 = index into the variant table below
 static int fdn_conv64_dbg = 0;            // ablation bits, see Conv64Args::dbg
+static int fdn_conv64_shell_slabs = 1;    // fused dgrad: 1 = inner box + 6 shell slabs, 0 = one launch over the padded grid
 
 template <int MT, int NW, int CS>
 struct Conv64Cfg {
@@ -52,7 +53,6 @@ void conv64_mfma_kernel(Conv64Args p) {
     using C = Conv64Cfg<MT, NW, CS>;
     constexpr int NT = C::NT, ROWB = C::ROWB, CH = C::CH, KG = C::KG;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* mtab = (int*)(smem + p.rows * ROWB);          // output voxel index of each tile row's output voxel, -1 if unused
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -62,18 +62,22 @@ void conv64_mfma_kernel(Conv64Args p) {
     const int wave_m = wave % C::WM;
     const int wave_n = wave / C::WM;
 
-    // ---- which tile ----
-    const int tiles_per_n = p.ntd * p.nth * p.ntw;
-    int b = blockIdx.x;
+    // ---- which region, which tile ----
+    int ri = 0;
+    while (ri + 1 < p.nreg && (int)blockIdx.x >= p.reg[ri + 1].first_block) ++ri;
+    const Conv64Region R = p.reg[ri];             // wave-uniform: lives in SGPRs
+    const int tiles_per_n = R.ntd * R.nth * R.ntw;
+    int b = (int)blockIdx.x - R.first_block;
     const int n = b / tiles_per_n;
     b -= n * tiles_per_n;
-    const int tdi = b / (p.nth * p.ntw);
-    b -= tdi * (p.nth * p.ntw);
-    const int thi = b / p.ntw;
-    const int p0d = tdi * p.td, p0h = thi * p.th, p0w = (b - thi * p.ntw) * p.tw;
+    const int tdi = b / (R.nth * R.ntw);
+    b -= tdi * (R.nth * R.ntw);
+    const int thi = b / R.ntw;
+    int* mtab = (int*)(smem + R.rows * ROWB);          // output voxel index of each tile row, -1 if unused
+    const int p0d = R.obd + tdi * R.td, p0h = R.obh + thi * R.th, p0w = R.obw + (b - thi * R.ntw) * R.tw;
 
-    const int nv = p.td * p.th * p.tw;
-    const int thtw = p.th * p.tw;
+    const int nv = R.td * R.th * R.tw;
+    const int thtw = R.th * R.tw;
 
     // ---- output voxel of each tile row: padded-grid voxel index (bit 31 clear), or -1 ----
     for (int m = tid; m < C::MCAP; m += 256) {
@@ -81,9 +85,9 @@ void conv64_mfma_kernel(Conv64Args p) {
         if (m < nv) {
             const int md = m / thtw;
             const int r2 = m - md * thtw;
-            const int mh = r2 / p.tw;
-            const int pd = p0d + md, ph = p0h + mh, pw = p0w + (r2 - mh * p.tw);
-            if (pd < p.OD && ph < p.OH && pw < p.OW) {
+            const int mh = r2 / R.tw;
+            const int pd = p0d + md, ph = p0h + mh, pw = p0w + (r2 - mh * R.tw);
+            if (pd < R.obd + R.ebd && ph < R.obh + R.ebh && pw < R.obw + R.ebw) {
                 g = ((n * p.OD + pd) * p.OH + ph) * p.OW + pw;
                 if (p.fout) {
                     // fused fold: rows strictly inside the input volume are redirected to dz_prev (tag bit 30)
@@ -104,8 +108,8 @@ void conv64_mfma_kernel(Conv64Args p) {
         m = m < nv ? m : nv - 1;
         const int md = m / thtw;
         const int r2 = m - md * thtw;
-        const int mh = r2 / p.tw;
-        row0[mi] = (md * p.hh + mh) * p.hw + (r2 - mh * p.tw);
+        const int mh = r2 / R.tw;
+        row0[mi] = (md * R.hh + mh) * R.hw + (r2 - mh * R.tw);
     }
 
     f32x16 acc[MT][NT];
@@ -119,10 +123,12 @@ void conv64_mfma_kernel(Conv64Args p) {
     const int chunk = tid % CH;
     const int rsub = tid / CH;
     constexpr int RPP = 256 / CH;                      // rows staged per pass
-    const int rows_eff = (p.dbg & 4) ? 0 : p.rows;
+    const int rows_eff = (p.dbg & 4) ? 0 : R.rows;
     const int bstride = (p.dbg & 1) ? 0 : 128;
     const size_t in_n = (size_t)n * p.ID * p.IH * p.IW;
-    const int q0d = p0d - 1 + p.off, q0h = p0h - 1 + p.off, q0w = p0w - 1 + p.off;
+    // staged box origin in input coordinates: output p reads input p + tap - 1 + off, first staged tap is (ta0,tb0,tc0)
+    const int q0d = p0d - 1 + p.off + R.ta0, q0h = p0h - 1 + p.off + R.tb0, q0w = p0w - 1 + p.off + R.tc0;
+    const int ntap = (R.ta1 - R.ta0 + 1) * (R.tb1 - R.tb0 + 1) * (R.tc1 - R.tc0 + 1);
 
 #pragma unroll 1
     for (int sl = 0; sl < CS; ++sl) {
@@ -139,10 +145,10 @@ void conv64_mfma_kernel(Conv64Args p) {
                 const int r = r0 + u * RPP + rsub;
                 v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (r < rows_eff) {
-                    const int zd = fdn_div20(r, p.mg_hhhw);
-                    const int r2 = r - zd * p.hh * p.hw;
-                    const int zh = fdn_div20(r2, p.mg_hw);
-                    int qd = q0d + zd, qh = q0h + zh, qw = q0w + (r2 - zh * p.hw);
+                    const int zd = fdn_div20(r, R.mg_hhhw);
+                    const int r2 = r - zd * R.hh * R.hw;
+                    const int zh = fdn_div20(r2, R.mg_hw);
+                    int qd = q0d + zd, qh = q0h + zh, qw = q0w + (r2 - zh * R.hw);
                     bool ok = true;
                     if (p.zero_mode) {
                         ok = (unsigned)qd < (unsigned)p.ID && (unsigned)qh < (unsigned)p.IH && (unsigned)qw < (unsigned)p.IW;
@@ -166,15 +172,16 @@ void conv64_mfma_kernel(Conv64Args p) {
         // stream index of (slice, tap, local k-group gl): half = cin/32, g = k-group within the half
         const int half = (sl * KG) >> 2, g0 = (sl * KG) & 3;
         const f32x4* bp = (const f32x4*)p.wp + ((size_t)half * 27 * 4 + g0) * 128 + kh * 64 + wave_n * (NT * 32) + li;
-        int ta = 0, tb = 0, tc = 0;
+        int ta = R.ta0, tb = R.tb0, tc = R.tc0;
 #pragma unroll 1
-        for (int tap = 0; tap < 27; ++tap) {
+        for (int it = 0; it < ntap; ++it) {
+            const int tap = (ta * 3 + tb) * 3 + tc;
             f32x4 bv[KG][NT];
 #pragma unroll
             for (int g = 0; g < KG; ++g)
 #pragma unroll
                 for (int nn = 0; nn < NT; ++nn) bv[g][nn] = bp[(tap * 4 + g) * bstride + nn * 32];
-            const int tapoff = (ta * p.hh + tb) * p.hw + tc;
+            const int tapoff = ((ta - R.ta0) * R.hh + (tb - R.tb0)) * R.hw + (tc - R.tc0);
             f32x4 av[MT][KG];
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi) {
@@ -193,7 +200,7 @@ void conv64_mfma_kernel(Conv64Args p) {
 #pragma unroll
                         for (int nn = 0; nn < NT; ++nn)
                             acc[mi][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][g][s], bv[g][nn][s], acc[mi][nn], 0, 0, 0);
-            if (++tc == 3) { tc = 0; if (++tb == 3) { tb = 0; ++ta; } }
+            if (++tc > R.tc1) { tc = R.tc0; if (++tb > R.tb1) { tb = R.tb0; ++ta; } }
         }
     }
     if (p.dbg & 8) return;
@@ -371,13 +378,16 @@ extern "C" int fdn_pack_conv64_weights(const float* w, float* wp_fwd, float* wp_
 // --------------------------------------------------------------------------------------------
 namespace {
 
+// an output box of the (OD,OH,OW) grid and the tap range that is non-zero for it
+struct Box { int od, oh, ow, ed, eh, ew, ta0, ta1, tb0, tb1, tc0, tc1; };
 struct Plan { FdnTile t; double cost; };
 
 // estimated time of a launch in units of "one M row through all 27x64 K steps on one CU"
-double plan_cost(const FdnTile& t, int N, int mcap, int cs) {
+double plan_cost(const FdnTile& t, int N, int mcap, int cs, const Box& bx) {
     const double tiles = (double)N * t.ntd * t.nth * t.ntw;
-    const double rows = (double)(t.td + 2) * (t.th + 2) * (t.tw + 2);
-    const double per_tile = mcap + 0.02 * rows + 3.0 * cs + 4.0;     // MFMA work + staging + barriers + epilogue
+    const double rows = (double)(t.td + bx.ta1 - bx.ta0) * (t.th + bx.tb1 - bx.tb0) * (t.tw + bx.tc1 - bx.tc0);
+    const double tapfrac = (bx.ta1 - bx.ta0 + 1) * (bx.tb1 - bx.tb0 + 1) * (bx.tc1 - bx.tc0 + 1) / 27.0;
+    const double per_tile = mcap * tapfrac + 0.02 * rows + 3.0 * cs + 4.0;     // MFMA work + staging + barriers + epilogue
     const double per_cu_max = (double)((long long)((tiles + 255) / 256));
     const double per_cu_avg = tiles / 256.0;
     // the launch ends when the busiest CU does (measured: 24^3 N=8 runs 11 % faster as 1728 tiles of 64 voxels, 7 per CU,
@@ -385,33 +395,48 @@ double plan_cost(const FdnTile& t, int N, int mcap, int cs) {
     return (0.95 * per_cu_max + 0.05 * per_cu_avg) * per_tile;
 }
 
-Plan best_plan(int N, int OD, int OH, int OW, int mcap, int max_rows, int cs) {
-    Plan best{{1, 1, 2, OD, OH, (OW + 1) / 2}, 1e30};
-    for (int td = 1; td <= OD && td <= mcap; ++td)
-        for (int th = 1; th <= OH && td * th <= mcap; ++th)
-            for (int tw = 1; tw <= OW && td * th * tw <= mcap; ++tw) {
-                if ((td + 2) * (th + 2) * (tw + 2) > max_rows) continue;
-                FdnTile t{td, th, tw, (OD + td - 1) / td, (OH + th - 1) / th, (OW + tw - 1) / tw};
-                const double c = plan_cost(t, N, mcap, cs);
+Plan best_plan(int N, const Box& bx, int mcap, int max_rows, int cs) {
+    Plan best{{1, 1, 1, bx.ed, bx.eh, bx.ew}, 1e30};
+    const int da = bx.ta1 - bx.ta0, db = bx.tb1 - bx.tb0, dc = bx.tc1 - bx.tc0;
+    for (int td = 1; td <= bx.ed && td <= mcap; ++td)
+        for (int th = 1; th <= bx.eh && td * th <= mcap; ++th)
+            for (int tw = 1; tw <= bx.ew && td * th * tw <= mcap; ++tw) {
+                if ((td + da) * (th + db) * (tw + dc) > max_rows) continue;
+                FdnTile t{td, th, tw, (bx.ed + td - 1) / td, (bx.eh + th - 1) / th, (bx.ew + tw - 1) / tw};
+                const double c = plan_cost(t, N, mcap, cs, bx);
                 if (c < best.cost) best = {t, c};
             }
     return best;
 }
 
 template <int MT, int NW, int CS>
-Plan plan_for(int N, int OD, int OH, int OW) {
+Plan plan_for(int N, const Box& bx) {
     using C = Conv64Cfg<MT, NW, CS>;
-    return best_plan(N, OD, OH, OW, C::MCAP, C::MAXROWS, CS);
+    return best_plan(N, bx, C::MCAP, C::MAXROWS, CS);
 }
 
 template <int MT, int NW, int CS>
-int launch_conv64(Conv64Args& a, const FdnTile& t, hipStream_t s) {
+int launch_conv64(Conv64Args& a, const Box* boxes, int nbox, hipStream_t s) {
     using C = Conv64Cfg<MT, NW, CS>;
-    a.td = t.td; a.th = t.th; a.tw = t.tw; a.ntd = t.ntd; a.nth = t.nth; a.ntw = t.ntw;
-    a.hh = t.th + 2; a.hw = t.tw + 2;
-    a.rows = (t.td + 2) * a.hh * a.hw;
-    a.mg_hhhw = fdn_magic20(a.hh * a.hw);
-    a.mg_hw = fdn_magic20(a.hw);
+    int first = 0, max_rows = 0;
+    a.nreg = 0;
+    for (int i = 0; i < nbox; ++i) {
+        const Box& bx = boxes[i];
+        if (bx.ed <= 0 || bx.eh <= 0 || bx.ew <= 0) continue;
+        const FdnTile t = plan_for<MT, NW, CS>(a.N, bx).t;
+        Conv64Region& r = a.reg[a.nreg++];
+        r.first_block = first;
+        r.obd = bx.od; r.obh = bx.oh; r.obw = bx.ow; r.ebd = bx.ed; r.ebh = bx.eh; r.ebw = bx.ew;
+        r.ta0 = bx.ta0; r.ta1 = bx.ta1; r.tb0 = bx.tb0; r.tb1 = bx.tb1; r.tc0 = bx.tc0; r.tc1 = bx.tc1;
+        r.td = t.td; r.th = t.th; r.tw = t.tw; r.ntd = t.ntd; r.nth = t.nth; r.ntw = t.ntw;
+        r.hh = t.th + (bx.tb1 - bx.tb0); r.hw = t.tw + (bx.tc1 - bx.tc0);
+        r.rows = (t.td + (bx.ta1 - bx.ta0)) * r.hh * r.hw;
+        r.mg_hhhw = fdn_magic20(r.hh * r.hw);
+        r.mg_hw = fdn_magic20(r.hw);
+        first += a.N * t.ntd * t.nth * t.ntw;
+        if (r.rows > max_rows) max_rows = r.rows;
+    }
+    if (a.nreg == 0) return FDN_OK;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)conv64_mfma_kernel<MT, NW, CS>,
@@ -419,17 +444,41 @@ int launch_conv64(Conv64Args& a, const FdnTile& t, hipStream_t s) {
         if (e != hipSuccess) { fdn_set_error("conv64: hipFuncSetAttribute: %s", hipGetErrorString(e)); return FDN_ERR_HIP; }
         attr_set = true;
     }
-    const long long grid = (long long)a.N * t.ntd * t.nth * t.ntw;
-    const size_t lds = (size_t)a.rows * C::ROWB + C::MCAP * 4;
-    hipLaunchKernelGGL((conv64_mfma_kernel<MT, NW, CS>), dim3((unsigned)grid), dim3(256), lds, s, a);
+    const size_t lds = (size_t)max_rows * C::ROWB + C::MCAP * 4;
+    hipLaunchKernelGGL((conv64_mfma_kernel<MT, NW, CS>), dim3((unsigned)first), dim3(256), lds, s, a);
     FDN_CHECK_LAUNCH("conv64_mfma_kernel");
     return FDN_OK;
+}
+
+// pick the variant from the first (dominant) box, then launch all boxes as regions of ONE launch
+int launch_boxes(Conv64Args& a, const Box* boxes, int nbox, hipStream_t s) {
+    const Box& bx = boxes[0];
+    // variant table: 1:<2,1,2> 2:<2,1,4> 3:<1,1,2> 4:<1,1,4> 5:<1,2,2> 6:<1,2,4>
+    const double c[7] = {1e30, plan_for<2, 1, 2>(a.N, bx).cost, plan_for<2, 1, 4>(a.N, bx).cost, plan_for<1, 1, 2>(a.N, bx).cost,
+                         1e30, plan_for<1, 2, 2>(a.N, bx).cost, 1e30};
+    int v = fdn_conv64_force_layout;
+    if (v < 1 || v > 6) {
+        // auto: cheapest of the variants that measured best on MI355X (tools/bench_kernels.py): <2,1,cs2> on large grids
+        // (48^3: 122 TF), <1,2,cs2> or <2,1,cs4> on 24^3, <1,1,cs2> on 26^3
+        v = 1;
+        if (c[2] < c[v]) v = 2;
+        if (c[3] < c[v]) v = 3;
+        if (c[5] < c[v]) v = 5;
+    }
+    switch (v) {
+        case 1: return launch_conv64<2, 1, 2>(a, boxes, nbox, s);
+        case 2: return launch_conv64<2, 1, 4>(a, boxes, nbox, s);
+        case 3: return launch_conv64<1, 1, 2>(a, boxes, nbox, s);
+        case 4: return launch_conv64<1, 1, 4>(a, boxes, nbox, s);
+        case 5: return launch_conv64<1, 2, 2>(a, boxes, nbox, s);
+        default: return launch_conv64<1, 2, 4>(a, boxes, nbox, s);
+    }
 }
 
 }  // namespace
 
 FdnTile fdn_plan_tile(int N, int OD, int OH, int OW, int max_vox, int max_halo_rows, int) {
-    return best_plan(N, OD, OH, OW, max_vox, max_halo_rows, 2).t;
+    return best_plan(N, Box{0, 0, 0, OD, OH, OW, 0, 2, 0, 2, 0, 2}, max_vox, max_halo_rows, 2).t;
 }
 
 int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, const float* residual, float* y,
@@ -440,27 +489,19 @@ int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, 
     a.fskip = fskip; a.fy = fy; a.fout = fout;
     a.N = N; a.ID = ID; a.IH = IH; a.IW = IW; a.OD = OD; a.OH = OH; a.OW = OW;
     a.off = off; a.zero_mode = zero_mode; a.act = act; a.alpha = alpha; a.dbg = fdn_conv64_dbg;
-    // variant table: 1:<2,1,2> 2:<2,1,4> 3:<1,1,2> 4:<1,1,4> 5:<1,2,2> 6:<1,2,4>
-    const Plan pl[7] = {Plan{{}, 1e30}, plan_for<2, 1, 2>(N, OD, OH, OW), plan_for<2, 1, 4>(N, OD, OH, OW),
-                        plan_for<1, 1, 2>(N, OD, OH, OW), plan_for<1, 1, 4>(N, OD, OH, OW),
-                        plan_for<1, 2, 2>(N, OD, OH, OW), plan_for<1, 2, 4>(N, OD, OH, OW)};
-    int v = fdn_conv64_force_layout;
-    if (v < 1 || v > 6) {
-        // auto: cheapest of the variants that measured best on MI355X (tools/bench_kernels.py): <2,1,cs2> on large grids
-        // (48^3/50^3: 122 / 107 TF), <1,2,cs2> or <2,1,cs4> on 24^3, <1,1,cs2> on 26^3
-        v = 1;
-        if (pl[2].cost < pl[v].cost) v = 2;
-        if (pl[3].cost < pl[v].cost) v = 3;
-        if (pl[5].cost < pl[v].cost) v = 5;
-    }
-    switch (v) {
-        case 1: return launch_conv64<2, 1, 2>(a, pl[1].t, s);
-        case 2: return launch_conv64<2, 1, 4>(a, pl[2].t, s);
-        case 3: return launch_conv64<1, 1, 2>(a, pl[3].t, s);
-        case 4: return launch_conv64<1, 1, 4>(a, pl[4].t, s);
-        case 5: return launch_conv64<1, 2, 2>(a, pl[5].t, s);
-        default: return launch_conv64<1, 2, 4>(a, pl[6].t, s);
-    }
+    const Box full{0, 0, 0, OD, OH, OW, 0, 2, 0, 2, 0, 2};
+    if (!(fout && zero_mode && off == -1 && fdn_conv64_shell_slabs)) return launch_boxes(a, &full, 1, s);
+    // Fused dgrad on the padded grid (OD = ID+2): padded index p <-> position P = p-1 reads dz[p - 2 + tap], zero outside.
+    // The inner box p in [1,ID]^3 needs all 27 taps.  Every shell position has at least one coordinate at 0 or ID+1, where
+    // only tap 2 (resp. tap 0) of that dimension can reach a real voxel: six disjoint 1-voxel slabs with 9 taps each
+    // (and a 1-deep staging box in the slab's normal direction) replace the (ID+2)^3 - ID^3 extra positions of a plain
+    // padded launch at a third of their MFMA work.  All seven regions go out as ONE launch.
+    const Box boxes[7] = {
+        {1, 1, 1, ID, IH, IW, 0, 2, 0, 2, 0, 2},
+        {0, 0, 0, 1, OH, OW, 2, 2, 0, 2, 0, 2},       {ID + 1, 0, 0, 1, OH, OW, 0, 0, 0, 2, 0, 2},     // d faces, full (h,w)
+        {1, 0, 0, ID, 1, OW, 0, 2, 2, 2, 0, 2},       {1, IH + 1, 0, ID, 1, OW, 0, 2, 0, 0, 0, 2},     // h faces, d inner
+        {1, 1, 0, ID, IH, 1, 0, 2, 0, 2, 2, 2},       {1, 1, IW + 1, ID, IH, 1, 0, 2, 0, 2, 0, 0}};    // w faces, d,h inner
+    return launch_boxes(a, boxes, 7, s);
 }
 
 int fdn_conv64_launch(const float* x, const float* wpack, const float* bias, const float* residual, float* y, int N,
@@ -487,3 +528,4 @@ int fdn_fold_halo_border_launch(const float* s0, const float* s1, const float* s
 
 extern "C" int fdn_debug_set_conv64_mt(int layout) { fdn_conv64_force_layout = layout; return FDN_OK; }
 extern "C" int fdn_debug_set_conv64_dbg(int bits) { fdn_conv64_dbg = bits; return FDN_OK; }
+extern "C" int fdn_debug_set_conv64_shell_slabs(int on) { fdn_conv64_shell_slabs = on; return FDN_OK; }

@@ -353,8 +353,8 @@ __device__ __forceinline__ int pairs_of(int i, int n, int* o, int* a) {
 
 __global__ __launch_bounds__(256) void conv_cout1_dgrad_folded_kernel(const float* __restrict__ dz, const float* __restrict__ w,
                                                                        const float* __restrict__ yprev, int act, float alpha,
-                                                                       float* __restrict__ out, int N, int D, int H, int W,
-                                                                       int lddz, int dz_coff) {
+                                                                       float* __restrict__ out, float* __restrict__ bpart,
+                                                                       int N, int D, int H, int W, int lddz, int dz_coff) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* wl = sm;                 // 27 * 64 weights
     float* z = sm + 27 * 64;        // 9 rows * W
@@ -362,6 +362,7 @@ __global__ __launch_bounds__(256) void conv_cout1_dgrad_folded_kernel(const floa
     for (int i = threadIdx.x; i < 27 * 64; i += 256) wl[i] = w[i];
     const int q = threadIdx.x & 15, g = threadIdx.x >> 4;
     const int nrows = N * D * H;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
         const int n = row / (D * H);
         const int r2 = row - n * (D * H);
@@ -393,7 +394,26 @@ __global__ __launch_bounds__(256) void conv_cout1_dgrad_folded_kernel(const floa
                 acc.z *= fdn_act_grad(y.z, act, alpha); acc.w *= fdn_act_grad(y.w, act, alpha);
             }
             *(f32x4*)(out + o) = acc;
+            bsum += acc;
         }
+    }
+    if (bpart) {
+        // BiasAddGrad of the producing layer = per-channel sum of dz_prev: fold the 4 position slots of a wave
+        // (lane bits 4,5), then the 4 waves through LDS; one 64-float partial per block
+        __syncthreads();
+        float* red = sm;                        // reuse the weight area
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = bsum[e];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            bsum[e] = v;
+        }
+        if ((threadIdx.x & 63) < 16) *(f32x4*)(red + (threadIdx.x >> 6) * 64 + q * 4) = bsum;
+        __syncthreads();
+        if (threadIdx.x < 64)
+            bpart[(size_t)blockIdx.x * 64 + threadIdx.x] = (red[threadIdx.x] + red[64 + threadIdx.x]) +
+                                                            (red[128 + threadIdx.x] + red[192 + threadIdx.x]);
     }
 }
 
@@ -577,15 +597,21 @@ int fdn_wgrad_cout1_launch(const float* x, const float* dz, float* dw, void* ws,
 }
 
 extern "C" int fdn_conv_cout1_dgrad_folded(const float* dz, const float* w, const float* y_prev, int act, float alpha,
-                                           float* dz_prev, int N, int D, int H, int W, int lddz, int dz_coff, void* stream) {
+                                           float* dz_prev, float* dbias_prev, void* workspace, size_t workspace_bytes, int N,
+                                           int D, int H, int W, int lddz, int dz_coff, void* stream) {
     FDN_REQUIRE(dz && w && dz_prev && N > 0 && D > 0 && H > 0 && W > 0, "fdn_conv_cout1_dgrad_folded: bad argument");
     FDN_REQUIRE(W <= 4096, "fdn_conv_cout1_dgrad_folded: W too large for the row stage");
     const int nrows = N * D * H;
-    const int nb = nrows < 4096 ? nrows : 4096;
+    const int nb = nrows < 2048 ? nrows : 2048;
+    if (dbias_prev && (!workspace || workspace_bytes < (size_t)nb * 64 * sizeof(float))) {
+        fdn_set_error("fdn_conv_cout1_dgrad_folded: workspace %zu < %zu bytes", workspace_bytes, (size_t)nb * 64 * sizeof(float));
+        return FDN_ERR_WORKSPACE;
+    }
     const size_t lds = (size_t)(27 * 64 + 9 * W + 16) * sizeof(float);
     hipLaunchKernelGGL(conv_cout1_dgrad_folded_kernel, dim3(nb), dim3(256), lds, (hipStream_t)stream, dz, w, y_prev, act,
-                       alpha, dz_prev, N, D, H, W, lddz, dz_coff);
+                       alpha, dz_prev, dbias_prev ? (float*)workspace : nullptr, N, D, H, W, lddz, dz_coff);
     FDN_CHECK_LAUNCH("conv_cout1_dgrad_folded_kernel");
+    if (dbias_prev) return reduce_partials((const float*)workspace, dbias_prev, nb, 64, (hipStream_t)stream);
     return FDN_OK;
 }
 

@@ -105,6 +105,7 @@ class FlowNetModel:
         assert off == n
         self.is_kernel = torch.tensor(is_kernel, device=self.device)
         self._ws = None
+        self._ws_bias = None
         self._side = None              # second HIP stream for the weight-gradient launches
         self.overlap_wgrad = False     # measured +0.7 % at cfg2 (kernels already fill the chip); off so per-kernel timings stay clean
         self._cache = None
@@ -237,21 +238,23 @@ class FlowNetModel:
             self._ws = torch.empty((nbytes + 3) // 4, device=self.device, dtype=torch.float32)
         return self._ws
 
-    def _wgrad(self, x, dz, L, x2=None, lddz=None, dz_coff=0):
+    def _wgrad(self, x, dz, L, x2=None, lddz=None, dz_coff=0, bias=True):
         """Weight (+bias) gradient of layer L into the flat gradient buffer.  Weight gradients are leaves of the backward
         graph (nothing downstream reads them before the optimizer), so they run on a second HIP stream and fill the tails
         of the dgrad chain's kernels; backward() joins the streams before returning."""
         N, D, H, W = x.shape[:4]
         ws = self._workspace(ops.wgrad_workspace_bytes(N, D, H, W, L.cin, L.cout, L.k))
         if not self.overlap_wgrad:
-            ops.conv3d_wgrad(x, dz, L.k, L.cin, L.cout, x2=x2, dw=L.gw, dbias=L.gb, workspace=ws, lddz=lddz, dz_coff=dz_coff)
+            ops.conv3d_wgrad(x, dz, L.k, L.cin, L.cout, x2=x2, dw=L.gw, dbias=L.gb if bias else None, workspace=ws, lddz=lddz,
+                             dz_coff=dz_coff)
             return
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
         main = torch.cuda.current_stream()
         self._side.wait_stream(main)                      # dz (and the workspace allocation) are ready
         with torch.cuda.stream(self._side):
-            ops.conv3d_wgrad(x, dz, L.k, L.cin, L.cout, x2=x2, dw=L.gw, dbias=L.gb, workspace=ws, lddz=lddz, dz_coff=dz_coff)
+            ops.conv3d_wgrad(x, dz, L.k, L.cin, L.cout, x2=x2, dw=L.gw, dbias=L.gb if bias else None, workspace=ws, lddz=lddz,
+                             dz_coff=dz_coff)
         for t in (x, dz, x2):                             # keep the caching allocator from recycling them too early
             if t is not None:
                 t.record_stream(self._side)
@@ -292,9 +295,13 @@ class FlowNetModel:
             g = c["heads"][hidx]
             c["heads"][hidx] = None
             self._wgrad(g, dpred, L2, lddz=3, dz_coff=hidx)
-            dz_g = ops.conv_cout1_dgrad_folded(dpred, L2.w, tuple(g.shape[:4]), g, ACT_RELU, lddz=3, dz_coff=hidx)
+            # the folded head dgrad also emits the bias gradient of the 64->64 head conv (sum of dz_g) while it has it in registers
+            if self._ws_bias is None:
+                self._ws_bias = torch.empty(2048 * 64, device=self.device, dtype=torch.float32)
+            dz_g = ops.conv_cout1_dgrad_folded(dpred, L2.w, tuple(g.shape[:4]), g, ACT_RELU, lddz=3, dz_coff=hidx,
+                                               dbias_prev=L1.gb, workspace=self._ws_bias)
             del g
-            self._wgrad(rb.t, dz_g, L1)
+            self._wgrad(rb.t, dz_g, L1, bias=False)
             pad = self._pad_like(rb.t)
             y_m, a_m = act_of(rb) if hidx == 2 else (None, ACT_NONE)
             ops.conv3d_dgrad_fused(dz_g, L1.wp_d, pad, dz, skip=dz if hidx > 0 else None, y_prev=y_m, act=a_m)

@@ -87,13 +87,19 @@ def conv3d_dgrad(dz, w, wpack_dgrad=None, out=None, lddz=None, dz_coff=0, spatia
     return out
 
 
-def conv_cout1_dgrad_folded(dz, w, spatial, y_prev=None, act=ACT_NONE, alpha=LEAKY_ALPHA, lddz=1, dz_coff=0, out=None):
-    """64->1 head dgrad + halo fold + act'(y_prev) in one kernel.  Returns (N,D,H,W,64)."""
+def conv_cout1_dgrad_folded(dz, w, spatial, y_prev=None, act=ACT_NONE, alpha=LEAKY_ALPHA, lddz=1, dz_coff=0, out=None,
+                            dbias_prev=None, workspace=None):
+    """64->1 head dgrad + halo fold + act'(y_prev) in one kernel.  Returns (N,D,H,W,64).  With dbias_prev (64 floats) it
+    also emits the producing layer's bias gradient (sum of the result over voxels); needs a >= 512 KB workspace."""
     N, D, H, W = spatial
     if out is None:
         out = torch.empty((N, D, H, W, 64), device=dz.device, dtype=torch.float32)
+    if dbias_prev is not None and workspace is None:
+        workspace = torch.empty(2048 * 64, device=dz.device, dtype=torch.float32)
+    wsb = 0 if workspace is None else workspace.numel() * workspace.element_size()
     check(_lib.load().fdn_conv_cout1_dgrad_folded(_p(dz, "dz"), _p(w, "w"), _p(y_prev, allow_none=True), act, float(alpha),
-                                                  _p(out), N, D, H, W, lddz, dz_coff, _stream()), "fdn_conv_cout1_dgrad_folded")
+                                                  _p(out), _p(dbias_prev, allow_none=True), _p(workspace, allow_none=True), wsb,
+                                                  N, D, H, W, lddz, dz_coff, _stream()), "fdn_conv_cout1_dgrad_folded")
     return out
 
 

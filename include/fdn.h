@@ -61,9 +61,12 @@ int fdn_conv3d_dgrad(const float* dz, const float* w, const float* wpack, float*
 
 /* The 64->1 head conv's input gradient with the halo fold and the producer's activation gradient fused
  * (no padded intermediate): dz_prev[i] = act'(y_prev[i]) * sum_{(o,t): clamp(o+t-1)=i} w[t] * dz[o].
- * dz rows at dz[voxel*lddz + dz_coff]; y_prev may be NULL.  SR4DFlowNet.py:40,43,46 under tape.gradient. */
+ * dz rows at dz[voxel*lddz + dz_coff]; y_prev may be NULL.  If dbias_prev != NULL it also receives
+ * BiasAddGrad of the producing layer (per-channel sum of dz_prev, 64 floats), using `workspace`
+ * (>= 2048*64*4 bytes).  SR4DFlowNet.py:39-46 under tape.gradient. */
 int fdn_conv_cout1_dgrad_folded(const float* dz, const float* w, const float* y_prev, int act, float alpha,
-                                float* dz_prev, int N, int D, int H, int W, int lddz, int dz_coff, void* stream);
+                                float* dz_prev, float* dbias_prev, void* workspace, size_t workspace_bytes, int N,
+                                int D, int H, int W, int lddz, int dz_coff, void* stream);
 
 /* MirrorPadGrad + gradient fan-in + activation gradient in one pass:
  * dz_prev[i] = (sum_s sum_{P: clamp(P)=i} dxpad_s[P] + skip[i]) * act'(y_prev[i]).

@@ -84,6 +84,8 @@ def test_conv64_dgrad_fused_fold(ops, fdn, shape, layout):
     dx = O.conv3d_dgrad(dz.astype(np.float64), w.astype(np.float64), (N, D, H, W, 64))
     _, wd = ops.pack_conv64_weights(dev(w))
     fdn._lib.load().fdn_debug_set_conv64_mt(layout)
+    # odd layouts also exercise the single padded-grid launch; the default is inner box + six 9-tap shell slabs
+    fdn._lib.load().fdn_debug_set_conv64_shell_slabs(0 if layout in (1, 3, 5) else 1)
     try:
         pad = torch.full((N, D + 2, H + 2, W + 2, 64), float("nan"), device="cuda")
         out = torch.full((N, D, H, W, 64), float("nan"), device="cuda")
@@ -100,6 +102,7 @@ def test_conv64_dgrad_fused_fold(ops, fdn, shape, layout):
         close(acc, O.act_bwd_from_output(6 * dx, y, O.ACT_RELU), name="fused fan-in of 3")
     finally:
         fdn._lib.load().fdn_debug_set_conv64_mt(0)
+        fdn._lib.load().fdn_debug_set_conv64_shell_slabs(1)
 
 
 @pytest.mark.parametrize("shape", SHAPES + [(2, 16, 16, 16)])
@@ -145,6 +148,9 @@ def test_thin_layers(ops, shape):
           O.conv3d_dgrad(dzo, f64(w1), x.shape) * (ymask > 0), name="64->1 dgrad folded+relu")
     close(ops.conv_cout1_dgrad_folded(dev(dpred), dev(w1), (N, D, H, W), lddz=3, dz_coff=1),
           O.conv3d_dgrad(dzo, f64(w1), x.shape), name="64->1 dgrad folded")
+    dbp = torch.full((64,), float("nan"), device="cuda")
+    ops.conv_cout1_dgrad_folded(dev(dpred), dev(w1), (N, D, H, W), dev(ymask), O.ACT_RELU, lddz=3, dz_coff=1, dbias_prev=dbp)
+    close(dbp, O.bias_grad(O.conv3d_dgrad(dzo, f64(w1), x.shape) * (ymask > 0)), name="64->1 dgrad folded: fused bias grad")
     dw, db = ops.conv3d_wgrad(dev(x), dev(dpred), 3, 64, 1, want_bias=True, lddz=3, dz_coff=1)
     close(dw, O.conv3d_wgrad(f64(x), dzo, 3), name="64->1 wgrad")
     close(db, O.bias_grad(dzo), name="64->1 bias grad")
