@@ -46,7 +46,7 @@ class ConvTimer:
         self.ops = ops
         self.records = []
         self.enabled = False
-        self._fwd, self._dgrad = ops.conv3d_fwd, ops.conv3d_dgrad
+        self._fwd, self._dgrad, self._dgrad_fused = ops.conv3d_fwd, ops.conv3d_dgrad, ops.conv3d_dgrad_fused
 
     def install(self):
         ops, rec = self.ops, self.records
@@ -67,7 +67,15 @@ class ConvTimer:
             rec.append(("dgrad", dz.shape[0] * dz.shape[1] * dz.shape[2] * dz.shape[3], e0, e1))
             return out
 
-        ops.conv3d_fwd, ops.conv3d_dgrad = fwd, dgrad
+        def dgrad_fused(dz, *a, **k):
+            if not self.enabled:
+                return self._dgrad_fused(dz, *a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); out = self._dgrad_fused(dz, *a, **k); e1.record()
+            rec.append(("dgrad", dz.shape[0] * dz.shape[1] * dz.shape[2] * dz.shape[3], e0, e1))
+            return out
+
+        ops.conv3d_fwd, ops.conv3d_dgrad, ops.conv3d_dgrad_fused = fwd, dgrad, dgrad_fused
 
     def summary(self):
         n = len(self.records)
