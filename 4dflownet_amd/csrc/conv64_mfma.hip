@@ -9,10 +9,13 @@
 //     64/CS input channels into LDS (256/CS bytes per voxel row, 16-B chunks XOR-swizzled by row so the A-fragment
 //     ds_read_b128 spreads over all banks).  The boundary rule (edge clamp for forward == SYMMETRIC p=1, zero for
 //     dgrad) is applied while staging, so the K loop is branch-free.
-//   * Latency hiding is by OCCUPANCY, not by software pipelining: the kernel is kept under 128 VGPRs and
-//     (with CS=4) under ~40 KB of LDS so 4 workgroups share a CU (4 waves per SIMD); while one stages or stores,
-//     the others keep the matrix pipe busy.  Measured on MI355X: a persistent, register-prefetching variant of this
-//     kernel (2 waves/SIMD, 256 VGPRs) was slower -- see DESIGN.md.
+//   * Latency hiding is by co-resident workgroups, not by software pipelining across phases: 2 workgroups per CU with
+//     CS=2 (<= 80 KB LDS each; the variant that measures best on large grids), up to 4-6 with CS=4 / the small layouts;
+//     while one stages or stores, the others keep the matrix pipe busy.  Within a phase, ALL staging loads of a slice are
+//     issued before the first LDS write (one memory round trip).  Measured on MI355X: persistent register-prefetching,
+//     producer/consumer wave specialisation, start staggering and s_setprio were all slower or null -- see DESIGN.md.
+//   * One launch covers up to 7 REGIONS (conv64_args.h): forward = 1 region; fused dgrad = the inner D^3 box + six
+//     9-tap shell slabs of the padded grid.
 //   * Wave layouts <MT,NW>:  <2,1>: tile 256 voxels, wave = 64 voxels x 64 cout;  <1,1>: 128 voxels, wave =
 //     32 x 64;  <1,2>: 64 voxels, wave = 32 voxels x 32 cout (fine load balance on small grids).
 //     Accumulators: MT x (2/NW) tiles of 32x32 (16 VGPRs each).
