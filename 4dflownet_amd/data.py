@@ -114,6 +114,10 @@ class PatchHandler3D:
             shard = (parallel.rank(), parallel.world_size())
         return _BatchedDataset(self, indexes, shuffle, seed, shard)
 
+    def load_data_using_patch_index(self, indexes):
+        """The tf.py_function bridge of the reference (PatchHandler3D.py:40-47) is unnecessary here; same result."""
+        return self.load_patches_from_index_file(indexes)
+
     @staticmethod
     def _cell(c):
         if hasattr(c, "numpy"):

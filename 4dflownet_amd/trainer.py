@@ -238,6 +238,12 @@ class TrainerController:
             print(msg)
 
     # ------------------------------------------------------------------ checkpoints
+    def save_latest_model(self, epoch):
+        """TrainerController.py:78-82 (defined but never called by the reference's loop; kept for API parity)."""
+        if epoch > 0 and epoch % 10 == 0:
+            self.model.save('%s-latest.h5' % self.model_path)
+            print('Saving current model - %s\n' % time.ctime())
+
     def save_best_model(self):
         """TrainerController.py:347-363: '<dir>/<name>-best.h5' + optimizer.pkl = [iterations, m..., v...]."""
         self.model.save('%s-best.h5' % self.model_path)
