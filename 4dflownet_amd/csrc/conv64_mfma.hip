@@ -50,7 +50,8 @@ struct Conv64Cfg {
     static constexpr int LDS_BYTES = MAXROWS * ROWB + MCAP * 4;
 };
 
-template <int MT, int NW, int CS>
+// GEN = false: a single region with all 27 taps (every forward launch) -- tap ranges are compile-time constants.
+template <int MT, int NW, int CS, bool GEN>
 __global__ __launch_bounds__(256, (Conv64Cfg<MT, NW, CS>::WG_PER_CU > 8 ? 8 : Conv64Cfg<MT, NW, CS>::WG_PER_CU))
 void conv64_mfma_kernel(Conv64Args p) {
     using C = Conv64Cfg<MT, NW, CS>;
@@ -67,8 +68,13 @@ void conv64_mfma_kernel(Conv64Args p) {
 
     // ---- which region, which tile ----
     int ri = 0;
-    while (ri + 1 < p.nreg && (int)blockIdx.x >= p.reg[ri + 1].first_block) ++ri;
-    const Conv64Region R = p.reg[ri];             // wave-uniform: lives in SGPRs
+    if (GEN) {
+        while (ri + 1 < p.nreg && (int)blockIdx.x >= p.reg[ri + 1].first_block) ++ri;
+        ri = __builtin_amdgcn_readfirstlane(ri);  // provably wave-uniform -> the region fields load into SGPRs
+    }
+    const Conv64Region R = p.reg[ri];
+    const int ta0 = GEN ? R.ta0 : 0, ta1 = GEN ? R.ta1 : 2, tb0 = GEN ? R.tb0 : 0, tb1 = GEN ? R.tb1 : 2;
+    const int tc0 = GEN ? R.tc0 : 0, tc1 = GEN ? R.tc1 : 2;
     const int tiles_per_n = R.ntd * R.nth * R.ntw;
     int b = (int)blockIdx.x - R.first_block;
     const int n = b / tiles_per_n;
@@ -130,8 +136,8 @@ void conv64_mfma_kernel(Conv64Args p) {
     const int bstride = (p.dbg & 1) ? 0 : 128;
     const size_t in_n = (size_t)n * p.ID * p.IH * p.IW;
     // staged box origin in input coordinates: output p reads input p + tap - 1 + off, first staged tap is (ta0,tb0,tc0)
-    const int q0d = p0d - 1 + p.off + R.ta0, q0h = p0h - 1 + p.off + R.tb0, q0w = p0w - 1 + p.off + R.tc0;
-    const int ntap = (R.ta1 - R.ta0 + 1) * (R.tb1 - R.tb0 + 1) * (R.tc1 - R.tc0 + 1);
+    const int q0d = p0d - 1 + p.off + ta0, q0h = p0h - 1 + p.off + tb0, q0w = p0w - 1 + p.off + tc0;
+    const int ntap = (ta1 - ta0 + 1) * (tb1 - tb0 + 1) * (tc1 - tc0 + 1);
 
 #pragma unroll 1
     for (int sl = 0; sl < CS; ++sl) {
@@ -175,7 +181,7 @@ void conv64_mfma_kernel(Conv64Args p) {
         // stream index of (slice, tap, local k-group gl): half = cin/32, g = k-group within the half
         const int half = (sl * KG) >> 2, g0 = (sl * KG) & 3;
         const f32x4* bp = (const f32x4*)p.wp + ((size_t)half * 27 * 4 + g0) * 128 + kh * 64 + wave_n * (NT * 32) + li;
-        int ta = R.ta0, tb = R.tb0, tc = R.tc0;
+        int ta = ta0, tb = tb0, tc = tc0;
 #pragma unroll 1
         for (int it = 0; it < ntap; ++it) {
             const int tap = (ta * 3 + tb) * 3 + tc;
@@ -184,7 +190,7 @@ void conv64_mfma_kernel(Conv64Args p) {
             for (int g = 0; g < KG; ++g)
 #pragma unroll
                 for (int nn = 0; nn < NT; ++nn) bv[g][nn] = bp[(tap * 4 + g) * bstride + nn * 32];
-            const int tapoff = ((ta - R.ta0) * R.hh + (tb - R.tb0)) * R.hw + (tc - R.tc0);
+            const int tapoff = ((ta - ta0) * R.hh + (tb - tb0)) * R.hw + (tc - tc0);
             f32x4 av[MT][KG];
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi) {
@@ -203,7 +209,7 @@ void conv64_mfma_kernel(Conv64Args p) {
 #pragma unroll
                         for (int nn = 0; nn < NT; ++nn)
                             acc[mi][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][g][s], bv[g][nn][s], acc[mi][nn], 0, 0, 0);
-            if (++tc > R.tc1) { tc = R.tc0; if (++tb > R.tb1) { tb = R.tb0; ++ta; } }
+            if (++tc > tc1) { tc = tc0; if (++tb > tb1) { tb = tb0; ++ta; } }
         }
     }
     if (p.dbg & 8) return;
@@ -442,13 +448,19 @@ int launch_conv64(Conv64Args& a, const Box* boxes, int nbox, hipStream_t s) {
     if (a.nreg == 0) return FDN_OK;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv64_mfma_kernel<MT, NW, CS>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv64_mfma_kernel<MT, NW, CS, true>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)conv64_mfma_kernel<MT, NW, CS, false>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) { fdn_set_error("conv64: hipFuncSetAttribute: %s", hipGetErrorString(e)); return FDN_ERR_HIP; }
         attr_set = true;
     }
     const size_t lds = (size_t)max_rows * C::ROWB + C::MCAP * 4;
-    hipLaunchKernelGGL((conv64_mfma_kernel<MT, NW, CS>), dim3((unsigned)first), dim3(256), lds, s, a);
+    const Conv64Region& r0 = a.reg[0];
+    const bool simple = a.nreg == 1 && r0.ta0 == 0 && r0.ta1 == 2 && r0.tb0 == 0 && r0.tb1 == 2 && r0.tc0 == 0 && r0.tc1 == 2;
+    if (simple) hipLaunchKernelGGL((conv64_mfma_kernel<MT, NW, CS, false>), dim3((unsigned)first), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((conv64_mfma_kernel<MT, NW, CS, true>), dim3((unsigned)first), dim3(256), lds, s, a);
     FDN_CHECK_LAUNCH("conv64_mfma_kernel");
     return FDN_OK;
 }
