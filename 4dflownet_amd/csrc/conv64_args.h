@@ -1,6 +1,7 @@
 // Argument block of the 64->64 3x3x3 conv kernel (conv64_mfma.hip).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 
 // One launch covers up to 7 REGIONS of the output grid.  A region is an output box [ob, ob+eb) with the tap range
 // [t0, t1] per dimension that can be non-zero for it, tiled with its own tile shape; workgroups
@@ -18,6 +19,7 @@ struct Conv64Region {
     int hh, hw;                 // staged box dims: th + (tb1-tb0), tw + (tc1-tc0)   (depth: td + (ta1-ta0))
     int rows;                   // staged rows
     unsigned mg_hhhw, mg_hw;    // magic divisors for staged-row decomposition
+    int swz_hs, swz_wm;         // bf16 kernel: LDS chunk swizzle of staged voxel (zh,zw) = ((zh >> swz_hs) + ((zw >> 2) & swz_wm)) & 3
 };
 
 struct Conv64Args {
@@ -35,6 +37,26 @@ struct Conv64Args {
     int act;
     float alpha;
     int dbg;                // ablation bits (bench only): 1 = B stream stride 0, 4 = no staging loads, 8 = no epilogue
+    int nreg;
+    Conv64Region reg[7];
+};
+
+// bf16-activation variant (conv64_bf16.hip): activations / gradients are bf16 NDHWC, accumulation fp32.
+struct Conv64BfArgs {
+    const uint16_t* x;      // (N,ID,IH,IW,64) bf16
+    const uint16_t* wp;     // packed bf16 operand stream (fdn_pack_conv64_weights_bf16)
+    const float* bias;
+    const uint16_t* res;    // forward: residual (N,OD,OH,OW,64) bf16 or null
+    uint16_t* y;            // forward output bf16
+    float* ypad;            // dgrad: fp32 padded-grid scratch (only rows that still need the border fold are written)
+    const uint16_t* fskip;  // fused fold (dgrad): gradient to add, producer output for act', finished dz_prev
+    const uint16_t* fy;
+    uint16_t* fout;
+    int N, ID, IH, IW, OD, OH, OW;
+    int off, zero_mode;
+    int act;
+    float alpha;
+    int dbg;
     int nreg;
     Conv64Region reg[7];
 };

@@ -1,0 +1,493 @@
+// conv3d 3x3x3, 64 -> 64 channels, bf16 activations / fp32 accumulation, NDHWC: implicit GEMM on
+// v_mfma_f32_32x32x16_bf16 (BASELINE.json configs[3]: the bf16 variant of SR4DFlowNet.py:93-120 and its dgrad).
+//
+// At bf16 MFMA rate (32 cycles per 32x32x16, 16x the fp32 rate) an operand fragment (1 KB) has to feed several MFMAs or
+// the LDS / L1 pipes become the bound, and the layer only has N = 64 output channels.  Hence, differently from the
+// fp32 kernel (conv64_mfma.hip):
+//   * MFMA orientation is C[cout][voxel] = W[cout][k] * X[k][voxel]: A = weights, B = voxels.  With the cout rows of the
+//     packed weight stream permuted (sigma below) a lane ends up holding 16 CONSECUTIVE cout of ONE voxel -> the epilogue is
+//     two 16-B stores (and two 16-B loads for the residual / skip / mask) per lane and 32x32 block, no row loop.
+//   * A wave owns 32 cout x 32 (h,w) positions x MT consecutive d planes (MT accumulator blocks).  The voxel fragment of
+//     staged plane p is the operand of output planes p, p-1, p-2 with the depth taps a = 0,1,2 ("depth slide"): per
+//     (b, c, 16 cin) a wave reads MT+2 voxel fragments (LDS) and 3 weight fragments (L1/L2) for 3*MT MFMAs.
+//     MT = 8: 10 + 3 KB per 24 MFMAs (768 cycles) per wave -> LDS 53 B/clk/CU (21 %), L1 16 B/clk/CU (25 %).
+//   * Workgroup = 4 waves = 2 cout halves x 2 halves of a (th x tw <= 64)-position plane block; tile = MT x th x tw voxels
+//     (8x8x8 on the large grids).  Input box + halo is staged in 2 slices of 32 cin (64 B per voxel row, <= 80 KB -> two
+//     workgroups per CU: one stages / stores while the other feeds the matrix pipe).
+//   * Same region table / boundary rules / fused-fold epilogue as the fp32 kernel (conv64_args.h).
+#include "fdn_common.h"
+#include "conv64_args.h"
+#include <type_traits>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+static int fdn_conv64bf_force_mt = 0;    // 0 = auto, 4 / 8 = force the variant (bench hook)
+static int fdn_conv64bf_dbg = 0;
+
+template <int MT>
+struct Conv64BfCfg {
+    static constexpr int ROWB = 64;                       // bytes per staged voxel row (32 cin bf16)
+    static constexpr int MCAP = MT * 64;                  // mtab entries (plane-major, 64 per plane)
+    static constexpr int WG_PER_CU = 2;
+    static constexpr int MAXROWS_LDS = ((160 * 1024 / WG_PER_CU) - MCAP * 4 - 256) / ROWB;
+    static constexpr int MAXROWS = MAXROWS_LDS > 1200 ? 1200 : MAXROWS_LDS;
+    static constexpr int LDS_BYTES = MAXROWS * ROWB + MCAP * 4;
+};
+
+__device__ __forceinline__ bf16x8 ld_bf16x8(const void* p) { return __builtin_bit_cast(bf16x8, *(const u32x4*)p); }
+
+// 16 fp32 -> 16 bf16 (round to nearest even), two 16-B stores
+__device__ __forceinline__ void st_bf16x16(uint16_t* dst, const float (&z)[16]) {
+    bf16x8 lo, hi;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { lo[r] = (__bf16)z[r]; hi[r] = (__bf16)z[8 + r]; }
+    *(u32x4*)dst = __builtin_bit_cast(u32x4, lo);
+    *(u32x4*)(dst + 8) = __builtin_bit_cast(u32x4, hi);
+}
+__device__ __forceinline__ void ld_bf16x16(const uint16_t* src, float (&z)[16]) {
+    const bf16x8 lo = ld_bf16x8(src), hi = ld_bf16x8(src + 8);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { z[r] = (float)lo[r]; z[8 + r] = (float)hi[r]; }
+}
+
+// GEN = false: one region, all 27 taps (forward).
+template <int MT, bool GEN>
+__global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
+    using C = Conv64BfCfg<MT>;
+    constexpr int ROWB = C::ROWB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int j = lane & 31;
+    const int kh = lane >> 5;
+    const int wn = wave & 1;      // cout half
+    const int wm = wave >> 1;     // half of the plane block
+
+    int ri = 0;
+    if (GEN) {
+        while (ri + 1 < p.nreg && (int)blockIdx.x >= p.reg[ri + 1].first_block) ++ri;
+        ri = __builtin_amdgcn_readfirstlane(ri);
+    }
+    const Conv64Region R = p.reg[ri];
+    const int ta0 = GEN ? R.ta0 : 0, tb0 = GEN ? R.tb0 : 0, tb1 = GEN ? R.tb1 : 2;
+    const int tc0 = GEN ? R.tc0 : 0, tc1 = GEN ? R.tc1 : 2;
+    const int na = GEN ? R.ta1 - R.ta0 + 1 : 3;          // depth taps: 3, or 1 on the d-face slabs
+    const int tiles_per_n = R.ntd * R.nth * R.ntw;
+    int b = (int)blockIdx.x - R.first_block;
+    const int n = b / tiles_per_n;
+    b -= n * tiles_per_n;
+    const int tdi = b / (R.nth * R.ntw);
+    b -= tdi * (R.nth * R.ntw);
+    const int thi = b / R.ntw;
+    int* mtab = (int*)(smem + R.rows * ROWB);
+    const int p0d = R.obd + tdi * R.td, p0h = R.obh + thi * R.th, p0w = R.obw + (b - thi * R.ntw) * R.tw;
+    const int prn = R.th * R.tw;                          // positions per plane block (<= 64)
+
+    // ---- output voxel of each (plane, position): output-grid voxel index, tagged (bit 30) if finished by the fused fold ----
+    for (int m = tid; m < C::MCAP; m += 256) {
+        int g = -1;
+        const int md = m >> 6, pr = m & 63;
+        if (md < R.td && pr < prn) {
+            const int mh = pr / R.tw;
+            const int pd = p0d + md, ph = p0h + mh, pw = p0w + (pr - mh * R.tw);
+            if (pd < R.obd + R.ebd && ph < R.obh + R.ebh && pw < R.obw + R.ebw) {
+                g = ((n * p.OD + pd) * p.OH + ph) * p.OW + pw;
+                if (p.fout) {
+                    const int id = pd - 1, ih = ph - 1, iw = pw - 1;
+                    if (id >= 1 && id <= p.ID - 2 && ih >= 1 && ih <= p.IH - 2 && iw >= 1 && iw <= p.IW - 2)
+                        g = (((n * p.ID + id) * p.IH + ih) * p.IW + iw) | (1 << 30);
+                }
+            }
+        }
+        mtab[m] = g;
+    }
+
+    // ---- this lane's voxel row inside a staged plane ----
+    // LDS image: 64 B per staged voxel (zd,zh,zw), its four 16-B chunks XOR-permuted by f(zh,zw) (Conv64Region::swz_*).
+    // A ds_read_b128 is served in 16-lane groups = 4 runs of 4 consecutive w at 4 different h of the 4x8 block: the runs
+    // cover the four 64-B quarters of a bank row, f = zh & 3 separates the runs -> conflict-free for every tap shift.
+    int row0, mh0, mw0;
+    {
+        int pr = wm * 32 + j;
+        pr = pr < prn ? pr : prn - 1;
+        mh0 = pr / R.tw;
+        mw0 = pr - mh0 * R.tw;
+        row0 = mh0 * R.hw + mw0;
+    }
+    const int pstride = R.hh * R.hw;
+    const int npl = R.td + na - 1;                        // staged planes
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+
+    const int chunk = tid & 3;
+    const int rsub = tid >> 2;
+    const int rows_eff = (p.dbg & 4) ? 0 : R.rows;
+    const int wstride = (p.dbg & 1) ? 0 : 1;
+    const size_t in_n = (size_t)n * p.ID * p.IH * p.IW;
+    const int q0d = p0d - 1 + p.off + ta0, q0h = p0h - 1 + p.off + tb0, q0w = p0w - 1 + p.off + tc0;
+    const int nbc = (tb1 - tb0 + 1) * (tc1 - tc0 + 1);
+
+#pragma unroll 1
+    for (int sl = 0; sl < 2; ++sl) {
+        if (sl) __syncthreads();
+        // ---- stage input box + halo, cin [32 sl, 32 sl + 32): 4 chunks of 16 B per row ----
+        const uint16_t* xh = p.x + sl * 32 + chunk * 8;
+        constexpr int U = 8;
+        for (int r0 = 0; r0 < rows_eff; r0 += 64 * U) {
+            u32x4 v[U];
+            unsigned fs = 0;                                  // 2-bit swizzle of each of the U rows
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int r = r0 + u * 64 + rsub;
+                v[u] = (u32x4){0u, 0u, 0u, 0u};
+                if (r < rows_eff) {
+                    const int zd = fdn_div20(r, R.mg_hhhw);
+                    const int r2 = r - zd * pstride;
+                    const int zh = fdn_div20(r2, R.mg_hw);
+                    const int zw = r2 - zh * R.hw;
+                    fs |= (unsigned)(((zh >> R.swz_hs) + ((zw >> 2) & R.swz_wm)) & 3) << (2 * u);
+                    int qd = q0d + zd, qh = q0h + zh, qw = q0w + zw;
+                    bool ok = true;
+                    if (p.zero_mode) {
+                        ok = (unsigned)qd < (unsigned)p.ID && (unsigned)qh < (unsigned)p.IH && (unsigned)qw < (unsigned)p.IW;
+                    } else {
+                        qd = min(max(qd, 0), p.ID - 1);
+                        qh = min(max(qh, 0), p.IH - 1);
+                        qw = min(max(qw, 0), p.IW - 1);
+                    }
+                    if (ok) v[u] = *(const u32x4*)(xh + (in_n + ((size_t)qd * p.IH + qh) * p.IW + qw) * 64);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int r = r0 + u * 64 + rsub;
+                if (r < rows_eff) *(u32x4*)(smem + r * ROWB + ((chunk ^ ((fs >> (2 * u)) & 3)) << 4)) = v[u];
+            }
+        }
+        __syncthreads();
+
+        // ---- K loop: (b,c) pairs x 2 groups of 16 cin; weights of the next pair are prefetched into registers ----
+        // stream: [slice][b*3+c][g][a][kh][cout row 64] x 16 B
+        const u32x4* wbase = (const u32x4*)p.wp + (size_t)sl * (9 * 2 * 3 * 128) + kh * 64 + wn * 32 + j;
+        u32x4 wq[2][3];
+        auto load_w = [&](int tb, int tc) {
+            const int bc = tb * 3 + tc;
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+                    if (!GEN || a < na) wq[g][a] = wbase[(((bc * 2 + g) * 3 + ta0 + a) * 128) * wstride];
+        };
+        // one (b,c) step: FULL = every plane and depth tap present (no predicates: the compiler batches the LDS reads)
+        auto kstep = [&](auto fullc, int db, int dc, const bf16x8 (&wv)[2][3]) {
+            constexpr bool FULL = decltype(fullc)::value;
+            const int f = (((mh0 + db) >> R.swz_hs) + (((mw0 + dc) >> 2) & R.swz_wm)) & 3;
+            const char* lbase = smem + (row0 + db * R.hw + dc) * ROWB;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const char* lg = lbase + ((((g << 1) | kh) ^ f) << 4);
+#pragma unroll
+                for (int pl = 0; pl < MT + 2; ++pl) {
+                    if (!FULL && pl >= npl) continue;
+                    const bf16x8 xv = ld_bf16x8(lg + pl * pstride * ROWB);
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        const int md = pl - a;
+                        if (md < 0 || md >= MT) continue;
+                        if (!FULL && a >= na) continue;
+                        acc[md] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[g][a], xv, acc[md], 0, 0, 0);
+                    }
+                }
+            }
+        };
+        const bool full = !GEN || (R.td == MT && na == 3);
+        int tb = tb0, tc = tc0;
+        load_w(tb, tc);
+#pragma unroll 1
+        for (int it = 0; it < nbc; ++it) {
+            bf16x8 wv[2][3];
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int a = 0; a < 3; ++a) wv[g][a] = __builtin_bit_cast(bf16x8, wq[g][a]);
+            const int db = tb - tb0, dc = tc - tc0;
+            if (++tc > tc1) { tc = tc0; ++tb; }
+            if (it + 1 < nbc) load_w(tb, tc);
+            if (full) kstep(std::true_type{}, db, dc, wv);
+            else kstep(std::false_type{}, db, dc, wv);
+        }
+    }
+    if (p.dbg & 8) return;
+
+    // ---- epilogue: lane (j,kh) holds cout [wn*32 + kh*16, +16) of the voxel at position wm*32 + j of every plane ----
+    const float slope = p.act == FDN_ACT_RELU ? 0.f : (p.act == FDN_ACT_LEAKY ? p.alpha : 1.f);
+    const int cofs = wn * 32 + kh * 16;
+    float bv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bv[r] = 0.f;
+    if (p.bias) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) {
+            const f32x4 t = *(const f32x4*)(p.bias + cofs + r);
+            bv[r] = t.x; bv[r + 1] = t.y; bv[r + 2] = t.z; bv[r + 3] = t.w;
+        }
+    }
+#pragma unroll
+    for (int md = 0; md < MT; ++md) {
+        const int g = mtab[md * 64 + wm * 32 + j];
+        if (g < 0) continue;
+        float z[16];
+        if (p.fout) {
+            if (g & (1 << 30)) {
+                const size_t o = (size_t)(g & ~(1 << 30)) * 64 + cofs;
+                float sk[16], ym[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { sk[r] = 0.f; ym[r] = 1.f; }
+                if (p.fskip) ld_bf16x16(p.fskip + o, sk);
+                if (p.fy) ld_bf16x16(p.fy + o, ym);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = (acc[md][r] + sk[r]) * (ym[r] > 0.f ? 1.f : slope);
+                st_bf16x16(p.fout + o, z);
+            } else {
+                float* o = p.ypad + (size_t)g * 64 + cofs;
+#pragma unroll
+                for (int r = 0; r < 16; r += 4)
+                    *(f32x4*)(o + r) = (f32x4){acc[md][r], acc[md][r + 1], acc[md][r + 2], acc[md][r + 3]};
+            }
+        } else {
+            const size_t o = (size_t)g * 64 + cofs;
+            float rv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+            if (p.res) ld_bf16x16(p.res + o, rv);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float t = acc[md][r] + bv[r] + rv[r];
+                z[r] = t > 0.f ? t : slope * t;
+            }
+            st_bf16x16(p.y + o, z);
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// border fold (bf16 tensors, fp32 scratch): surface voxels of dz_prev after a fused-fold dgrad launch
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fold_halo_border_bf16_kernel(const float* __restrict__ s0, const float* __restrict__ s1,
+                                                                     const float* __restrict__ s2, int nsrc,
+                                                                     const uint16_t* __restrict__ skip,
+                                                                     const uint16_t* __restrict__ yprev, int act, float alpha,
+                                                                     uint16_t* __restrict__ out, int N, int D, int H, int W) {
+    const int ID = D > 2 ? D - 2 : 0, IH = H > 2 ? H - 2 : 0;
+    const int nd_faces = (D > 1 ? 2 : 1) * H * W;
+    const int nh_faces = ID * (H > 1 ? 2 : 1) * W;
+    const int nw_faces = ID * IH * (W > 1 ? 2 : 1);
+    const int per_n = nd_faces + nh_faces + nw_faces;
+    const int64_t total = (int64_t)N * per_n * 8;
+    const int PH = H + 2, PW = W + 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i & 7);
+        int s = (int)((i >> 3) % per_n);
+        const int n = (int)((i >> 3) / per_n);
+        int d, h, w;
+        if (s < nd_faces) {
+            d = (s / (H * W)) ? D - 1 : 0; s %= H * W; h = s / W; w = s % W;
+        } else if ((s -= nd_faces) < nh_faces) {
+            const int f = s / (ID * W); s %= ID * W; h = f ? H - 1 : 0; d = 1 + s / W; w = s % W;
+        } else {
+            s -= nh_faces;
+            const int f = s / (ID * IH); s %= ID * IH; w = f ? W - 1 : 0; d = 1 + s / IH; h = 1 + s % IH;
+        }
+        int pd[3], ph[3], pw[3];
+        int nd = 0, nh = 0, nw = 0;
+        pd[nd++] = d + 1; if (d == 0) pd[nd++] = 0; if (d == D - 1) pd[nd++] = D + 1;
+        ph[nh++] = h + 1; if (h == 0) ph[nh++] = 0; if (h == H - 1) ph[nh++] = H + 1;
+        pw[nw++] = w + 1; if (w == 0) pw[nw++] = 0; if (w == W - 1) pw[nw++] = W + 1;
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+        for (int a = 0; a < nd; ++a)
+            for (int b = 0; b < nh; ++b)
+                for (int c = 0; c < nw; ++c) {
+                    const int64_t off = (((((int64_t)n * (D + 2) + pd[a]) * PH + ph[b]) * PW + pw[c]) * 16 + c8 * 2);
+                    a0 += ((const f32x4*)s0)[off]; a1 += ((const f32x4*)s0)[off + 1];
+                    if (nsrc > 1) { a0 += ((const f32x4*)s1)[off]; a1 += ((const f32x4*)s1)[off + 1]; }
+                    if (nsrc > 2) { a0 += ((const f32x4*)s2)[off]; a1 += ((const f32x4*)s2)[off + 1]; }
+                }
+        float z[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        const int64_t o = ((((int64_t)n * D + d) * H + h) * W + w) * 64 + c8 * 8;
+        if (skip) {
+            const bf16x8 t = ld_bf16x8(skip + o);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) z[r] += (float)t[r];
+        }
+        if (yprev) {
+            const bf16x8 t = ld_bf16x8(yprev + o);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) z[r] *= fdn_act_grad((float)t[r], act, alpha);
+        }
+        bf16x8 q;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) q[r] = (__bf16)z[r];
+        *(u32x4*)(out + o) = __builtin_bit_cast(u32x4, q);
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// weight packing: Keras (27,64,64)[tap][cin][cout] fp32 -> bf16 operand streams
+//   [slice = cin/32][b*3+c][g = (cin%32)/16][a][kh][row 64][8]  with cin = 32 slice + 16 g + 8 kh + k, tap = (a,b,c),
+//   cout = 32 (row/32) + sigma(row%32),  sigma(q) = 16 ((q>>2)&1) + (q&3) + 4 (q>>3)   (accumulator row -> lane-contiguous)
+//   dgrad stream: contraction over the layer's cout, rows = the layer's cin, taps flipped.
+// --------------------------------------------------------------------------------------------
+__global__ void pack_conv64_bf16_kernel(const float* __restrict__ w, uint16_t* __restrict__ wf, uint16_t* __restrict__ wd) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 27 * 64 * 64) return;
+    const int k = idx & 7;
+    const int row = (idx >> 3) & 63;
+    const int kh = (idx >> 9) & 1;
+    int rest = idx >> 10;
+    const int a = rest % 3; rest /= 3;
+    const int g = rest & 1; rest >>= 1;
+    const int bc = rest % 9;
+    const int sl = rest / 9;
+    const int tap = a * 9 + bc;
+    const int kk = sl * 32 + g * 16 + kh * 8 + k;
+    const int q = row & 31;
+    const int jj = (row & 32) + 16 * ((q >> 2) & 1) + (q & 3) + 4 * (q >> 3);
+    if (wf) { const __bf16 v = (__bf16)w[(tap * 64 + kk) * 64 + jj]; wf[idx] = __builtin_bit_cast(uint16_t, v); }
+    if (wd) { const __bf16 v = (__bf16)w[((26 - tap) * 64 + jj) * 64 + kk]; wd[idx] = __builtin_bit_cast(uint16_t, v); }
+}
+
+extern "C" int fdn_pack_conv64_weights_bf16(const float* w, uint16_t* wp_fwd, uint16_t* wp_dgrad, void* stream) {
+    FDN_REQUIRE(w != nullptr, "fdn_pack_conv64_weights_bf16: w is NULL");
+    hipLaunchKernelGGL(pack_conv64_bf16_kernel, dim3((27 * 64 * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w,
+                       wp_fwd, wp_dgrad);
+    FDN_CHECK_LAUNCH("fdn_pack_conv64_weights_bf16");
+    return FDN_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// host side
+// --------------------------------------------------------------------------------------------
+namespace {
+
+struct Box { int od, oh, ow, ed, eh, ew, ta0, ta1, tb0, tb1, tc0, tc1; };
+struct Plan { FdnTile t; double cost; };
+
+// tile = td planes (<= MT) of th x tw (<= 64) positions; a tile's MFMA time does not depend on how full the plane block is
+Plan best_plan(int N, const Box& bx, int mt, int max_rows) {
+    Plan best{{1, 1, 1, bx.ed, bx.eh, bx.ew}, 1e30};
+    const int da = bx.ta1 - bx.ta0, db = bx.tb1 - bx.tb0, dc = bx.tc1 - bx.tc0;
+    const double ntap = (da + 1) * (db + 1) * (dc + 1);
+    for (int td = 1; td <= bx.ed && td <= mt; ++td)
+        for (int th = 1; th <= bx.eh && th <= 64; ++th)
+            for (int tw = 1; tw <= bx.ew && th * tw <= 64; ++tw) {
+                const int rows = (td + da) * (th + db) * (tw + dc);
+                if (rows > max_rows) continue;
+                FdnTile t{td, th, tw, (bx.ed + td - 1) / td, (bx.eh + th - 1) / th, (bx.ew + tw - 1) / tw};
+                const double tiles = (double)N * t.ntd * t.nth * t.ntw;
+                // tiles with td < mt (or a single depth tap) run the predicated K loop: ~1.5x per MFMA
+                const double slow = (td == mt && da == 2) ? 1.0 : 1.5;
+                const double per_tile = slow * td * ntap * 64.0 / 27.0 + 0.05 * rows + 16.0;
+                const double c = (0.9 * (double)((long long)((tiles + 255) / 256)) + 0.1 * tiles / 256.0) * per_tile;
+                if (c < best.cost) best = {t, c};
+            }
+    return best;
+}
+
+template <int MT>
+int launch_bf16(Conv64BfArgs& a, const Box* boxes, int nbox, hipStream_t s) {
+    using C = Conv64BfCfg<MT>;
+    int first = 0, max_rows = 0;
+    a.nreg = 0;
+    for (int i = 0; i < nbox; ++i) {
+        const Box& bx = boxes[i];
+        if (bx.ed <= 0 || bx.eh <= 0 || bx.ew <= 0) continue;
+        const FdnTile t = best_plan(a.N, bx, MT, C::MAXROWS).t;
+        Conv64Region& r = a.reg[a.nreg++];
+        r.first_block = first;
+        r.obd = bx.od; r.obh = bx.oh; r.obw = bx.ow; r.ebd = bx.ed; r.ebh = bx.eh; r.ebw = bx.ew;
+        r.ta0 = bx.ta0; r.ta1 = bx.ta1; r.tb0 = bx.tb0; r.tb1 = bx.tb1; r.tc0 = bx.tc0; r.tc1 = bx.tc1;
+        r.td = t.td; r.th = t.th; r.tw = t.tw; r.ntd = t.ntd; r.nth = t.nth; r.ntw = t.ntw;
+        r.hh = t.th + (bx.tb1 - bx.tb0); r.hw = t.tw + (bx.tc1 - bx.tc0);
+        r.rows = (t.td + (bx.ta1 - bx.ta0)) * r.hh * r.hw;
+        r.mg_hhhw = fdn_magic20(r.hh * r.hw);
+        r.mg_hw = fdn_magic20(r.hw);
+        // swizzle mode by tile shape: rows of >= 4 h values per 32 positions -> by zh; one long w row -> by w quad;
+        // a column (tw <= 2) -> by h quad
+        r.swz_hs = t.tw <= 2 ? 2 : 0;
+        r.swz_wm = t.tw >= 16 ? 3 : 0;
+        first += a.N * t.ntd * t.nth * t.ntw;
+        if (r.rows > max_rows) max_rows = r.rows;
+    }
+    if (a.nreg == 0) return FDN_OK;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv64_bf16_kernel<MT, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)conv64_bf16_kernel<MT, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    C::LDS_BYTES);
+        if (e != hipSuccess) { fdn_set_error("conv64_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return FDN_ERR_HIP; }
+        attr_set = true;
+    }
+    const size_t lds = (size_t)max_rows * C::ROWB + C::MCAP * 4;
+    const Conv64Region& r0 = a.reg[0];
+    const bool simple = a.nreg == 1 && r0.ta0 == 0 && r0.ta1 == 2 && r0.tb0 == 0 && r0.tb1 == 2 && r0.tc0 == 0 &&
+                        r0.tc1 == 2 && r0.td == MT;
+    if (simple) hipLaunchKernelGGL((conv64_bf16_kernel<MT, false>), dim3((unsigned)first), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((conv64_bf16_kernel<MT, true>), dim3((unsigned)first), dim3(256), lds, s, a);
+    FDN_CHECK_LAUNCH("conv64_bf16_kernel");
+    return FDN_OK;
+}
+
+int launch_boxes(Conv64BfArgs& a, const Box* boxes, int nbox, hipStream_t s) {
+    int mt = fdn_conv64bf_force_mt;
+    if (mt != 4 && mt != 8)
+        mt = best_plan(a.N, boxes[0], 8, Conv64BfCfg<8>::MAXROWS).cost <= best_plan(a.N, boxes[0], 4, Conv64BfCfg<4>::MAXROWS).cost ? 8 : 4;
+    return mt == 8 ? launch_bf16<8>(a, boxes, nbox, s) : launch_bf16<4>(a, boxes, nbox, s);
+}
+
+}  // namespace
+
+int fdn_conv64_bf16_launch(const uint16_t* x, const uint16_t* wpack, const float* bias, const uint16_t* residual, uint16_t* y,
+                           float* ypad, const uint16_t* fskip, const uint16_t* fy, uint16_t* fout, int N, int ID, int IH,
+                           int IW, int OD, int OH, int OW, int off, int zero_mode, int act, float alpha, hipStream_t s) {
+    Conv64BfArgs a;
+    a.x = x; a.wp = wpack; a.bias = bias; a.res = residual; a.y = y; a.ypad = ypad;
+    a.fskip = fskip; a.fy = fy; a.fout = fout;
+    a.N = N; a.ID = ID; a.IH = IH; a.IW = IW; a.OD = OD; a.OH = OH; a.OW = OW;
+    a.off = off; a.zero_mode = zero_mode; a.act = act; a.alpha = alpha; a.dbg = fdn_conv64bf_dbg;
+    const Box full{0, 0, 0, OD, OH, OW, 0, 2, 0, 2, 0, 2};
+    if (!(fout && zero_mode && off == -1)) return launch_boxes(a, &full, 1, s);
+    // fused dgrad on the padded grid: inner box (27 taps) + six 1-voxel shell slabs (9 taps), as in conv64_mfma.hip
+    const Box boxes[7] = {
+        {1, 1, 1, ID, IH, IW, 0, 2, 0, 2, 0, 2},
+        {0, 0, 0, 1, OH, OW, 2, 2, 0, 2, 0, 2},       {ID + 1, 0, 0, 1, OH, OW, 0, 0, 0, 2, 0, 2},
+        {1, 0, 0, ID, 1, OW, 0, 2, 2, 2, 0, 2},       {1, IH + 1, 0, ID, 1, OW, 0, 2, 0, 0, 0, 2},
+        {1, 1, 0, ID, IH, 1, 0, 2, 0, 2, 2, 2},       {1, 1, IW + 1, ID, IH, 1, 0, 2, 0, 2, 0, 0}};
+    return launch_boxes(a, boxes, 7, s);
+}
+
+int fdn_fold_halo_border_bf16_launch(const float* s0, const float* s1, const float* s2, int nsrc, const uint16_t* skip,
+                                     const uint16_t* yprev, int act, float alpha, uint16_t* out, int N, int D, int H, int W,
+                                     hipStream_t s) {
+    const int ID = D > 2 ? D - 2 : 0, IH = H > 2 ? H - 2 : 0;
+    const int64_t per_n = (int64_t)(D > 1 ? 2 : 1) * H * W + (int64_t)ID * (H > 1 ? 2 : 1) * W + (int64_t)ID * IH * (W > 1 ? 2 : 1);
+    const int64_t total = (int64_t)N * per_n * 8;
+    int64_t nb = (total + 255) / 256;
+    if (nb < 1) nb = 1;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(fold_halo_border_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, s, s0, s1, s2, nsrc, skip, yprev, act,
+                       alpha, out, N, D, H, W);
+    FDN_CHECK_LAUNCH("fold_halo_border_bf16_kernel");
+    return FDN_OK;
+}
+
+extern "C" int fdn_debug_set_conv64_bf16_mt(int mt) { fdn_conv64bf_force_mt = mt; return FDN_OK; }
+extern "C" int fdn_debug_set_conv64_bf16_dbg(int bits) { fdn_conv64bf_dbg = bits; return FDN_OK; }

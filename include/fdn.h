@@ -134,6 +134,29 @@ int fdn_adam_step(float* w, const float* g, float* m, float* v, const uint8_t* i
                   float lr_t, float b1, float b2, float eps, float l2_grad_scale, const float* l2_scale_dev,
                   void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * bf16 activation path (BASELINE.json configs[3]: patch 32, res x4, bf16).  The reference has no bf16
+ * mode (TF runs fp32); semantics = the fp32 entry points above with every activation / activation-gradient
+ * tensor stored as bfloat16 (uint16_t bit patterns, round-to-nearest-even on store), fp32 accumulation,
+ * fp32 parameters, gradients of parameters and optimizer state.
+ * ------------------------------------------------------------------------------------------------ */
+
+/* fp32 Keras kernel (27,64,64) -> bf16 operand streams (27*64*64 uint16_t each) for the two entry points below. */
+int fdn_pack_conv64_weights_bf16(const float* w, uint16_t* wp_fwd, uint16_t* wp_dgrad, void* stream);
+
+/* fdn_conv3d_fwd for (Cin,Cout,K) = (64,64,3) with bf16 x / residual / y.  SR4DFlowNet.py:93-120. */
+int fdn_conv64_fwd_bf16(const uint16_t* x, const uint16_t* wpack, const float* bias, const uint16_t* residual,
+                        uint16_t* y, int N, int D, int H, int W, int act, float alpha, void* stream);
+
+/* fdn_conv3d_dgrad_fused / fdn_fold_halo_border with bf16 dz / skip / y_prev / dz_prev; the padded scratch
+ * dxpad (N,D+2,H+2,W+2,64) stays fp32 (only positions the border fold reads are written). */
+int fdn_conv64_dgrad_fused_bf16(const uint16_t* dz, const uint16_t* wpack, float* dxpad, const uint16_t* skip,
+                                const uint16_t* y_prev, int act, float alpha, uint16_t* dz_prev, int N, int D, int H,
+                                int W, void* stream);
+int fdn_fold_halo_border_bf16(const float* dxpad0, const float* dxpad1, const float* dxpad2, int nsrc,
+                              const uint16_t* skip, const uint16_t* y_prev, int act, float alpha, uint16_t* dz_prev,
+                              int N, int D, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

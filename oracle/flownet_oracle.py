@@ -29,6 +29,18 @@ ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-7   # tf.keras.optimizers.Adam defau
 # ----------------------------------------------------------------------------
 # elementwise helpers
 # ----------------------------------------------------------------------------
+def bf16_round(a):
+    """Round to the nearest bfloat16 (ties to even), returned in the input's dtype.  Models the store of an
+    activation tensor in the bf16 variant of the path (BASELINE.json configs[3]; no reference counterpart)."""
+    a = np.asarray(a)
+    f = np.ascontiguousarray(a, dtype=np.float32)
+    u = f.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16 << 16).astype(np.uint32)
+    out = r.view(np.float32).reshape(f.shape)
+    out = np.where(np.isfinite(f), out, f)
+    return out.astype(a.dtype if a.dtype.kind == "f" else np.float32)
+
+
 def act_fwd(z, act, alpha=LEAKY_ALPHA):
     if act == ACT_NONE:
         return z
