@@ -12,9 +12,15 @@
 //     (b, c, 16 cin) a wave reads MT+2 voxel fragments (LDS) and 3 weight fragments (L1/L2) for 3*MT MFMAs.
 //     MT = 8: 10 + 3 KB per 24 MFMAs (768 cycles) per wave -> LDS 53 B/clk/CU (21 %), L1 16 B/clk/CU (25 %).
 //   * Workgroup = 4 waves = 2 cout halves x 2 halves of a (th x tw <= 64)-position plane block; tile = MT x th x tw voxels
-//     (8x8x8 on the large grids).  Input box + halo is staged in 2 slices of 32 cin (64 B per voxel row, <= 80 KB -> two
-//     workgroups per CU: one stages / stores while the other feeds the matrix pipe).
+//     (8x8x8 on the large grids), two workgroups per CU.
+//   * The input box + halo is staged in 4 slices of 16 cin (32 B per voxel row = exactly one MFMA K step) into TWO LDS
+//     buffers: while the K loop runs on slice s, the global loads of slice s+1 are issued (step 0) and written to the other
+//     buffer (step 2) -- 8 loads of 16 B per thread, so staging costs 32 transient VGPRs and one barrier per slice and only
+//     the first slice of a tile is exposed.  Weight fragments are prefetched two (b,c) steps ahead into two register sets.
+//   * LDS image (Conv64Region::hs, swz_*): conflict-free ds_read_b128 for every tap shift, SQ_LDS_BANK_CONFLICT = 0.
 //   * Same region table / boundary rules / fused-fold epilogue as the fp32 kernel (conv64_args.h).
+// Measured on MI355X (tools/bench_bf16.py, tools/mfma_peak_bf16.hip): a pure MFMA loop sustains 1.90 PFLOP/s on this part
+// (clock drops to ~1.8 GHz under bf16 matrix load; nominal 2.5 PFLOP/s at 2.4 GHz).
 #include "fdn_common.h"
 #include "conv64_args.h"
 #include <type_traits>
@@ -23,16 +29,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 static int fdn_conv64bf_force_mt = 0;    // 0 = auto, 4 / 8 = force the variant (bench hook)
-static int fdn_conv64bf_dbg = 0;
+static int fdn_conv64bf_dbg = 0;         // ablation bits: 1 = weight stride 0, 2 = no XCD remap, 4 = staging loads from a cache-resident 32 KB, 8 = no epilogue
 
 template <int MT>
 struct Conv64BfCfg {
-    static constexpr int ROWB = 64;                       // bytes per staged voxel row (32 cin bf16)
+    static constexpr int ROWB = 32;                       // bytes per staged voxel row and slice (16 cin bf16)
     static constexpr int MCAP = MT * 64;                  // mtab entries (plane-major, 64 per plane)
-    static constexpr int WG_PER_CU = 2;
-    static constexpr int MAXROWS_LDS = ((160 * 1024 / WG_PER_CU) - MCAP * 4 - 256) / ROWB;
-    static constexpr int MAXROWS = MAXROWS_LDS > 1200 ? 1200 : MAXROWS_LDS;
-    static constexpr int LDS_BYTES = MAXROWS * ROWB + MCAP * 4;
+    static constexpr int NP = 8;                          // staging passes of 128 rows -> at most 1024 staged voxels
+    static constexpr int MAXROWS = NP * 128;
+    static constexpr int LDS_BUDGET = 160 * 1024 / 2 - 256;                   // two workgroups per CU
+    static constexpr int MAXLROWS = (LDS_BUDGET - MCAP * 4) / (2 * ROWB);     // LDS rows per buffer
 };
 
 __device__ __forceinline__ bf16x8 ld_bf16x8(const void* p) { return __builtin_bit_cast(bf16x8, *(const u32x4*)p); }
@@ -51,11 +57,14 @@ __device__ __forceinline__ void ld_bf16x16(const uint16_t* src, float (&z)[16]) 
     for (int r = 0; r < 8; ++r) { z[r] = (float)lo[r]; z[8 + r] = (float)hi[r]; }
 }
 
-// GEN = false: one region, all 27 taps (forward).
-template <int MT, bool GEN>
+// FAST = true : every region of the launch has all 27 taps and td == MT (forward; the inner box of a fused dgrad): 9 unrolled
+//               (b,c) steps per slice with register-prefetched weights and in-loop staging of the next slice.
+// FAST = false: shell slabs / ragged tiles: rolled loop, predicated planes and taps.
+template <int MT, bool FAST>
 __global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
+    constexpr bool GEN = !FAST;
     using C = Conv64BfCfg<MT>;
-    constexpr int ROWB = C::ROWB;
+    constexpr int ROWB = C::ROWB, NP = C::NP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -66,25 +75,91 @@ __global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
     const int wn = wave & 1;      // cout half
     const int wm = wave >> 1;     // half of the plane block
 
-    int ri = 0;
-    if (GEN) {
-        while (ri + 1 < p.nreg && (int)blockIdx.x >= p.reg[ri + 1].first_block) ++ri;
-        ri = __builtin_amdgcn_readfirstlane(ri);
+    // ---- XCD-aware tile order: workgroup ids are dealt round-robin to the 8 XCDs; give each XCD one contiguous run of
+    // tiles so that neighbouring tiles (shared halo voxels) meet in the same L2 ----
+    int bid = (int)blockIdx.x;
+    if (!(p.dbg & 2)) {
+        const int total = (int)gridDim.x, q = total >> 3, rem = total & 7, x = bid & 7;
+        bid = x * q + (x < rem ? x : rem) + (bid >> 3);
     }
+    int ri = 0;
+    while (ri + 1 < p.nreg && bid >= p.reg[ri + 1].first_block) ++ri;
+    ri = __builtin_amdgcn_readfirstlane(ri);
     const Conv64Region R = p.reg[ri];
-    const int ta0 = GEN ? R.ta0 : 0, tb0 = GEN ? R.tb0 : 0, tb1 = GEN ? R.tb1 : 2;
-    const int tc0 = GEN ? R.tc0 : 0, tc1 = GEN ? R.tc1 : 2;
+    const int ta0 = GEN ? R.ta0 : 0, tb0 = GEN ? R.tb0 : 0, tc0 = GEN ? R.tc0 : 0;
     const int na = GEN ? R.ta1 - R.ta0 + 1 : 3;          // depth taps: 3, or 1 on the d-face slabs
+    const int nb = GEN ? R.tb1 - R.tb0 + 1 : 3, nc = GEN ? R.tc1 - R.tc0 + 1 : 3;
     const int tiles_per_n = R.ntd * R.nth * R.ntw;
-    int b = (int)blockIdx.x - R.first_block;
+    int b = bid - R.first_block;
     const int n = b / tiles_per_n;
     b -= n * tiles_per_n;
     const int tdi = b / (R.nth * R.ntw);
     b -= tdi * (R.nth * R.ntw);
     const int thi = b / R.ntw;
-    int* mtab = (int*)(smem + R.rows * ROWB);
+    const int bufB = R.lrows * ROWB;
+    int* mtab = (int*)(smem + 2 * bufB);
     const int p0d = R.obd + tdi * R.td, p0h = R.obh + thi * R.th, p0w = R.obw + (b - thi * R.ntw) * R.tw;
     const int prn = R.th * R.tw;                          // positions per plane block (<= 64)
+
+    // ---- staging descriptors of this thread: NP staged voxels x one 16-B chunk (the same for every slice) ----
+    const int chunk = tid & 1;
+    const int q0d = p0d - 1 + p.off + ta0, q0h = p0h - 1 + p.off + tb0, q0w = p0w - 1 + p.off + tc0;
+    const int cstride = R.hh * R.hw;                      // staged voxels per plane
+    int gv[NP];                                           // input voxel index (clamped), sign bit set = store zeros
+    int lo[NP];                                           // LDS byte offset inside a buffer, -1 = nothing to stage
+    {
+        const int rows_eff = R.rows;
+        const int in_n = n * p.ID * p.IH * p.IW;
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int r = u * 128 + (tid >> 1);
+            gv[u] = 0; lo[u] = -1;
+            if (r < rows_eff) {
+                const int zd = fdn_div20(r, R.mg_hhhw);
+                const int r2 = r - zd * cstride;
+                const int zh = fdn_div20(r2, R.mg_hw);
+                const int zw = r2 - zh * R.hw;
+                const int f = ((zh >> R.swz_hs) + ((zw >> 2) & R.swz_wm)) & 1;
+                lo[u] = ((zd * R.hh + zh) * R.hs + zw) * ROWB + ((chunk ^ f) << 4);
+                int qd = q0d + zd, qh = q0h + zh, qw = q0w + zw;
+                const bool inside = (unsigned)qd < (unsigned)p.ID && (unsigned)qh < (unsigned)p.IH && (unsigned)qw < (unsigned)p.IW;
+                qd = min(max(qd, 0), p.ID - 1);
+                qh = min(max(qh, 0), p.IH - 1);
+                qw = min(max(qw, 0), p.IW - 1);
+                gv[u] = in_n + (qd * p.IH + qh) * p.IW + qw;
+                if (p.dbg & 4) gv[u] = r & 255;          // ablation: real data, but always the same 32 KB (cache hits)
+                if (p.zero_mode && !inside) gv[u] |= (int)0x80000000;
+            }
+        }
+    }
+    const uint16_t* xchunk = p.x + chunk * 8;
+    u32x4 sv[NP];
+    auto stage_load = [&](int sl) {       // unconditional loads (clamped address), zero selection afterwards
+#pragma unroll
+        for (int u = 0; u < NP; ++u) sv[u] = *(const u32x4*)(xchunk + (size_t)(gv[u] & 0x7fffffff) * 64 + sl * 16);
+    };
+    auto stage_write = [&](char* buf) {
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            if (gv[u] < 0) sv[u] = (u32x4){0u, 0u, 0u, 0u};
+            if (lo[u] >= 0) *(u32x4*)(buf + lo[u]) = sv[u];
+        }
+    };
+    stage_load(0);
+
+    // ---- weight fragments: stream [slice 4][b*3+c][a][kh][cout row 64] x 16 B, two register sets, two steps ahead ----
+    const int wstride = (p.dbg & 1) ? 0 : 1;
+    const u32x4* wbase = (const u32x4*)p.wp + kh * 64 + wn * 32 + j;
+    u32x4 wq[2][3];
+    auto load_w = [&](u32x4 (&dst)[3], int sl, int tb, int tc) {
+        const int bc = tb * 3 + tc;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            if (!GEN || a < na) dst[a] = wbase[((((sl & 3) * 9 + bc) * 3 + ta0 + a) * 128) * wstride];
+    };
+    // step `it` of a slice -> tap (tb0 + it / nc, tc0 + it % nc); nb * nc is 9 or 3
+    load_w(wq[0], 0, tb0, tc0);
+    load_w(wq[1], 0, tb0 + (nc == 1 ? 1 : 0), tc0 + (nc == 1 ? 0 : 1));
 
     // ---- output voxel of each (plane, position): output-grid voxel index, tagged (bit 30) if finished by the fused fold ----
     for (int m = tid; m < C::MCAP; m += 256) {
@@ -105,19 +180,16 @@ __global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
         mtab[m] = g;
     }
 
-    // ---- this lane's voxel row inside a staged plane ----
-    // LDS image: 64 B per staged voxel (zd,zh,zw), its four 16-B chunks XOR-permuted by f(zh,zw) (Conv64Region::swz_*).
-    // A ds_read_b128 is served in 16-lane groups = 4 runs of 4 consecutive w at 4 different h of the 4x8 block: the runs
-    // cover the four 64-B quarters of a bank row, f = zh & 3 separates the runs -> conflict-free for every tap shift.
-    int row0, mh0, mw0;
+    // ---- this lane's voxel inside a staged plane ----
+    int mh0, mw0;
     {
         int pr = wm * 32 + j;
         pr = pr < prn ? pr : prn - 1;
         mh0 = pr / R.tw;
         mw0 = pr - mh0 * R.tw;
-        row0 = mh0 * R.hw + mw0;
     }
-    const int pstride = R.hh * R.hw;
+    const int lrow0 = mh0 * R.hs + mw0;
+    const int pstrideB = R.hh * R.hs * ROWB;              // LDS bytes per staged plane
     const int npl = R.td + na - 1;                        // staged planes
 
     f32x16 acc[MT];
@@ -126,102 +198,70 @@ __global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
 
-    const int chunk = tid & 3;
-    const int rsub = tid >> 2;
-    const int rows_eff = (p.dbg & 4) ? 0 : R.rows;
-    const int wstride = (p.dbg & 1) ? 0 : 1;
-    const size_t in_n = (size_t)n * p.ID * p.IH * p.IW;
-    const int q0d = p0d - 1 + p.off + ta0, q0h = p0h - 1 + p.off + tb0, q0w = p0w - 1 + p.off + tc0;
-    const int nbc = (tb1 - tb0 + 1) * (tc1 - tc0 + 1);
-
-#pragma unroll 1
-    for (int sl = 0; sl < 2; ++sl) {
-        if (sl) __syncthreads();
-        // ---- stage input box + halo, cin [32 sl, 32 sl + 32): 4 chunks of 16 B per row ----
-        const uint16_t* xh = p.x + sl * 32 + chunk * 8;
-        constexpr int U = 8;
-        for (int r0 = 0; r0 < rows_eff; r0 += 64 * U) {
-            u32x4 v[U];
-            unsigned fs = 0;                                  // 2-bit swizzle of each of the U rows
+    // one (b,c) step on buffer `buf`: FULL = every plane and depth tap present (no predicates)
+    auto kstep = [&](auto fullc, const char* buf, int db, int dc, const u32x4 (&wsrc)[3]) {
+        constexpr bool FULL = decltype(fullc)::value;
+        bf16x8 wv[3];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int r = r0 + u * 64 + rsub;
-                v[u] = (u32x4){0u, 0u, 0u, 0u};
-                if (r < rows_eff) {
-                    const int zd = fdn_div20(r, R.mg_hhhw);
-                    const int r2 = r - zd * pstride;
-                    const int zh = fdn_div20(r2, R.mg_hw);
-                    const int zw = r2 - zh * R.hw;
-                    fs |= (unsigned)(((zh >> R.swz_hs) + ((zw >> 2) & R.swz_wm)) & 3) << (2 * u);
-                    int qd = q0d + zd, qh = q0h + zh, qw = q0w + zw;
-                    bool ok = true;
-                    if (p.zero_mode) {
-                        ok = (unsigned)qd < (unsigned)p.ID && (unsigned)qh < (unsigned)p.IH && (unsigned)qw < (unsigned)p.IW;
-                    } else {
-                        qd = min(max(qd, 0), p.ID - 1);
-                        qh = min(max(qh, 0), p.IH - 1);
-                        qw = min(max(qw, 0), p.IW - 1);
-                    }
-                    if (ok) v[u] = *(const u32x4*)(xh + (in_n + ((size_t)qd * p.IH + qh) * p.IW + qw) * 64);
-                }
-            }
+        for (int a = 0; a < 3; ++a) wv[a] = __builtin_bit_cast(bf16x8, wsrc[a]);
+        const int f = (((mh0 + db) >> R.swz_hs) + (((mw0 + dc) >> 2) & R.swz_wm)) & 1;
+        const char* lp = buf + (lrow0 + db * R.hs + dc) * ROWB + ((kh ^ f) << 4);
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int r = r0 + u * 64 + rsub;
-                if (r < rows_eff) *(u32x4*)(smem + r * ROWB + ((chunk ^ ((fs >> (2 * u)) & 3)) << 4)) = v[u];
+        for (int pl = 0; pl < MT + 2; ++pl) {
+            if (!FULL && pl >= npl) continue;
+            const bf16x8 xv = ld_bf16x8(lp + pl * pstrideB);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const int md = pl - a;
+                if (md < 0 || md >= MT) continue;
+                if (!FULL && a >= na) continue;
+                acc[md] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[a], xv, acc[md], 0, 0, 0);
             }
         }
-        __syncthreads();
+    };
 
-        // ---- K loop: (b,c) pairs x 2 groups of 16 cin; weights of the next pair are prefetched into registers ----
-        // stream: [slice][b*3+c][g][a][kh][cout row 64] x 16 B
-        const u32x4* wbase = (const u32x4*)p.wp + (size_t)sl * (9 * 2 * 3 * 128) + kh * 64 + wn * 32 + j;
-        u32x4 wq[2][3];
-        auto load_w = [&](int tb, int tc) {
-            const int bc = tb * 3 + tc;
+    stage_write(smem);
+    __syncthreads();
+    if (FAST) {
+        // 9 unrolled steps per slice; weights two steps ahead (running into the next slice); the next slice's voxels are
+        // loaded behind step 0's weight refill and written to the other buffer at step 7.  No branch sits between a load
+        // and its use, so every wait is a counted vmcnt (the last slice, which has nothing to prefetch, is peeled).
+        auto fast_slice = [&](auto prefetchc, int sl) {
+            constexpr bool PREFETCH = decltype(prefetchc)::value;
+            const char* cur = smem + (sl & 1) * bufB;
+            char* nxt = smem + ((sl + 1) & 1) * bufB;
 #pragma unroll
-            for (int g = 0; g < 2; ++g)
-#pragma unroll
-                for (int a = 0; a < 3; ++a)
-                    if (!GEN || a < na) wq[g][a] = wbase[(((bc * 2 + g) * 3 + ta0 + a) * 128) * wstride];
-        };
-        // one (b,c) step: FULL = every plane and depth tap present (no predicates: the compiler batches the LDS reads)
-        auto kstep = [&](auto fullc, int db, int dc, const bf16x8 (&wv)[2][3]) {
-            constexpr bool FULL = decltype(fullc)::value;
-            const int f = (((mh0 + db) >> R.swz_hs) + (((mw0 + dc) >> 2) & R.swz_wm)) & 3;
-            const char* lbase = smem + (row0 + db * R.hw + dc) * ROWB;
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const char* lg = lbase + ((((g << 1) | kh) ^ f) << 4);
-#pragma unroll
-                for (int pl = 0; pl < MT + 2; ++pl) {
-                    if (!FULL && pl >= npl) continue;
-                    const bf16x8 xv = ld_bf16x8(lg + pl * pstride * ROWB);
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) {
-                        const int md = pl - a;
-                        if (md < 0 || md >= MT) continue;
-                        if (!FULL && a >= na) continue;
-                        acc[md] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[g][a], xv, acc[md], 0, 0, 0);
-                    }
-                }
+            for (int it = 0; it < 9; ++it) {
+                kstep(std::true_type{}, cur, it / 3, it % 3, wq[it & 1]);
+                if (PREFETCH || it < 7)
+                    load_w(wq[it & 1], sl + (it + 2) / 9, tb0 + ((it + 2) % 9) / 3, tc0 + ((it + 2) % 9) % 3);
+                if (PREFETCH && it == 0) stage_load(sl + 1);
+                if (PREFETCH && it == 7) stage_write(nxt);
+                // keep every step's loads inside the step: under register pressure the scheduler otherwise sinks the
+                // weight refills down to their first use, i.e. prefetch distance 0
+                __builtin_amdgcn_sched_barrier(0);
             }
+            __syncthreads();
         };
-        const bool full = !GEN || (R.td == MT && na == 3);
-        int tb = tb0, tc = tc0;
-        load_w(tb, tc);
 #pragma unroll 1
-        for (int it = 0; it < nbc; ++it) {
-            bf16x8 wv[2][3];
-#pragma unroll
-            for (int g = 0; g < 2; ++g)
-#pragma unroll
-                for (int a = 0; a < 3; ++a) wv[g][a] = __builtin_bit_cast(bf16x8, wq[g][a]);
-            const int db = tb - tb0, dc = tc - tc0;
-            if (++tc > tc1) { tc = tc0; ++tb; }
-            if (it + 1 < nbc) load_w(tb, tc);
-            if (full) kstep(std::true_type{}, db, dc, wv);
-            else kstep(std::false_type{}, db, dc, wv);
+        for (int sl = 0; sl < 3; ++sl) fast_slice(std::true_type{}, sl);
+        fast_slice(std::false_type{}, 3);
+    } else {
+#pragma unroll 1
+        for (int sl = 0; sl < 4; ++sl) {
+            const char* cur = smem + (sl & 1) * bufB;
+            char* nxt = smem + ((sl + 1) & 1) * bufB;
+            // shell slabs / ragged tiles: rolled loop, predicated planes and taps, weights loaded in step
+            if (sl < 3) stage_load(sl + 1);
+#pragma unroll 1
+            for (int it = 0; it < nb * nc; ++it) {
+                const int db = it / nc, dc = it - db * nc;
+                u32x4 w3[3] = {};
+                load_w(w3, sl, tb0 + db, tc0 + dc);
+                kstep(std::false_type{}, cur, db, dc, w3);
+            }
+            if (sl < 3) stage_write(nxt);
+            __syncthreads();
         }
     }
     if (p.dbg & 8) return;
@@ -340,7 +380,7 @@ __global__ __launch_bounds__(256) void fold_halo_border_bf16_kernel(const float*
 
 // --------------------------------------------------------------------------------------------
 // weight packing: Keras (27,64,64)[tap][cin][cout] fp32 -> bf16 operand streams
-//   [slice = cin/32][b*3+c][g = (cin%32)/16][a][kh][row 64][8]  with cin = 32 slice + 16 g + 8 kh + k, tap = (a,b,c),
+//   [slice = cin/16][b*3+c][a][kh][row 64][8]  with cin = 16 slice + 8 kh + k, tap = (a,b,c),
 //   cout = 32 (row/32) + sigma(row%32),  sigma(q) = 16 ((q>>2)&1) + (q&3) + 4 (q>>3)   (accumulator row -> lane-contiguous)
 //   dgrad stream: contraction over the layer's cout, rows = the layer's cin, taps flipped.
 // --------------------------------------------------------------------------------------------
@@ -352,11 +392,10 @@ __global__ void pack_conv64_bf16_kernel(const float* __restrict__ w, uint16_t* _
     const int kh = (idx >> 9) & 1;
     int rest = idx >> 10;
     const int a = rest % 3; rest /= 3;
-    const int g = rest & 1; rest >>= 1;
     const int bc = rest % 9;
     const int sl = rest / 9;
     const int tap = a * 9 + bc;
-    const int kk = sl * 32 + g * 16 + kh * 8 + k;
+    const int kk = sl * 16 + kh * 8 + k;
     const int q = row & 31;
     const int jj = (row & 32) + 16 * ((q >> 2) & 1) + (q & 3) + 4 * (q >> 3);
     if (wf) { const __bf16 v = (__bf16)w[(tap * 64 + kk) * 64 + jj]; wf[idx] = __builtin_bit_cast(uint16_t, v); }
@@ -380,7 +419,9 @@ struct Box { int od, oh, ow, ed, eh, ew, ta0, ta1, tb0, tb1, tc0, tc1; };
 struct Plan { FdnTile t; double cost; };
 
 // tile = td planes (<= MT) of th x tw (<= 64) positions; a tile's MFMA time does not depend on how full the plane block is
-Plan best_plan(int N, const Box& bx, int mt, int max_rows) {
+int lds_hs(int hw) { int hs = hw; while ((hs & 7) != 4) ++hs; return hs; }
+
+Plan best_plan(int N, const Box& bx, int mt, int max_rows, int max_lrows) {
     Plan best{{1, 1, 1, bx.ed, bx.eh, bx.ew}, 1e30};
     const int da = bx.ta1 - bx.ta0, db = bx.tb1 - bx.tb0, dc = bx.tc1 - bx.tc0;
     const double ntap = (da + 1) * (db + 1) * (dc + 1);
@@ -388,7 +429,7 @@ Plan best_plan(int N, const Box& bx, int mt, int max_rows) {
         for (int th = 1; th <= bx.eh && th <= 64; ++th)
             for (int tw = 1; tw <= bx.ew && th * tw <= 64; ++tw) {
                 const int rows = (td + da) * (th + db) * (tw + dc);
-                if (rows > max_rows) continue;
+                if (rows > max_rows || (td + da) * (th + db) * lds_hs(tw + dc) > max_lrows) continue;
                 FdnTile t{td, th, tw, (bx.ed + td - 1) / td, (bx.eh + th - 1) / th, (bx.ew + tw - 1) / tw};
                 const double tiles = (double)N * t.ntd * t.nth * t.ntw;
                 // tiles with td < mt (or a single depth tap) run the predicated K loop: ~1.5x per MFMA
@@ -400,56 +441,68 @@ Plan best_plan(int N, const Box& bx, int mt, int max_rows) {
     return best;
 }
 
+template <int MT, bool FAST>
+int launch_regions(Conv64BfArgs& a, hipStream_t s) {
+    using C = Conv64BfCfg<MT>;
+    if (a.nreg == 0) return FDN_OK;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv64_bf16_kernel<MT, FAST>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BUDGET);
+        if (e != hipSuccess) { fdn_set_error("conv64_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return FDN_ERR_HIP; }
+        attr_set = true;
+    }
+    int blocks = 0, max_lrows = 0;
+    for (int i = 0; i < a.nreg; ++i) {
+        Conv64Region& r = a.reg[i];
+        r.first_block = blocks;
+        blocks += a.N * r.ntd * r.nth * r.ntw;
+        if (r.lrows > max_lrows) max_lrows = r.lrows;
+    }
+    // every region's mtab sits behind ITS two buffers; size the allocation for the largest region
+    const size_t lds = (size_t)max_lrows * C::ROWB * 2 + C::MCAP * 4;
+    hipLaunchKernelGGL((conv64_bf16_kernel<MT, FAST>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+    FDN_CHECK_LAUNCH("conv64_bf16_kernel");
+    return FDN_OK;
+}
+
+// plan every box, then launch the full-tap / full-depth regions with the FAST kernel and the rest with the general one
 template <int MT>
 int launch_bf16(Conv64BfArgs& a, const Box* boxes, int nbox, hipStream_t s) {
     using C = Conv64BfCfg<MT>;
-    int first = 0, max_rows = 0;
-    a.nreg = 0;
+    Conv64BfArgs fast = a, slow = a;
+    fast.nreg = slow.nreg = 0;
     for (int i = 0; i < nbox; ++i) {
         const Box& bx = boxes[i];
         if (bx.ed <= 0 || bx.eh <= 0 || bx.ew <= 0) continue;
-        const FdnTile t = best_plan(a.N, bx, MT, C::MAXROWS).t;
-        Conv64Region& r = a.reg[a.nreg++];
-        r.first_block = first;
+        const FdnTile t = best_plan(a.N, bx, MT, C::MAXROWS, C::MAXLROWS).t;
+        const bool is_fast = t.td == MT && bx.ta0 == 0 && bx.ta1 == 2 && bx.tb0 == 0 && bx.tb1 == 2 && bx.tc0 == 0 && bx.tc1 == 2;
+        Conv64BfArgs& dst = is_fast ? fast : slow;
+        Conv64Region& r = dst.reg[dst.nreg++];
         r.obd = bx.od; r.obh = bx.oh; r.obw = bx.ow; r.ebd = bx.ed; r.ebh = bx.eh; r.ebw = bx.ew;
         r.ta0 = bx.ta0; r.ta1 = bx.ta1; r.tb0 = bx.tb0; r.tb1 = bx.tb1; r.tc0 = bx.tc0; r.tc1 = bx.tc1;
         r.td = t.td; r.th = t.th; r.tw = t.tw; r.ntd = t.ntd; r.nth = t.nth; r.ntw = t.ntw;
         r.hh = t.th + (bx.tb1 - bx.tb0); r.hw = t.tw + (bx.tc1 - bx.tc0);
         r.rows = (t.td + (bx.ta1 - bx.ta0)) * r.hh * r.hw;
+        r.hs = lds_hs(r.hw);
+        r.lrows = (t.td + (bx.ta1 - bx.ta0)) * r.hh * r.hs;
         r.mg_hhhw = fdn_magic20(r.hh * r.hw);
         r.mg_hw = fdn_magic20(r.hw);
         // swizzle mode by tile shape: rows of >= 4 h values per 32 positions -> by zh; one long w row -> by w quad;
         // a column (tw <= 2) -> by h quad
         r.swz_hs = t.tw <= 2 ? 2 : 0;
-        r.swz_wm = t.tw >= 16 ? 3 : 0;
-        first += a.N * t.ntd * t.nth * t.ntw;
-        if (r.rows > max_rows) max_rows = r.rows;
+        r.swz_wm = t.tw >= 16 ? 1 : 0;
     }
-    if (a.nreg == 0) return FDN_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv64_bf16_kernel<MT, true>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)conv64_bf16_kernel<MT, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    C::LDS_BYTES);
-        if (e != hipSuccess) { fdn_set_error("conv64_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return FDN_ERR_HIP; }
-        attr_set = true;
-    }
-    const size_t lds = (size_t)max_rows * C::ROWB + C::MCAP * 4;
-    const Conv64Region& r0 = a.reg[0];
-    const bool simple = a.nreg == 1 && r0.ta0 == 0 && r0.ta1 == 2 && r0.tb0 == 0 && r0.tb1 == 2 && r0.tc0 == 0 &&
-                        r0.tc1 == 2 && r0.td == MT;
-    if (simple) hipLaunchKernelGGL((conv64_bf16_kernel<MT, false>), dim3((unsigned)first), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((conv64_bf16_kernel<MT, true>), dim3((unsigned)first), dim3(256), lds, s, a);
-    FDN_CHECK_LAUNCH("conv64_bf16_kernel");
-    return FDN_OK;
+    const int rc = launch_regions<MT, true>(fast, s);
+    if (rc != FDN_OK) return rc;
+    return launch_regions<MT, false>(slow, s);
 }
 
 int launch_boxes(Conv64BfArgs& a, const Box* boxes, int nbox, hipStream_t s) {
     int mt = fdn_conv64bf_force_mt;
     if (mt != 4 && mt != 8)
-        mt = best_plan(a.N, boxes[0], 8, Conv64BfCfg<8>::MAXROWS).cost <= best_plan(a.N, boxes[0], 4, Conv64BfCfg<4>::MAXROWS).cost ? 8 : 4;
+        mt = best_plan(a.N, boxes[0], 8, Conv64BfCfg<8>::MAXROWS, Conv64BfCfg<8>::MAXLROWS).cost <=
+                     best_plan(a.N, boxes[0], 4, Conv64BfCfg<4>::MAXROWS, Conv64BfCfg<4>::MAXLROWS).cost ? 8 : 4;
     return mt == 8 ? launch_bf16<8>(a, boxes, nbox, s) : launch_bf16<4>(a, boxes, nbox, s);
 }
 
