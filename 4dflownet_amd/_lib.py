@@ -38,6 +38,14 @@ SIGNATURES = {
     "fdn_conv64_fwd_bf16": (c_i, [c_fp] * 5 + [c_i] * 5 + [c_f, c_fp]),
     "fdn_conv64_dgrad_fused_bf16": (c_i, [c_fp] * 5 + [c_i, c_f, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "fdn_fold_halo_border_bf16": (c_i, [c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_f, c_fp, c_i, c_i, c_i, c_i, c_fp]),
+    "fdn_input_features_bf16": (c_i, [c_fp] * 8 + [c_i64, c_fp]),
+    "fdn_conv3d_fwd_bf16": (c_i, [c_fp] * 7 + [c_i] * 10 + [c_f, c_fp]),
+    "fdn_conv3d_wgrad_bf16_workspace_bytes": (c_sz, [c_i] * 7),
+    "fdn_conv3d_wgrad_bf16": (c_i, [c_fp] * 6 + [c_sz] + [c_i] * 9 + [c_fp]),
+    "fdn_conv_cout1_dgrad_folded_bf16": (c_i, [c_fp, c_fp, c_fp, c_i, c_f, c_fp, c_fp, c_fp, c_sz, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "fdn_conv1x1_dgrad_bf16": (c_i, [c_fp] * 6 + [c_i64, c_fp]),
+    "fdn_upsample_trilinear_fwd_bf16": (c_i, [c_fp, c_fp] + [c_i] * 6 + [c_fp]),
+    "fdn_upsample_trilinear_bwd_bf16": (c_i, [c_fp, c_fp, c_i, c_f, c_fp] + [c_i] * 6 + [c_fp]),
 }
 
 

@@ -16,23 +16,29 @@ void fdn_set_error(const char* fmt, ...) {
 extern "C" int fdn_version(void) { return 100; }
 extern "C" const char* fdn_last_error(void) { return g_err; }
 
-// small-channel kernels (small_convs.hip)
-int fdn_conv_cin3_fwd_launch(const float* x, const float* w, const float* bias, float* y, int N, int D, int H, int W,
-                             int act, float alpha, hipStream_t s);
-int fdn_conv_cout1_fwd_launch(const float* x, const float* w, const float* bias, float* y, int N, int D, int H, int W,
-                              int ldy, int y_coff, int act, float alpha, hipStream_t s);
-int fdn_conv1x1_fwd_launch(const float* xa, const float* xb, const float* w, const float* bias, float* y, int64_t nvox,
-                           int act, float alpha, hipStream_t s);
+// small-channel kernels (small_convs.hip), templated on the activation storage type (float / uint16_t = bf16 bits)
+template <typename T> int fdn_conv_cin3_fwd_launch(const T* x, const float* w, const float* bias, T* y, int N, int D, int H,
+                                                   int W, int act, float alpha, hipStream_t s);
+template <typename T> int fdn_conv_cout1_fwd_launch(const T* x, const float* w, const float* bias, float* y, int N, int D,
+                                                    int H, int W, int ldy, int y_coff, int act, float alpha, hipStream_t s);
+template <typename T> int fdn_conv1x1_fwd_launch(const T* xa, const T* xb, const float* w, const float* bias, T* y,
+                                                 int64_t nvox, int act, float alpha, hipStream_t s);
+template <typename T> int fdn_conv1x1_dgrad_launch(const T* dz, const float* w, const T* ya, const T* yb, T* dxa, T* dxb,
+                                                   int64_t nvox, hipStream_t s);
 int fdn_conv_cout1_dgrad_launch(const float* dz, const float* w, float* dxpad, int N, int D, int H, int W, int lddz,
                                 int dz_coff, hipStream_t s);
-int fdn_wgrad_cin3_launch(const float* x, const float* dz, float* dw, void* ws, size_t ws_bytes, int N, int D, int H,
-                          int W, hipStream_t s);
-int fdn_wgrad_cout1_launch(const float* x, const float* dz, float* dw, void* ws, size_t ws_bytes, int N, int D, int H,
-                           int W, int lddz, int dz_coff, hipStream_t s);
-int fdn_wgrad_1x1_launch(const float* xa, const float* xb, const float* dz, float* dw, void* ws, size_t ws_bytes,
-                         int64_t nvox, hipStream_t s);
-int fdn_bias_grad_launch(const float* dz, float* db, void* ws, size_t ws_bytes, int64_t nvox, int C, int lddz,
-                         int dz_coff, hipStream_t s);
+template <typename T> int fdn_wgrad_cin3_launch(const T* x, const T* dz, float* dw, void* ws, size_t ws_bytes, int N, int D,
+                                                int H, int W, hipStream_t s);
+template <typename T> int fdn_wgrad_cout1_launch(const T* x, const float* dz, float* dw, void* ws, size_t ws_bytes, int N,
+                                                 int D, int H, int W, int lddz, int dz_coff, hipStream_t s);
+template <typename T> int fdn_conv_cout1_dgrad_folded_launch(const float* dz, const float* w, const T* y_prev, int act,
+                                                             float alpha, T* dz_prev, float* dbias_prev, void* workspace,
+                                                             size_t workspace_bytes, int N, int D, int H, int W, int lddz,
+                                                             int dz_coff, hipStream_t s);
+template <typename T> int fdn_wgrad_1x1_launch(const T* xa, const T* xb, const T* dz, float* dw, void* ws, size_t ws_bytes,
+                                               int64_t nvox, hipStream_t s);
+template <typename T> int fdn_bias_grad_launch(const T* dz, float* db, void* ws, size_t ws_bytes, int64_t nvox, int C,
+                                               int lddz, int dz_coff, hipStream_t s);
 size_t fdn_small_wgrad_workspace_bytes(int Cin, int Cout, int K);
 
 extern "C" int fdn_conv3d_fwd(const float* x, const float* x2, const float* w, const float* wpack, const float* bias,
@@ -171,4 +177,101 @@ extern "C" int fdn_fold_halo_border_bf16(const float* dxpad0, const float* dxpad
     FDN_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "fdn_fold_halo_border_bf16: bad dims");
     return fdn_fold_halo_border_bf16_launch(dxpad0, dxpad1, dxpad2, nsrc, skip, y_prev, act, alpha, dz_prev, N, D, H, W,
                                             (hipStream_t)stream);
+}
+
+extern "C" int fdn_conv1x1_dgrad(const float* dz, const float* w, const float* ya, const float* yb, float* dxa, float* dxb,
+                                 int64_t nvox, void* stream) {
+    FDN_REQUIRE(dz && w && ya && yb && dxa && dxb && nvox > 0, "fdn_conv1x1_dgrad: NULL argument or nvox<=0");
+    return fdn_conv1x1_dgrad_launch<float>(dz, w, ya, yb, dxa, dxb, nvox, (hipStream_t)stream);
+}
+
+extern "C" int fdn_conv_cout1_dgrad_folded(const float* dz, const float* w, const float* y_prev, int act, float alpha,
+                                           float* dz_prev, float* dbias_prev, void* workspace, size_t workspace_bytes, int N,
+                                           int D, int H, int W, int lddz, int dz_coff, void* stream) {
+    return fdn_conv_cout1_dgrad_folded_launch<float>(dz, w, y_prev, act, alpha, dz_prev, dbias_prev, workspace, workspace_bytes,
+                                                     N, D, H, W, lddz, dz_coff, (hipStream_t)stream);
+}
+
+// ---- bf16 activation path: the thin layers and the generic conv entry points ----
+extern "C" int fdn_conv1x1_dgrad_bf16(const uint16_t* dz, const float* w, const uint16_t* ya, const uint16_t* yb,
+                                      uint16_t* dxa, uint16_t* dxb, int64_t nvox, void* stream) {
+    FDN_REQUIRE(dz && w && ya && yb && dxa && dxb && nvox > 0, "fdn_conv1x1_dgrad_bf16: NULL argument or nvox<=0");
+    return fdn_conv1x1_dgrad_launch<uint16_t>(dz, w, ya, yb, dxa, dxb, nvox, (hipStream_t)stream);
+}
+
+extern "C" int fdn_conv_cout1_dgrad_folded_bf16(const float* dz, const float* w, const uint16_t* y_prev, int act, float alpha,
+                                                uint16_t* dz_prev, float* dbias_prev, void* workspace, size_t workspace_bytes,
+                                                int N, int D, int H, int W, int lddz, int dz_coff, void* stream) {
+    return fdn_conv_cout1_dgrad_folded_launch<uint16_t>(dz, w, y_prev, act, alpha, dz_prev, dbias_prev, workspace,
+                                                        workspace_bytes, N, D, H, W, lddz, dz_coff, (hipStream_t)stream);
+}
+
+extern "C" int fdn_conv3d_fwd_bf16(const uint16_t* x, const uint16_t* x2, const float* w, const uint16_t* wpack,
+                                   const float* bias, const uint16_t* residual, void* y, int N, int D, int H, int W, int Cin,
+                                   int Cout, int K, int ldy, int y_coff, int act, float alpha, void* stream) {
+    FDN_REQUIRE(x && y, "fdn_conv3d_fwd_bf16: x/y is NULL");
+    FDN_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "fdn_conv3d_fwd_bf16: bad dims N=%d D=%d H=%d W=%d", N, D, H, W);
+    FDN_REQUIRE(act >= FDN_ACT_NONE && act <= FDN_ACT_LEAKY, "fdn_conv3d_fwd_bf16: bad act %d", act);
+    hipStream_t s = (hipStream_t)stream;
+    if (Cin == 64 && Cout == 64 && K == 3) {
+        FDN_REQUIRE(ldy == 64 && y_coff == 0, "fdn_conv3d_fwd_bf16: 64->64 path writes dense rows");
+        return fdn_conv64_fwd_bf16(x, wpack, bias, residual, (uint16_t*)y, N, D, H, W, act, alpha, stream);
+    }
+    FDN_REQUIRE(residual == nullptr, "fdn_conv3d_fwd_bf16: residual only on the 64->64 path");
+    if (Cin == 3 && Cout == 64 && K == 3) {
+        FDN_REQUIRE(w && ldy == 64 && y_coff == 0, "fdn_conv3d_fwd_bf16(3->64): needs w, dense output");
+        return fdn_conv_cin3_fwd_launch<uint16_t>(x, w, bias, (uint16_t*)y, N, D, H, W, act, alpha, s);
+    }
+    if (Cin == 64 && Cout == 1 && K == 3) {
+        FDN_REQUIRE(w && ldy >= 1 && y_coff >= 0 && y_coff < ldy, "fdn_conv3d_fwd_bf16(64->1): bad w/ldy/y_coff");
+        return fdn_conv_cout1_fwd_launch<uint16_t>(x, w, bias, (float*)y, N, D, H, W, ldy, y_coff, act, alpha, s);
+    }
+    if (Cin == 128 && Cout == 64 && K == 1) {
+        FDN_REQUIRE(w && x2 && ldy == 64 && y_coff == 0, "fdn_conv3d_fwd_bf16(1x1 128->64): needs w, x2, dense output");
+        return fdn_conv1x1_fwd_launch<uint16_t>(x, x2, w, bias, (uint16_t*)y, (int64_t)N * D * H * W, act, alpha, s);
+    }
+    fdn_set_error("fdn_conv3d_fwd_bf16: unsupported (Cin=%d,Cout=%d,K=%d)", Cin, Cout, K);
+    return FDN_ERR_UNSUPPORTED;
+}
+
+extern "C" size_t fdn_conv3d_wgrad_bf16_workspace_bytes(int N, int D, int H, int W, int Cin, int Cout, int K) {
+    if (Cin == 64 && Cout == 64 && K == 3) return fdn_wgrad64_bf16_workspace_bytes(N, D, H, W);
+    return fdn_small_wgrad_workspace_bytes(Cin, Cout, K);
+}
+
+extern "C" int fdn_conv3d_wgrad_bf16(const uint16_t* x, const uint16_t* x2, const void* dz, float* dw, float* dbias,
+                                     void* workspace, size_t workspace_bytes, int N, int D, int H, int W, int Cin, int Cout,
+                                     int K, int lddz, int dz_coff, void* stream) {
+    FDN_REQUIRE(x && dz && dw, "fdn_conv3d_wgrad_bf16: x/dz/dw is NULL");
+    FDN_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "fdn_conv3d_wgrad_bf16: bad dims");
+    const size_t need = fdn_conv3d_wgrad_bf16_workspace_bytes(N, D, H, W, Cin, Cout, K);
+    if (workspace_bytes < need || (need && !workspace)) {
+        fdn_set_error("fdn_conv3d_wgrad_bf16: workspace %zu < %zu bytes", workspace_bytes, need);
+        return FDN_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t nvox = (int64_t)N * D * H * W;
+    const uint16_t* dzb = (const uint16_t*)dz;
+    int rc;
+    if (Cin == 64 && Cout == 64 && K == 3) {
+        FDN_REQUIRE(lddz == 64 && dz_coff == 0, "fdn_conv3d_wgrad_bf16: 64->64 path reads dense dz rows");
+        rc = fdn_wgrad64_bf16_launch(x, dzb, dw, workspace, workspace_bytes, N, D, H, W, s);
+    } else if (Cin == 3 && Cout == 64 && K == 3) {
+        FDN_REQUIRE(lddz == 64 && dz_coff == 0, "fdn_conv3d_wgrad_bf16(3->64): dense dz rows");
+        rc = fdn_wgrad_cin3_launch<uint16_t>(x, dzb, dw, workspace, workspace_bytes, N, D, H, W, s);
+    } else if (Cin == 64 && Cout == 1 && K == 3) {      // the head's dz is the fp32 prediction gradient
+        rc = fdn_wgrad_cout1_launch<uint16_t>(x, (const float*)dz, dw, workspace, workspace_bytes, N, D, H, W, lddz, dz_coff, s);
+        if (rc != FDN_OK) return rc;
+        if (dbias) return fdn_bias_grad_launch<float>((const float*)dz, dbias, workspace, workspace_bytes, nvox, 1, lddz, dz_coff, s);
+        return FDN_OK;
+    } else if (Cin == 128 && Cout == 64 && K == 1) {
+        FDN_REQUIRE(x2 && lddz == 64 && dz_coff == 0, "fdn_conv3d_wgrad_bf16(1x1): needs x2, dense dz rows");
+        rc = fdn_wgrad_1x1_launch<uint16_t>(x, x2, dzb, dw, workspace, workspace_bytes, nvox, s);
+    } else {
+        fdn_set_error("fdn_conv3d_wgrad_bf16: unsupported (Cin=%d,Cout=%d,K=%d)", Cin, Cout, K);
+        return FDN_ERR_UNSUPPORTED;
+    }
+    if (rc != FDN_OK) return rc;
+    if (dbias) return fdn_bias_grad_launch<uint16_t>(dzb, dbias, workspace, workspace_bytes, nvox, Cout, lddz, dz_coff, s);
+    return FDN_OK;
 }

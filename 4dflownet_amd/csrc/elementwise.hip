@@ -8,17 +8,18 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // src/Network/SR4DFlowNet.py:10-15
 // ---------------------------------------------------------------------------------------------
+template <typename T>
 __global__ void input_features_kernel(const float* __restrict__ u, const float* __restrict__ v, const float* __restrict__ w,
                                       const float* __restrict__ mu, const float* __restrict__ mv,
-                                      const float* __restrict__ mw, float* __restrict__ phase, float* __restrict__ pc,
+                                      const float* __restrict__ mw, T* __restrict__ phase, T* __restrict__ pc,
                                       int64_t nvox) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvox; i += (int64_t)gridDim.x * blockDim.x) {
         const float a = u[i], b = v[i], c = w[i];
         const float speed = sqrtf(a * a + b * b + c * c);
         const float ma = mu[i], mb = mv[i], mc = mw[i];
         const float mag = sqrtf(ma * ma + mb * mb + mc * mc);
-        phase[i * 3 + 0] = a; phase[i * 3 + 1] = b; phase[i * 3 + 2] = c;
-        pc[i * 3 + 0] = mag * speed; pc[i * 3 + 1] = mag; pc[i * 3 + 2] = speed;
+        fdn_st1(phase + i * 3 + 0, a); fdn_st1(phase + i * 3 + 1, b); fdn_st1(phase + i * 3 + 2, c);
+        fdn_st1(pc + i * 3 + 0, mag * speed); fdn_st1(pc + i * 3 + 1, mag); fdn_st1(pc + i * 3 + 2, speed);
     }
 }
 
@@ -76,7 +77,8 @@ __device__ __forceinline__ void lerp_coeff(int o, float scale, int n, int& lo, i
     f = src - fl;
 }
 
-__global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int D,
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int D,
                                                             int H, int W, int C4, int R, float sd, float sh, float sw) {
     const int OD = D * R, OH = H * R, OW = W * R;
     const int64_t total = (int64_t)N * OD * OH * OW * C4;
@@ -92,8 +94,8 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restri
         lerp_coeff(od, sd, D, d0, d1, fd);
         lerp_coeff(oh, sh, H, h0, h1, fh);
         lerp_coeff(ow, sw, W, w0, w1, fw);
-        const f32x4* xb = (const f32x4*)x + (int64_t)n * D * H * W * C4 + c4;
-#define XAT(dd, hh, ww) xb[(((int64_t)(dd)*H + (hh)) * W + (ww)) * C4]
+        const T* xb = x + ((int64_t)n * D * H * W * C4 + c4) * 4;
+#define XAT(dd, hh, ww) fdn_ld4(xb + (((int64_t)(dd)*H + (hh)) * W + (ww)) * C4 * 4)
         // innermost (z) first, then y, then x -- the order of the reference's two resize passes
         const f32x4 a00 = XAT(d0, h0, w0), a01 = XAT(d0, h0, w1), a10 = XAT(d0, h1, w0), a11 = XAT(d0, h1, w1);
         const f32x4 b00 = XAT(d1, h0, w0), b01 = XAT(d1, h0, w1), b10 = XAT(d1, h1, w0), b11 = XAT(d1, h1, w1);
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restri
         const f32x4 a0 = a00 + (a01 - a00) * fw, a1 = a10 + (a11 - a10) * fw;
         const f32x4 b0 = b00 + (b01 - b00) * fw, b1 = b10 + (b11 - b10) * fw;
         const f32x4 a = a0 + (a1 - a0) * fh, b = b0 + (b1 - b0) * fh;
-        ((f32x4*)y)[i] = a + (b - a) * fd;
+        fdn_st4(y + i * 4, a + (b - a) * fd);
     }
 }
 
@@ -122,8 +124,9 @@ __device__ __forceinline__ void axis_range(int i, float inv_scale, int m, int& o
     o1 = min(m - 1, (int)ceilf((float)(i + 1) * inv_scale) + 1);
 }
 
-__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ yprev,
-                                                            int act, float alpha, float* __restrict__ dx, int N, int D,
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ yprev,
+                                                            int act, float alpha, T* __restrict__ dx, int N, int D,
                                                             int H, int W, int C4, int R, float sd, float sh, float sw) {
     const int OD = D * R, OH = H * R, OW = W * R;
     const int64_t total = (int64_t)N * D * H * W * C4;
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
         if (sd == 0.f) { od0 = 0; od1 = OD - 1; }
         if (sh == 0.f) { oh0 = 0; oh1 = OH - 1; }
         if (sw == 0.f) { ow0 = 0; ow1 = OW - 1; }
-        const f32x4* gb = (const f32x4*)dy + (int64_t)n * OD * OH * OW * C4 + c4;
+        const T* gb = dy + ((int64_t)n * OD * OH * OW * C4 + c4) * 4;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         for (int od = od0; od <= od1; ++od) {
             const float wd = axis_weight(od, d, sd, D);
@@ -155,18 +158,18 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
                 for (int ow = ow0; ow <= ow1; ++ow) {
                     const float ww = axis_weight(ow, w, sw, W);
                     if (ww == 0.f) continue;
-                    acch += gb[(((int64_t)od * OH + oh) * OW + ow) * C4] * ww;
+                    acch += fdn_ld4(gb + (((int64_t)od * OH + oh) * OW + ow) * C4 * 4) * ww;
                 }
                 accd += acch * wh;
             }
             acc += accd * wd;
         }
         if (yprev) {
-            const f32x4 y = ((const f32x4*)yprev)[i];
+            const f32x4 y = fdn_ld4(yprev + i * 4);
             acc.x *= fdn_act_grad(y.x, act, alpha); acc.y *= fdn_act_grad(y.y, act, alpha);
             acc.z *= fdn_act_grad(y.z, act, alpha); acc.w *= fdn_act_grad(y.w, act, alpha);
         }
-        ((f32x4*)dx)[i] = acc;
+        fdn_st4(dx + i * 4, acc);
     }
 }
 
@@ -291,13 +294,22 @@ float axis_scale(int n, int R) {
 
 }  // namespace
 
-extern "C" int fdn_input_features(const float* u, const float* v, const float* w, const float* mu, const float* mv,
-                                  const float* mw, float* phase, float* pc, int64_t nvox, void* stream) {
+template <typename T>
+static int input_features_t(const float* u, const float* v, const float* w, const float* mu, const float* mv, const float* mw,
+                            T* phase, T* pc, int64_t nvox, void* stream) {
     FDN_REQUIRE(u && v && w && mu && mv && mw && phase && pc && nvox > 0, "fdn_input_features: NULL argument or nvox<=0");
-    hipLaunchKernelGGL(input_features_kernel, dim3(grid_for(nvox)), dim3(256), 0, (hipStream_t)stream, u, v, w, mu, mv, mw,
+    hipLaunchKernelGGL(input_features_kernel<T>, dim3(grid_for(nvox)), dim3(256), 0, (hipStream_t)stream, u, v, w, mu, mv, mw,
                        phase, pc, nvox);
     FDN_CHECK_LAUNCH("input_features_kernel");
     return FDN_OK;
+}
+extern "C" int fdn_input_features(const float* u, const float* v, const float* w, const float* mu, const float* mv,
+                                  const float* mw, float* phase, float* pc, int64_t nvox, void* stream) {
+    return input_features_t<float>(u, v, w, mu, mv, mw, phase, pc, nvox, stream);
+}
+extern "C" int fdn_input_features_bf16(const float* u, const float* v, const float* w, const float* mu, const float* mv,
+                                       const float* mw, uint16_t* phase, uint16_t* pc, int64_t nvox, void* stream) {
+    return input_features_t<uint16_t>(u, v, w, mu, mv, mw, phase, pc, nvox, stream);
 }
 
 extern "C" int fdn_fold_halo(const float* dxpad0, const float* dxpad1, const float* dxpad2, int nsrc, const float* skip,
@@ -313,23 +325,39 @@ extern "C" int fdn_fold_halo(const float* dxpad0, const float* dxpad1, const flo
     return FDN_OK;
 }
 
-extern "C" int fdn_upsample_trilinear_fwd(const float* x, float* y, int N, int D, int H, int W, int C, int R, void* stream) {
+template <typename T>
+static int upsample_fwd_t(const T* x, T* y, int N, int D, int H, int W, int C, int R, void* stream) {
     FDN_REQUIRE(x && y && C % 4 == 0 && R >= 1 && N > 0 && D > 0 && H > 0 && W > 0, "fdn_upsample_trilinear_fwd: bad argument");
     const int64_t total = (int64_t)N * D * R * H * R * W * R * (C / 4);
-    hipLaunchKernelGGL(upsample_fwd_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, x, y, N, D, H, W,
-                       C / 4, R, axis_scale(D, R), axis_scale(H, R), axis_scale(W, R));
+    hipLaunchKernelGGL(upsample_fwd_kernel<T>, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, x, y, N, D, H,
+                       W, C / 4, R, axis_scale(D, R), axis_scale(H, R), axis_scale(W, R));
     FDN_CHECK_LAUNCH("upsample_fwd_kernel");
     return FDN_OK;
 }
-
-extern "C" int fdn_upsample_trilinear_bwd(const float* dy, const float* y_prev, int act, float alpha, float* dx, int N, int D,
-                                          int H, int W, int C, int R, void* stream) {
+template <typename T>
+static int upsample_bwd_t(const T* dy, const T* y_prev, int act, float alpha, T* dx, int N, int D, int H, int W, int C, int R,
+                          void* stream) {
     FDN_REQUIRE(dy && dx && C % 4 == 0 && R >= 1 && N > 0 && D > 0 && H > 0 && W > 0, "fdn_upsample_trilinear_bwd: bad argument");
     const int64_t total = (int64_t)N * D * H * W * (C / 4);
-    hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, dy, y_prev, act,
+    hipLaunchKernelGGL(upsample_bwd_kernel<T>, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, dy, y_prev, act,
                        alpha, dx, N, D, H, W, C / 4, R, axis_scale(D, R), axis_scale(H, R), axis_scale(W, R));
     FDN_CHECK_LAUNCH("upsample_bwd_kernel");
     return FDN_OK;
+}
+extern "C" int fdn_upsample_trilinear_fwd(const float* x, float* y, int N, int D, int H, int W, int C, int R, void* stream) {
+    return upsample_fwd_t<float>(x, y, N, D, H, W, C, R, stream);
+}
+extern "C" int fdn_upsample_trilinear_bwd(const float* dy, const float* y_prev, int act, float alpha, float* dx, int N, int D,
+                                          int H, int W, int C, int R, void* stream) {
+    return upsample_bwd_t<float>(dy, y_prev, act, alpha, dx, N, D, H, W, C, R, stream);
+}
+extern "C" int fdn_upsample_trilinear_fwd_bf16(const uint16_t* x, uint16_t* y, int N, int D, int H, int W, int C, int R,
+                                               void* stream) {
+    return upsample_fwd_t<uint16_t>(x, y, N, D, H, W, C, R, stream);
+}
+extern "C" int fdn_upsample_trilinear_bwd_bf16(const uint16_t* dy, const uint16_t* y_prev, int act, float alpha, uint16_t* dx,
+                                               int N, int D, int H, int W, int C, int R, void* stream) {
+    return upsample_bwd_t<uint16_t>(dy, y_prev, act, alpha, dx, N, D, H, W, C, R, stream);
 }
 
 extern "C" int fdn_loss_metrics(const float* pred, const float* uh, const float* vh, const float* wh, const float* mask,

@@ -9,6 +9,27 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+typedef unsigned fdn_u32x2 __attribute__((ext_vector_type(2)));
+
+// Activation storage: float, or bfloat16 held as its uint16_t bit pattern (the bf16 path of BASELINE.json configs[3]).
+// Arithmetic is always fp32; a bf16 store rounds to nearest even.
+__device__ __forceinline__ float fdn_ld1(const float* p) { return *p; }
+__device__ __forceinline__ float fdn_ld1(const uint16_t* p) { return __builtin_bit_cast(float, (unsigned)*p << 16); }
+__device__ __forceinline__ void fdn_st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void fdn_st1(uint16_t* p, float v) { const __bf16 b = (__bf16)v; *p = __builtin_bit_cast(uint16_t, b); }
+__device__ __forceinline__ f32x4 fdn_ld4(const float* p) { return *(const f32x4*)p; }
+__device__ __forceinline__ f32x4 fdn_ld4(const uint16_t* p) {
+    const fdn_u32x2 r = *(const fdn_u32x2*)p;
+    return (f32x4){__builtin_bit_cast(float, r.x << 16), __builtin_bit_cast(float, r.x & 0xffff0000u),
+                   __builtin_bit_cast(float, r.y << 16), __builtin_bit_cast(float, r.y & 0xffff0000u)};
+}
+__device__ __forceinline__ void fdn_st4(float* p, f32x4 v) { *(f32x4*)p = v; }
+__device__ __forceinline__ void fdn_st4(uint16_t* p, f32x4 v) {
+    typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+    const bf4 b = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    *(fdn_u32x2*)p = __builtin_bit_cast(fdn_u32x2, b);
+}
+
 void fdn_set_error(const char* fmt, ...);
 
 #define FDN_CHECK_LAUNCH(name)                                                         \
@@ -70,3 +91,6 @@ int fdn_conv64_bf16_launch(const uint16_t* x, const uint16_t* wpack, const float
 int fdn_fold_halo_border_bf16_launch(const float* s0, const float* s1, const float* s2, int nsrc, const uint16_t* skip,
                                      const uint16_t* yprev, int act, float alpha, uint16_t* out, int N, int D, int H, int W,
                                      hipStream_t s);
+size_t fdn_wgrad64_bf16_workspace_bytes(int N, int D, int H, int W);
+int fdn_wgrad64_bf16_launch(const uint16_t* x, const uint16_t* dz, float* dw, void* ws, size_t ws_bytes, int N, int D, int H,
+                            int W, hipStream_t s);

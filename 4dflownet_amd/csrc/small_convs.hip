@@ -11,8 +11,9 @@ __device__ __forceinline__ int clampi(int v, int hi) { return min(max(v, 0), hi)
 // -------------------------------------------------------------------------------------------------
 // forward 3 -> 64, k=3.  Block = 64 voxels x 4 cout-groups of 16; weights (81 x 64) in LDS.
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void conv_cin3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                             const float* __restrict__ bias, float* __restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(256) void conv_cin3_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, T* __restrict__ y,
                                                              int N, int D, int H, int W, int act, float alpha) {
     __shared__ __attribute__((aligned(16))) float ws[81 * 64];
     for (int i = threadIdx.x; i < 81 * 64; i += 256) ws[i] = w[i];
@@ -36,27 +37,28 @@ __global__ __launch_bounds__(256) void conv_cin3_fwd_kernel(const float* __restr
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const int qw = clampi(wv + c - 1, W - 1);
-                const float* xp = x + (nb + ((int64_t)qd * H + qh) * W + qw) * 3;
-                const float x0 = xp[0], x1 = xp[1], x2 = xp[2];
+                const T* xp = x + (nb + ((int64_t)qd * H + qh) * W + qw) * 3;
+                const float x0 = fdn_ld1(xp), x1 = fdn_ld1(xp + 1), x2 = fdn_ld1(xp + 2);
                 const float* wp = ws + ((a * 3 + b) * 3 + c) * 192 + q * 16;
 #pragma unroll
                 for (int j = 0; j < 16; ++j) acc[j] += x0 * wp[j] + x1 * wp[64 + j] + x2 * wp[128 + j];
             }
         }
     }
-    float* yp = y + v * 64 + q * 16;
+    T* yp = y + v * 64 + q * 16;
 #pragma unroll
     for (int j = 0; j < 16; j += 4) {
         f32x4 o = {fdn_act(acc[j], act, alpha), fdn_act(acc[j + 1], act, alpha), fdn_act(acc[j + 2], act, alpha),
                    fdn_act(acc[j + 3], act, alpha)};
-        *(f32x4*)(yp + j) = o;
+        fdn_st4(yp + j, o);
     }
 }
 
 // -------------------------------------------------------------------------------------------------
 // forward 64 -> 1, k=3.  16 lanes per voxel (4 channels each), 27 coalesced row reads, 16-lane reduce.
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void conv_cout1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+template <typename T>
+__global__ __launch_bounds__(256) void conv_cout1_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ bias, float* __restrict__ y,
                                                               int N, int D, int H, int W, int ldy, int y_coff, int act,
                                                               float alpha) {
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256) void conv_cout1_fwd_kernel(const float* __rest
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const int qw = clampi(wv + c - 1, W - 1);
-                    const f32x4 xv = *(const f32x4*)(x + (nb + ((int64_t)qd * H + qh) * W + qw) * 64 + c4 * 4);
+                    const f32x4 xv = fdn_ld4(x + (nb + ((int64_t)qd * H + qh) * W + qw) * 64 + c4 * 4);
                     const f32x4 wt = *(const f32x4*)(ws + ((a * 3 + b) * 3 + c) * 64 + c4 * 4);
                     s += xv.x * wt.x + xv.y * wt.y + xv.z * wt.z + xv.w * wt.w;
                 }
@@ -96,9 +98,10 @@ __global__ __launch_bounds__(256) void conv_cout1_fwd_kernel(const float* __rest
 // -------------------------------------------------------------------------------------------------
 // forward 1x1x1 (64 + 64) -> 64.  Thread = (voxel, 16 couts); weights (128 x 64) in LDS.
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void conv1x1_fwd_kernel(const float* __restrict__ xa, const float* __restrict__ xb,
+template <typename T>
+__global__ __launch_bounds__(256) void conv1x1_fwd_kernel(const T* __restrict__ xa, const T* __restrict__ xb,
                                                            const float* __restrict__ w, const float* __restrict__ bias,
-                                                           float* __restrict__ y, int64_t nvox, int act, float alpha) {
+                                                           T* __restrict__ y, int64_t nvox, int act, float alpha) {
     __shared__ __attribute__((aligned(16))) float ws[128 * 64];
     for (int i = threadIdx.x; i < 128 * 64; i += 256) ws[i] = w[i];
     __syncthreads();
@@ -109,11 +112,11 @@ __global__ __launch_bounds__(256) void conv1x1_fwd_kernel(const float* __restric
         for (int j = 0; j < 16; ++j) acc[j] = bias ? bias[q * 16 + j] : 0.f;
 #pragma unroll 1
         for (int src = 0; src < 2; ++src) {
-            const float* xp = (src ? xb : xa) + v * 64;
+            const T* xp = (src ? xb : xa) + v * 64;
             const float* wsrc = ws + src * 64 * 64 + q * 16;
 #pragma unroll 4
             for (int k4 = 0; k4 < 16; ++k4) {
-                const f32x4 xv = *(const f32x4*)(xp + k4 * 4);
+                const f32x4 xv = fdn_ld4(xp + k4 * 4);
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     const float xs = xv[kk];
@@ -123,21 +126,22 @@ __global__ __launch_bounds__(256) void conv1x1_fwd_kernel(const float* __restric
                 }
             }
         }
-        float* yp = y + v * 64 + q * 16;
+        T* yp = y + v * 64 + q * 16;
 #pragma unroll
         for (int j = 0; j < 16; j += 4) {
             f32x4 o = {fdn_act(acc[j], act, alpha), fdn_act(acc[j + 1], act, alpha), fdn_act(acc[j + 2], act, alpha),
                        fdn_act(acc[j + 3], act, alpha)};
-            *(f32x4*)(yp + j) = o;
+            fdn_st4(yp + j, o);
         }
     }
 }
 
 // 1x1 backward w.r.t. inputs, fused with the ReLU masks of the two producers.
 // thread = (voxel, 16 of the 128 input channels); Wt[co][ci] in LDS.
-__global__ __launch_bounds__(256) void conv1x1_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ w,
-                                                             const float* __restrict__ ya, const float* __restrict__ yb,
-                                                             float* __restrict__ dxa, float* __restrict__ dxb, int64_t nvox) {
+template <typename T>
+__global__ __launch_bounds__(256) void conv1x1_dgrad_kernel(const T* __restrict__ dz, const float* __restrict__ w,
+                                                             const T* __restrict__ ya, const T* __restrict__ yb,
+                                                             T* __restrict__ dxa, T* __restrict__ dxb, int64_t nvox) {
     __shared__ __attribute__((aligned(16))) float wt[64 * 128];
     for (int i = threadIdx.x; i < 128 * 64; i += 256) {
         const int ci = i >> 6, co = i & 63;
@@ -149,10 +153,10 @@ __global__ __launch_bounds__(256) void conv1x1_dgrad_kernel(const float* __restr
         float acc[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-        const float* dp = dz + v * 64;
+        const T* dp = dz + v * 64;
 #pragma unroll 4
         for (int k4 = 0; k4 < 16; ++k4) {
-            const f32x4 dv = *(const f32x4*)(dp + k4 * 4);
+            const f32x4 dv = fdn_ld4(dp + k4 * 4);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const float ds = dv[kk];
@@ -163,14 +167,14 @@ __global__ __launch_bounds__(256) void conv1x1_dgrad_kernel(const float* __restr
         }
         const int half = q >> 2;
         const int cofs = (q & 3) * 16;
-        const float* yp = (half ? yb : ya) + v * 64 + cofs;
-        float* op = (half ? dxb : dxa) + v * 64 + cofs;
+        const T* yp = (half ? yb : ya) + v * 64 + cofs;
+        T* op = (half ? dxb : dxa) + v * 64 + cofs;
 #pragma unroll
         for (int j = 0; j < 16; j += 4) {
-            const f32x4 yv = *(const f32x4*)(yp + j);
+            const f32x4 yv = fdn_ld4(yp + j);
             f32x4 o = {yv.x > 0.f ? acc[j] : 0.f, yv.y > 0.f ? acc[j + 1] : 0.f, yv.z > 0.f ? acc[j + 2] : 0.f,
                        yv.w > 0.f ? acc[j + 3] : 0.f};
-            *(f32x4*)(op + j) = o;
+            fdn_st4(op + j, o);
         }
     }
 }
@@ -223,7 +227,8 @@ __global__ __launch_bounds__(256) void conv_cout1_dgrad_kernel(const float* __re
 // weight gradients of the thin layers: per-block partials in workspace, then reduce_partials.
 // -------------------------------------------------------------------------------------------------
 // 3 -> 64: one wave owns the full (81 x 64) output (lane = cout, 81 accumulators), waves take voxels round-robin.
-__global__ __launch_bounds__(256) void wgrad_cin3_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_cin3_kernel(const T* __restrict__ x, const T* __restrict__ dz,
                                                           float* __restrict__ partial, int N, int D, int H, int W) {
     __shared__ float red[81 * 64];
     const int lane = threadIdx.x & 63;
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(256) void wgrad_cin3_kernel(const float* __restrict
         const int d = r / (H * W); r -= d * H * W;
         const int h = r / W;
         const int w0 = r - h * W;
-        const float g = dz[v * 64 + lane];
+        const float g = fdn_ld1(dz + v * 64 + lane);
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const int qd = clampi(d + a - 1, D - 1);
@@ -250,11 +255,11 @@ __global__ __launch_bounds__(256) void wgrad_cin3_kernel(const float* __restrict
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const int qw = clampi(w0 + c - 1, W - 1);
-                    const float* xp = x + (nb + ((int64_t)qd * H + qh) * W + qw) * 3;
+                    const T* xp = x + (nb + ((int64_t)qd * H + qh) * W + qw) * 3;
                     const int t = ((a * 3 + b) * 3 + c) * 3;
-                    acc[t] += xp[0] * g;
-                    acc[t + 1] += xp[1] * g;
-                    acc[t + 2] += xp[2] * g;
+                    acc[t] += fdn_ld1(xp) * g;
+                    acc[t + 1] += fdn_ld1(xp + 1) * g;
+                    acc[t + 2] += fdn_ld1(xp + 2) * g;
                 }
             }
         }
@@ -274,7 +279,8 @@ __global__ __launch_bounds__(256) void wgrad_cin3_kernel(const float* __restrict
 
 // 64 -> 1: iterate over rows of PADDED input positions so each x row is read once.  Thread = (position slot g,
 // 4 channels q); the 9 dz rows a padded (d,h) row can touch are staged in LDS (zero-padded), 27 float4 accumulators.
-__global__ __launch_bounds__(256) void wgrad_cout1_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_cout1_kernel(const T* __restrict__ x, const float* __restrict__ dz,
                                                            float* __restrict__ partial, int N, int D, int H, int W,
                                                            int lddz, int dz_coff) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -302,9 +308,9 @@ __global__ __launch_bounds__(256) void wgrad_cout1_kernel(const float* __restric
         }
         __syncthreads();
         const int qd = clampi(pd - 1, D - 1), qh = clampi(ph - 1, H - 1);
-        const float* xrow = x + (((int64_t)n * D + qd) * H + qh) * W * 64 + q * 4;
+        const T* xrow = x + (((int64_t)n * D + qd) * H + qh) * W * 64 + q * 4;
         for (int pw = g; pw < PW; pw += 16) {
-            const f32x4 xv = *(const f32x4*)(xrow + (int64_t)clampi(pw - 1, W - 1) * 64);
+            const f32x4 xv = fdn_ld4(xrow + (int64_t)clampi(pw - 1, W - 1) * 64);
 #pragma unroll
             for (int k = 0; k < 9; ++k)
 #pragma unroll
@@ -351,9 +357,10 @@ __device__ __forceinline__ int pairs_of(int i, int n, int* o, int* a) {
     return cnt;   // <= 3 by construction
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void conv_cout1_dgrad_folded_kernel(const float* __restrict__ dz, const float* __restrict__ w,
-                                                                       const float* __restrict__ yprev, int act, float alpha,
-                                                                       float* __restrict__ out, float* __restrict__ bpart,
+                                                                       const T* __restrict__ yprev, int act, float alpha,
+                                                                       T* __restrict__ out, float* __restrict__ bpart,
                                                                        int N, int D, int H, int W, int lddz, int dz_coff) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* wl = sm;                 // 27 * 64 weights
@@ -389,11 +396,11 @@ __global__ __launch_bounds__(256) void conv_cout1_dgrad_folded_kernel(const floa
             }
             const int64_t o = ((((int64_t)n * D + d) * H + h) * W + wv) * 64 + q * 4;
             if (yprev) {
-                const f32x4 y = *(const f32x4*)(yprev + o);
+                const f32x4 y = fdn_ld4(yprev + o);
                 acc.x *= fdn_act_grad(y.x, act, alpha); acc.y *= fdn_act_grad(y.y, act, alpha);
                 acc.z *= fdn_act_grad(y.z, act, alpha); acc.w *= fdn_act_grad(y.w, act, alpha);
             }
-            *(f32x4*)(out + o) = acc;
+            fdn_st4(out + o, acc);
             bsum += acc;
         }
     }
@@ -418,8 +425,9 @@ __global__ __launch_bounds__(256) void conv_cout1_dgrad_folded_kernel(const floa
 }
 
 // 1x1 (64+64) -> 64: thread owns ci = tid>>1 and 32 couts; voxel chunks staged through LDS.
-__global__ __launch_bounds__(256) void wgrad_1x1_kernel(const float* __restrict__ xa, const float* __restrict__ xb,
-                                                         const float* __restrict__ dz, float* __restrict__ partial,
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_1x1_kernel(const T* __restrict__ xa, const T* __restrict__ xb,
+                                                         const T* __restrict__ dz, float* __restrict__ partial,
                                                          int64_t nvox) {
     constexpr int CH = 32;   // voxels per chunk
     __shared__ __attribute__((aligned(16))) float xs[CH * 128];
@@ -434,13 +442,13 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const float* __restrict_
         for (int i = threadIdx.x; i < CH * 32; i += 256) {      // float4 units: 16 from xa + 16 from xb per voxel
             const int vv = i >> 5, c4 = i & 31;
             f32x4 val = {0.f, 0.f, 0.f, 0.f};
-            if (v0 + vv < nvox) val = *(const f32x4*)((c4 < 16 ? xa : xb) + (v0 + vv) * 64 + (c4 & 15) * 4);
+            if (v0 + vv < nvox) val = fdn_ld4((c4 < 16 ? xa : xb) + (v0 + vv) * 64 + (c4 & 15) * 4);
             *(f32x4*)(xs + vv * 128 + c4 * 4) = val;
         }
         for (int i = threadIdx.x; i < CH * 16; i += 256) {
             const int vv = i >> 4, c4 = i & 15;
             f32x4 val = {0.f, 0.f, 0.f, 0.f};
-            if (v0 + vv < nvox) val = *(const f32x4*)(dz + (v0 + vv) * 64 + c4 * 4);
+            if (v0 + vv < nvox) val = fdn_ld4(dz + (v0 + vv) * 64 + c4 * 4);
             *(f32x4*)(zs + vv * 64 + c4 * 4) = val;
         }
         __syncthreads();
@@ -461,21 +469,22 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const float* __restrict_
 }
 
 // bias gradient: db[c] = sum_v dz[v*ld + coff + c]
-__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dz, float* __restrict__ partial,
+template <typename T>
+__global__ __launch_bounds__(256) void bias_grad_kernel(const T* __restrict__ dz, float* __restrict__ partial,
                                                          int64_t nvox, int C, int lddz, int dz_coff) {
     __shared__ float red[256];
     float s = 0.f;
     if (C == 64) {
         const int c = threadIdx.x & 63;
         for (int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); v < nvox; v += (int64_t)gridDim.x * 4)
-            s += dz[v * lddz + dz_coff + c];
+            s += fdn_ld1(dz + v * lddz + dz_coff + c);
         red[threadIdx.x] = s;
         __syncthreads();
         if (threadIdx.x < 64)
             partial[(size_t)blockIdx.x * 64 + c] = (red[c] + red[64 + c]) + (red[128 + c] + red[192 + c]);
     } else {   // C == 1
         for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvox; v += (int64_t)gridDim.x * 256)
-            s += dz[v * lddz + dz_coff];
+            s += fdn_ld1(dz + v * lddz + dz_coff);
         red[threadIdx.x] = s;
         __syncthreads();
         for (int st = 128; st > 0; st >>= 1) {
@@ -533,37 +542,42 @@ size_t fdn_small_wgrad_workspace_bytes(int Cin, int Cout, int K) {
     return (size_t)kSmallBlocks * elems * sizeof(float);
 }
 
-int fdn_conv_cin3_fwd_launch(const float* x, const float* w, const float* bias, float* y, int N, int D, int H, int W,
-                             int act, float alpha, hipStream_t s) {
+// Launchers, templated on the activation storage type T (float, or uint16_t = bf16 bits); parameters, parameter
+// gradients, the 64->1 heads' output (the prediction) and its gradient are always fp32.
+template <typename T>
+int fdn_conv_cin3_fwd_launch(const T* x, const float* w, const float* bias, T* y, int N, int D, int H, int W, int act,
+                             float alpha, hipStream_t s) {
     const int64_t nvox = (int64_t)N * D * H * W;
-    hipLaunchKernelGGL(conv_cin3_fwd_kernel, dim3((unsigned)((nvox + 63) / 64)), dim3(256), 0, s, x, w, bias, y, N, D, H,
+    hipLaunchKernelGGL(conv_cin3_fwd_kernel<T>, dim3((unsigned)((nvox + 63) / 64)), dim3(256), 0, s, x, w, bias, y, N, D, H,
                        W, act, alpha);
     FDN_CHECK_LAUNCH("conv_cin3_fwd_kernel");
     return FDN_OK;
 }
 
-int fdn_conv_cout1_fwd_launch(const float* x, const float* w, const float* bias, float* y, int N, int D, int H, int W,
-                              int ldy, int y_coff, int act, float alpha, hipStream_t s) {
+template <typename T>
+int fdn_conv_cout1_fwd_launch(const T* x, const float* w, const float* bias, float* y, int N, int D, int H, int W, int ldy,
+                              int y_coff, int act, float alpha, hipStream_t s) {
     const int64_t nvox = (int64_t)N * D * H * W;
-    hipLaunchKernelGGL(conv_cout1_fwd_kernel, dim3(nblocks_for(nvox, 16, 8192)), dim3(256), 0, s, x, w, bias, y, N, D, H,
+    hipLaunchKernelGGL(conv_cout1_fwd_kernel<T>, dim3(nblocks_for(nvox, 16, 8192)), dim3(256), 0, s, x, w, bias, y, N, D, H,
                        W, ldy, y_coff, act, alpha);
     FDN_CHECK_LAUNCH("conv_cout1_fwd_kernel");
     return FDN_OK;
 }
 
-int fdn_conv1x1_fwd_launch(const float* xa, const float* xb, const float* w, const float* bias, float* y, int64_t nvox,
-                           int act, float alpha, hipStream_t s) {
-    hipLaunchKernelGGL(conv1x1_fwd_kernel, dim3(nblocks_for(nvox, 64, 2048)), dim3(256), 0, s, xa, xb, w, bias, y, nvox,
+template <typename T>
+int fdn_conv1x1_fwd_launch(const T* xa, const T* xb, const float* w, const float* bias, T* y, int64_t nvox, int act,
+                           float alpha, hipStream_t s) {
+    hipLaunchKernelGGL(conv1x1_fwd_kernel<T>, dim3(nblocks_for(nvox, 64, 2048)), dim3(256), 0, s, xa, xb, w, bias, y, nvox,
                        act, alpha);
     FDN_CHECK_LAUNCH("conv1x1_fwd_kernel");
     return FDN_OK;
 }
 
-extern "C" int fdn_conv1x1_dgrad(const float* dz, const float* w, const float* ya, const float* yb, float* dxa,
-                                 float* dxb, int64_t nvox, void* stream) {
-    FDN_REQUIRE(dz && w && ya && yb && dxa && dxb && nvox > 0, "fdn_conv1x1_dgrad: NULL argument or nvox<=0");
-    hipLaunchKernelGGL(conv1x1_dgrad_kernel, dim3(nblocks_for(nvox, 32, 2048)), dim3(256), 0, (hipStream_t)stream, dz, w,
-                       ya, yb, dxa, dxb, nvox);
+template <typename T>
+int fdn_conv1x1_dgrad_launch(const T* dz, const float* w, const T* ya, const T* yb, T* dxa, T* dxb, int64_t nvox,
+                             hipStream_t s) {
+    hipLaunchKernelGGL(conv1x1_dgrad_kernel<T>, dim3(nblocks_for(nvox, 32, 2048)), dim3(256), 0, s, dz, w, ya, yb, dxa, dxb,
+                       nvox);
     FDN_CHECK_LAUNCH("conv1x1_dgrad_kernel");
     return FDN_OK;
 }
@@ -577,28 +591,30 @@ int fdn_conv_cout1_dgrad_launch(const float* dz, const float* w, float* dxpad, i
     return FDN_OK;
 }
 
-int fdn_wgrad_cin3_launch(const float* x, const float* dz, float* dw, void* ws, size_t, int N, int D, int H, int W,
-                          hipStream_t s) {
+template <typename T>
+int fdn_wgrad_cin3_launch(const T* x, const T* dz, float* dw, void* ws, size_t, int N, int D, int H, int W, hipStream_t s) {
     const int64_t nvox = (int64_t)N * D * H * W;
     const int nb = nblocks_for(nvox, 4 * 32, kSmallBlocks);
-    hipLaunchKernelGGL(wgrad_cin3_kernel, dim3(nb), dim3(256), 0, s, x, dz, (float*)ws, N, D, H, W);
+    hipLaunchKernelGGL(wgrad_cin3_kernel<T>, dim3(nb), dim3(256), 0, s, x, dz, (float*)ws, N, D, H, W);
     FDN_CHECK_LAUNCH("wgrad_cin3_kernel");
     return reduce_partials((const float*)ws, dw, nb, 81 * 64, s);
 }
 
-int fdn_wgrad_cout1_launch(const float* x, const float* dz, float* dw, void* ws, size_t, int N, int D, int H, int W,
-                           int lddz, int dz_coff, hipStream_t s) {
+template <typename T>
+int fdn_wgrad_cout1_launch(const T* x, const float* dz, float* dw, void* ws, size_t, int N, int D, int H, int W, int lddz,
+                           int dz_coff, hipStream_t s) {
     const int nrows = N * (D + 2) * (H + 2);
     const int nb = nrows < kSmallBlocks ? nrows : kSmallBlocks;
     const size_t lds = (size_t)(((9 * (W + 4) + 3) & ~3) + 4 * 27 * 64) * sizeof(float);
-    hipLaunchKernelGGL(wgrad_cout1_kernel, dim3(nb), dim3(256), lds, s, x, dz, (float*)ws, N, D, H, W, lddz, dz_coff);
+    hipLaunchKernelGGL(wgrad_cout1_kernel<T>, dim3(nb), dim3(256), lds, s, x, dz, (float*)ws, N, D, H, W, lddz, dz_coff);
     FDN_CHECK_LAUNCH("wgrad_cout1_kernel");
     return reduce_partials((const float*)ws, dw, nb, 27 * 64, s);
 }
 
-extern "C" int fdn_conv_cout1_dgrad_folded(const float* dz, const float* w, const float* y_prev, int act, float alpha,
-                                           float* dz_prev, float* dbias_prev, void* workspace, size_t workspace_bytes, int N,
-                                           int D, int H, int W, int lddz, int dz_coff, void* stream) {
+template <typename T>
+int fdn_conv_cout1_dgrad_folded_launch(const float* dz, const float* w, const T* y_prev, int act, float alpha, T* dz_prev,
+                                       float* dbias_prev, void* workspace, size_t workspace_bytes, int N, int D, int H, int W,
+                                       int lddz, int dz_coff, hipStream_t s) {
     FDN_REQUIRE(dz && w && dz_prev && N > 0 && D > 0 && H > 0 && W > 0, "fdn_conv_cout1_dgrad_folded: bad argument");
     FDN_REQUIRE(W <= 4096, "fdn_conv_cout1_dgrad_folded: W too large for the row stage");
     const int nrows = N * D * H;
@@ -608,27 +624,47 @@ extern "C" int fdn_conv_cout1_dgrad_folded(const float* dz, const float* w, cons
         return FDN_ERR_WORKSPACE;
     }
     const size_t lds = (size_t)(27 * 64 + 9 * W + 16) * sizeof(float);
-    hipLaunchKernelGGL(conv_cout1_dgrad_folded_kernel, dim3(nb), dim3(256), lds, (hipStream_t)stream, dz, w, y_prev, act,
-                       alpha, dz_prev, dbias_prev ? (float*)workspace : nullptr, N, D, H, W, lddz, dz_coff);
+    hipLaunchKernelGGL(conv_cout1_dgrad_folded_kernel<T>, dim3(nb), dim3(256), lds, s, dz, w, y_prev, act, alpha, dz_prev,
+                       dbias_prev ? (float*)workspace : nullptr, N, D, H, W, lddz, dz_coff);
     FDN_CHECK_LAUNCH("conv_cout1_dgrad_folded_kernel");
-    if (dbias_prev) return reduce_partials((const float*)workspace, dbias_prev, nb, 64, (hipStream_t)stream);
+    if (dbias_prev) return reduce_partials((const float*)workspace, dbias_prev, nb, 64, s);
     return FDN_OK;
 }
 
-int fdn_wgrad_1x1_launch(const float* xa, const float* xb, const float* dz, float* dw, void* ws, size_t, int64_t nvox,
-                         hipStream_t s) {
+template <typename T>
+int fdn_wgrad_1x1_launch(const T* xa, const T* xb, const T* dz, float* dw, void* ws, size_t, int64_t nvox, hipStream_t s) {
     const int nb = nblocks_for(nvox, 32 * 4, kSmallBlocks);
-    hipLaunchKernelGGL(wgrad_1x1_kernel, dim3(nb), dim3(256), 0, s, xa, xb, dz, (float*)ws, nvox);
+    hipLaunchKernelGGL(wgrad_1x1_kernel<T>, dim3(nb), dim3(256), 0, s, xa, xb, dz, (float*)ws, nvox);
     FDN_CHECK_LAUNCH("wgrad_1x1_kernel");
     return reduce_partials((const float*)ws, dw, nb, 128 * 64, s);
 }
 
-int fdn_bias_grad_launch(const float* dz, float* db, void* ws, size_t ws_bytes, int64_t nvox, int C, int lddz,
-                         int dz_coff, hipStream_t s) {
+template <typename T>
+int fdn_bias_grad_launch(const T* dz, float* db, void* ws, size_t ws_bytes, int64_t nvox, int C, int lddz, int dz_coff,
+                         hipStream_t s) {
     if (C != 64 && C != 1) { fdn_set_error("bias_grad: unsupported C=%d", C); return FDN_ERR_UNSUPPORTED; }
     const int nb = nblocks_for(nvox, C == 64 ? 4 * 64 : 256 * 16, kSmallBlocks);
     if (ws_bytes < (size_t)nb * C * sizeof(float)) { fdn_set_error("bias_grad: workspace too small"); return FDN_ERR_WORKSPACE; }
-    hipLaunchKernelGGL(bias_grad_kernel, dim3(nb), dim3(256), 0, s, dz, (float*)ws, nvox, C, lddz, dz_coff);
+    hipLaunchKernelGGL(bias_grad_kernel<T>, dim3(nb), dim3(256), 0, s, dz, (float*)ws, nvox, C, lddz, dz_coff);
     FDN_CHECK_LAUNCH("bias_grad_kernel");
     return reduce_partials((const float*)ws, db, nb, C, s);
 }
+
+// explicit instantiations used by api.hip
+#define FDN_INSTANTIATE_SMALL(T)                                                                                               \
+    template int fdn_conv_cin3_fwd_launch<T>(const T*, const float*, const float*, T*, int, int, int, int, int, float,         \
+                                             hipStream_t);                                                                     \
+    template int fdn_conv_cout1_fwd_launch<T>(const T*, const float*, const float*, float*, int, int, int, int, int, int, int, \
+                                              float, hipStream_t);                                                             \
+    template int fdn_conv1x1_fwd_launch<T>(const T*, const T*, const float*, const float*, T*, int64_t, int, float,            \
+                                           hipStream_t);                                                                       \
+    template int fdn_conv1x1_dgrad_launch<T>(const T*, const float*, const T*, const T*, T*, T*, int64_t, hipStream_t);        \
+    template int fdn_wgrad_cin3_launch<T>(const T*, const T*, float*, void*, size_t, int, int, int, int, hipStream_t);         \
+    template int fdn_wgrad_cout1_launch<T>(const T*, const float*, float*, void*, size_t, int, int, int, int, int, int,        \
+                                           hipStream_t);                                                                       \
+    template int fdn_conv_cout1_dgrad_folded_launch<T>(const float*, const float*, const T*, int, float, T*, float*, void*,    \
+                                                       size_t, int, int, int, int, int, int, hipStream_t);                     \
+    template int fdn_wgrad_1x1_launch<T>(const T*, const T*, const T*, float*, void*, size_t, int64_t, hipStream_t);           \
+    template int fdn_bias_grad_launch<T>(const T*, float*, void*, size_t, int64_t, int, int, int, hipStream_t);
+FDN_INSTANTIATE_SMALL(float)
+FDN_INSTANTIATE_SMALL(uint16_t)

@@ -1,0 +1,214 @@
+// Weight gradient of the 3x3x3 64 -> 64 conv with bf16 activations / activation gradients, fp32 result
+// (bf16 variant of wgrad64_mfma.hip; Conv3DBackpropFilterV2 behind tape.gradient, TrainerController.py:223):
+//   dW[a,b,c][ci][co] = sum_{n,o} x[n, clamp(o + (a,b,c) - 1)][ci] * dz[n,o][co]
+//
+// Same decomposition as the fp32 kernel: grid = (S splits of the tile list) x (3 depth taps a); a workgroup (4 waves =
+// 2x2 quadrants of (ci,co)) keeps 9 accumulators (b,c) x 32x32 in registers across all of its tiles, partial sums go to
+// workspace[S][27][64][64] and wgrad64_reduce_kernel sums over S.
+//
+// v_mfma_f32_32x32x16_bf16 contracts 16 voxels per instruction, and both operands are "k-strided" in the NDHWC LDS image
+// (a lane needs 8 consecutive VOXELS of one channel).  gfx950's transposing LDS read delivers exactly that:
+// ds_read_b64_tr_b16 hands lane c of a 16-lane group the 4 voxels (rows) of channel c out of a 4-voxel x 16-channel block.
+//   * k-step = the 16 voxels (2 h-rows x 8 w) of one (d, h-pair); lanes 0-31 take h-row 0, lanes 32-63 h-row 1.
+//   * dz: 2 transposing reads (w 0-3, 4-7) -> B operand, shared by the 9 taps.
+//   * x : per b, 3 transposing reads of the halo row (w 0-3, 4-7, 8-11); the operands of the three c taps are 16-bit
+//     funnel shifts of that 12-voxel window (c = 1: 4 x v_alignbit; c = 0, 2: register selection).
+//     11 LDS reads + 12 VALU per 9 MFMAs instead of 20 reads.
+//   * LDS image: 128 B per voxel, the two 64-B halves swapped on rows with bit 1 set -> any 4 consecutive rows x 64 B
+//     cover all 64 banks (conflict-free transposing reads); every k-step offset is a multiple of 4 rows, so the per-lane
+//     addresses are computed once and the steps are immediates.
+#include "fdn_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef short v4i16 __attribute__((ext_vector_type(4)));
+
+__global__ void wgrad64_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int S);   // wgrad64_mfma.hip
+
+struct Wgrad64BfArgs {
+    const uint16_t* x;
+    const uint16_t* dz;
+    float* partial;
+    int N, D, H, W;
+    int ntd, nth, ntw, ntiles, S;
+};
+
+namespace {
+constexpr int TD = 2, TH = 8, TW = 8;
+constexpr int XH = TH + 2, XW = TW + 2;
+constexpr int XROWS = TD * XH * XW;      // 200
+constexpr int ZROWS = TD * TH * TW;      // 128
+constexpr int XPAD = XROWS + 2;          // the w 8-11 read of the last halo row runs 2 rows past the image
+constexpr int LDS_BYTES = (XPAD + ZROWS) * 128;
+}  // namespace
+
+__device__ __forceinline__ u32x2 tr_read(const char* lds_addr) {
+    const v4i16 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4i16 __attribute__((address_space(3)))*)lds_addr);
+    return __builtin_bit_cast(u32x2, r);
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad64_bf16_kernel(Wgrad64BfArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* xs = smem;
+    char* zs = smem + XPAD * 128;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 31;
+    const int kh = lane >> 5;
+    const int mq = wave & 1, nq = wave >> 1;
+    const int a = blockIdx.y;        // kernel-depth tap
+    const int split = blockIdx.x;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // ---- per-lane addresses of the transposing reads at k-step (d 0, h-pair 0) ----
+    // lane: 16-lane group g = lane >> 4 (h-row g >> 1, channel block 16 (g & 1)), p = lane & 15 supplies the 8 bytes
+    // [row + (p >> 2)][16 (g & 1) + 4 (p & 3) ...] of its group's 4 x 16 block.
+    const int g = lane >> 4, pq = lane & 15;
+    const int chan_b = (g & 1) * 32 + (pq & 3) * 8;               // byte offset inside the wave's 64-B half
+    int xoff[3][3], zoff[2];
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int row = ((g >> 1) + b) * XW + 4 * q + (pq >> 2);
+            xoff[b][q] = row * 128 + (((mq ^ (row >> 1)) & 1) << 6) + chan_b;
+        }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int row = (g >> 1) * TW + 4 * q + (pq >> 2);
+        zoff[q] = row * 128 + (((nq ^ (row >> 1)) & 1) << 6) + chan_b;
+    }
+
+    const int tiles_per_n = p.ntd * p.nth * p.ntw;
+    const int c16 = tid & 7;    // 16-B chunk within a 128-B row
+    const int rsub = tid >> 3;  // 0..31
+
+    // tile staging is software-pipelined through registers (as in the fp32 kernel): the K loop reads only LDS
+    constexpr int XP = (XROWS + 31) / 32, ZP = (ZROWS + 31) / 32;
+    u32x4 xv[XP], zv[ZP];
+    auto prefetch = [&](int tile) {
+        int b = tile;
+        const int n = b / tiles_per_n;
+        b -= n * tiles_per_n;
+        const int tdi = b / (p.nth * p.ntw);
+        b -= tdi * (p.nth * p.ntw);
+        const int thi = b / p.ntw;
+        const int p0d = tdi * TD, p0h = thi * TH, p0w = (b - thi * p.ntw) * TW;
+        const size_t vox_n = (size_t)n * p.D * p.H * p.W;
+#pragma unroll
+        for (int u = 0; u < XP; ++u) {          // x rows, edge clamp applied here
+            int r = u * 32 + rsub;
+            r = r < XROWS ? r : XROWS - 1;
+            const int zd = r / (XH * XW);
+            const int r2 = r - zd * (XH * XW);
+            const int zh = r2 / XW;
+            const int qd = min(max(p0d + zd + a - 1, 0), p.D - 1);
+            const int qh = min(max(p0h + zh - 1, 0), p.H - 1);
+            const int qw = min(max(p0w + (r2 - zh * XW) - 1, 0), p.W - 1);
+            xv[u] = *(const u32x4*)(p.x + (vox_n + ((size_t)qd * p.H + qh) * p.W + qw) * 64 + c16 * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < ZP; ++u) {          // dz rows, zero outside the volume
+            const int r = u * 32 + rsub;
+            const int zd = r / (TH * TW);
+            const int r2 = r - zd * (TH * TW);
+            const int zh = r2 / TW;
+            const int qd = p0d + zd, qh = p0h + zh, qw = p0w + (r2 - zh * TW);
+            const bool ok = qd < p.D && qh < p.H && qw < p.W;
+            const int cd = min(qd, p.D - 1), ch = min(qh, p.H - 1), cw = min(qw, p.W - 1);
+            zv[u] = *(const u32x4*)(p.dz + (vox_n + ((size_t)cd * p.H + ch) * p.W + cw) * 64 + c16 * 8);
+            if (!ok) zv[u] = (u32x4){0u, 0u, 0u, 0u};
+        }
+    };
+    if (split < p.ntiles) prefetch(split);
+    for (int tile = split; tile < p.ntiles; tile += p.S) {
+        __syncthreads();   // previous tile fully consumed
+#pragma unroll
+        for (int u = 0; u < XP; ++u) {
+            const int r = u * 32 + rsub;
+            if (r < XROWS) *(u32x4*)(xs + r * 128 + ((c16 ^ (((r >> 1) & 1) << 2)) << 4)) = xv[u];
+        }
+#pragma unroll
+        for (int u = 0; u < ZP; ++u) {
+            const int r = u * 32 + rsub;
+            *(u32x4*)(zs + r * 128 + ((c16 ^ (((r >> 1) & 1) << 2)) << 4)) = zv[u];
+        }
+        __syncthreads();
+        if (tile + p.S < p.ntiles) prefetch(tile + p.S);
+
+        // ---- 8 k-steps of 16 voxels: (d, h-pair) ----
+#pragma unroll
+        for (int kd = 0; kd < TD; ++kd) {
+#pragma unroll
+            for (int hp = 0; hp < TH / 2; ++hp) {
+                const int dX = (kd * XH * XW + hp * 2 * XW) * 128;
+                const int dZ = (kd * TH * TW + hp * 2 * TW) * 128;
+                const u32x2 z0 = tr_read(zs + zoff[0] + dZ), z1 = tr_read(zs + zoff[1] + dZ);
+                const bf16x8 bv = __builtin_bit_cast(bf16x8, (u32x4){z0.x, z0.y, z1.x, z1.y});
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    const u32x2 g0 = tr_read(xs + xoff[b][0] + dX), g1 = tr_read(xs + xoff[b][1] + dX),
+                                g2 = tr_read(xs + xoff[b][2] + dX);
+                    const bf16x8 a0 = __builtin_bit_cast(bf16x8, (u32x4){g0.x, g0.y, g1.x, g1.y});
+                    const bf16x8 a1 = __builtin_bit_cast(
+                        bf16x8, (u32x4){__builtin_amdgcn_alignbit(g0.y, g0.x, 16), __builtin_amdgcn_alignbit(g1.x, g0.y, 16),
+                                        __builtin_amdgcn_alignbit(g1.y, g1.x, 16), __builtin_amdgcn_alignbit(g2.x, g1.y, 16)});
+                    const bf16x8 a2 = __builtin_bit_cast(bf16x8, (u32x4){g0.y, g1.x, g1.y, g2.x});
+                    acc[b * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bv, acc[b * 3 + 0], 0, 0, 0);
+                    acc[b * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bv, acc[b * 3 + 1], 0, 0, 0);
+                    acc[b * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bv, acc[b * 3 + 2], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- write this workgroup's partial dW for taps (a, b, c) ----
+    float* out = p.partial + ((size_t)split * 27 + a * 9) * 4096;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = mq * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            out[(size_t)t * 4096 + ci * 64 + nq * 32 + li] = acc[t][r];
+        }
+}
+
+namespace {
+int wgrad64bf_splits(int N, int D, int H, int W) {
+    const long long ntiles = (long long)N * ((D + TD - 1) / TD) * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+    long long S = 170;                 // 3*170 = 510 workgroups ~ 2 per CU
+    if (ntiles / 2 < S) S = ntiles / 2 > 0 ? ntiles / 2 : 1;
+    return (int)S;
+}
+}  // namespace
+
+size_t fdn_wgrad64_bf16_workspace_bytes(int N, int D, int H, int W) {
+    return (size_t)wgrad64bf_splits(N, D, H, W) * 27 * 4096 * sizeof(float);
+}
+
+int fdn_wgrad64_bf16_launch(const uint16_t* x, const uint16_t* dz, float* dw, void* ws, size_t ws_bytes, int N, int D, int H,
+                            int W, hipStream_t s) {
+    Wgrad64BfArgs a;
+    a.x = x; a.dz = dz; a.partial = (float*)ws;
+    a.N = N; a.D = D; a.H = H; a.W = W;
+    a.ntd = (D + TD - 1) / TD; a.nth = (H + TH - 1) / TH; a.ntw = (W + TW - 1) / TW;
+    a.ntiles = N * a.ntd * a.nth * a.ntw;
+    a.S = wgrad64bf_splits(N, D, H, W);
+    if (ws_bytes < (size_t)a.S * 27 * 4096 * sizeof(float)) {
+        fdn_set_error("wgrad64_bf16: workspace too small");
+        return FDN_ERR_WORKSPACE;
+    }
+    hipLaunchKernelGGL(wgrad64_bf16_kernel, dim3(a.S, 3), dim3(256), LDS_BYTES, s, a);
+    FDN_CHECK_LAUNCH("wgrad64_bf16_kernel");
+    hipLaunchKernelGGL(wgrad64_reduce_kernel, dim3((27 * 1024 + 255) / 256), dim3(256), 0, s, (const float*)ws, dw, a.S);
+    FDN_CHECK_LAUNCH("wgrad64_reduce_kernel");
+    return FDN_OK;
+}

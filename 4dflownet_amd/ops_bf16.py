@@ -1,15 +1,19 @@
 """Operator layer of the bf16 activation path (BASELINE.json configs[3]): torch.bfloat16 activation tensors,
-fp32 parameters -> raw pointers -> lib4dflow_hip.so.  Same rules as ops.py: GPU only, no fallback."""
+fp32 parameters / parameter gradients / prediction -> raw pointers -> lib4dflow_hip.so.
+
+Same function names and argument meaning as ops.py, so network.py selects one of the two modules by dtype.
+Same rules: GPU only, no fallback."""
 import torch
 
 from . import _lib
 from ._lib import FdnError, check
-from .ops import ACT_NONE, ACT_RELU, ACT_LEAKY, LEAKY_ALPHA, _stream
+from .ops import (ACT_NONE, ACT_RELU, ACT_LEAKY, LEAKY_ALPHA, _stream, loss_metrics, l2_sumsq, adam_step)  # noqa: F401
 
 BF16 = torch.bfloat16
+ACT_DTYPE = BF16
 
 
-def _pb(t, name="tensor", allow_none=False, dtype=BF16):
+def _pt(t, dtype, name="tensor", allow_none=False):
     if t is None:
         if allow_none:
             return None
@@ -23,12 +27,29 @@ def _pb(t, name="tensor", allow_none=False, dtype=BF16):
     return t.data_ptr()
 
 
+def _pb(t, name="tensor", allow_none=False):
+    return _pt(t, BF16, name, allow_none)
+
+
 def _pf(t, name="tensor", allow_none=False):
-    return _pb(t, name, allow_none, torch.float32)
+    return _pt(t, torch.float32, name, allow_none)
+
+
+def input_features(u, v, w, mu, mv, mw, phase=None, pc=None):
+    shp = u.shape[:-1] if u.shape[-1] == 1 else u.shape
+    if phase is None:
+        phase = torch.empty(tuple(shp) + (3,), device=u.device, dtype=BF16)
+    if pc is None:
+        pc = torch.empty(tuple(shp) + (3,), device=u.device, dtype=BF16)
+    check(_lib.load().fdn_input_features_bf16(_pf(u), _pf(v), _pf(w), _pf(mu), _pf(mv), _pf(mw), _pb(phase), _pb(pc),
+                                              u.numel(), _stream()), "fdn_input_features_bf16")
+    return phase, pc
 
 
 def pack_conv64_weights(w, wp_fwd=None, wp_dgrad=None, want_dgrad=True):
     """fp32 (3,3,3,64,64) -> bf16 operand streams (27*64*64 each)."""
+    if tuple(w.shape) != (3, 3, 3, 64, 64):
+        raise FdnError("pack_conv64_weights: expected (3,3,3,64,64), got %s" % (tuple(w.shape),))
     if wp_fwd is None:
         wp_fwd = torch.empty(27 * 64 * 64, device=w.device, dtype=BF16)
     if wp_dgrad is None and want_dgrad:
@@ -36,6 +57,26 @@ def pack_conv64_weights(w, wp_fwd=None, wp_dgrad=None, want_dgrad=True):
     check(_lib.load().fdn_pack_conv64_weights_bf16(_pf(w, "w"), _pb(wp_fwd), _pb(wp_dgrad, allow_none=True), _stream()),
           "fdn_pack_conv64_weights_bf16")
     return wp_fwd, wp_dgrad
+
+
+def conv3d_fwd(x, w, bias=None, act=ACT_NONE, alpha=LEAKY_ALPHA, residual=None, x2=None, wpack=None, out=None,
+               ldy=None, y_coff=0):
+    """x bf16 (N,D,H,W,Cin[/2 if x2]); w fp32 Keras layout; output bf16, except Cout == 1 (prediction) -> fp32."""
+    N, D, H, W = x.shape[:4]
+    K, Cin, Cout = w.shape[0], w.shape[3], w.shape[4]
+    odt = torch.float32 if Cout == 1 else BF16
+    if out is None:
+        out = torch.empty((N, D, H, W, Cout), device=x.device, dtype=odt)
+        ldy = Cout
+    elif ldy is None:
+        ldy = out.shape[-1]
+    if Cin == 64 and Cout == 64 and K == 3 and wpack is None:
+        wpack, _ = pack_conv64_weights(w, want_dgrad=False)
+    check(_lib.load().fdn_conv3d_fwd_bf16(_pb(x, "x"), _pb(x2, allow_none=True), _pf(w, "w"), _pb(wpack, allow_none=True),
+                                          _pf(bias, allow_none=True), _pb(residual, allow_none=True), _pt(out, odt, "out"),
+                                          N, D, H, W, Cin, Cout, K, ldy, y_coff, act, float(alpha), _stream()),
+          "fdn_conv3d_fwd_bf16")
+    return out
 
 
 def conv64_fwd(x, wpack, bias=None, act=ACT_NONE, alpha=LEAKY_ALPHA, residual=None, out=None):
@@ -50,7 +91,7 @@ def conv64_fwd(x, wpack, bias=None, act=ACT_NONE, alpha=LEAKY_ALPHA, residual=No
     return out
 
 
-def conv64_dgrad_fused(dz, wpack_dgrad, dxpad, out, skip=None, y_prev=None, act=ACT_NONE, alpha=LEAKY_ALPHA):
+def conv3d_dgrad_fused(dz, wpack_dgrad, dxpad, out, skip=None, y_prev=None, act=ACT_NONE, alpha=LEAKY_ALPHA):
     N, D, H, W = dz.shape[:4]
     check(_lib.load().fdn_conv64_dgrad_fused_bf16(_pb(dz, "dz"), _pb(wpack_dgrad, "wpack"), _pf(dxpad, "dxpad"),
                                                   _pb(skip, allow_none=True), _pb(y_prev, allow_none=True), act,
@@ -59,10 +100,84 @@ def conv64_dgrad_fused(dz, wpack_dgrad, dxpad, out, skip=None, y_prev=None, act=
     return out
 
 
+conv64_dgrad_fused = conv3d_dgrad_fused
+
+
 def fold_halo_border(dxpads, out, skip=None, y_prev=None, act=ACT_NONE, alpha=LEAKY_ALPHA):
     N, D, H, W = out.shape[:4]
     ptrs = [_pf(t) for t in dxpads] + [None] * (3 - len(dxpads))
     check(_lib.load().fdn_fold_halo_border_bf16(ptrs[0], ptrs[1], ptrs[2], len(dxpads), _pb(skip, allow_none=True),
                                                 _pb(y_prev, allow_none=True), act, float(alpha), _pb(out), N, D, H, W,
                                                 _stream()), "fdn_fold_halo_border_bf16")
+    return out
+
+
+def conv_cout1_dgrad_folded(dz, w, spatial, y_prev=None, act=ACT_NONE, alpha=LEAKY_ALPHA, lddz=1, dz_coff=0, out=None,
+                            dbias_prev=None, workspace=None):
+    """64->1 head dgrad (dz = fp32 prediction gradient) + halo fold + act'(y_prev): bf16 (N,D,H,W,64)."""
+    N, D, H, W = spatial
+    if out is None:
+        out = torch.empty((N, D, H, W, 64), device=dz.device, dtype=BF16)
+    if dbias_prev is not None and workspace is None:
+        workspace = torch.empty(2048 * 64, device=dz.device, dtype=torch.float32)
+    wsb = 0 if workspace is None else workspace.numel() * workspace.element_size()
+    check(_lib.load().fdn_conv_cout1_dgrad_folded_bf16(_pf(dz, "dz"), _pf(w, "w"), _pb(y_prev, allow_none=True), act,
+                                                       float(alpha), _pb(out), _pf(dbias_prev, allow_none=True),
+                                                       _pf(workspace, allow_none=True), wsb, N, D, H, W, lddz, dz_coff,
+                                                       _stream()), "fdn_conv_cout1_dgrad_folded_bf16")
+    return out
+
+
+def conv1x1_dgrad(dz, w, ya, yb, dxa=None, dxb=None):
+    nvox = dz.numel() // 64
+    if dxa is None:
+        dxa = torch.empty_like(ya)
+    if dxb is None:
+        dxb = torch.empty_like(yb)
+    check(_lib.load().fdn_conv1x1_dgrad_bf16(_pb(dz), _pf(w), _pb(ya), _pb(yb), _pb(dxa), _pb(dxb), nvox, _stream()),
+          "fdn_conv1x1_dgrad_bf16")
+    return dxa, dxb
+
+
+def wgrad_workspace_bytes(N, D, H, W, Cin, Cout, K):
+    return int(_lib.load().fdn_conv3d_wgrad_bf16_workspace_bytes(N, D, H, W, Cin, Cout, K))
+
+
+def conv3d_wgrad(x, dz, K, Cin, Cout, x2=None, want_bias=False, dw=None, dbias=None, workspace=None, lddz=None,
+                 dz_coff=0):
+    """x bf16; dz bf16, except Cout == 1 where dz is the fp32 prediction gradient; dw / dbias fp32."""
+    N, D, H, W = x.shape[:4]
+    if lddz is None:
+        lddz = dz.shape[-1]
+    if dw is None:
+        dw = torch.empty((K, K, K, Cin, Cout), device=x.device, dtype=torch.float32)
+    if want_bias and dbias is None:
+        dbias = torch.empty((Cout,), device=x.device, dtype=torch.float32)
+    need = wgrad_workspace_bytes(N, D, H, W, Cin, Cout, K)
+    if workspace is None:
+        workspace = torch.empty((need + 3) // 4, device=x.device, dtype=torch.float32)
+    check(_lib.load().fdn_conv3d_wgrad_bf16(_pb(x, "x"), _pb(x2, allow_none=True),
+                                            _pt(dz, torch.float32 if Cout == 1 else BF16, "dz"), _pf(dw, "dw"),
+                                            _pf(dbias, allow_none=True), _pf(workspace, "workspace"),
+                                            workspace.numel() * workspace.element_size(), N, D, H, W, Cin, Cout, K, lddz,
+                                            dz_coff, _stream()), "fdn_conv3d_wgrad_bf16")
+    return dw, dbias
+
+
+def upsample_trilinear_fwd(x, R, out=None):
+    N, D, H, W, C = x.shape
+    if out is None:
+        out = torch.empty((N, D * R, H * R, W * R, C), device=x.device, dtype=BF16)
+    check(_lib.load().fdn_upsample_trilinear_fwd_bf16(_pb(x), _pb(out), N, D, H, W, C, R, _stream()),
+          "fdn_upsample_trilinear_fwd_bf16")
+    return out
+
+
+def upsample_trilinear_bwd(dy, R, y_prev=None, act=ACT_NONE, alpha=LEAKY_ALPHA, out=None):
+    N, OD, OH, OW, C = dy.shape
+    D, H, W = OD // R, OH // R, OW // R
+    if out is None:
+        out = torch.empty((N, D, H, W, C), device=dy.device, dtype=BF16)
+    check(_lib.load().fdn_upsample_trilinear_bwd_bf16(_pb(dy), _pb(y_prev, allow_none=True), act, float(alpha), _pb(out), N,
+                                                      D, H, W, C, R, _stream()), "fdn_upsample_trilinear_bwd_bf16")
     return out

@@ -157,6 +157,27 @@ int fdn_fold_halo_border_bf16(const float* dxpad0, const float* dxpad1, const fl
                               const uint16_t* skip, const uint16_t* y_prev, int act, float alpha, uint16_t* dz_prev,
                               int N, int D, int H, int W, void* stream);
 
+/* The remaining entry points of the path in bf16 storage: same contracts as the fp32 functions of the same
+ * name.  Parameters, parameter gradients, the 64->1 heads' output (the prediction, `y` of Cout=1) and its
+ * gradient (`dz` of Cout=1) stay fp32. */
+int fdn_input_features_bf16(const float* u, const float* v, const float* w, const float* mu, const float* mv,
+                            const float* mw, uint16_t* phase, uint16_t* pc, int64_t nvox, void* stream);
+int fdn_conv3d_fwd_bf16(const uint16_t* x, const uint16_t* x2, const float* w, const uint16_t* wpack, const float* bias,
+                        const uint16_t* residual, void* y, int N, int D, int H, int W, int Cin, int Cout, int K, int ldy,
+                        int y_coff, int act, float alpha, void* stream);
+size_t fdn_conv3d_wgrad_bf16_workspace_bytes(int N, int D, int H, int W, int Cin, int Cout, int K);
+int fdn_conv3d_wgrad_bf16(const uint16_t* x, const uint16_t* x2, const void* dz, float* dw, float* dbias, void* workspace,
+                          size_t workspace_bytes, int N, int D, int H, int W, int Cin, int Cout, int K, int lddz,
+                          int dz_coff, void* stream);
+int fdn_conv_cout1_dgrad_folded_bf16(const float* dz, const float* w, const uint16_t* y_prev, int act, float alpha,
+                                     uint16_t* dz_prev, float* dbias_prev, void* workspace, size_t workspace_bytes,
+                                     int N, int D, int H, int W, int lddz, int dz_coff, void* stream);
+int fdn_conv1x1_dgrad_bf16(const uint16_t* dz, const float* w, const uint16_t* ya, const uint16_t* yb, uint16_t* dxa,
+                           uint16_t* dxb, int64_t nvox, void* stream);
+int fdn_upsample_trilinear_fwd_bf16(const uint16_t* x, uint16_t* y, int N, int D, int H, int W, int C, int R, void* stream);
+int fdn_upsample_trilinear_bwd_bf16(const uint16_t* dy, const uint16_t* y_prev, int act, float alpha, uint16_t* dx, int N,
+                                    int D, int H, int W, int C, int R, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

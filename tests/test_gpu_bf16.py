@@ -98,3 +98,80 @@ def test_conv64_dgrad_fused_bf16(bops, fdn, shape, mt):
         close_bf16(out, O.act_bwd_from_output(dx + skip, y, O.ACT_LEAKY), name="bf16 fused dgrad+border")
     finally:
         lib.fdn_debug_set_conv64_bf16_mt(0)
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 8, 8), (1, 5, 7, 9), (1, 10, 12, 16), (3, 4, 4, 2), (2, 16, 16, 16), (1, 1, 1, 1)])
+def test_conv64_wgrad_bf16(bops, shape):
+    """fp32 result from bf16 operands: products exact, accumulation fp32 -> fp32-level agreement with the oracle."""
+    rng = np.random.default_rng(13)
+    N, D, H, W = shape
+    x = rb(rng.normal(size=(N, D, H, W, 64)))
+    dz = rb(rng.normal(size=(N, D, H, W, 64)))
+    ref = O.conv3d_wgrad(x, dz, 3)
+    dw, db = bops.conv3d_wgrad(devb(x), devb(dz), 3, 64, 64, want_bias=True)
+    close_f32(dw, ref, name="wgrad64 bf16")
+    close_f32(db, O.bias_grad(dz), name="bias grad 64 bf16")
+
+
+@pytest.mark.parametrize("shape", [(2, 6, 6, 6), (1, 5, 7, 9), (1, 1, 2, 3)])
+def test_thin_layers_bf16(bops, shape):
+    rng = np.random.default_rng(14)
+    N, D, H, W = shape
+    f64 = lambda a: a.astype(np.float64)
+    # 3 -> 64
+    x3 = rb(rng.normal(size=(N, D, H, W, 3)))
+    w3 = (rng.normal(size=(3, 3, 3, 3, 64)) * 0.2).astype(np.float32)
+    b = rng.normal(size=64).astype(np.float32)
+    close_bf16(bops.conv3d_fwd(devb(x3), dev(w3), dev(b), O.ACT_RELU), O.conv3d_fwd(x3, f64(w3), f64(b), O.ACT_RELU), name="3->64 fwd")
+    dz = rb(rng.normal(size=(N, D, H, W, 64)))
+    dw, db = bops.conv3d_wgrad(devb(x3), devb(dz), 3, 3, 64, want_bias=True)
+    close_f32(dw, O.conv3d_wgrad(x3, dz, 3), name="3->64 wgrad")
+    close_f32(db, O.bias_grad(dz), name="3->64 bias grad")
+    # 64 -> 1: bf16 input, fp32 prediction written into channel 1 of an (N,V,3) tensor
+    x = rb(rng.normal(size=(N, D, H, W, 64)))
+    w1 = (rng.normal(size=(3, 3, 3, 64, 1)) * 0.1).astype(np.float32)
+    b1 = rng.normal(size=1).astype(np.float32)
+    out = torch.zeros((N, D, H, W, 3), device="cuda")
+    bops.conv3d_fwd(devb(x), dev(w1), dev(b1), O.ACT_NONE, out=out, ldy=3, y_coff=1)
+    ref = np.zeros((N, D, H, W, 3)); ref[..., 1:2] = O.conv3d_fwd(x, f64(w1), f64(b1))
+    close_f32(out, ref, name="64->1 fwd")
+    dpred = rng.normal(size=(N, D, H, W, 3)).astype(np.float32)
+    dzo = f64(dpred[..., 1:2])
+    ymask = rb(rng.normal(size=(N, D, H, W, 64)))
+    refd = O.conv3d_dgrad(dzo, f64(w1), x.shape) * (ymask > 0)
+    dbp = torch.full((64,), float("nan"), device="cuda")
+    got = bops.conv_cout1_dgrad_folded(dev(dpred), dev(w1), (N, D, H, W), devb(ymask), O.ACT_RELU, lddz=3, dz_coff=1, dbias_prev=dbp)
+    close_bf16(got, refd, name="64->1 dgrad folded+relu")
+    close_f32(dbp, O.bias_grad(refd), tol=3e-3, name="fused bias grad (sum of the unrounded fp32 values)")
+    dw, db = bops.conv3d_wgrad(devb(x), dev(dpred), 3, 64, 1, want_bias=True, lddz=3, dz_coff=1)
+    close_f32(dw, O.conv3d_wgrad(x, dzo, 3), name="64->1 wgrad")
+    close_f32(db, O.bias_grad(dzo), name="64->1 bias grad")
+    # 1x1x1 (64+64) -> 64
+    xa = rb(rng.normal(size=(N, D, H, W, 64)))
+    xb = rb(rng.normal(size=(N, D, H, W, 64)))
+    wk = (rng.normal(size=(1, 1, 1, 128, 64)) * 0.1).astype(np.float32)
+    cat = np.concatenate([xa, xb], -1)
+    close_bf16(bops.conv3d_fwd(devb(xa), dev(wk), dev(b), O.ACT_RELU, x2=devb(xb)), O.conv3d_fwd(cat, f64(wk), f64(b), O.ACT_RELU), name="1x1 fwd")
+    dcat = O.conv3d_dgrad(dz, f64(wk), cat.shape)
+    da, dbb = bops.conv1x1_dgrad(devb(dz), dev(wk), devb(xa), devb(xb))
+    close_bf16(da, dcat[..., :64] * (xa > 0), name="1x1 dgrad a")
+    close_bf16(dbb, dcat[..., 64:] * (xb > 0), name="1x1 dgrad b")
+    dw, db = bops.conv3d_wgrad(devb(xa), devb(dz), 1, 128, 64, x2=devb(xb), want_bias=True)
+    close_f32(dw, O.conv3d_wgrad(cat, dz, 1), name="1x1 wgrad")
+
+
+@pytest.mark.parametrize("R", [2, 4])
+def test_upsample_and_features_bf16(bops, R):
+    rng = np.random.default_rng(15)
+    x = rb(rng.normal(size=(2, 5, 4, 6, 64)))
+    ref = O.upsample_trilinear_fwd(x, R, f32_coeffs=True)
+    close_bf16(bops.upsample_trilinear_fwd(devb(x), R), ref, name="upsample fwd")
+    dy = rb(rng.normal(size=ref.shape))
+    y = rb(rng.normal(size=x.shape))
+    refb = O.upsample_trilinear_bwd(dy, x.shape[1:4], R, f32_coeffs=True)
+    close_bf16(bops.upsample_trilinear_bwd(devb(dy), R), refb, name="upsample bwd")
+    close_bf16(bops.upsample_trilinear_bwd(devb(dy), R, devb(y), O.ACT_LEAKY, 0.2), O.act_bwd_from_output(refb, y, O.ACT_LEAKY), name="upsample bwd+mask")
+    batch = O.synthetic_batch(2, 6, 2, seed=11)
+    ph, pc = bops.input_features(*[dev(a) for a in batch[:6]])
+    rph, rpc = O.input_features(*[a.astype(np.float64) for a in batch[:6]])
+    close_bf16(ph, rph, name="phase"); close_bf16(pc, rpc, name="pc")
