@@ -24,11 +24,13 @@
 #include "fdn_common.h"
 #include "conv64_args.h"
 #include <type_traits>
+#include <stdio.h>
+#include <stdlib.h>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-static int fdn_conv64bf_force_mt = 0;    // 0 = auto, 4 / 8 = force the variant (bench hook)
+static int fdn_conv64bf_force_mt = 0;    // test/bench hook: 0 = auto, 4 / 8 = force the variant, +16 = full-depth tiles only
 static int fdn_conv64bf_dbg = 0;         // ablation bits: 1 = weight stride 0, 2 = no XCD remap, 4 = staging loads from a cache-resident 32 KB, 8 = no epilogue
 
 template <int MT>
@@ -223,19 +225,21 @@ __global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
     stage_write(smem);
     __syncthreads();
     if (FAST) {
-        // 9 unrolled steps per slice; weights two steps ahead (running into the next slice); the next slice's voxels are
-        // loaded behind step 0's weight refill and written to the other buffer at step 7.  No branch sits between a load
-        // and its use, so every wait is a counted vmcnt (the last slice, which has nothing to prefetch, is peeled).
-        auto fast_slice = [&](auto prefetchc, int sl) {
+        // 9 unrolled steps per slice; weights two steps ahead (running into the next slice) in two register sets; the next
+        // slice's voxels are loaded behind step 0's weight refill and written to the other buffer at step 7.  No branch
+        // sits between a load and its use, so every wait is a counted vmcnt.  A slice has an odd number of steps, so the
+        // register set of step `it` alternates from slice to slice (PAR); all four slices are straight-line code.
+        auto fast_slice = [&](auto prefetchc, auto parc, int sl) {
             constexpr bool PREFETCH = decltype(prefetchc)::value;
+            constexpr int PAR = decltype(parc)::value;
             const char* cur = smem + (sl & 1) * bufB;
             char* nxt = smem + ((sl + 1) & 1) * bufB;
 #pragma unroll
             for (int it = 0; it < 9; ++it) {
-                kstep(std::true_type{}, cur, it / 3, it % 3, wq[it & 1]);
+                kstep(std::true_type{}, cur, it / 3, it % 3, wq[(it + PAR) & 1]);
                 if (PREFETCH || it < 7)
-                    load_w(wq[it & 1], sl + (it + 2) / 9, tb0 + ((it + 2) % 9) / 3, tc0 + ((it + 2) % 9) % 3);
-                if (PREFETCH && it == 0) stage_load(sl + 1);
+                    load_w(wq[(it + PAR) & 1], sl + (it + 2) / 9, tb0 + ((it + 2) % 9) / 3, tc0 + ((it + 2) % 9) % 3);
+                if (PREFETCH && it == 0) stage_load((sl + 1) & 3);
                 if (PREFETCH && it == 7) stage_write(nxt);
                 // keep every step's loads inside the step: under register pressure the scheduler otherwise sinks the
                 // weight refills down to their first use, i.e. prefetch distance 0
@@ -244,8 +248,10 @@ __global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
             __syncthreads();
         };
 #pragma unroll 1
-        for (int sl = 0; sl < 3; ++sl) fast_slice(std::true_type{}, sl);
-        fast_slice(std::false_type{}, 3);
+        for (int sl = 0; sl < 4; sl += 2) {
+            fast_slice(std::true_type{}, std::integral_constant<int, 0>{}, sl);
+            fast_slice(std::true_type{}, std::integral_constant<int, 1>{}, sl + 1);
+        }
     } else {
 #pragma unroll 1
         for (int sl = 0; sl < 4; ++sl) {
@@ -422,10 +428,11 @@ struct Plan { FdnTile t; double cost; };
 int lds_hs(int hw) { int hs = hw; while ((hs & 7) != 4) ++hs; return hs; }
 
 Plan best_plan(int N, const Box& bx, int mt, int max_rows, int max_lrows) {
+    const bool full_only = (fdn_conv64bf_force_mt & 16) && bx.ed >= mt;
     Plan best{{1, 1, 1, bx.ed, bx.eh, bx.ew}, 1e30};
     const int da = bx.ta1 - bx.ta0, db = bx.tb1 - bx.tb0, dc = bx.tc1 - bx.tc0;
     const double ntap = (da + 1) * (db + 1) * (dc + 1);
-    for (int td = 1; td <= bx.ed && td <= mt; ++td)
+    for (int td = full_only ? mt : 1; td <= bx.ed && td <= mt; ++td)
         for (int th = 1; th <= bx.eh && th <= 64; ++th)
             for (int tw = 1; tw <= bx.ew && th * tw <= 64; ++tw) {
                 const int rows = (td + da) * (th + db) * (tw + dc);
@@ -492,6 +499,10 @@ int launch_bf16(Conv64BfArgs& a, const Box* boxes, int nbox, hipStream_t s) {
         // a column (tw <= 2) -> by h quad
         r.swz_hs = t.tw <= 2 ? 2 : 0;
         r.swz_wm = t.tw >= 16 ? 1 : 0;
+        if (getenv("FDN_DEBUG_PLAN"))
+            fprintf(stderr, "conv64_bf16<MT=%d> box %d: out (%d,%d,%d)+(%d,%d,%d) taps a[%d,%d] b[%d,%d] c[%d,%d] tile %dx%dx%d x(%d,%d,%d) rows %d lrows %d hs %d %s\n",
+                    MT, i, bx.od, bx.oh, bx.ow, bx.ed, bx.eh, bx.ew, bx.ta0, bx.ta1, bx.tb0, bx.tb1, bx.tc0, bx.tc1, t.td, t.th,
+                    t.tw, t.ntd, t.nth, t.ntw, r.rows, r.lrows, r.hs, is_fast ? "FAST" : "general");
     }
     const int rc = launch_regions<MT, true>(fast, s);
     if (rc != FDN_OK) return rc;
@@ -499,7 +510,7 @@ int launch_bf16(Conv64BfArgs& a, const Box* boxes, int nbox, hipStream_t s) {
 }
 
 int launch_boxes(Conv64BfArgs& a, const Box* boxes, int nbox, hipStream_t s) {
-    int mt = fdn_conv64bf_force_mt;
+    int mt = fdn_conv64bf_force_mt & 15;
     if (mt != 4 && mt != 8)
         mt = best_plan(a.N, boxes[0], 8, Conv64BfCfg<8>::MAXROWS, Conv64BfCfg<8>::MAXLROWS).cost <=
                      best_plan(a.N, boxes[0], 4, Conv64BfCfg<4>::MAXROWS, Conv64BfCfg<4>::MAXLROWS).cost ? 8 : 4;

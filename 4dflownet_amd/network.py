@@ -12,7 +12,7 @@ import math
 import numpy as np
 import torch
 
-from . import ops
+from . import ops, ops_bf16
 from ._lib import FdnError
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = ops.ACT_NONE, ops.ACT_RELU, ops.ACT_LEAKY
@@ -58,9 +58,18 @@ class _T:
 
 
 class FlowNetModel:
-    def __init__(self, res_increase, low_resblock=8, hi_resblock=4, device=None, seed=0):
+    def __init__(self, res_increase, low_resblock=8, hi_resblock=4, device=None, seed=0, dtype="float32"):
+        """dtype: storage type of activations and activation gradients -- "float32" (the reference's arithmetic) or
+        "bfloat16" (BASELINE.json configs[3]; parameters, their gradients, the prediction and the optimizer stay fp32)."""
         if not torch.cuda.is_available():
             raise FdnError("FlowNetModel needs a ROCm GPU: the hot path is HIP-only (no CPU fallback)")
+        dtype = {"float32": "float32", "fp32": "float32", "f32": "float32", torch.float32: "float32",
+                 "bfloat16": "bfloat16", "bf16": "bfloat16", torch.bfloat16: "bfloat16"}.get(dtype)
+        if dtype is None:
+            raise ValueError("dtype must be 'float32' or 'bfloat16'")
+        self.dtype = dtype
+        self.ops = ops if dtype == "float32" else ops_bf16
+        self.act_dtype = torch.float32 if dtype == "float32" else torch.bfloat16
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.res_increase = int(res_increase)
         self.low_resblock = int(low_resblock)
@@ -77,7 +86,7 @@ class FlowNetModel:
         self.layers = []
         off = 0
         n64 = sum(1 for _, k, ci, co, _ in self.specs if (k, ci, co) == (3, 64, 64))
-        self._packs = torch.empty((n64, 2, 27 * 64 * 64), device=self.device, dtype=torch.float32)
+        self._packs = torch.empty((n64, 2, 27 * 64 * 64), device=self.device, dtype=self.act_dtype)
         i64 = 0
         for name, k, ci, co, ub in self.specs:
             L = _Layer()
@@ -129,7 +138,7 @@ class FlowNetModel:
         """Re-derive the MFMA operand streams after any parameter update (Adam step, load_weights)."""
         for L in self.layers:
             if L.wp_f is not None:
-                ops.pack_conv64_weights(L.w, L.wp_f, L.wp_d)
+                self.ops.pack_conv64_weights(L.w, L.wp_f, L.wp_d)
 
     @property
     def trainable_variables(self):
@@ -171,7 +180,7 @@ class FlowNetModel:
         return t.contiguous()
 
     def _conv(self, x, L, act, residual=None, x2=None, out=None, ldy=None, y_coff=0):
-        return ops.conv3d_fwd(x, L.w, L.b, act, ops.LEAKY_ALPHA, residual, x2, L.wp_f, out, ldy, y_coff)
+        return self.ops.conv3d_fwd(x, L.w, L.b, act, ops.LEAKY_ALPHA, residual, x2, L.wp_f, out, ldy, y_coff)
 
     def forward(self, inputs, training=False):
         """inputs: [u, v, w, u_mag, v_mag, w_mag], each (B,P,P,P,1) or (B,P,P,P).  Returns a device tensor
@@ -183,9 +192,9 @@ class FlowNetModel:
             B, D, H, W = u.shape
         R = self.res_increase
         Ls = self.layers
-        phase = torch.empty((B, D, H, W, 3), device=self.device)
-        pc = torch.empty((B, D, H, W, 3), device=self.device)
-        ops.input_features(u, v, w, mu, mv, mw, phase, pc)
+        phase = torch.empty((B, D, H, W, 3), device=self.device, dtype=self.act_dtype)
+        pc = torch.empty((B, D, H, W, 3), device=self.device, dtype=self.act_dtype)
+        self.ops.input_features(u, v, w, mu, mv, mw, phase, pc)
         a0 = self._conv(pc, Ls[0], ACT_RELU)
         a1 = self._conv(a0, Ls[1], ACT_RELU)
         p0 = self._conv(phase, Ls[2], ACT_RELU)
@@ -199,7 +208,7 @@ class FlowNetModel:
         nb = self.low_resblock + self.hi_resblock
         for i in range(nb + 1):
             if i == self.low_resblock and R > 1:
-                up_out = _T(ops.upsample_trilinear_fwd(rb.t, R), ACT_NONE)
+                up_out = _T(self.ops.upsample_trilinear_fwd(rb.t, R), ACT_NONE)
                 up = (rb, up_out)
                 rb = up_out
             if i == nb:
@@ -243,9 +252,9 @@ class FlowNetModel:
         graph (nothing downstream reads them before the optimizer), so they run on a second HIP stream and fill the tails
         of the dgrad chain's kernels; backward() joins the streams before returning."""
         N, D, H, W = x.shape[:4]
-        ws = self._workspace(ops.wgrad_workspace_bytes(N, D, H, W, L.cin, L.cout, L.k))
+        ws = self._workspace(self.ops.wgrad_workspace_bytes(N, D, H, W, L.cin, L.cout, L.k))
         if not self.overlap_wgrad:
-            ops.conv3d_wgrad(x, dz, L.k, L.cin, L.cout, x2=x2, dw=L.gw, dbias=L.gb if bias else None, workspace=ws, lddz=lddz,
+            self.ops.conv3d_wgrad(x, dz, L.k, L.cin, L.cout, x2=x2, dw=L.gw, dbias=L.gb if bias else None, workspace=ws, lddz=lddz,
                              dz_coff=dz_coff)
             return
         if self._side is None:
@@ -253,7 +262,7 @@ class FlowNetModel:
         main = torch.cuda.current_stream()
         self._side.wait_stream(main)                      # dz (and the workspace allocation) are ready
         with torch.cuda.stream(self._side):
-            ops.conv3d_wgrad(x, dz, L.k, L.cin, L.cout, x2=x2, dw=L.gw, dbias=L.gb if bias else None, workspace=ws, lddz=lddz,
+            self.ops.conv3d_wgrad(x, dz, L.k, L.cin, L.cout, x2=x2, dw=L.gw, dbias=L.gb if bias else None, workspace=ws, lddz=lddz,
                              dz_coff=dz_coff)
         for t in (x, dz, x2):                             # keep the caching allocator from recycling them too early
             if t is not None:
@@ -268,8 +277,8 @@ class FlowNetModel:
         are finished by the conv epilogue, the surface by one small border kernel."""
         out = torch.empty_like(dz)
         pad = self._pad_like(dz)
-        ops.conv3d_dgrad_fused(dz, L.wp_d, pad, out, skip=skip, y_prev=y_prev, act=act)
-        ops.fold_halo_border([pad], out, skip, y_prev, act)
+        self.ops.conv3d_dgrad_fused(dz, L.wp_d, pad, out, skip=skip, y_prev=y_prev, act=act)
+        self.ops.fold_halo_border([pad], out, skip, y_prev, act)
         return out
 
     def backward(self, dpred):
@@ -298,18 +307,18 @@ class FlowNetModel:
             # the folded head dgrad also emits the bias gradient of the 64->64 head conv (sum of dz_g) while it has it in registers
             if self._ws_bias is None:
                 self._ws_bias = torch.empty(2048 * 64, device=self.device, dtype=torch.float32)
-            dz_g = ops.conv_cout1_dgrad_folded(dpred, L2.w, tuple(g.shape[:4]), g, ACT_RELU, lddz=3, dz_coff=hidx,
+            dz_g = self.ops.conv_cout1_dgrad_folded(dpred, L2.w, tuple(g.shape[:4]), g, ACT_RELU, lddz=3, dz_coff=hidx,
                                                dbias_prev=L1.gb, workspace=self._ws_bias)
             del g
             self._wgrad(rb.t, dz_g, L1, bias=False)
             pad = self._pad_like(rb.t)
             y_m, a_m = act_of(rb) if hidx == 2 else (None, ACT_NONE)
-            ops.conv3d_dgrad_fused(dz_g, L1.wp_d, pad, dz, skip=dz if hidx > 0 else None, y_prev=y_m, act=a_m)
+            self.ops.conv3d_dgrad_fused(dz_g, L1.wp_d, pad, dz, skip=dz if hidx > 0 else None, y_prev=y_m, act=a_m)
             pads.append(pad)
             del dz_g
             li += 2
         y_m, a_m = act_of(rb)
-        ops.fold_halo_border(pads, dz, None, y_m, a_m)
+        self.ops.fold_halo_border(pads, dz, None, y_m, a_m)
         del pads, pad
         li = len(Ls) - 6
         nb = self.low_resblock + self.hi_resblock
@@ -318,7 +327,7 @@ class FlowNetModel:
             if up is not None and i == self.low_resblock:
                 # dz currently holds d(up_out) (linear producer): pull it through the upsample
                 y_m, a_m = act_of(up[0])
-                dz = ops.upsample_trilinear_bwd(dz, R, y_m, a_m)
+                dz = self.ops.upsample_trilinear_bwd(dz, R, y_m, a_m)
             if i == 0:
                 break
             x, h, out = c["blocks"][i - 1]
@@ -336,7 +345,7 @@ class FlowNetModel:
         self._wgrad(c["c0"], dz, Ls[5])
         dz_c0 = self._dgrad_fold(dz, Ls[5], None, c["c0"], ACT_RELU)
         self._wgrad(c["p1"], dz_c0, Ls[4], x2=c["a1"])
-        dz_p1, dz_a1 = ops.conv1x1_dgrad(dz_c0, Ls[4].w, c["p1"], c["a1"])
+        dz_p1, dz_a1 = self.ops.conv1x1_dgrad(dz_c0, Ls[4].w, c["p1"], c["a1"])
         for (first, second, src, dzz) in ((Ls[2], Ls[3], "p", dz_p1), (Ls[0], Ls[1], "a", dz_a1)):
             x0 = c[src + "0"]
             self._wgrad(x0, dzz, second)
@@ -356,10 +365,10 @@ class SR4DFlowNet:
         self.res_increase = res_increase
 
     def build_network(self, u, v, w, u_mag, v_mag, w_mag, low_resblock=8, hi_resblock=4, channel_nr=64, device=None,
-                      seed=0):
+                      seed=0, dtype="float32"):
         channel_nr = 64   # noqa: F841  (the reference overwrites the argument)
         for t in (u, v, w, u_mag, v_mag, w_mag):
             shp = getattr(t, "shape", None)
             if shp is not None and len(shp) == 5 and shp[-1] != 1:
                 raise ValueError("inputs must have a single channel, got shape %s" % (tuple(shp),))
-        return FlowNetModel(self.res_increase, low_resblock, hi_resblock, device=device, seed=seed)
+        return FlowNetModel(self.res_increase, low_resblock, hi_resblock, device=device, seed=seed, dtype=dtype)

@@ -63,7 +63,7 @@ class _Optimizer:
 
 class TrainerController:
     def __init__(self, patch_size, res_increase, initial_learning_rate=1e-4, quicksave_enable=True,
-                 network_name='4DFlowNet', low_resblock=8, hi_resblock=4, device=None, seed=0):
+                 network_name='4DFlowNet', low_resblock=8, hi_resblock=4, device=None, seed=0, dtype='float32'):
         self.div_weight = 0            # divergence loss is dead code in the reference (TrainerController.py:23,121)
         self.non_fluid_weight = 1
         self.res_increase = res_increase
@@ -75,7 +75,8 @@ class TrainerController:
         u, v, w = Input(input_shape, 'u'), Input(input_shape, 'v'), Input(input_shape, 'w')
         u_mag, v_mag, w_mag = Input(input_shape, 'u_mag'), Input(input_shape, 'v_mag'), Input(input_shape, 'w_mag')
         net = SR4DFlowNet(res_increase)
-        self.model = net.build_network(u, v, w, u_mag, v_mag, w_mag, low_resblock, hi_resblock, device=device, seed=seed)
+        self.model = net.build_network(u, v, w, u_mag, v_mag, w_mag, low_resblock, hi_resblock, device=device, seed=seed,
+                                       dtype=dtype)
         self.device = self.model.device
 
         names = ['train_loss', 'val_loss', 'train_accuracy', 'val_accuracy', 'train_mse', 'val_mse', 'train_div',

@@ -326,41 +326,53 @@ def count_params(params):
 # ----------------------------------------------------------------------------
 # network forward / backward  (SR4DFlowNet.build_network, SR4DFlowNet.py:7-51)
 # ----------------------------------------------------------------------------
-def network_forward(params, inputs, res_increase, low_resblock=8, hi_resblock=4, f32_coeffs=False):
+def _bf16_hooks(bf16):
+    """(r, wq): activation-store rounding and the weight view of a layer under the bf16 variant of the path
+    (BASELINE.json configs[3]).  Rounding points = where 4dflownet_amd stores a bf16 tensor: every 64-channel
+    activation / activation gradient, the 3-channel input features, the upsample output; the MFMA operand copy of the
+    64->64 kernels.  Everything else (thin-layer weights, prediction, parameter gradients) stays full precision."""
+    if not bf16:
+        return (lambda a: a), (lambda w: w)
+    return bf16_round, (lambda w: bf16_round(w) if w.shape == (3, 3, 3, 64, 64) else w)
+
+
+def network_forward(params, inputs, res_increase, low_resblock=8, hi_resblock=4, f32_coeffs=False, bf16=False):
     """inputs: 6 arrays (N,P,P,P,1).  Returns pred (N,PR,PR,PR,3) and a cache for backward."""
+    r, wq = _bf16_hooks(bf16)
     u, v, w, mu, mv, mw = inputs
     phase, pc = input_features(u, v, w, mu, mv, mw)
+    phase, pc = r(phase), r(pc)
     P = params
     c = {"phase": phase, "pc": pc}
-    c["a0"] = conv3d_fwd(pc, P[0]["w"], P[0]["b"], ACT_RELU)
-    c["a1"] = conv3d_fwd(c["a0"], P[1]["w"], P[1]["b"], ACT_RELU)
-    c["p0"] = conv3d_fwd(phase, P[2]["w"], P[2]["b"], ACT_RELU)
-    c["p1"] = conv3d_fwd(c["p0"], P[3]["w"], P[3]["b"], ACT_RELU)
+    c["a0"] = r(conv3d_fwd(pc, P[0]["w"], P[0]["b"], ACT_RELU))
+    c["a1"] = r(conv3d_fwd(c["a0"], wq(P[1]["w"]), P[1]["b"], ACT_RELU))
+    c["p0"] = r(conv3d_fwd(phase, P[2]["w"], P[2]["b"], ACT_RELU))
+    c["p1"] = r(conv3d_fwd(c["p0"], wq(P[3]["w"]), P[3]["b"], ACT_RELU))
     c["cat"] = np.concatenate([c["p1"], c["a1"]], axis=-1)          # :23  [phase, pc]
-    c["c0"] = conv3d_fwd(c["cat"], P[4]["w"], P[4]["b"], ACT_RELU)
-    c["c1"] = conv3d_fwd(c["c0"], P[5]["w"], P[5]["b"], ACT_RELU)
+    c["c0"] = r(conv3d_fwd(c["cat"], P[4]["w"], P[4]["b"], ACT_RELU))
+    c["c1"] = r(conv3d_fwd(c["c0"], wq(P[5]["w"]), P[5]["b"], ACT_RELU))
     rb = c["c1"]
     li = 6
     c["blocks"] = []
     for i in range(low_resblock + hi_resblock):
         if i == low_resblock:
             c["up_in"] = rb
-            rb = upsample_trilinear_fwd(rb, res_increase, f32_coeffs)
+            rb = r(upsample_trilinear_fwd(rb, res_increase, f32_coeffs))
             c["up_out"] = rb
-        h = conv3d_fwd(rb, P[li]["w"], None, ACT_LEAKY)
-        out = conv3d_fwd(h, P[li + 1]["w"], None, ACT_LEAKY, residual=rb)
+        h = r(conv3d_fwd(rb, wq(P[li]["w"]), None, ACT_LEAKY))
+        out = r(conv3d_fwd(h, wq(P[li + 1]["w"]), None, ACT_LEAKY, residual=rb))
         c["blocks"].append((rb, h, out))
         rb = out
         li += 2
     if hi_resblock == 0:
         c["up_in"] = rb
-        rb = upsample_trilinear_fwd(rb, res_increase, f32_coeffs)
+        rb = r(upsample_trilinear_fwd(rb, res_increase, f32_coeffs))
         c["up_out"] = rb
     c["rb"] = rb
     outs = []
     c["heads"] = []
     for hidx in range(3):
-        g = conv3d_fwd(rb, P[li]["w"], P[li]["b"], ACT_RELU)
+        g = r(conv3d_fwd(rb, wq(P[li]["w"]), P[li]["b"], ACT_RELU))
         o = conv3d_fwd(g, P[li + 1]["w"], P[li + 1]["b"], ACT_NONE)
         c["heads"].append(g)
         outs.append(o)
@@ -369,8 +381,9 @@ def network_forward(params, inputs, res_increase, low_resblock=8, hi_resblock=4,
     return pred, c
 
 
-def network_backward(params, c, dpred, res_increase, low_resblock=8, hi_resblock=4, f32_coeffs=False):
+def network_backward(params, c, dpred, res_increase, low_resblock=8, hi_resblock=4, f32_coeffs=False, bf16=False):
     """Gradients of sum_b loss_b w.r.t. every parameter, given dpred.  Returns list of {"w","b"}."""
+    r, wq = _bf16_hooks(bf16)
     P = params
     G = [{"w": None, "b": None} for _ in P]
     rb = c["rb"]
@@ -383,39 +396,43 @@ def network_backward(params, c, dpred, res_increase, low_resblock=8, hi_resblock
         G[li + 1]["b"] = bias_grad(dz_o)
         dg = conv3d_dgrad(dz_o, P[li + 1]["w"], g.shape)
         dz_g = act_bwd_from_output(dg, g, ACT_RELU)
+        G[li]["b"] = bias_grad(dz_g)                 # the HIP path sums this before the store rounds it
+        dz_g = r(dz_g)
         G[li]["w"] = conv3d_wgrad(rb, dz_g, 3)
-        G[li]["b"] = bias_grad(dz_g)
-        d_rb = d_rb + conv3d_dgrad(dz_g, P[li]["w"], rb.shape)
+        d_rb = d_rb + conv3d_dgrad(dz_g, wq(P[li]["w"]), rb.shape)
+        if hidx < 2:
+            d_rb = r(d_rb)            # fan-in chained through a stored tensor; the third add is rounded after act'
         li += 2
     li = len(P) - 6
     d_out = d_rb                      # gradient w.r.t. block output (post activation)
     nblocks = low_resblock + hi_resblock
     if hi_resblock == 0:
-        d_out = upsample_trilinear_bwd(d_out, c["up_in"].shape[1:4], res_increase, f32_coeffs)
+        d_out = upsample_trilinear_bwd(r(d_out), c["up_in"].shape[1:4], res_increase, f32_coeffs)
     for i in reversed(range(nblocks)):
         x, h, out = c["blocks"][i]
         li -= 2
-        dz_out = act_bwd_from_output(d_out, out, ACT_LEAKY)
+        dz_out = r(act_bwd_from_output(d_out, out, ACT_LEAKY))
         G[li + 1]["w"] = conv3d_wgrad(h, dz_out, 3)
-        dh = conv3d_dgrad(dz_out, P[li + 1]["w"], h.shape)
-        dz_h = act_bwd_from_output(dh, h, ACT_LEAKY)
+        dh = conv3d_dgrad(dz_out, wq(P[li + 1]["w"]), h.shape)
+        dz_h = r(act_bwd_from_output(dh, h, ACT_LEAKY))
         G[li]["w"] = conv3d_wgrad(x, dz_h, 3)
-        d_out = conv3d_dgrad(dz_h, P[li]["w"], x.shape) + dz_out
+        d_out = conv3d_dgrad(dz_h, wq(P[li]["w"]), x.shape) + dz_out
         if i == low_resblock:
+            d_out = r(d_out)          # stored (producer of this block input is the linear upsample) before U^T
             d_out = upsample_trilinear_bwd(d_out, c["up_in"].shape[1:4], res_increase, f32_coeffs)
     assert li == 6
-    dz_c1 = act_bwd_from_output(d_out, c["c1"], ACT_RELU)
+    dz_c1 = r(act_bwd_from_output(d_out, c["c1"], ACT_RELU))
     G[5]["w"] = conv3d_wgrad(c["c0"], dz_c1, 3); G[5]["b"] = bias_grad(dz_c1)
-    dz_c0 = act_bwd_from_output(conv3d_dgrad(dz_c1, P[5]["w"], c["c0"].shape), c["c0"], ACT_RELU)
+    dz_c0 = r(act_bwd_from_output(conv3d_dgrad(dz_c1, wq(P[5]["w"]), c["c0"].shape), c["c0"], ACT_RELU))
     G[4]["w"] = conv3d_wgrad(c["cat"], dz_c0, 1); G[4]["b"] = bias_grad(dz_c0)
     dcat = conv3d_dgrad(dz_c0, P[4]["w"], c["cat"].shape)
-    dz_p1 = act_bwd_from_output(dcat[..., :64], c["p1"], ACT_RELU)
-    dz_a1 = act_bwd_from_output(dcat[..., 64:], c["a1"], ACT_RELU)
+    dz_p1 = r(act_bwd_from_output(dcat[..., :64], c["p1"], ACT_RELU))
+    dz_a1 = r(act_bwd_from_output(dcat[..., 64:], c["a1"], ACT_RELU))
     G[3]["w"] = conv3d_wgrad(c["p0"], dz_p1, 3); G[3]["b"] = bias_grad(dz_p1)
-    dz_p0 = act_bwd_from_output(conv3d_dgrad(dz_p1, P[3]["w"], c["p0"].shape), c["p0"], ACT_RELU)
+    dz_p0 = r(act_bwd_from_output(conv3d_dgrad(dz_p1, wq(P[3]["w"]), c["p0"].shape), c["p0"], ACT_RELU))
     G[2]["w"] = conv3d_wgrad(c["phase"], dz_p0, 3); G[2]["b"] = bias_grad(dz_p0)
     G[1]["w"] = conv3d_wgrad(c["a0"], dz_a1, 3); G[1]["b"] = bias_grad(dz_a1)
-    dz_a0 = act_bwd_from_output(conv3d_dgrad(dz_a1, P[1]["w"], c["a0"].shape), c["a0"], ACT_RELU)
+    dz_a0 = r(act_bwd_from_output(conv3d_dgrad(dz_a1, wq(P[1]["w"]), c["a0"].shape), c["a0"], ACT_RELU))
     G[0]["w"] = conv3d_wgrad(c["pc"], dz_a0, 3); G[0]["b"] = bias_grad(dz_a0)
     for g, p in zip(G, P):
         if p["b"] is None:
@@ -445,26 +462,26 @@ def adam_step_tf(w, g, m, v, t, lr, b1=ADAM_B1, b2=ADAM_B2, eps=ADAM_EPS):
     w[:] = w - lr_t * m / (np.sqrt(v) + eps)
 
 
-def loss_and_grads(params, batch, res_increase, low_resblock=8, hi_resblock=4, f32_coeffs=False):
+def loss_and_grads(params, batch, res_increase, low_resblock=8, hi_resblock=4, f32_coeffs=False, bf16=False):
     """batch = (u,v,w,u_mag,v_mag,w_mag,u_hr,v_hr,w_hr,venc,mask) as the loader yields them
     (PatchHandler3D.py:78-81).  Returns dict with per-sample loss (incl. L2), mse, rel-error,
     l2 scalar, pred and the gradient list of sum_b(loss_b) = sum_b mse_b + B*L2."""
     u, v, w, mu, mv, mw, uh, vh, wh, venc, mask = batch
     hires = np.concatenate([uh, vh, wh], axis=-1)
-    pred, cache = network_forward(params, (u, v, w, mu, mv, mw), res_increase, low_resblock, hi_resblock, f32_coeffs)
+    pred, cache = network_forward(params, (u, v, w, mu, mv, mw), res_increase, low_resblock, hi_resblock, f32_coeffs, bf16)
     mse, dpred = masked_mse_loss_fwd_bwd(pred, hires, mask)
     rel = relative_error(pred, hires, mask)
     l2 = l2_regularizer(params)
-    grads = network_backward(params, cache, dpred, res_increase, low_resblock, hi_resblock, f32_coeffs)
+    grads = network_backward(params, cache, dpred, res_increase, low_resblock, hi_resblock, f32_coeffs, bf16)
     B = u.shape[0]
     for g, p in zip(grads, params):
         g["w"] = g["w"] + (B * 2 * L2_LAMBDA) * p["w"]
     return {"loss": mse + l2, "mse": mse, "rel_err": rel, "l2": l2, "pred": pred, "grads": grads}
 
 
-def train_step(params, state, batch, lr, res_increase, low_resblock=8, hi_resblock=4, f32_coeffs=False):
+def train_step(params, state, batch, lr, res_increase, low_resblock=8, hi_resblock=4, f32_coeffs=False, bf16=False):
     """One TrainerController.train_step.  state = {"t":int, "m":[...], "v":[...]} (created on first call)."""
-    out = loss_and_grads(params, batch, res_increase, low_resblock, hi_resblock, f32_coeffs)
+    out = loss_and_grads(params, batch, res_increase, low_resblock, hi_resblock, f32_coeffs, bf16)
     if not state:
         state["t"] = 0
         state["m"] = [{"w": np.zeros_like(p["w"]), "b": None if p["b"] is None else np.zeros_like(p["b"])} for p in params]

@@ -48,7 +48,11 @@ def bops(fdn):
     return importlib.import_module("4dflownet_amd.ops_bf16")
 
 
-SHAPES = [(2, 8, 8, 8), (1, 5, 7, 9), (1, 10, 12, 16), (3, 4, 4, 2), (1, 1, 1, 1), (1, 16, 16, 16), (1, 3, 20, 11)]
+SHAPES = [(2, 8, 8, 8), (1, 5, 7, 9), (1, 10, 12, 16), (3, 4, 4, 2), (1, 1, 1, 1), (1, 16, 16, 16), (1, 3, 20, 11),
+          (3, 24, 24, 24), (1, 17, 9, 12)]
+# conv64 variants: 0 = planner, 4 / 8 = forced MT, +16 = full-depth tiles only (exercises the unrolled FAST kernel even
+# where the planner would cut a small grid into thin tiles)
+VARIANTS = [0, 4, 8, 20, 24]
 
 
 def rb(a):
@@ -56,7 +60,7 @@ def rb(a):
 
 
 @pytest.mark.parametrize("shape", SHAPES)
-@pytest.mark.parametrize("mt", [0, 4, 8])
+@pytest.mark.parametrize("mt", VARIANTS)
 def test_conv64_fwd_bf16(bops, fdn, shape, mt):
     rng = np.random.default_rng(11)
     N, D, H, W = shape
@@ -78,7 +82,7 @@ def test_conv64_fwd_bf16(bops, fdn, shape, mt):
 
 
 @pytest.mark.parametrize("shape", SHAPES + [(1, 2, 3, 1)])
-@pytest.mark.parametrize("mt", [0, 4, 8])
+@pytest.mark.parametrize("mt", VARIANTS)
 def test_conv64_dgrad_fused_bf16(bops, fdn, shape, mt):
     rng = np.random.default_rng(12)
     N, D, H, W = shape

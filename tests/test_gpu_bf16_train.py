@@ -1,0 +1,123 @@
+"""End-to-end parity of the bf16 activation path (BASELINE.json configs[3]) on the GPU.
+
+Oracle = the float64 restatement with the HIP path's bf16 store points emulated (oracle._bf16_hooks).  Per kernel the
+two sides agree to one bf16 ulp (tests/test_gpu_bf16.py, the precise gate).  End to end they cannot agree better than
+the quantisation step: a difference d in a layer's input makes a fraction ~d/ulp of its outputs round the other way, so
+the relative L2 distance grows like sqrt(d*ulp) per layer and saturates near one bf16 ulp (2^-8 = 4e-3) -- measured
+(tools/dbg_bf16.py): 4e-7 after the first conv, 5e-4 after six, 5e-3 at the last residual block, 8e-3 on the
+prediction, 1-6e-2 on the gradients of the earliest layers (tiny test volumes: 2 x 8^3 voxels per gradient).
+Tolerances: prediction 3e-2, per-layer gradients 1.5e-1 (relative L2); a wrong rounding point or operand layout gives
+O(1).  The distance to the un-rounded fp32 network is reported by the second test."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import flownet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def l2_rel(got, ref):
+    got = np.asarray(got, np.float64); ref = np.asarray(ref, np.float64)
+    return np.linalg.norm((got - ref).ravel()) / max(np.linalg.norm(ref.ravel()), 1e-30)
+
+
+def make(P, R, LB, HB, seed, dtype, wscale=3.0):
+    trainer_mod = importlib.import_module("4dflownet_amd.trainer")
+    tc = trainer_mod.TrainerController(P, R, initial_learning_rate=1e-3, quicksave_enable=False, low_resblock=LB,
+                                       hi_resblock=HB, seed=seed, dtype=dtype)
+    params = O.init_params(seed, LB, HB, np.float64)
+    rng = np.random.default_rng(seed + 1)
+    arrays = []
+    for p in params:
+        p["w"] = (p["w"] * wscale).astype(np.float32).astype(np.float64)
+        arrays.append(p["w"].astype(np.float32))
+        if p["b"] is not None:
+            p["b"] = rng.normal(0, 0.05, p["b"].shape).astype(np.float32).astype(np.float64)
+            arrays.append(p["b"].astype(np.float32))
+    tc.model.set_weights(arrays)
+    return tc, params
+
+
+@pytest.mark.parametrize("P,R,LB,HB,B", [(8, 2, 1, 1, 2), (8, 1, 2, 1, 2), (4, 4, 1, 1, 1), (6, 2, 2, 0, 2)])
+def test_bf16_train_step_matches_bf16_oracle(fdn, P, R, LB, HB, B):
+    tc, params = make(P, R, LB, HB, seed=3, dtype="bfloat16")
+    assert tc.model.act_dtype == torch.bfloat16
+    batch = O.synthetic_batch(B, P, R, seed=31)
+    b64 = tuple(a.astype(np.float64) for a in batch)
+    ref = O.loss_and_grads(params, b64, R, LB, HB, f32_coeffs=True, bf16=True)
+    inputs, hires, venc, mask = tc._unpack(batch)
+    pred = tc.model.forward(inputs, training=True)
+    assert pred.dtype == torch.float32
+    cache = tc.model._cache
+    assert cache["rb"].t.dtype == torch.bfloat16
+    out, dpred = fdn.ops.loss_metrics(pred, hires[0], hires[1], hires[2], mask)
+    g = tc.model.backward(dpred).cpu().numpy().astype(np.float64)
+    assert np.isfinite(g).all()
+    assert l2_rel(pred.cpu().numpy(), ref["pred"]) < 3e-2
+    assert l2_rel(out[:, 0].cpu().numpy(), ref["mse"]) < 3e-2
+    isk = tc.model.is_kernel.cpu().numpy().astype(np.float64)
+    g_total = g + B * 2 * O.L2_LAMBDA * tc.model.flat_w.cpu().numpy().astype(np.float64) * isk
+    gref = O.flatten(ref["grads"])
+    worst = 0.0
+    for L in tc.model.layers:
+        sl = slice(L.w_off, L.w_off + L.w.numel())
+        e = l2_rel(g_total[sl], gref[sl])
+        worst = max(worst, e)
+        assert e < 1.5e-1, (L.name, "kernel grad", e)
+        if L.b is not None:
+            sb = slice(L.b_off, L.b_off + L.cout)
+            eb = l2_rel(g_total[sb], gref[sb])
+            assert eb < 1.5e-1, (L.name, "bias grad", eb)
+    print("bf16 vs bf16-oracle: pred %.2e, worst layer grad %.2e" % (l2_rel(pred.cpu().numpy(), ref["pred"]), worst))
+    # the full step runs and updates every parameter by at most lr
+    w0 = tc.model.flat_w.clone()
+    loss = tc.train_step(batch)
+    assert torch.isfinite(loss).all()
+    dw = (tc.model.flat_w - w0).abs().max().item()
+    assert 0 < dw <= 1.05e-3
+
+
+def test_bf16_distance_to_fp32_network(fdn):
+    """bf16 storage vs the fp32 network on the same weights / inputs: a few 1e-3 relative (L2) on the prediction,
+    ~1e-2 on the gradients -- reported, and bounded loosely so a broken rounding mode would show."""
+    P, R, LB, HB, B = 8, 2, 1, 1, 2
+    tcb, params = make(P, R, LB, HB, seed=4, dtype="bfloat16")
+    batch = O.synthetic_batch(B, P, R, seed=41)
+    b64 = tuple(a.astype(np.float64) for a in batch)
+    ref = O.loss_and_grads(params, b64, R, LB, HB, f32_coeffs=True)            # exact fp32-semantics network
+    inputs, hires, venc, mask = tcb._unpack(batch)
+    pred = tcb.model.forward(inputs, training=True)
+    out, dpred = fdn.ops.loss_metrics(pred, hires[0], hires[1], hires[2], mask)
+    g = tcb.model.backward(dpred).cpu().numpy().astype(np.float64)
+    isk = tcb.model.is_kernel.cpu().numpy().astype(np.float64)
+    g_total = g + B * 2 * O.L2_LAMBDA * tcb.model.flat_w.cpu().numpy().astype(np.float64) * isk
+    ep = l2_rel(pred.cpu().numpy(), ref["pred"])
+    eg = l2_rel(g_total, O.flatten(ref["grads"]))
+    print("bf16 vs fp32 network: pred %.2e, grads %.2e" % (ep, eg))
+    assert ep < 5e-2 and eg < 2e-1
+
+
+def test_cfg4_size_batch_additivity(fdn):
+    """BASELINE.json configs[3] geometry (patch 32, res x4, LB 8, HB 4): the gradient of a batch is the sum of the
+    per-sample gradients (samples never interact; tape.gradient of the (B,) loss sums over the batch).  Checked at
+    B = 2 against two B = 1 passes -- a size-independent property at the full 128^3 high-res grid."""
+    P, R, LB, HB = 32, 4, 8, 4
+    tc, _ = make(P, R, LB, HB, seed=5, dtype="bfloat16", wscale=1.0)
+    batch = O.synthetic_batch(2, P, R, seed=51)
+
+    def grads(sl):
+        inputs, hires, venc, mask = tc._unpack(tuple(a[sl] for a in batch))
+        pred = tc.model.forward(inputs, training=True)
+        out, dpred = fdn.ops.loss_metrics(pred, hires[0], hires[1], hires[2], mask)
+        return tc.model.backward(dpred).double().clone(), out[:, 0].double().clone()
+
+    g01, l01 = grads(slice(0, 2))
+    g0, l0 = grads(slice(0, 1))
+    g1, l1 = grads(slice(1, 2))
+    assert torch.isfinite(g01).all()
+    assert torch.allclose(l01, torch.cat([l0, l1]), rtol=1e-5, atol=0)
+    err = (g01 - (g0 + g1)).norm() / g01.norm()
+    assert err < 1e-4, err.item()
