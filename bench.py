@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2516.6       # dense bf16: 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz (tools/mfma_peak_bf16.hip sustains 1895)
 FLOP_PER_VOXEL_CONV64 = 2.0 * 27 * 64 * 64   # 3.0576 GFLOP per 24^3 patch = 221 184 FLOP/voxel
 
 
@@ -46,7 +47,7 @@ class ConvTimer:
         self.ops = ops
         self.records = []
         self.enabled = False
-        self._fwd, self._dgrad, self._dgrad_fused = ops.conv3d_fwd, ops.conv3d_dgrad, ops.conv3d_dgrad_fused
+        self._fwd, self._dgrad, self._dgrad_fused = ops.conv3d_fwd, getattr(ops, "conv3d_dgrad", None), ops.conv3d_dgrad_fused
 
     def install(self):
         ops, rec = self.ops, self.records
@@ -75,7 +76,9 @@ class ConvTimer:
             rec.append(("dgrad", dz.shape[0] * dz.shape[1] * dz.shape[2] * dz.shape[3], e0, e1))
             return out
 
-        ops.conv3d_fwd, ops.conv3d_dgrad, ops.conv3d_dgrad_fused = fwd, dgrad, dgrad_fused
+        ops.conv3d_fwd, ops.conv3d_dgrad_fused = fwd, dgrad_fused
+        if self._dgrad is not None:
+            ops.conv3d_dgrad = dgrad
 
     def summary(self):
         n = len(self.records)
@@ -128,8 +131,14 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--low", type=int, default=8)
     ap.add_argument("--hi", type=int, default=4)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="storage type of activations / activation gradients (bf16 = BASELINE.json configs[3] arithmetic)")
+    ap.add_argument("--config", choices=["cfg2", "cfg4"], default="cfg2",
+                    help="cfg2 = the headline workload (defaults above); cfg4 = patch 32, res x4, batch 4, bf16 (secondary metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.config == "cfg4":
+        args.patch, args.res, args.batch, args.dtype = 32, 4, 4, "bf16"
 
     parallel = importlib.import_module("4dflownet_amd.parallel")
     rank, world, local_rank = parallel.init_from_env()
@@ -142,10 +151,11 @@ def main():
     trainer = importlib.import_module("4dflownet_amd.trainer")
     fdn._lib.load()                                   # fail loudly if the HIP library is missing
     P, R, B, LB, HB = args.patch, args.res, args.batch, args.low, args.hi
+    bf16 = args.dtype == "bf16"
     tc = trainer.TrainerController(P, R, initial_learning_rate=1e-4, quicksave_enable=False, low_resblock=LB,
-                                   hi_resblock=HB, device=device, seed=0)
+                                   hi_resblock=HB, device=device, seed=0, dtype="bfloat16" if bf16 else "float32")
     batch = synthetic_batch(B, P, R, 1234 + rank, device)
-    timer = ConvTimer(fdn.ops)
+    timer = ConvTimer(tc.model.ops)
     timer.install()
 
     for _ in range(args.warmup):
@@ -169,8 +179,15 @@ def main():
         return
     n_launch, avg_ms, avg_flop = timer.summary()
     achieved = avg_flop / (avg_ms * 1e-3) / 1e12
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+    # forward FLOPs per patch from the layer list (328.83 GFLOP at cfg2), train step = 3x
+    fwd_flop = 0.0
+    hr_from = 6 + 2 * LB
+    for i, (_, k, ci, co, _) in enumerate(tc.model.specs):
+        vox = P ** 3 * (R ** 3 if i >= hr_from else 1)
+        fwd_flop += 2.0 * k ** 3 * ci * co * vox
     line = {
-        "metric": "3D patches/sec (train step, patch=24, res×2)",
+        "metric": "3D patches/sec (train step, patch=%d, res×%d)" % (P, R),
         "value": args.steps * B * world / dt,
         "unit": "patches/s",
         "n_gpus": world,
@@ -180,19 +197,20 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "bf16" if bf16 else "f32",
         "data": "synthetic (SURVEY 8d: default_rng(1234+rank) inputs, Glorot-uniform default_rng(0) weights)",
-        "config": {"workload": "cfg2 train_step: patch_size=%d res_increase=%d batch=%d/GPU low_resblock=%d hi_resblock=%d fp32"
-                               % (P, R, B, LB, HB), "global_batch": B * world, "parallelism": "dp%d" % world},
-        "roofline": {"bound": "mfma", "kernel": "conv64_mfma_kernel (3x3x3 64->64 fwd + dgrad launches)",
-                     "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic_bytes(),
+        "config": {"workload": "%s train_step: patch_size=%d res_increase=%d batch=%d/GPU low_resblock=%d hi_resblock=%d %s"
+                               % (args.config, P, R, B, LB, HB, "bf16 activations, fp32 accumulation/parameters" if bf16 else "fp32"),
+                   "global_batch": B * world, "parallelism": "dp%d" % world},
+        "roofline": {"bound": "mfma", "kernel": "%s (3x3x3 64->64 fwd + dgrad launches)" % ("conv64_bf16_kernel" if bf16 else "conv64_mfma_kernel"),
+                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                     "frac": achieved / peak, "traffic": None if bf16 else pmc_traffic_bytes(),
                      "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_pmc_traffic.json)",
-                     "algorithmic_bytes_per_launch": avg_flop / FLOP_PER_VOXEL_CONV64 * 512.0 + 442368.0,
+                     "algorithmic_bytes_per_launch": avg_flop / FLOP_PER_VOXEL_CONV64 * (256.0 if bf16 else 512.0) + (221184.0 if bf16 else 442368.0),
                      "launches_timed": n_launch, "avg_launch_ms": avg_ms, "avg_launch_gflop": avg_flop / 1e9},
-        "train_step_tflops": args.steps * B * world / dt * 986.5e9 / 1e12,
+        "train_step_tflops": args.steps * B * world / dt * 3.0 * fwd_flop / 1e12,
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and not bf16:
         line["cpu_baseline"] = cpu_baseline(P, R, LB, HB)
     print(json.dumps(line))
 
