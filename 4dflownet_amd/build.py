@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib4dflow_hip.so")
-SOURCES = ["api.hip", "conv64_mfma.hip", "conv64_bf16.hip", "wgrad64_mfma.hip", "wgrad64_bf16.hip", "small_convs.hip", "elementwise.hip", "patch_gather.hip"]
+SOURCES = ["api.hip", "conv64_mfma.hip", "conv64_bf16.hip", "wgrad64_mfma.hip", "wgrad64_bf16.hip", "small_convs.hip", "heads_mfma.hip", "elementwise.hip", "patch_gather.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-I", os.path.join(ROOT, "include"), "-I", CSRC]
 

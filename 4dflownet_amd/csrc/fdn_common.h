@@ -23,6 +23,14 @@ __device__ __forceinline__ f32x4 fdn_ld4(const uint16_t* p) {
     return (f32x4){__builtin_bit_cast(float, r.x << 16), __builtin_bit_cast(float, r.x & 0xffff0000u),
                    __builtin_bit_cast(float, r.y << 16), __builtin_bit_cast(float, r.y & 0xffff0000u)};
 }
+// raw (still packed) 4-element loads for register prefetch rings: convert at the point of use, not at the load
+__device__ __forceinline__ f32x4 fdn_ld4_raw(const float* p) { return *(const f32x4*)p; }
+__device__ __forceinline__ fdn_u32x2 fdn_ld4_raw(const uint16_t* p) { return *(const fdn_u32x2*)p; }
+__device__ __forceinline__ f32x4 fdn_cvt4(f32x4 r) { return r; }
+__device__ __forceinline__ f32x4 fdn_cvt4(fdn_u32x2 r) {
+    return (f32x4){__builtin_bit_cast(float, r.x << 16), __builtin_bit_cast(float, r.x & 0xffff0000u),
+                   __builtin_bit_cast(float, r.y << 16), __builtin_bit_cast(float, r.y & 0xffff0000u)};
+}
 __device__ __forceinline__ void fdn_st4(float* p, f32x4 v) { *(f32x4*)p = v; }
 __device__ __forceinline__ void fdn_st4(uint16_t* p, f32x4 v) {
     typedef __bf16 bf4 __attribute__((ext_vector_type(4)));

@@ -1,0 +1,190 @@
+// The three 64 -> 1 head convolutions (SR4DFlowNet.py:40,43,46) -- forward, input gradient (with the halo fold and the
+// producer's activation gradient) and weight gradient -- as small fp32 MFMA GEMMs plus a scalar stencil, instead of 1728
+// VALU FMAs per voxel.  With one output channel the 3x3x3 conv factors into
+//     forward : z[v][t] = sum_c x[v][c] w[t][c]            (V x 64) x (64 x 27) GEMM, per voxel, no neighbours
+//               y[o]    = b + sum_t z[clamp(o + t - 1)][t]  27-point gather of scalars
+//     backward: A[i][t] = sum_{o : clamp(o + t - 1) = i} dz[o]   (scalar stencil: 1 term inside the volume, up to 8 at a
+//                                                                 corner -- this IS MirrorPadGrad, applied to scalars)
+//               dx[i][c] = act'(y_prev[i][c]) sum_t A[i][t] w[t][c]      (V x 27) x (27 x 64) GEMM
+//               dW[t][c] = sum_i A[i][t] x[i][c]                         (27 x V) x (V x 64) GEMM
+// so every 64-channel row is touched once (forward: once per tile incl. halo) and the kernels run at the HBM roof.
+// All three use v_mfma_f32_32x32x2_f32 (K is 64, 27 or the voxel count): fp32 products and accumulation exactly like the
+// VALU kernels they replace, for both activation storage types T (float / bf16 bits; bf16 -> fp32 is exact).
+#include "fdn_common.h"
+#include <type_traits>
+#include <stdlib.h>
+
+namespace {
+
+__device__ __forceinline__ int clampi(int v, int hi) { return min(max(v, 0), hi); }
+
+constexpr int H_TD = 4, H_TH = 8, H_TW = 8;                 // forward tile: 256 outputs, one per thread
+constexpr int H_XD = H_TD + 2, H_XH = H_TH + 2, H_XW = H_TW + 2;
+constexpr int H_HV = H_XD * H_XH * H_XW;                    // 600 halo voxels
+constexpr int H_NMT = (H_HV + 31) / 32;                     // 19 M-tiles of 32 halo voxels (+1 dummy slot: 5 per wave)
+constexpr int H_HVP = 20 * 32 + 1;                          // z plane stride: all 20 slots (no row predicate), odd (conflict-free)
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward.  Phase 1: z[hv][t] for the 600 halo voxels of the tile (19 M-tiles of 32 voxels over 4 waves; A fragments are
+// 16-B chunks straight from global, K order permuted like conv64_mfma.hip: lane (i,kh) holds cin 8g+4kh+{0..3}).
+// Phase 2: one output per thread = 27 LDS reads.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256, 2) void head_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ y, int N, int D,
+                                                          int H, int W, int ntd, int nth, int ntw, int iters, int ldy, int y_coff,
+                                                          int act, float alpha, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) float zbuf[];      // [27][H_HVP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    const int tiles_per_n = ntd * nth * ntw, ntiles = N * tiles_per_n;
+
+    // K order: a lane holds E = 16 B / sizeof(T) consecutive channels per chunk (4 fp32 / 8 bf16): lane (i,kh), chunk g,
+    // element s  <->  cin = 2E g + E kh + s.   B fragments: w[t = li][that cin], zero for the 5 padding columns.
+    constexpr int E = 16 / (int)sizeof(T), NCH = 32 / E;
+    float wb[NCH][E];
+#pragma unroll
+    for (int g = 0; g < NCH; ++g)
+#pragma unroll
+        for (int s = 0; s < E; ++s) wb[g][s] = li < 27 ? w[li * 64 + 2 * E * g + E * kh + s] : 0.f;
+    const float b0 = bias ? bias[0] : 0.f;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    // Each wave owns M-tiles wave, wave+4, ... of a tile: 5 steps per tile (the 20th slot is a dummy on wave 3).  A step's
+    // NCH 16-B chunk loads are issued TWO steps ahead into a ring of three register buffers (kept packed; converted at
+    // use); 5 steps per tile x 3 buffers -> the schedule repeats every 3 tiles, which are unrolled.  All control flow is
+    // uniform and branch-free around the loads (tile indices past the end are clamped, their stores predicated), so every
+    // wait is a counted vmcnt.  16-B lane loads matter: with 8-B loads the L1 sees every 64-B sector 8 times.
+    // lane-constant part of the addressing: halo coordinates of this lane's row in each of its 5 M-tile slots
+    int zpk[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        int hv = (wave + 4 * k) * 32 + li;
+        hv = hv < H_HV ? hv : H_HV - 1;
+        const int zd = hv / (H_XH * H_XW);
+        const int r2 = hv - zd * (H_XH * H_XW);
+        const int zh = r2 / H_XW;
+        zpk[k] = zd | (zh << 8) | ((r2 - zh * H_XW) << 16);
+    }
+    struct TileOrg { int n, d, h, w; };
+    auto decode = [&](int tile) {
+        int b = min(tile, ntiles - 1);
+        TileOrg o;
+        o.n = b / tiles_per_n;
+        b -= o.n * tiles_per_n;
+        const int tdi = b / (nth * ntw);
+        b -= tdi * (nth * ntw);
+        const int thi = b / ntw;
+        o.d = tdi * H_TD; o.h = thi * H_TH; o.w = (b - thi * ntw) * H_TW;
+        return o;
+    };
+    auto load_tile = [&](const TileOrg& o, int k, u32x4 (&av)[NCH]) {
+        const int zd = zpk[k] & 255, zh = (zpk[k] >> 8) & 255, zw = zpk[k] >> 16;
+        const int qd = clampi(o.d + zd - 1, D - 1), qh = clampi(o.h + zh - 1, H - 1), qw = clampi(o.w + zw - 1, W - 1);
+        const T* xp = x + ((size_t)o.n * D * H * W + ((size_t)qd * H + qh) * W + qw) * 64 + kh * E;
+#pragma unroll
+        for (int g = 0; g < NCH; ++g) av[g] = *(const u32x4*)(xp + g * 2 * E);
+    };
+    const int G = gridDim.x;
+    // 32 MFMAs of one M-tile slot into acc
+    auto mfma_step = [&](const u32x4 (&src)[NCH], f32x16& acc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < NCH; ++g) {
+            float a[E];
+            if constexpr (E == 4) {
+                const f32x4 f = __builtin_bit_cast(f32x4, src[g]);     // (bit_cast of src[g][s] miscompiles: all four = element 0)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) a[s] = f[s];
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    a[2 * s] = __builtin_bit_cast(float, src[g][s] << 16);
+                    a[2 * s + 1] = __builtin_bit_cast(float, src[g][s] & 0xffff0000u);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < E; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wb[g][s], acc, 0, 0, 0);
+        }
+    };
+    // C[voxel row][tap li] -> zbuf[tap][row]; rows of the dummy slot land in the padding
+    float* zw0 = zbuf + li * H_HVP + wave * 32 + 4 * kh;
+    auto z_store = [&](const f32x16& acc, int k) {
+        if (li < 27 && !(dbg & 1)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zw0[k * 128 + (r & 3) + 8 * (r >> 2)] = acc[r];
+        }
+    };
+    // phase 2: one output per thread
+    auto stencil = [&](const TileOrg& o, bool valid) {
+        __syncthreads();
+        const int od = tid >> 6, oh = (tid >> 3) & 7, ow = tid & 7;
+        const int pd = o.d + od, ph = o.h + oh, pw = o.w + ow;
+        float s = b0;
+        if (!(dbg & 2)) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int bb = 0; bb < 3; ++bb)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        s += zbuf[((a * 3 + bb) * 3 + c) * H_HVP + ((od + a) * H_XH + oh + bb) * H_XW + ow + c];
+        }
+        if (valid && pd < D && ph < H && pw < W && !(dbg & 4))
+            y[((size_t)o.n * D * H * W + ((size_t)pd * H + ph) * W + pw) * ldy + y_coff] = fdn_act(s, act, alpha);
+        __syncthreads();               // zbuf is rewritten by the next tile
+    };
+    u32x4 buf[3][NCH];
+    TileOrg cur = decode(blockIdx.x), nxt = decode(blockIdx.x + G);
+    load_tile(cur, 0, buf[0]);
+    load_tile(cur, 1, buf[1]);
+    auto do_tile = [&](auto basec, int tile) {
+        constexpr int BASE = decltype(basec)::value;        // ring position of this tile's step 0
+        f32x16 acc[2];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            load_tile(k + 2 < 5 ? cur : nxt, (k + 2) % 5, buf[(BASE + k + 2) % 3]);
+            __builtin_amdgcn_sched_barrier(0);      // hipcc otherwise sinks the loads below the 32 MFMAs (distance 2 -> 1)
+            mfma_step(buf[(BASE + k) % 3], acc[k & 1]);
+            if (k > 0) z_store(acc[(k - 1) & 1], k - 1);     // the previous slot's LDS writes ride in this slot's MFMA shadow
+        }
+        z_store(acc[0], 4);
+        stencil(cur, tile < ntiles);
+        cur = nxt;
+        nxt = decode(tile + 2 * G);
+    };
+#pragma unroll 1
+    for (int it = 0; it < iters; it += 3) {
+        const int t0 = blockIdx.x + it * G;
+        do_tile(std::integral_constant<int, 0>{}, t0);           // steps 0-4   -> ring 0,1,2,0,1
+        do_tile(std::integral_constant<int, 2>{}, t0 + G);       // steps 5-9   -> ring 2,0,1,2,0
+        do_tile(std::integral_constant<int, 1>{}, t0 + 2 * G);   // steps 10-14 -> ring 1,2,0,1,2
+    }
+}
+
+}  // namespace
+
+template <typename T>
+int fdn_head_fwd_launch(const T* x, const float* w, const float* bias, float* y, int N, int D, int H, int W, int ldy, int y_coff,
+                        int act, float alpha, hipStream_t s) {
+    const int ntd = (D + H_TD - 1) / H_TD, nth = (H + H_TH - 1) / H_TH, ntw = (W + H_TW - 1) / H_TW;
+    const size_t lds = (size_t)27 * H_HVP * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)head_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+        if (e != hipSuccess) { fdn_set_error("head_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return FDN_ERR_HIP; }
+        attr_set = true;
+    }
+    // persistent grid: every workgroup runs `iters` (a multiple of 3, see the kernel) tiles, at most 2 workgroups per CU
+    const int ntiles = N * ntd * nth * ntw;
+    const int iters = 3 * ((ntiles + 3 * 512 - 1) / (3 * 512));
+    const int grid = (ntiles + iters - 1) / iters;
+    const char* e = getenv("FDN_HEAD_DBG");
+    const int dbg = e ? atoi(e) : 0;
+    hipLaunchKernelGGL(head_fwd_kernel<T>, dim3((unsigned)grid), dim3(256), (dbg & 8) ? (size_t)100 * 1024 : lds, s, x, w, bias, y, N, D, H, W, ntd, nth, ntw,
+                       iters, ldy, y_coff, act, alpha, dbg);
+    FDN_CHECK_LAUNCH("head_fwd_kernel");
+    return FDN_OK;
+}
+template int fdn_head_fwd_launch<float>(const float*, const float*, const float*, float*, int, int, int, int, int, int, int, float, hipStream_t);
+template int fdn_head_fwd_launch<uint16_t>(const uint16_t*, const float*, const float*, float*, int, int, int, int, int, int, int, float, hipStream_t);
