@@ -188,3 +188,195 @@ int fdn_head_fwd_launch(const T* x, const float* w, const float* bias, float* y,
 }
 template int fdn_head_fwd_launch<float>(const float*, const float*, const float*, float*, int, int, int, int, int, int, int, float, hipStream_t);
 template int fdn_head_fwd_launch<uint16_t>(const uint16_t*, const float*, const float*, float*, int, int, int, int, int, int, int, float, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------------------------
+// input gradient of a head, with MirrorPadGrad and the producer's activation gradient:
+//   dx[i][c] = act'(y_prev[i][c]) * sum_t A[i][t] w[t][c],   A[i][t] = sum_{o : clamp(o + t - 1) = i} dz[o].
+// A is separable: per axis, with n[-1], n[0], n[+1] the dz neighbours of voxel i (zero outside the volume),
+//   interior : tap 0 -> n[+1]         tap 1 -> n[0]   tap 2 -> n[-1]
+//   i == 0   : tap 0 -> n[+1] + n[0]  tap 1 -> n[0]   tap 2 -> 0
+//   i == D-1 : tap 0 -> 0             tap 1 -> n[0]   tap 2 -> n[-1] + n[0]          (D == 1: all three -> n[0])
+// Tile = 4 x 8 x 8 voxels; the dz halo (600 scalars) is staged in LDS; a wave owns two M-tiles of 32 voxels (one d plane,
+// 4 h rows); lane = voxel computes the 27 folded taps from its 3x3x3 neighbourhood and feeds them as the B operand of
+// C[channel][voxel] = W^T[channel][tap] * A^T[tap][voxel]  (14 K-steps x 2 channel tiles of v_mfma_f32_32x32x2_f32).
+// The weight rows are permuted (sigma, as in conv64_bf16.hip) so a lane ends up with 16 consecutive channels of its voxel:
+// the mask loads and the stores are 16-B vectors.  Optional: per-channel sums of the result (BiasAddGrad of the producer).
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void head_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ w,
+                                                            const T* __restrict__ yprev, int act, float alpha,
+                                                            T* __restrict__ out, float* __restrict__ bpart, int N, int D, int H,
+                                                            int W, int ntd, int nth, int ntw, int lddz, int dz_coff) {
+    __shared__ float zs[2][H_HV + 8];           // dz halo of the current / next tile
+    __shared__ float bred[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    const int tiles_per_n = ntd * nth * ntw, ntiles = N * tiles_per_n;
+    const float slope = act == FDN_ACT_RELU ? 0.f : (act == FDN_ACT_LEAKY ? alpha : 1.f);
+
+    // A operand: W^T rows permuted: row q of channel tile m <-> channel 32 m + 16 ((q>>2)&1) + (q&3) + 4 (q>>3);
+    // lane (q = li, kh) holds w[t = 2s + kh][that channel] for the 14 K-steps
+    float wa[2][14];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int ch = 32 * m + 16 * ((li >> 2) & 1) + (li & 3) + 4 * (li >> 3);
+#pragma unroll
+        for (int s = 0; s < 14; ++s) wa[m][s] = (2 * s + kh) < 27 ? w[(2 * s + kh) * 64 + ch] : 0.f;
+    }
+    struct TileOrg { int n, d, h, w; };
+    auto decode = [&](int tile) {
+        int b = min(tile, ntiles - 1);
+        TileOrg o;
+        o.n = b / tiles_per_n;
+        b -= o.n * tiles_per_n;
+        const int tdi = b / (nth * ntw);
+        b -= tdi * (nth * ntw);
+        const int thi = b / ntw;
+        o.d = tdi * H_TD; o.h = thi * H_TH; o.w = (b - thi * ntw) * H_TW;
+        return o;
+    };
+    auto stage = [&](const TileOrg& o, float* dst) {            // zero outside the volume
+        for (int i = tid; i < H_HV; i += 256) {
+            const int zd = i / (H_XH * H_XW);
+            const int r2 = i - zd * (H_XH * H_XW);
+            const int zh = r2 / H_XW;
+            const int qd = o.d + zd - 1, qh = o.h + zh - 1, qw = o.w + (r2 - zh * H_XW) - 1;
+            float v = 0.f;
+            if ((unsigned)qd < (unsigned)D && (unsigned)qh < (unsigned)H && (unsigned)qw < (unsigned)W)
+                v = dz[((size_t)o.n * D * H * W + ((size_t)qd * H + qh) * W + qw) * lddz + dz_coff];
+            dst[i] = v;
+        }
+    };
+    float bsum[2][16];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bsum[m][r] = 0.f;
+
+    stage(decode(blockIdx.x), zs[0]);
+    int par = 0;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, par ^= 1) {
+        __syncthreads();                                         // zs[par] complete; zs[par^1] no longer read
+        if (tile + (int)gridDim.x < ntiles) stage(decode(tile + gridDim.x), zs[par ^ 1]);
+        const TileOrg o = decode(tile);
+        const float* z = zs[par];
+#pragma unroll 1
+        for (int mt = wave * 2; mt < wave * 2 + 2; ++mt) {       // M-tile: d plane mt >> 1, h rows 4 (mt & 1) .. +3
+            const int vd = mt >> 1, vh = 4 * (mt & 1) + (li >> 3), vw = li & 7;
+            const int gd = o.d + vd, gh = o.h + vh, gw = o.w + vw;
+            // 3x3x3 neighbourhood (halo coordinates vd..vd+2 etc.), then the per-axis fold transforms
+            float nb[3][3][3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) nb[a][b][c] = z[((vd + a) * H_XH + vh + b) * H_XW + vw + c];
+            // axis rule: f[0] = lo ? n[+1] + n[0] : (hi ? 0 : n[+1]); f[1] = n[0]; f[2] = hi ? n[-1] + n[0] : (lo ? 0 : n[-1]);
+            // with D == 1 (lo && hi): f[0] = f[2] = n[0].   n[-1] = index 0, n[0] = index 1, n[+1] = index 2.
+#define FDN_FOLD_AXIS(LO, HI, NM, N0, NP, F0, F2)                                  \
+            {                                                                      \
+                const float nm_ = NM, n0_ = N0, np_ = NP;                          \
+                F0 = (LO) ? ((HI) ? n0_ : np_ + n0_) : ((HI) ? 0.f : np_);         \
+                F2 = (HI) ? ((LO) ? n0_ : nm_ + n0_) : ((LO) ? 0.f : nm_);         \
+            }
+            const bool wl = gw == 0, wh = gw == W - 1, hl = gh == 0, hh = gh == H - 1, dl = gd == 0, dh = gd == D - 1;
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    float f0, f2;
+                    FDN_FOLD_AXIS(wl, wh, nb[a][b][0], nb[a][b][1], nb[a][b][2], f0, f2);
+                    nb[a][b][0] = f0; nb[a][b][2] = f2;              // now indexed by tap c
+                }
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float f0, f2;
+                    FDN_FOLD_AXIS(hl, hh, nb[a][0][c], nb[a][1][c], nb[a][2][c], f0, f2);
+                    nb[a][0][c] = f0; nb[a][2][c] = f2;
+                }
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float f0, f2;
+                    FDN_FOLD_AXIS(dl, dh, nb[0][b][c], nb[1][b][c], nb[2][b][c], f0, f2);
+                    nb[0][b][c] = f0; nb[2][b][c] = f2;
+                }
+#undef FDN_FOLD_AXIS
+            // B operand: lane (voxel, kh) supplies A[voxel][t = 2s + kh]
+            f32x16 acc[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 14; ++s) {
+                const int t0 = 2 * s, t1 = 2 * s + 1;
+                const float e0 = nb[t0 / 9][(t0 / 3) % 3][t0 % 3];
+                const float e1 = t1 < 27 ? nb[t1 / 9][(t1 / 3) % 3][t1 % 3] : 0.f;
+                const float bv = kh ? e1 : e0;
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[0][s], bv, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[1][s], bv, acc[1], 0, 0, 0);
+            }
+            // lane (voxel li, half kh) holds channels 32 m + 16 kh + r
+            const bool inside = gd < D && gh < H && gw < W;
+            const size_t vox = (size_t)o.n * D * H * W + ((size_t)min(gd, D - 1) * H + min(gh, H - 1)) * W + min(gw, W - 1);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const size_t e = vox * 64 + 32 * m + 16 * kh;
+#pragma unroll
+                for (int r4 = 0; r4 < 16; r4 += 4) {
+                    f32x4 v = {acc[m][r4], acc[m][r4 + 1], acc[m][r4 + 2], acc[m][r4 + 3]};
+                    if (yprev) {
+                        const f32x4 yv = fdn_ld4(yprev + e + r4);
+                        v.x *= yv.x > 0.f ? 1.f : slope; v.y *= yv.y > 0.f ? 1.f : slope;
+                        v.z *= yv.z > 0.f ? 1.f : slope; v.w *= yv.w > 0.f ? 1.f : slope;
+                    }
+                    if (inside) {
+                        fdn_st4(out + e + r4, v);
+                        bsum[m][r4] += v.x; bsum[m][r4 + 1] += v.y; bsum[m][r4 + 2] += v.z; bsum[m][r4 + 3] += v.w;
+                    }
+                }
+            }
+        }
+    }
+    if (bpart) {
+        // per-channel sums: fold the 32 voxel lanes of each half-wave, then the 4 waves through LDS
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = bsum[m][r];
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+                v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64);
+                if (li == 0) bred[wave][32 * m + 16 * kh + r] = v;
+            }
+        __syncthreads();
+        if (tid < 64) bpart[(size_t)blockIdx.x * 64 + tid] = (bred[0][tid] + bred[1][tid]) + (bred[2][tid] + bred[3][tid]);
+    }
+}
+
+}  // namespace
+
+// grid size of the persistent dgrad kernel = number of bias partial rows the caller must provide
+int fdn_head_dgrad_blocks(int N, int D, int H, int W) {
+    const long long ntiles = (long long)N * ((D + H_TD - 1) / H_TD) * ((H + H_TH - 1) / H_TH) * ((W + H_TW - 1) / H_TW);
+    return (int)(ntiles < 1024 ? ntiles : 1024);
+}
+
+template <typename T>
+int fdn_head_dgrad_launch(const float* dz, const float* w, const T* y_prev, int act, float alpha, T* dz_prev, float* bpart, int N,
+                          int D, int H, int W, int lddz, int dz_coff, hipStream_t s) {
+    const int ntd = (D + H_TD - 1) / H_TD, nth = (H + H_TH - 1) / H_TH, ntw = (W + H_TW - 1) / H_TW;
+    hipLaunchKernelGGL(head_dgrad_kernel<T>, dim3((unsigned)fdn_head_dgrad_blocks(N, D, H, W)), dim3(256), 0, s, dz, w, y_prev, act,
+                       alpha, dz_prev, bpart, N, D, H, W, ntd, nth, ntw, lddz, dz_coff);
+    FDN_CHECK_LAUNCH("head_dgrad_kernel");
+    return FDN_OK;
+}
+template int fdn_head_dgrad_launch<float>(const float*, const float*, const float*, int, float, float*, float*, int, int, int, int, int, int, hipStream_t);
+template int fdn_head_dgrad_launch<uint16_t>(const float*, const float*, const uint16_t*, int, float, uint16_t*, float*, int, int, int, int, int, int, hipStream_t);

@@ -558,6 +558,9 @@ int fdn_conv_cin3_fwd_launch(const T* x, const float* w, const float* bias, T* y
 // selectable for A/B runs (fdn_debug_set_heads_mfma(0))
 template <typename T> int fdn_head_fwd_launch(const T* x, const float* w, const float* bias, float* y, int N, int D, int H,
                                               int W, int ldy, int y_coff, int act, float alpha, hipStream_t s);
+template <typename T> int fdn_head_dgrad_launch(const float* dz, const float* w, const T* y_prev, int act, float alpha, T* dz_prev,
+                                                float* bpart, int N, int D, int H, int W, int lddz, int dz_coff, hipStream_t s);
+int fdn_head_dgrad_blocks(int N, int D, int H, int W);
 static int fdn_heads_use_mfma = 1;
 extern "C" int fdn_debug_set_heads_mfma(int on) { fdn_heads_use_mfma = on; return FDN_OK; }
 
@@ -624,6 +627,18 @@ int fdn_conv_cout1_dgrad_folded_launch(const float* dz, const float* w, const T*
                                        float* dbias_prev, void* workspace, size_t workspace_bytes, int N, int D, int H, int W,
                                        int lddz, int dz_coff, hipStream_t s) {
     FDN_REQUIRE(dz && w && dz_prev && N > 0 && D > 0 && H > 0 && W > 0, "fdn_conv_cout1_dgrad_folded: bad argument");
+    if (fdn_heads_use_mfma) {
+        const int nb = fdn_head_dgrad_blocks(N, D, H, W);
+        if (dbias_prev && (!workspace || workspace_bytes < (size_t)nb * 64 * sizeof(float))) {
+            fdn_set_error("fdn_conv_cout1_dgrad_folded: workspace %zu < %zu bytes", workspace_bytes, (size_t)nb * 64 * sizeof(float));
+            return FDN_ERR_WORKSPACE;
+        }
+        const int rc = fdn_head_dgrad_launch<T>(dz, w, y_prev, act, alpha, dz_prev, dbias_prev ? (float*)workspace : nullptr, N, D,
+                                                H, W, lddz, dz_coff, s);
+        if (rc != FDN_OK) return rc;
+        if (dbias_prev) return reduce_partials((const float*)workspace, dbias_prev, nb, 64, s);
+        return FDN_OK;
+    }
     FDN_REQUIRE(W <= 4096, "fdn_conv_cout1_dgrad_folded: W too large for the row stage");
     const int nrows = N * D * H;
     const int nb = nrows < 2048 ? nrows : 2048;
