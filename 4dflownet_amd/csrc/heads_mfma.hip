@@ -33,7 +33,7 @@ template <typename T>
 __global__ __launch_bounds__(256, 2) void head_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ y, int N, int D,
                                                           int H, int W, int ntd, int nth, int ntw, int iters, int ldy, int y_coff,
-                                                          int act, float alpha, int dbg) {
+                                                          int act, float alpha) {
     extern __shared__ __attribute__((aligned(16))) float zbuf[];      // [27][H_HVP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, kh = lane >> 5;
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void head_fwd_kernel(const T* __restrict__ 
     // C[voxel row][tap li] -> zbuf[tap][row]; rows of the dummy slot land in the padding
     float* zw0 = zbuf + li * H_HVP + wave * 32 + 4 * kh;
     auto z_store = [&](const f32x16& acc, int k) {
-        if (li < 27 && !(dbg & 1)) {
+        if (li < 27) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) zw0[k * 128 + (r & 3) + 8 * (r >> 2)] = acc[r];
         }
@@ -121,16 +121,14 @@ __global__ __launch_bounds__(256, 2) void head_fwd_kernel(const T* __restrict__ 
         const int od = tid >> 6, oh = (tid >> 3) & 7, ow = tid & 7;
         const int pd = o.d + od, ph = o.h + oh, pw = o.w + ow;
         float s = b0;
-        if (!(dbg & 2)) {
 #pragma unroll
-            for (int a = 0; a < 3; ++a)
+        for (int a = 0; a < 3; ++a)
 #pragma unroll
-                for (int bb = 0; bb < 3; ++bb)
+            for (int bb = 0; bb < 3; ++bb)
 #pragma unroll
-                    for (int c = 0; c < 3; ++c)
-                        s += zbuf[((a * 3 + bb) * 3 + c) * H_HVP + ((od + a) * H_XH + oh + bb) * H_XW + ow + c];
-        }
-        if (valid && pd < D && ph < H && pw < W && !(dbg & 4))
+                for (int c = 0; c < 3; ++c)
+                    s += zbuf[((a * 3 + bb) * 3 + c) * H_HVP + ((od + a) * H_XH + oh + bb) * H_XW + ow + c];
+        if (valid && pd < D && ph < H && pw < W)
             y[((size_t)o.n * D * H * W + ((size_t)pd * H + ph) * W + pw) * ldy + y_coff] = fdn_act(s, act, alpha);
         __syncthreads();               // zbuf is rewritten by the next tile
     };
@@ -171,7 +169,7 @@ int fdn_head_fwd_launch(const T* x, const float* w, const float* bias, float* y,
     const size_t lds = (size_t)27 * H_HVP * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)head_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)head_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { fdn_set_error("head_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return FDN_ERR_HIP; }
         attr_set = true;
     }
@@ -179,10 +177,8 @@ int fdn_head_fwd_launch(const T* x, const float* w, const float* bias, float* y,
     const int ntiles = N * ntd * nth * ntw;
     const int iters = 3 * ((ntiles + 3 * 512 - 1) / (3 * 512));
     const int grid = (ntiles + iters - 1) / iters;
-    const char* e = getenv("FDN_HEAD_DBG");
-    const int dbg = e ? atoi(e) : 0;
-    hipLaunchKernelGGL(head_fwd_kernel<T>, dim3((unsigned)grid), dim3(256), (dbg & 8) ? (size_t)100 * 1024 : lds, s, x, w, bias, y, N, D, H, W, ntd, nth, ntw,
-                       iters, ldy, y_coff, act, alpha, dbg);
+    hipLaunchKernelGGL(head_fwd_kernel<T>, dim3((unsigned)grid), dim3(256), lds, s, x, w, bias, y, N, D, H, W, ntd, nth, ntw, iters,
+                       ldy, y_coff, act, alpha);
     FDN_CHECK_LAUNCH("head_fwd_kernel");
     return FDN_OK;
 }
@@ -380,3 +376,197 @@ int fdn_head_dgrad_launch(const float* dz, const float* w, const T* y_prev, int 
 }
 template int fdn_head_dgrad_launch<float>(const float*, const float*, const float*, int, float, float*, float*, int, int, int, int, int, int, hipStream_t);
 template int fdn_head_dgrad_launch<uint16_t>(const float*, const float*, const uint16_t*, int, float, uint16_t*, float*, int, int, int, int, int, int, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight gradient of a head:  dW[t][c] = sum_i A[i][t] x[i][c]  with the same folded scalar stencil A as the input gradient
+// (MirrorPadGrad moved from the 64-channel rows onto the scalars).  C[tap][channel] accumulates in registers over all the
+// voxels of a persistent workgroup: per chunk of 32 voxels a wave computes A (lane = voxel) and transposes it through a
+// private LDS patch, stages the 32 x rows (coalesced 16-B loads, fp32 in LDS) and issues 16 K-steps x 2 channel tiles of
+// v_mfma_f32_32x32x2_f32.  Partials [grid][27*64] are summed by reduce_partials_kernel.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void head_wgrad_kernel(const T* __restrict__ x, const float* __restrict__ dz,
+                                                            float* __restrict__ partial, int N, int D, int H, int W, int ntd,
+                                                            int nth, int ntw, int lddz, int dz_coff) {
+    __shared__ float zs[2][H_HV + 8];
+    __shared__ __attribute__((aligned(16))) float xs[4][32 * 64];      // per wave: 32 voxels x 64 channels
+    __shared__ float as[4][32 * 33];                                   // per wave: A^T [tap][voxel], stride 33
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    const int tiles_per_n = ntd * nth * ntw, ntiles = N * tiles_per_n;
+    constexpr int E = 16 / (int)sizeof(T);          // elements per 16-B chunk
+    constexpr int CPR = 64 / E;                     // chunks per voxel row (16 fp32 / 8 bf16)
+    constexpr int NLD = 32 * CPR / 64;              // 16-B loads per lane and chunk of 32 voxels (8 / 4)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    struct TileOrg { int n, d, h, w; };
+    auto decode = [&](int tile) {
+        int b = min(tile, ntiles - 1);
+        TileOrg o;
+        o.n = b / tiles_per_n;
+        b -= o.n * tiles_per_n;
+        const int tdi = b / (nth * ntw);
+        b -= tdi * (nth * ntw);
+        const int thi = b / ntw;
+        o.d = tdi * H_TD; o.h = thi * H_TH; o.w = (b - thi * ntw) * H_TW;
+        return o;
+    };
+    auto stage = [&](const TileOrg& o, float* dst) {
+        for (int i = tid; i < H_HV; i += 256) {
+            const int zd = i / (H_XH * H_XW);
+            const int r2 = i - zd * (H_XH * H_XW);
+            const int zh = r2 / H_XW;
+            const int qd = o.d + zd - 1, qh = o.h + zh - 1, qw = o.w + (r2 - zh * H_XW) - 1;
+            float v = 0.f;
+            if ((unsigned)qd < (unsigned)D && (unsigned)qh < (unsigned)H && (unsigned)qw < (unsigned)W)
+                v = dz[((size_t)o.n * D * H * W + ((size_t)qd * H + qh) * W + qw) * lddz + dz_coff];
+            dst[i] = v;
+        }
+    };
+    // x rows of chunk mt of tile o: lane loads 16-B piece (lane % CPR) of rows lane / CPR + (64 / CPR) u
+    auto load_x = [&](const TileOrg& o, int mt, u32x4 (&v)[NLD]) {
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int row = lane / CPR + (64 / CPR) * u;
+            const int gd = min(o.d + (mt >> 1), D - 1), gh = min(o.h + 4 * (mt & 1) + (row >> 3), H - 1), gw = min(o.w + (row & 7), W - 1);
+            v[u] = *(const u32x4*)(x + ((size_t)o.n * D * H * W + ((size_t)gd * H + gh) * W + gw) * 64 + (lane % CPR) * E);
+        }
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    float* xw = xs[wave];
+    float* aw = as[wave];
+
+    TileOrg o = decode(blockIdx.x);
+    stage(o, zs[0]);
+    u32x4 xv[NLD];
+    if ((int)blockIdx.x < ntiles) load_x(o, wave * 2, xv);
+    int par = 0;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, par ^= 1) {
+        __syncthreads();
+        const bool has_next = tile + (int)gridDim.x < ntiles;
+        const TileOrg on = decode(tile + gridDim.x);
+        if (has_next) stage(on, zs[par ^ 1]);
+        const float* z = zs[par];
+#pragma unroll 1
+        for (int q = 0; q < 2; ++q) {
+            const int mt = wave * 2 + q;
+            // ---- x rows -> LDS (fp32), next chunk's loads in flight ----
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                const int row = lane / CPR + (64 / CPR) * u;
+                float* dst = xw + row * 64 + (lane % CPR) * E;
+                if constexpr (E == 4) {
+                    *(f32x4*)dst = __builtin_bit_cast(f32x4, xv[u]);
+                } else {
+                    f32x4 lo, hi;
+                    lo.x = __builtin_bit_cast(float, xv[u].x << 16); lo.y = __builtin_bit_cast(float, xv[u].x & 0xffff0000u);
+                    lo.z = __builtin_bit_cast(float, xv[u].y << 16); lo.w = __builtin_bit_cast(float, xv[u].y & 0xffff0000u);
+                    hi.x = __builtin_bit_cast(float, xv[u].z << 16); hi.y = __builtin_bit_cast(float, xv[u].z & 0xffff0000u);
+                    hi.z = __builtin_bit_cast(float, xv[u].w << 16); hi.w = __builtin_bit_cast(float, xv[u].w & 0xffff0000u);
+                    *(f32x4*)dst = lo; *(f32x4*)(dst + 4) = hi;
+                }
+            }
+            if (q == 0) load_x(o, mt + 1, xv);
+            else if (has_next) load_x(on, wave * 2, xv);
+            // ---- folded taps of this lane's voxel (see head_dgrad_kernel) ----
+            const int vd = mt >> 1, vh = 4 * (mt & 1) + (li >> 3), vw = li & 7;
+            const int gd = o.d + vd, gh = o.h + vh, gw = o.w + vw;
+            float nb[3][3][3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) nb[a][b][c] = z[((vd + a) * H_XH + vh + b) * H_XW + vw + c];
+            const bool wl = gw == 0, wh = gw == W - 1, hl = gh == 0, hh = gh == H - 1, dl = gd == 0, dh = gd == D - 1;
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    const float nm = nb[a][b][0], n0 = nb[a][b][1], np = nb[a][b][2];
+                    nb[a][b][0] = np + (wl ? n0 : 0.f);      // tap 0 <- n[+1] (+ n[0] on the low face)
+                    nb[a][b][2] = nm + (wh ? n0 : 0.f);      // tap 2 <- n[-1] (+ n[0] on the high face)
+                }
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float nm = nb[a][0][c], n0 = nb[a][1][c], np = nb[a][2][c];
+                    nb[a][0][c] = np + (hl ? n0 : 0.f);
+                    nb[a][2][c] = nm + (hh ? n0 : 0.f);
+                }
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float nm = nb[0][b][c], n0 = nb[1][b][c], np = nb[2][b][c];
+                    nb[0][b][c] = np + (dl ? n0 : 0.f);
+                    nb[2][b][c] = nm + (dh ? n0 : 0.f);
+                }
+            const bool inside = gd < D && gh < H && gw < W;
+            // A^T[tap][voxel]: half 0 writes taps 0..13, half 1 taps 14..26 (and zeros rows 27..31 once per chunk)
+#pragma unroll
+            for (int t = 0; t < 14; ++t) {
+                const int tt = t + 14 * kh;
+                const int t0 = t, t1 = t + 14;
+                const float e0 = nb[t0 / 9][(t0 / 3) % 3][t0 % 3];
+                const float e1 = t1 < 27 ? nb[t1 / 9][(t1 / 3) % 3][t1 % 3] : 0.f;
+                aw[tt * 33 + li] = inside ? (kh ? e1 : e0) : 0.f;
+            }
+            if (kh == 0) {
+#pragma unroll
+                for (int t = 28; t < 32; ++t) aw[t * 33 + li] = 0.f;
+            }
+            // wave-private LDS: make the writes visible to the other lanes of the wave
+            __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
+            __builtin_amdgcn_wave_barrier();
+            // ---- 16 K-steps of 2 voxels ----
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const float av = aw[li * 33 + 2 * s + kh];
+                const float b0 = xw[(2 * s + kh) * 64 + li], b1 = xw[(2 * s + kh) * 64 + 32 + li];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[1], 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();         // all reads done before the next chunk overwrites the patches
+        }
+        o = on;
+    }
+    // C[tap][channel]: lane (channel li of tile m, half kh) holds taps (r&3) + 8 (r>>2) + 4 kh; fold the 4 waves through LDS
+    __syncthreads();
+    float* red = &xs[0][0];                 // 4 x 27*64 floats fit in the x patches (4 x 2048)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int t = (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (t < 27) red[wave * 2048 + t * 64 + 32 * m + li] = acc[m][r];
+        }
+    __syncthreads();
+    for (int i = tid; i < 27 * 64; i += 256)
+        partial[(size_t)blockIdx.x * (27 * 64) + i] = (red[i] + red[2048 + i]) + (red[4096 + i] + red[6144 + i]);
+}
+
+}  // namespace
+
+int fdn_head_wgrad_blocks(int N, int D, int H, int W) {
+    const long long ntiles = (long long)N * ((D + H_TD - 1) / H_TD) * ((H + H_TH - 1) / H_TH) * ((W + H_TW - 1) / H_TW);
+    return (int)(ntiles < 512 ? ntiles : 512);
+}
+
+template <typename T>
+int fdn_head_wgrad_launch(const T* x, const float* dz, float* partial, int N, int D, int H, int W, int lddz, int dz_coff,
+                          hipStream_t s) {
+    const int ntd = (D + H_TD - 1) / H_TD, nth = (H + H_TH - 1) / H_TH, ntw = (W + H_TW - 1) / H_TW;
+    hipLaunchKernelGGL(head_wgrad_kernel<T>, dim3((unsigned)fdn_head_wgrad_blocks(N, D, H, W)), dim3(256), 0, s, x, dz, partial, N, D,
+                       H, W, ntd, nth, ntw, lddz, dz_coff);
+    FDN_CHECK_LAUNCH("head_wgrad_kernel");
+    return FDN_OK;
+}
+template int fdn_head_wgrad_launch<float>(const float*, const float*, float*, int, int, int, int, int, int, hipStream_t);
+template int fdn_head_wgrad_launch<uint16_t>(const uint16_t*, const float*, float*, int, int, int, int, int, int, hipStream_t);

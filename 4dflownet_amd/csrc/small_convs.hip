@@ -561,6 +561,9 @@ template <typename T> int fdn_head_fwd_launch(const T* x, const float* w, const 
 template <typename T> int fdn_head_dgrad_launch(const float* dz, const float* w, const T* y_prev, int act, float alpha, T* dz_prev,
                                                 float* bpart, int N, int D, int H, int W, int lddz, int dz_coff, hipStream_t s);
 int fdn_head_dgrad_blocks(int N, int D, int H, int W);
+template <typename T> int fdn_head_wgrad_launch(const T* x, const float* dz, float* partial, int N, int D, int H, int W, int lddz,
+                                                int dz_coff, hipStream_t s);
+int fdn_head_wgrad_blocks(int N, int D, int H, int W);
 static int fdn_heads_use_mfma = 1;
 extern "C" int fdn_debug_set_heads_mfma(int on) { fdn_heads_use_mfma = on; return FDN_OK; }
 
@@ -614,6 +617,12 @@ int fdn_wgrad_cin3_launch(const T* x, const T* dz, float* dw, void* ws, size_t, 
 template <typename T>
 int fdn_wgrad_cout1_launch(const T* x, const float* dz, float* dw, void* ws, size_t, int N, int D, int H, int W, int lddz,
                            int dz_coff, hipStream_t s) {
+    if (fdn_heads_use_mfma) {
+        const int nbm = fdn_head_wgrad_blocks(N, D, H, W);          // <= kSmallBlocks partial rows of 27*64
+        const int rc = fdn_head_wgrad_launch<T>(x, dz, (float*)ws, N, D, H, W, lddz, dz_coff, s);
+        if (rc != FDN_OK) return rc;
+        return reduce_partials((const float*)ws, dw, nbm, 27 * 64, s);
+    }
     const int nrows = N * (D + 2) * (H + 2);
     const int nb = nrows < kSmallBlocks ? nrows : kSmallBlocks;
     const size_t lds = (size_t)(((9 * (W + 4) + 3) & ~3) + 4 * 27 * 64) * sizeof(float);
