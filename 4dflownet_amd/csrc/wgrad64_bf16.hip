@@ -59,8 +59,17 @@ __global__ __launch_bounds__(256, 2) void wgrad64_bf16_kernel(Wgrad64BfArgs p) {
     const int li = lane & 31;
     const int kh = lane >> 5;
     const int mq = wave & 1, nq = wave >> 1;
-    const int a = blockIdx.y;        // kernel-depth tap
-    const int split = blockIdx.x;
+    // 1-D grid of 3 S workgroups (S % 8 == 0).  Workgroup ids are dealt round-robin to the 8 XCDs: the three depth-tap
+    // workgroups of one tile walk are consecutive ids of the SAME XCD (they read the same x / dz tiles at about the same
+    // time -> two of the three reads hit that XCD's L2), and an XCD's S/8 walks cover one contiguous eighth of the tile list
+    // (neighbouring tiles share halo rows).
+    const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3;
+    const int a = rr % 3;            // kernel-depth tap
+    const int kk = rr / 3;           // walk index inside the XCD, 0 .. S/8 - 1
+    const int split = kk * 8 + xcd;
+    const int spx = p.S >> 3;        // walks per XCD
+    const int tq = p.ntiles >> 3, trem = p.ntiles & 7;
+    const int t_begin = xcd * tq + (xcd < trem ? xcd : trem), t_end = t_begin + tq + (xcd < trem ? 1 : 0);
 
     f32x16 acc[9];
 #pragma unroll
@@ -128,8 +137,8 @@ __global__ __launch_bounds__(256, 2) void wgrad64_bf16_kernel(Wgrad64BfArgs p) {
             if (!ok) zv[u] = (u32x4){0u, 0u, 0u, 0u};
         }
     };
-    if (split < p.ntiles) prefetch(split);
-    for (int tile = split; tile < p.ntiles; tile += p.S) {
+    if (t_begin + kk < t_end) prefetch(t_begin + kk);
+    for (int tile = t_begin + kk; tile < t_end; tile += spx) {
         __syncthreads();   // previous tile fully consumed
 #pragma unroll
         for (int u = 0; u < XP; ++u) {
@@ -142,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void wgrad64_bf16_kernel(Wgrad64BfArgs p) {
             *(u32x4*)(zs + r * 128 + ((c16 ^ (((r >> 1) & 1) << 2)) << 4)) = zv[u];
         }
         __syncthreads();
-        if (tile + p.S < p.ntiles) prefetch(tile + p.S);
+        if (tile + spx < t_end) prefetch(tile + spx);
 
         // ---- 8 k-steps of 16 voxels: (d, h-pair) ----
 #pragma unroll
@@ -184,8 +193,8 @@ __global__ __launch_bounds__(256, 2) void wgrad64_bf16_kernel(Wgrad64BfArgs p) {
 namespace {
 int wgrad64bf_splits(int N, int D, int H, int W) {
     const long long ntiles = (long long)N * ((D + TD - 1) / TD) * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
-    long long S = 170;                 // 3*170 = 510 workgroups ~ 2 per CU
-    if (ntiles / 2 < S) S = ntiles / 2 > 0 ? ntiles / 2 : 1;
+    long long S = 168;                 // 3*168 = 504 workgroups ~ 2 per CU; a multiple of 8 (one walk set per XCD)
+    while (S > 8 && ntiles / 2 < S) S -= 8;
     return (int)S;
 }
 }  // namespace
@@ -206,7 +215,7 @@ int fdn_wgrad64_bf16_launch(const uint16_t* x, const uint16_t* dz, float* dw, vo
         fdn_set_error("wgrad64_bf16: workspace too small");
         return FDN_ERR_WORKSPACE;
     }
-    hipLaunchKernelGGL(wgrad64_bf16_kernel, dim3(a.S, 3), dim3(256), LDS_BYTES, s, a);
+    hipLaunchKernelGGL(wgrad64_bf16_kernel, dim3(3 * a.S), dim3(256), LDS_BYTES, s, a);
     FDN_CHECK_LAUNCH("wgrad64_bf16_kernel");
     hipLaunchKernelGGL(wgrad64_reduce_kernel, dim3((27 * 1024 + 255) / 256), dim3(256), 0, s, (const float*)ws, dw, a.S);
     FDN_CHECK_LAUNCH("wgrad64_reduce_kernel");
