@@ -153,29 +153,39 @@ __global__ __launch_bounds__(256, 2) void wgrad64_bf16_kernel(Wgrad64BfArgs p) {
         __syncthreads();
         if (tile + spx < t_end) prefetch(tile + spx);
 
-        // ---- 8 k-steps of 16 voxels: (d, h-pair) ----
-#pragma unroll
-        for (int kd = 0; kd < TD; ++kd) {
-#pragma unroll
-            for (int hp = 0; hp < TH / 2; ++hp) {
-                const int dX = (kd * XH * XW + hp * 2 * XW) * 128;
+        // ---- 8 k-steps of 16 voxels: (d, h-pair), each 3 groups (b) of 3 MFMAs.  The transposing reads of group q + 1 are
+        // issued before the MFMAs of group q (LDS latency is ~3 MFMA slots; hipcc on its own issues them right before use)
+        u32x2 gq[2][3], zq[2][2];
+        auto issue = [&](int q, u32x2 (&g)[3], u32x2 (&z)[2]) {       // q = (kd * 4 + hp) * 3 + b
+            const int ks = q / 3, b = q % 3, kd = ks / (TH / 2), hp = ks % (TH / 2);
+            const int dX = (kd * XH * XW + hp * 2 * XW) * 128;
+            g[0] = tr_read(xs + xoff[b][0] + dX); g[1] = tr_read(xs + xoff[b][1] + dX); g[2] = tr_read(xs + xoff[b][2] + dX);
+            if (b == 0) {
                 const int dZ = (kd * TH * TW + hp * 2 * TW) * 128;
-                const u32x2 z0 = tr_read(zs + zoff[0] + dZ), z1 = tr_read(zs + zoff[1] + dZ);
-                const bf16x8 bv = __builtin_bit_cast(bf16x8, (u32x4){z0.x, z0.y, z1.x, z1.y});
-#pragma unroll
-                for (int b = 0; b < 3; ++b) {
-                    const u32x2 g0 = tr_read(xs + xoff[b][0] + dX), g1 = tr_read(xs + xoff[b][1] + dX),
-                                g2 = tr_read(xs + xoff[b][2] + dX);
-                    const bf16x8 a0 = __builtin_bit_cast(bf16x8, (u32x4){g0.x, g0.y, g1.x, g1.y});
-                    const bf16x8 a1 = __builtin_bit_cast(
-                        bf16x8, (u32x4){__builtin_amdgcn_alignbit(g0.y, g0.x, 16), __builtin_amdgcn_alignbit(g1.x, g0.y, 16),
-                                        __builtin_amdgcn_alignbit(g1.y, g1.x, 16), __builtin_amdgcn_alignbit(g2.x, g1.y, 16)});
-                    const bf16x8 a2 = __builtin_bit_cast(bf16x8, (u32x4){g0.y, g1.x, g1.y, g2.x});
-                    acc[b * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bv, acc[b * 3 + 0], 0, 0, 0);
-                    acc[b * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bv, acc[b * 3 + 1], 0, 0, 0);
-                    acc[b * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bv, acc[b * 3 + 2], 0, 0, 0);
-                }
+                z[0] = tr_read(zs + zoff[0] + dZ); z[1] = tr_read(zs + zoff[1] + dZ);
             }
+        };
+        issue(0, gq[0], zq[0]);
+        bf16x8 bv;
+#pragma unroll
+        for (int q = 0; q < TD * (TH / 2) * 3; ++q) {
+            const int b = q % 3;
+            if (q + 1 < TD * (TH / 2) * 3) issue(q + 1, gq[(q + 1) & 1], zq[((q + 1) / 3) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const u32x2 g0 = gq[q & 1][0], g1 = gq[q & 1][1], g2 = gq[q & 1][2];
+            if (b == 0) {
+                const u32x2 z0 = zq[(q / 3) & 1][0], z1 = zq[(q / 3) & 1][1];
+                bv = __builtin_bit_cast(bf16x8, (u32x4){z0.x, z0.y, z1.x, z1.y});
+            }
+            const bf16x8 a0 = __builtin_bit_cast(bf16x8, (u32x4){g0.x, g0.y, g1.x, g1.y});
+            const bf16x8 a1 = __builtin_bit_cast(
+                bf16x8, (u32x4){__builtin_amdgcn_alignbit(g0.y, g0.x, 16), __builtin_amdgcn_alignbit(g1.x, g0.y, 16),
+                                __builtin_amdgcn_alignbit(g1.y, g1.x, 16), __builtin_amdgcn_alignbit(g2.x, g1.y, 16)});
+            const bf16x8 a2 = __builtin_bit_cast(bf16x8, (u32x4){g0.y, g1.x, g1.y, g2.x});
+            acc[b * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bv, acc[b * 3 + 0], 0, 0, 0);
+            acc[b * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bv, acc[b * 3 + 1], 0, 0, 0);
+            acc[b * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bv, acc[b * 3 + 2], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
