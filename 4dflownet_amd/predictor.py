@@ -15,11 +15,11 @@ from .network import Input, SR4DFlowNet
 from .tiler import PatchGenerator
 
 
-def prepare_network(patch_size, res_increase, low_resblock, hi_resblock, device=None):
-    """predictor.py:11-29."""
+def prepare_network(patch_size, res_increase, low_resblock, hi_resblock, device=None, dtype="float32"):
+    """predictor.py:11-29.  dtype="bfloat16" runs the forward with bf16 activation storage (fp32 weights / prediction)."""
     shape = (patch_size, patch_size, patch_size, 1)
     ins = [Input(shape, n) for n in ('u', 'v', 'w', 'u_mag', 'v_mag', 'w_mag')]
-    return SR4DFlowNet(res_increase).build_network(*ins, low_resblock, hi_resblock, device=device)
+    return SR4DFlowNet(res_increase).build_network(*ins, low_resblock, hi_resblock, device=device, dtype=dtype)
 
 
 def save_to_h5(output_filepath, col_name, dataset, compression=None):
@@ -83,10 +83,10 @@ def predict_file(network, input_filepath, output_filepath, patch_size, res_incre
 
 def main(data_dir='../data', filename='example_data.h5', output_dir="../result", output_filename='example_result.h5',
          model_path="../models/4DFlowNet/4DFlowNet.h5", patch_size=24, res_increase=2, batch_size=8,
-         round_small_values=True, low_resblock=8, hi_resblock=4):
-    """Same hard-coded surface as predictor.py:31-47."""
+         round_small_values=True, low_resblock=8, hi_resblock=4, dtype="float32"):
+    """Same hard-coded surface as predictor.py:31-47 (+ dtype)."""
     parallel.init_from_env()
-    network = prepare_network(patch_size, res_increase, low_resblock, hi_resblock)
+    network = prepare_network(patch_size, res_increase, low_resblock, hi_resblock, dtype=dtype)
     network.load_weights(model_path)
     if not os.path.isdir(output_dir) and parallel.rank() == 0:
         os.makedirs(output_dir)

@@ -121,3 +121,17 @@ def test_cfg4_size_batch_additivity(fdn):
     assert torch.allclose(l01, torch.cat([l0, l1]), rtol=1e-5, atol=0)
     err = (g01 - (g0 + g1)).norm() / g01.norm()
     assert err < 1e-4, err.item()
+
+
+def test_bf16_predict_close_to_fp32(fdn):
+    """Inference surface (Model.predict, predictor.prepare_network(dtype=...)): bf16 storage stays within the quantisation
+    distance of the fp32 network on the same weights."""
+    predictor = importlib.import_module("4dflownet_amd.predictor")
+    nf = predictor.prepare_network(8, 2, 2, 1, dtype="float32")
+    nb = predictor.prepare_network(8, 2, 2, 1, dtype="bfloat16")
+    nb.set_weights(nf.get_weights())
+    batch = O.synthetic_batch(3, 8, 2, seed=61)
+    pf = nf.predict(list(batch[:6]), batch_size=2)
+    pb = nb.predict(list(batch[:6]), batch_size=2)
+    assert pb.dtype == np.float32 and pb.shape == pf.shape == (3, 16, 16, 16, 3)
+    assert l2_rel(pb, pf) < 3e-2

@@ -24,7 +24,8 @@ class _Vol:
 def main():
     rank, world, local = parallel.init_from_env()
     torch.cuda.set_device(local)
-    net = predictor.prepare_network(24, 2, 8, 4)
+    dtype = "bfloat16" if "--bf16" in sys.argv else "float32"
+    net = predictor.prepare_network(24, 2, 8, 4, dtype=dtype)
     cases = []
     ds = data.ImageDataset()
     ds.load_vectorfield(os.path.join(ROOT, "tests", "golden", "data", "example_data.h5"), 0)
@@ -49,8 +50,8 @@ def main():
         out = pg.unpatchify(res)
         ts = time.perf_counter() - t1
         if rank == 0:
-            print("%-28s %4d patches on %d GPU(s): forward+gather %.3f s = %.1f patches/s; stitch %.3f s -> %s"
-                  % (name, len(res), world, dt, len(res) / dt, ts, out[0].shape))
+            print("%-28s %4d patches on %d GPU(s), %s: forward+gather %.3f s = %.1f patches/s; stitch %.3f s -> %s"
+                  % (name, len(res), world, dtype, dt, len(res) / dt, ts, out[0].shape))
 
 
 if __name__ == "__main__":
