@@ -77,33 +77,48 @@ __device__ __forceinline__ void lerp_coeff(int o, float scale, int n, int& lo, i
     f = src - fl;
 }
 
+// block = one output row (n, od, oh): the d / h interpolation coefficients are block-uniform; thread = one 16-B vector
+// (4 fp32 / 8 bf16 channels) of one output voxel, consecutive threads write consecutive vectors (32-bit index math only)
 template <typename T>
 __global__ __launch_bounds__(256) void upsample_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int D,
-                                                            int H, int W, int C4, int R, float sd, float sh, float sw) {
+                                                            int H, int W, int CV, int R, float sd, float sh, float sw) {
+    constexpr int E = FdnVec<T>::E;
     const int OD = D * R, OH = H * R, OW = W * R;
-    const int64_t total = (int64_t)N * OD * OH * OW * C4;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % C4);
-        int64_t v = i / C4;
-        const int ow = (int)(v % OW); v /= OW;
-        const int oh = (int)(v % OH); v /= OH;
-        const int od = (int)(v % OD);
-        const int n = (int)(v / OD);
-        int d0, d1, h0, h1, w0, w1;
-        float fd, fh, fw;
+    for (int row = blockIdx.x; row < N * OD * OH; row += gridDim.x) {
+        const int oh = row % OH;
+        const int t = row / OH;
+        const int od = t % OD, n = t / OD;
+        int d0, d1, h0, h1;
+        float fd, fh;
         lerp_coeff(od, sd, D, d0, d1, fd);
         lerp_coeff(oh, sh, H, h0, h1, fh);
-        lerp_coeff(ow, sw, W, w0, w1, fw);
-        const T* xb = x + ((int64_t)n * D * H * W * C4 + c4) * 4;
-#define XAT(dd, hh, ww) fdn_ld4(xb + (((int64_t)(dd)*H + (hh)) * W + (ww)) * C4 * 4)
-        // innermost (z) first, then y, then x -- the order of the reference's two resize passes
-        const f32x4 a00 = XAT(d0, h0, w0), a01 = XAT(d0, h0, w1), a10 = XAT(d0, h1, w0), a11 = XAT(d0, h1, w1);
-        const f32x4 b00 = XAT(d1, h0, w0), b01 = XAT(d1, h0, w1), b10 = XAT(d1, h1, w0), b11 = XAT(d1, h1, w1);
-#undef XAT
-        const f32x4 a0 = a00 + (a01 - a00) * fw, a1 = a10 + (a11 - a10) * fw;
-        const f32x4 b0 = b00 + (b01 - b00) * fw, b1 = b10 + (b11 - b10) * fw;
-        const f32x4 a = a0 + (a1 - a0) * fh, b = b0 + (b1 - b0) * fh;
-        fdn_st4(y + i * 4, a + (b - a) * fd);
+        const T* r00 = x + (((int64_t)n * D + d0) * H + h0) * W * CV * E;
+        const T* r01 = x + (((int64_t)n * D + d0) * H + h1) * W * CV * E;
+        const T* r10 = x + (((int64_t)n * D + d1) * H + h0) * W * CV * E;
+        const T* r11 = x + (((int64_t)n * D + d1) * H + h1) * W * CV * E;
+        T* yr = y + (int64_t)row * OW * CV * E;
+        for (int i = threadIdx.x; i < OW * CV; i += blockDim.x) {
+            const int ow = i / CV, cv = i - ow * CV;
+            int w0, w1;
+            float fw;
+            lerp_coeff(ow, sw, W, w0, w1, fw);
+            const int o0 = (w0 * CV + cv) * E, o1 = (w1 * CV + cv) * E;
+            float c000[E], c001[E], c010[E], c011[E], c100[E], c101[E], c110[E], c111[E];
+            FdnVec<T>::ld(r00 + o0, c000); FdnVec<T>::ld(r00 + o1, c001);
+            FdnVec<T>::ld(r01 + o0, c010); FdnVec<T>::ld(r01 + o1, c011);
+            FdnVec<T>::ld(r10 + o0, c100); FdnVec<T>::ld(r10 + o1, c101);
+            FdnVec<T>::ld(r11 + o0, c110); FdnVec<T>::ld(r11 + o1, c111);
+            // innermost (z) first, then y, then x -- the order of the reference's two resize passes
+            float o[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const float a0 = c000[e] + (c001[e] - c000[e]) * fw, a1 = c010[e] + (c011[e] - c010[e]) * fw;
+                const float b0 = c100[e] + (c101[e] - c100[e]) * fw, b1 = c110[e] + (c111[e] - c110[e]) * fw;
+                const float aa = a0 + (a1 - a0) * fh, bb = b0 + (b1 - b0) * fh;
+                o[e] = aa + (bb - aa) * fd;
+            }
+            FdnVec<T>::st(yr + (int64_t)i * E, o);
+        }
     }
 }
 
@@ -124,52 +139,76 @@ __device__ __forceinline__ void axis_range(int i, float inv_scale, int m, int& o
     o1 = min(m - 1, (int)ceilf((float)(i + 1) * inv_scale) + 1);
 }
 
+// Adjoint of the trilinear upsample, block = one LOW-res row (n, d, h).  Phase A folds the (<= 2R+1)^2 high-res rows that
+// touch it (block-uniform weights wd * wh) into one high-res-wide row in LDS (coalesced 16-B reads of dy, every dy row is
+// read by the <= 4 low-res rows it touches -- L2 hits); phase B folds that row along w, applies act'(y_prev), stores.
 template <typename T>
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ yprev,
                                                             int act, float alpha, T* __restrict__ dx, int N, int D,
-                                                            int H, int W, int C4, int R, float sd, float sh, float sw) {
+                                                            int H, int W, int CV, int R, float sd, float sh, float sw) {
+    constexpr int E = FdnVec<T>::E;
+    extern __shared__ __attribute__((aligned(16))) float rowbuf[];      // [OW][CV * E]
     const int OD = D * R, OH = H * R, OW = W * R;
-    const int64_t total = (int64_t)N * D * H * W * C4;
+    const int C = CV * E;
     const float isd = sd > 0.f ? 1.f / sd : 0.f, ish = sh > 0.f ? 1.f / sh : 0.f, isw = sw > 0.f ? 1.f / sw : 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % C4);
-        int64_t v = i / C4;
-        const int w = (int)(v % W); v /= W;
-        const int h = (int)(v % H); v /= H;
-        const int d = (int)(v % D);
-        const int n = (int)(v / D);
-        int od0, od1, oh0, oh1, ow0, ow1;
+    for (int row = blockIdx.x; row < N * D * H; row += gridDim.x) {
+        const int h = row % H;
+        const int t = row / H;
+        const int d = t % D, n = t / D;
+        int od0, od1, oh0, oh1;
         axis_range(d, isd, OD, od0, od1);
         axis_range(h, ish, OH, oh0, oh1);
-        axis_range(w, isw, OW, ow0, ow1);
         if (sd == 0.f) { od0 = 0; od1 = OD - 1; }
         if (sh == 0.f) { oh0 = 0; oh1 = OH - 1; }
-        if (sw == 0.f) { ow0 = 0; ow1 = OW - 1; }
-        const T* gb = dy + ((int64_t)n * OD * OH * OW * C4 + c4) * 4;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int od = od0; od <= od1; ++od) {
-            const float wd = axis_weight(od, d, sd, D);
-            if (wd == 0.f) continue;
-            f32x4 accd = {0.f, 0.f, 0.f, 0.f};
-            for (int oh = oh0; oh <= oh1; ++oh) {
-                const float wh = axis_weight(oh, h, sh, H);
-                if (wh == 0.f) continue;
-                f32x4 acch = {0.f, 0.f, 0.f, 0.f};
-                for (int ow = ow0; ow <= ow1; ++ow) {
-                    const float ww = axis_weight(ow, w, sw, W);
-                    if (ww == 0.f) continue;
-                    acch += fdn_ld4(gb + (((int64_t)od * OH + oh) * OW + ow) * C4 * 4) * ww;
+        __syncthreads();                                   // rowbuf of the previous row fully consumed
+        for (int i = threadIdx.x; i < OW * CV; i += blockDim.x) {
+            float acc[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc[e] = 0.f;
+            for (int od = od0; od <= od1; ++od) {
+                const float wd = axis_weight(od, d, sd, D);
+                if (wd == 0.f) continue;
+                float accd[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) accd[e] = 0.f;
+                for (int oh = oh0; oh <= oh1; ++oh) {
+                    const float wh = axis_weight(oh, h, sh, H);
+                    if (wh == 0.f) continue;
+                    float g[E];
+                    FdnVec<T>::ld(dy + ((((int64_t)n * OD + od) * OH + oh) * OW * CV + i) * E, g);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) accd[e] += g[e] * wh;
                 }
-                accd += acch * wh;
+#pragma unroll
+                for (int e = 0; e < E; ++e) acc[e] += accd[e] * wd;
             }
-            acc += accd * wd;
+#pragma unroll
+            for (int e = 0; e < E; ++e) rowbuf[i * E + e] = acc[e];
         }
-        if (yprev) {
-            const f32x4 y = fdn_ld4(yprev + i * 4);
-            acc.x *= fdn_act_grad(y.x, act, alpha); acc.y *= fdn_act_grad(y.y, act, alpha);
-            acc.z *= fdn_act_grad(y.z, act, alpha); acc.w *= fdn_act_grad(y.w, act, alpha);
+        __syncthreads();
+        for (int i = threadIdx.x; i < W * CV; i += blockDim.x) {
+            const int w = i / CV, cv = i - w * CV;
+            int ow0, ow1;
+            axis_range(w, isw, OW, ow0, ow1);
+            if (sw == 0.f) { ow0 = 0; ow1 = OW - 1; }
+            float acc[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc[e] = 0.f;
+            for (int ow = ow0; ow <= ow1; ++ow) {
+                const float ww = axis_weight(ow, w, sw, W);
+                if (ww == 0.f) continue;
+#pragma unroll
+                for (int e = 0; e < E; ++e) acc[e] += rowbuf[ow * C + cv * E + e] * ww;
+            }
+            const int64_t o = ((int64_t)row * W * CV + i) * E;
+            if (yprev) {
+                float yv[E];
+                FdnVec<T>::ld(yprev + o, yv);
+#pragma unroll
+                for (int e = 0; e < E; ++e) acc[e] *= fdn_act_grad(yv[e], act, alpha);
+            }
+            FdnVec<T>::st(dx + o, acc);
         }
-        fdn_st4(dx + i * 4, acc);
     }
 }
 
@@ -327,20 +366,33 @@ extern "C" int fdn_fold_halo(const float* dxpad0, const float* dxpad1, const flo
 
 template <typename T>
 static int upsample_fwd_t(const T* x, T* y, int N, int D, int H, int W, int C, int R, void* stream) {
-    FDN_REQUIRE(x && y && C % 4 == 0 && R >= 1 && N > 0 && D > 0 && H > 0 && W > 0, "fdn_upsample_trilinear_fwd: bad argument");
-    const int64_t total = (int64_t)N * D * R * H * R * W * R * (C / 4);
-    hipLaunchKernelGGL(upsample_fwd_kernel<T>, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, x, y, N, D, H,
-                       W, C / 4, R, axis_scale(D, R), axis_scale(H, R), axis_scale(W, R));
+    constexpr int E = 16 / (int)sizeof(T);
+    FDN_REQUIRE(x && y && C % E == 0 && R >= 1 && N > 0 && D > 0 && H > 0 && W > 0, "fdn_upsample_trilinear_fwd: bad argument");
+    const int64_t rows = (int64_t)N * D * R * H * R;
+    FDN_REQUIRE(rows < (1ll << 31), "fdn_upsample_trilinear_fwd: too many rows");
+    hipLaunchKernelGGL(upsample_fwd_kernel<T>, dim3((unsigned)(rows < 262144 ? rows : 262144)), dim3(256), 0, (hipStream_t)stream,
+                       x, y, N, D, H, W, C / E, R, axis_scale(D, R), axis_scale(H, R), axis_scale(W, R));
     FDN_CHECK_LAUNCH("upsample_fwd_kernel");
     return FDN_OK;
 }
 template <typename T>
 static int upsample_bwd_t(const T* dy, const T* y_prev, int act, float alpha, T* dx, int N, int D, int H, int W, int C, int R,
                           void* stream) {
-    FDN_REQUIRE(dy && dx && C % 4 == 0 && R >= 1 && N > 0 && D > 0 && H > 0 && W > 0, "fdn_upsample_trilinear_bwd: bad argument");
-    const int64_t total = (int64_t)N * D * H * W * (C / 4);
-    hipLaunchKernelGGL(upsample_bwd_kernel<T>, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, dy, y_prev, act,
-                       alpha, dx, N, D, H, W, C / 4, R, axis_scale(D, R), axis_scale(H, R), axis_scale(W, R));
+    constexpr int E = 16 / (int)sizeof(T);
+    FDN_REQUIRE(dy && dx && C % E == 0 && R >= 1 && N > 0 && D > 0 && H > 0 && W > 0, "fdn_upsample_trilinear_bwd: bad argument");
+    const int64_t rows = (int64_t)N * D * H;
+    const size_t lds = (size_t)W * R * C * sizeof(float);
+    FDN_REQUIRE(rows < (1ll << 31) && lds <= 160 * 1024, "fdn_upsample_trilinear_bwd: row of %d x %d channels does not fit the LDS stage", W * R, C);
+    if (lds > 48 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)upsample_bwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) { fdn_set_error("upsample_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return FDN_ERR_HIP; }
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL(upsample_bwd_kernel<T>, dim3((unsigned)(rows < 65536 ? rows : 65536)), dim3(256), lds, (hipStream_t)stream, dy,
+                       y_prev, act, alpha, dx, N, D, H, W, C / E, R, axis_scale(D, R), axis_scale(H, R), axis_scale(W, R));
     FDN_CHECK_LAUNCH("upsample_bwd_kernel");
     return FDN_OK;
 }

@@ -38,6 +38,35 @@ __device__ __forceinline__ void fdn_st4(uint16_t* p, f32x4 v) {
     *(fdn_u32x2*)p = __builtin_bit_cast(fdn_u32x2, b);
 }
 
+// one 16-B vector = FdnVec<T>::E consecutive elements (4 fp32 / 8 bf16) as fp32 values
+template <typename T> struct FdnVec;
+template <> struct FdnVec<float> {
+    static constexpr int E = 4;
+    __device__ __forceinline__ static void ld(const float* p, float (&v)[4]) {
+        const f32x4 t = *(const f32x4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    __device__ __forceinline__ static void st(float* p, const float (&v)[4]) { *(f32x4*)p = (f32x4){v[0], v[1], v[2], v[3]}; }
+};
+template <> struct FdnVec<uint16_t> {
+    static constexpr int E = 8;
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    __device__ __forceinline__ static void ld(const uint16_t* p, float (&v)[8]) {
+        const u4 r = *(const u4*)p;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __builtin_bit_cast(float, r[i] << 16);
+            v[2 * i + 1] = __builtin_bit_cast(float, r[i] & 0xffff0000u);
+        }
+    }
+    __device__ __forceinline__ static void st(uint16_t* p, const float (&v)[8]) {
+        typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+        bf8 b;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) b[i] = (__bf16)v[i];
+        *(u4*)p = __builtin_bit_cast(u4, b);
+    }
+};
+
 void fdn_set_error(const char* fmt, ...);
 
 #define FDN_CHECK_LAUNCH(name)                                                         \
