@@ -151,7 +151,13 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__
     const int OD = D * R, OH = H * R, OW = W * R;
     const int C = CV * E;
     const float isd = sd > 0.f ? 1.f / sd : 0.f, ish = sh > 0.f ? 1.f / sh : 0.f, isw = sw > 0.f ? 1.f / sw : 0.f;
-    for (int row = blockIdx.x; row < N * D * H; row += gridDim.x) {
+    // XCD-aware row order: block ids are dealt round-robin to the 8 XCDs; an XCD takes one contiguous run of low-res rows,
+    // so the high-res rows shared by neighbouring low-res rows are fetched into ITS L2 once (plain order: 3.8x dy from HBM)
+    const int nrows = N * D * H;
+    for (int it = blockIdx.x; it < nrows; it += gridDim.x) {
+        const int blk0 = it - (int)blockIdx.x, span = min((int)gridDim.x, nrows - blk0);     // rows of this sweep
+        const int q = span >> 3, rem = span & 7, xc = blockIdx.x & 7;
+        const int row = blk0 + xc * q + (xc < rem ? xc : rem) + ((int)blockIdx.x >> 3);
         const int h = row % H;
         const int t = row / H;
         const int d = t % D, n = t / D;

@@ -325,17 +325,22 @@ __global__ __launch_bounds__(256, 2) void head_dgrad_kernel(const float* __restr
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const size_t e = vox * 64 + 32 * m + 16 * kh;
+                constexpr int EV = FdnVec<T>::E;                 // 16-B vectors: 4 fp32 / 8 bf16 channels per access
 #pragma unroll
-                for (int r4 = 0; r4 < 16; r4 += 4) {
-                    f32x4 v = {acc[m][r4], acc[m][r4 + 1], acc[m][r4 + 2], acc[m][r4 + 3]};
+                for (int r0 = 0; r0 < 16; r0 += EV) {
+                    float v[EV];
+#pragma unroll
+                    for (int q = 0; q < EV; ++q) v[q] = acc[m][r0 + q];
                     if (yprev) {
-                        const f32x4 yv = fdn_ld4(yprev + e + r4);
-                        v.x *= yv.x > 0.f ? 1.f : slope; v.y *= yv.y > 0.f ? 1.f : slope;
-                        v.z *= yv.z > 0.f ? 1.f : slope; v.w *= yv.w > 0.f ? 1.f : slope;
+                        float yv[EV];
+                        FdnVec<T>::ld(yprev + e + r0, yv);
+#pragma unroll
+                        for (int q = 0; q < EV; ++q) v[q] *= yv[q] > 0.f ? 1.f : slope;
                     }
                     if (inside) {
-                        fdn_st4(out + e + r4, v);
-                        bsum[m][r4] += v.x; bsum[m][r4 + 1] += v.y; bsum[m][r4 + 2] += v.z; bsum[m][r4 + 3] += v.w;
+                        FdnVec<T>::st(out + e + r0, v);
+#pragma unroll
+                        for (int q = 0; q < EV; ++q) bsum[m][r0 + q] += v[q];
                     }
                 }
             }

@@ -89,15 +89,16 @@ class ConvTimer:
         return n, total_ms / n, total_flop / n
 
 
-def pmc_traffic_bytes():
-    """HBM bytes per conv64 launch from the committed rocprofv3 PMC passes (profiles/r1_pmc_traffic.json, produced by
-    tools/pmc_traffic.py from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command, read side doubled as
-    MI355X_MICROARCH.md prescribes for gfx950).  Launch-weighted over the conv64 variants; None if the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+def pmc_traffic_bytes(fname="r1_pmc_traffic.json", kernel="conv64_mfma_kernel"):
+    """HBM bytes per conv64 launch from the committed rocprofv3 PMC passes (profiles/r1_pmc_traffic.json for the fp32
+    workload, r1_cfg4_pmc_traffic.json for cfg4; produced by tools/pmc_traffic.py from separate --pmc FETCH_SIZE / --pmc
+    WRITE_SIZE runs of this same command, read side doubled as MI355X_MICROARCH.md prescribes for gfx950).
+    Launch-weighted over the conv64 variants; None if the file is absent."""
+    path = os.path.join(ROOT, "profiles", fname)
     if not os.path.exists(path):
         return None
     d = json.load(open(path))
-    rows = [(v["launches"], v["hbm_bytes_per_launch"]) for k, v in d.items() if "conv64_mfma_kernel" in k]
+    rows = [(v["launches"], v["hbm_bytes_per_launch"]) for k, v in d.items() if kernel in k]
     n = sum(r[0] for r in rows)
     return sum(r[0] * r[1] for r in rows) / n if n else None
 
@@ -204,8 +205,10 @@ def main():
                    "global_batch": B * world, "parallelism": "dp%d" % world},
         "roofline": {"bound": "mfma", "kernel": "%s (3x3x3 64->64 fwd + dgrad launches)" % ("conv64_bf16_kernel" if bf16 else "conv64_mfma_kernel"),
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                     "frac": achieved / peak, "traffic": None if bf16 else pmc_traffic_bytes(),
-                     "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_pmc_traffic.json)",
+                     "frac": achieved / peak,
+                     "traffic": (pmc_traffic_bytes("r1_cfg4_pmc_traffic.json", "conv64_bf16_kernel") if args.config == "cfg4" else None)
+                                if bf16 else pmc_traffic_bytes(),
+                     "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r1%s_pmc_traffic.json)" % ("_cfg4" if bf16 else ""),
                      "algorithmic_bytes_per_launch": avg_flop / FLOP_PER_VOXEL_CONV64 * (256.0 if bf16 else 512.0) + (221184.0 if bf16 else 442368.0),
                      "launches_timed": n_launch, "avg_launch_ms": avg_ms, "avg_launch_gflop": avg_flop / 1e9},
         "train_step_tflops": args.steps * B * world / dt * 3.0 * fwd_flop / 1e12,
