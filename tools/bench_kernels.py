@@ -59,7 +59,7 @@ def main():
                 lib.fdn_debug_set_conv64_shell_slabs(0)
                 rep("conv64 dgrad fused, one padded launch", timeit(lambda: (ops.conv3d_dgrad_fused(dz, wd, pad, dxo, skip=x, y_prev=y, act=ops.ACT_LEAKY), ops.fold_halo_border([pad], dxo, x, y, ops.ACT_LEAKY)), args.iters))
                 lib.fdn_debug_set_conv64_shell_slabs(1)
-            if args.ablate and v in (1, 2):
+            if args.ablate and v in (1, 2, 5):
                 for dbg, name in ((1, "B stride 0"), (4, "no staging loads"), (8, "no epilogue"), (13, "all three")):
                     lib.fdn_debug_set_conv64_dbg(dbg)
                     rep("   ablation %s" % name, timeit(lambda: ops.conv3d_fwd(x, w, None, ops.ACT_RELU, wpack=wf, out=y), args.iters))
