@@ -181,16 +181,24 @@ void conv64_mfma_kernel(Conv64Args p) {
         // stream index of (slice, tap, local k-group gl): half = cin/32, g = k-group within the half
         const int half = (sl * KG) >> 2, g0 = (sl * KG) & 3;
         const f32x4* bp = (const f32x4*)p.wp + ((size_t)half * 27 * 4 + g0) * 128 + kh * 64 + wave_n * (NT * 32) + li;
+        // the weight fragments of tap it + 1 are loaded (into a second register set) before the MFMAs of tap it; the
+        // sched_barriers pin them there -- left alone, hipcc sinks the loads down to their first use
         int ta = ta0, tb = tb0, tc = tc0;
-#pragma unroll 1
-        for (int it = 0; it < ntap; ++it) {
-            const int tap = (ta * 3 + tb) * 3 + tc;
-            f32x4 bv[KG][NT];
+        f32x4 bv[KG][NT], bn[KG][NT];
+        auto load_b = [&](f32x4 (&dst)[KG][NT], int tap) {
 #pragma unroll
             for (int g = 0; g < KG; ++g)
 #pragma unroll
-                for (int nn = 0; nn < NT; ++nn) bv[g][nn] = bp[(tap * 4 + g) * bstride + nn * 32];
+                for (int nn = 0; nn < NT; ++nn) dst[g][nn] = bp[(tap * 4 + g) * bstride + nn * 32];
+        };
+        load_b(bv, (ta * 3 + tb) * 3 + tc);
+#pragma unroll 1
+        for (int it = 0; it < ntap; ++it) {
             const int tapoff = ((ta - ta0) * R.hh + (tb - tb0)) * R.hw + (tc - tc0);
+            if (++tc > tc1) { tc = tc0; if (++tb > tb1) { tb = tb0; ++ta; } }
+            const int tnext = it + 1 < ntap ? (ta * 3 + tb) * 3 + tc : 0;       // harmless reload on the last tap
+            load_b(bn, tnext);
+            __builtin_amdgcn_sched_barrier(0);
             f32x4 av[MT][KG];
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi) {
@@ -209,7 +217,11 @@ void conv64_mfma_kernel(Conv64Args p) {
 #pragma unroll
                         for (int nn = 0; nn < NT; ++nn)
                             acc[mi][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][g][s], bv[g][nn][s], acc[mi][nn], 0, 0, 0);
-            if (++tc > tc1) { tc = tc0; if (++tb > tb1) { tb = tb0; ++ta; } }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < KG; ++g)
+#pragma unroll
+                for (int nn = 0; nn < NT; ++nn) bv[g][nn] = bn[g][nn];
         }
     }
     if (p.dbg & 8) return;
