@@ -49,7 +49,7 @@ def main():
         dxo = torch.empty_like(x)
         flop = 2.0 * 27 * 64 * 64 * N * P ** 3
         rep = lambda name, ms: print("%-34s N=%d P=%d : %8.3f ms  %7.2f TF  %5.1f %% of peak" % (name, N, P, ms, flop / ms * 1e-9, flop / ms * 1e-9 / PEAK * 100))
-        for v in (1, 2, 3, 5, 0):
+        for v in (1, 2, 3, 4, 5, 6, 0):
             lib.fdn_debug_set_conv64_mt(v)
             rep("conv64 fwd %s" % VARIANTS[v], timeit(lambda: ops.conv3d_fwd(x, w, None, ops.ACT_RELU, wpack=wf, out=y), args.iters))
             rep("conv64 fwd+res+leaky %s" % VARIANTS[v], timeit(lambda: ops.conv3d_fwd(x, w, None, ops.ACT_LEAKY, 0.2, dz, wpack=wf, out=y), args.iters))
