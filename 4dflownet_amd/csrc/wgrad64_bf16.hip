@@ -40,7 +40,8 @@ constexpr int XH = TH + 2, XW = TW + 2;
 constexpr int XROWS = TD * XH * XW;      // 200
 constexpr int ZROWS = TD * TH * TW;      // 128
 constexpr int XPAD = XROWS + 2;          // the w 8-11 read of the last halo row runs 2 rows past the image
-constexpr int LDS_BYTES = (XPAD + ZROWS) * 128;
+constexpr int LUT_ROWS = 7 * 32 + 4 * 32;   // XP*32 x rows + ZP*32 dz rows
+constexpr int LDS_BYTES = (XPAD + ZROWS) * 128 + LUT_ROWS * 4;
 }  // namespace
 
 __device__ __forceinline__ u32x2 tr_read(const char* lds_addr) {
@@ -103,6 +104,23 @@ __global__ __launch_bounds__(256, 2) void wgrad64_bf16_kernel(Wgrad64BfArgs p) {
     // tile staging is software-pipelined through registers (as in the fp32 kernel): the K loop reads only LDS
     constexpr int XP = (XROWS + 31) / 32, ZP = (ZROWS + 31) / 32;
     u32x4 xv[XP], zv[ZP];
+    // Row -> element-offset table for tiles that lie completely inside the volume (no clamping): one LDS read replaces
+    // the ~25 integer instructions of the row decode, which otherwise sit between the barrier and the first MFMA of a tile
+    int* lut = (int*)(smem + (XPAD + ZROWS) * 128);
+    for (int i = tid; i < LUT_ROWS; i += 256) {
+        int v;
+        if (i < XP * 32) {
+            const int r = i < XROWS ? i : XROWS - 1;
+            const int zd = r / (XH * XW), r2 = r - zd * (XH * XW), zh = r2 / XW;
+            v = ((zd * p.H + zh) * p.W + (r2 - zh * XW)) * 64;
+        } else {
+            const int r = i - XP * 32;
+            const int zd = r / (TH * TW), r2 = r - zd * (TH * TW), zh = r2 / TW;
+            v = ((zd * p.H + zh) * p.W + (r2 - zh * TW)) * 64;
+        }
+        lut[i] = v;
+    }
+    __syncthreads();
     auto prefetch = [&](int tile) {
         int b = tile;
         const int n = b / tiles_per_n;
@@ -112,6 +130,16 @@ __global__ __launch_bounds__(256, 2) void wgrad64_bf16_kernel(Wgrad64BfArgs p) {
         const int thi = b / p.ntw;
         const int p0d = tdi * TD, p0h = thi * TH, p0w = (b - thi * p.ntw) * TW;
         const size_t vox_n = (size_t)n * p.D * p.H * p.W;
+        if (p0d + a - 1 >= 0 && p0d + TD + a - 2 < p.D && p0h >= 1 && p0h + TH < p.H && p0w >= 1 && p0w + TW < p.W) {
+            // interior tile (uniform branch): addresses = tile origin + table
+            const uint16_t* xb = p.x + (vox_n + ((size_t)(p0d + a - 1) * p.H + (p0h - 1)) * p.W + (p0w - 1)) * 64 + c16 * 8;
+            const uint16_t* zb = p.dz + (vox_n + ((size_t)p0d * p.H + p0h) * p.W + p0w) * 64 + c16 * 8;
+#pragma unroll
+            for (int u = 0; u < XP; ++u) xv[u] = *(const u32x4*)(xb + lut[u * 32 + rsub]);
+#pragma unroll
+            for (int u = 0; u < ZP; ++u) zv[u] = *(const u32x4*)(zb + lut[XP * 32 + u * 32 + rsub]);
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < XP; ++u) {          // x rows, edge clamp applied here
             int r = u * 32 + rsub;
