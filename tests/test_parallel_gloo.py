@@ -76,3 +76,59 @@ def test_sampler_covers_everything_once_per_epoch():
         for rows in s:
             seen.extend(rows.tolist())
     assert sorted(seen) == list(range(50))
+
+
+class _FakeNet:
+    """Stands in for FlowNetModel in predict_patches: a deterministic function of the inputs on CPU tensors."""
+    res_increase = 2
+    device = torch.device("cpu")
+
+    def forward(self, ins):
+        u = torch.as_tensor(np.asarray(ins[0], dtype=np.float32))[..., 0]          # (B,P,P,P)
+        up = u.repeat_interleave(2, 1).repeat_interleave(2, 2).repeat_interleave(2, 3)
+        m = torch.as_tensor(np.asarray(ins[3], dtype=np.float32))[..., 0].mean(dim=(1, 2, 3))
+        return torch.stack([up, 2 * up, up + m[:, None, None, None]], dim=-1)
+
+
+def _patches(n, P=4, seed=9):
+    rng = np.random.default_rng(seed)
+    vel = [rng.normal(size=(n, P, P, P, 1)).astype(np.float32) for _ in range(3)]
+    mag = [rng.uniform(size=(n, P, P, P, 1)).astype(np.float32) for _ in range(3)]
+    return vel, mag
+
+
+def _predict_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    parallel = importlib.import_module("4dflownet_amd.parallel")
+    predictor = importlib.import_module("4dflownet_amd.predictor")
+    parallel.init_from_env(backend="gloo")
+    out = []
+    for n in (5, 1, 4):                         # ragged: 3 + 2, 1 + 0, 2 + 2 patches per rank
+        vel, mag = _patches(n)
+        out.append(predictor.predict_patches(_FakeNet(), vel, mag, batch_size=2))
+    parallel.barrier()
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_cfg5_patch_list_sharded_over_ranks_and_all_gathered():
+    """Inference: the patch list is split contiguously over ranks, every rank ends up with the complete,
+    correctly ordered result (all_gather, no other collective)."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_predict_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for k, n in enumerate((5, 1, 4)):
+        vel, mag = _patches(n)
+        ref = _FakeNet().forward([v for v in vel] + [m for m in mag]).numpy().astype(np.float64)
+        for r in range(world):
+            got = res[r][1][k]
+            assert got.shape == (n, 8, 8, 8, 3) and got.dtype == np.float64
+            np.testing.assert_array_equal(got, ref)
