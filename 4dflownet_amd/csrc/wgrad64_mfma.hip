@@ -118,16 +118,22 @@ __global__ __launch_bounds__(256, 2) void wgrad64_mfma_kernel(Wgrad64Args p) {
             for (int kk = 0; kk < TH; ++kk) {
                 const char* xr = xa + ((kd * XH + kk) * XW) * 256;
                 const char* zr = zb + ((kd * TH + kk) * TW) * 256;
+                // the 10 LDS reads of voxel pair w2 + 1 are issued before the 9 MFMAs of pair w2 (pinned: hipcc would sink them)
+                float bq[2], aq[2][9];
+                auto issue = [&](int w2, float& bv, float (&av)[9]) {
+                    bv = *(const float*)(zr + w2 * 512);
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) av[t] = *(const float*)(xr + w2 * 512 + ((t / 3) * XW + (t % 3)) * 256);
+                };
+                issue(0, bq[0], aq[0]);
 #pragma unroll
                 for (int w2 = 0; w2 < TW / 2; ++w2) {
-                    const float bv = *(const float*)(zr + w2 * 512);
-                    float av[9];
+                    if (w2 + 1 < TW / 2) issue(w2 + 1, bq[(w2 + 1) & 1], aq[(w2 + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int t = 0; t < 9; ++t)
-                        av[t] = *(const float*)(xr + w2 * 512 + ((t / 3) * XW + (t % 3)) * 256);
-#pragma unroll
-                    for (int t = 0; t < 9; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[w2 & 1][t], bq[w2 & 1], acc[t], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
