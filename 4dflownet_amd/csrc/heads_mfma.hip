@@ -42,11 +42,25 @@ __global__ __launch_bounds__(256, 2) void head_fwd_kernel(const T* __restrict__ 
     // K order: a lane holds E = 16 B / sizeof(T) consecutive channels per chunk (4 fp32 / 8 bf16): lane (i,kh), chunk g,
     // element s  <->  cin = 2E g + E kh + s.   B fragments: w[t = li][that cin], zero for the 5 padding columns.
     constexpr int E = 16 / (int)sizeof(T), NCH = 32 / E;
+    // bf16 storage: the chunk IS the v_mfma_f32_32x32x16_bf16 operand (k = 8 kh + s of 16-channel block g), and the fp32
+    // weights enter as an exact-to-2^-17 bf16 pair w = hi + lo: two bf16 MFMAs per block (8 per M-tile, 32 cycles each)
+    // instead of 32 fp32 MFMAs of 64 cycles -- the z-GEMM drops from the matrix-bound to the HBM-bound side.
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
     float wb[NCH][E];
+    bf16x8 wh[NCH], wl[NCH];
 #pragma unroll
     for (int g = 0; g < NCH; ++g)
 #pragma unroll
-        for (int s = 0; s < E; ++s) wb[g][s] = li < 27 ? w[li * 64 + 2 * E * g + E * kh + s] : 0.f;
+        for (int s = 0; s < E; ++s) {
+            const float wv = li < 27 ? w[li * 64 + 2 * E * g + E * kh + s] : 0.f;
+            if constexpr (E == 8) {
+                const __bf16 h = (__bf16)wv;
+                wh[g][s] = h;
+                wl[g][s] = (__bf16)(wv - (float)h);
+            } else {
+                wb[g][s] = wv;
+            }
+        }
     const float b0 = bias ? bias[0] : 0.f;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     // Each wave owns M-tiles wave, wave+4, ... of a tile: 5 steps per tile (the 20th slot is a dummy on wave 3).  A step's
@@ -91,20 +105,15 @@ __global__ __launch_bounds__(256, 2) void head_fwd_kernel(const T* __restrict__ 
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
         for (int g = 0; g < NCH; ++g) {
-            float a[E];
             if constexpr (E == 4) {
                 const f32x4 f = __builtin_bit_cast(f32x4, src[g]);     // (bit_cast of src[g][s] miscompiles: all four = element 0)
 #pragma unroll
-                for (int s = 0; s < 4; ++s) a[s] = f[s];
+                for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f[s], wb[g][s], acc, 0, 0, 0);
             } else {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    a[2 * s] = __builtin_bit_cast(float, src[g][s] << 16);
-                    a[2 * s + 1] = __builtin_bit_cast(float, src[g][s] & 0xffff0000u);
-                }
+                const bf16x8 a = __builtin_bit_cast(bf16x8, src[g]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wh[g], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wl[g], acc, 0, 0, 0);
             }
-#pragma unroll
-            for (int s = 0; s < E; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wb[g][s], acc, 0, 0, 0);
         }
     };
     // C[voxel row][tap li] -> zbuf[tap][row]; rows of the dummy slot land in the padding
