@@ -139,6 +139,28 @@ void conv64_mfma_kernel(Conv64Args p) {
     const int q0d = p0d - 1 + p.off + ta0, q0h = p0h - 1 + p.off + tb0, q0w = p0w - 1 + p.off + tc0;
     const int ntap = (ta1 - ta0 + 1) * (tb1 - tb0 + 1) * (tc1 - tc0 + 1);
 
+    // fragment ring + its loaders (see the K loop)
+    f32x4 A[KG][MT], B[KG][NT];
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, 27 * 64 * 64 * 4, 0x00020000);
+    const int wvoff = (kh * 64 + wave_n * (NT * 32) + li) * 16;
+    const int tap_first = (ta0 * 3 + tb0) * 3 + tc0;
+    // byte offset of (slice, tap, local k-group) in the packed stream [cin/32][tap][g][kh][cout][s]
+    auto wsoff = [&](int sl_, int tap, int g) -> int {
+        return ((((sl_ * KG) >> 2) * 27 * 4 + ((sl_ * KG) & 3)) * 128 + (tap * 4 + g) * bstride) * 16;
+    };
+    auto ldb = [&](int g, int so) {
+#pragma unroll
+        for (int nn = 0; nn < NT; ++nn)
+            B[g][nn] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff + nn * 512, so, 0));
+    };
+    auto lda = [&](int g, int tapoff_) {
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+            const int row = row0[mi] + tapoff_;
+            A[g][mi] = *(const f32x4*)(smem + row * ROWB + ((((g * 2 + kh) ^ (row / CS)) & (CH - 1)) << 4));
+        }
+    };
+
 #pragma unroll 1
     for (int sl = 0; sl < CS; ++sl) {
         if (sl) __syncthreads();  // everyone finished reading the previous slice
@@ -177,51 +199,57 @@ void conv64_mfma_kernel(Conv64Args p) {
         }
         __syncthreads();
 
-        // ---- K loop over 27 taps x KG k-groups of this slice ----
-        // stream index of (slice, tap, local k-group gl): half = cin/32, g = k-group within the half
-        const int half = (sl * KG) >> 2, g0 = (sl * KG) & 3;
-        const f32x4* bp = (const f32x4*)p.wp + ((size_t)half * 27 * 4 + g0) * 128 + kh * 64 + wave_n * (NT * 32) + li;
-        // the weight fragments of tap it + 1 are loaded (into a second register set) before the MFMAs of tap it; the
-        // sched_barriers pin them there -- left alone, hipcc sinks the loads down to their first use
-        int ta = ta0, tb = tb0, tc = tc0;
-        f32x4 bv[KG][NT], bn[KG][NT];
-        auto load_b = [&](f32x4 (&dst)[KG][NT], int tap) {
+        // ---- K loop over the taps x KG k-groups (8 cin) of this slice ----
+        // One step = one k-group of one tap: MT A fragments (LDS) + NT B fragments (weight stream) feed 4*MT*NT MFMAs.  The
+        // fragments live in a ring of KG slots indexed by the k-group: right after the first MFMAs of step g have issued,
+        // slot g-1 -- consumed by the previous step -- is refilled for its next use KG-1 steps later, so every load and LDS
+        // read issues in the shadow of MFMAs and has ~KG-1 steps to land; no register copies, no waits at tap boundaries.
+        // (Measured: with all side work batched at the tap boundary the matrix pipe idled ~7 % of the K loop.)
+        {
+            int ta = ta0, tb = tb0, tc = tc0, tapoff = 0;
+            if (sl == 0) {
 #pragma unroll
-            for (int g = 0; g < KG; ++g)
-#pragma unroll
-                for (int nn = 0; nn < NT; ++nn) dst[g][nn] = bp[(tap * 4 + g) * bstride + nn * 32];
-        };
-        load_b(bv, (ta * 3 + tb) * 3 + tc);
-#pragma unroll 1
-        for (int it = 0; it < ntap; ++it) {
-            const int tapoff = ((ta - ta0) * R.hh + (tb - tb0)) * R.hw + (tc - tc0);
-            if (++tc > tc1) { tc = tc0; if (++tb > tb1) { tb = tb0; ++ta; } }
-            const int tnext = it + 1 < ntap ? (ta * 3 + tb) * 3 + tc : 0;       // harmless reload on the last tap
-            load_b(bn, tnext);
-            __builtin_amdgcn_sched_barrier(0);
-            f32x4 av[MT][KG];
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi) {
-                const int row = row0[mi] + tapoff;
-                const int sw = (row / CS) & (CH - 1);
-                const char* base = smem + row * ROWB;
-#pragma unroll
-                for (int g = 0; g < KG; ++g) av[mi][g] = *(const f32x4*)(base + (((g * 2 + kh) ^ sw) << 4));
+                for (int g = 0; g < KG - 1; ++g) ldb(g, wsoff(0, tap_first, g));
             }
 #pragma unroll
-            for (int g = 0; g < KG; ++g)
+            for (int g = 0; g < KG - 1; ++g) lda(g, 0);
+            const int sln = sl + 1 < CS ? sl + 1 : sl;            // harmless reload after the last slice
+#pragma unroll 1
+            for (int it = 0; it < ntap; ++it) {
+                int na = ta, nb = tb, nc = tc;
+                if (++nc > tc1) { nc = tc0; if (++nb > tb1) { nb = tb0; ++na; } }
+                const bool last = it + 1 == ntap;
+                const int tapoff_n = last ? tapoff : ((na - ta0) * R.hh + (nb - tb0)) * R.hw + (nc - tc0);
+                const int tap_cur = (ta * 3 + tb) * 3 + tc;
+                const int tap_nxt = last ? tap_first : (na * 3 + nb) * 3 + nc;
+                const int sl_nxt = last ? sln : sl;
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
+                for (int g = 0; g < KG; ++g) {
 #pragma unroll
                     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
                         for (int nn = 0; nn < NT; ++nn)
-                            acc[mi][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][g][s], bv[g][nn][s], acc[mi][nn], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+                            acc[mi][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[g][mi][0], B[g][nn][0], acc[mi][nn], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (g == 0) {
+                        ldb(KG - 1, wsoff(sl, tap_cur, KG - 1));
+                        lda(KG - 1, tapoff);
+                    } else {
+                        ldb(g - 1, wsoff(sl_nxt, tap_nxt, g - 1));
+                        lda(g - 1, tapoff_n);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int g = 0; g < KG; ++g)
+                    for (int s = 1; s < 4; ++s)
 #pragma unroll
-                for (int nn = 0; nn < NT; ++nn) bv[g][nn] = bn[g][nn];
+                        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                            for (int nn = 0; nn < NT; ++nn)
+                                acc[mi][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[g][mi][s], B[g][nn][s], acc[mi][nn], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                ta = na; tb = nb; tc = nc; tapoff = tapoff_n;
+            }
         }
     }
     if (p.dbg & 8) return;
@@ -403,20 +431,22 @@ namespace {
 struct Box { int od, oh, ow, ed, eh, ew, ta0, ta1, tb0, tb1, tc0, tc1; };
 struct Plan { FdnTile t; double cost; };
 
-// estimated time of a launch in units of "one M row through all 27x64 K steps on one CU"
-double plan_cost(const FdnTile& t, int N, int mcap, int cs, const Box& bx) {
+// estimated time of a launch in units of "one M row through all 27x64 K steps on one CU".  Fitted to tools/bench_kernels.py
+// on MI355X after the K loop got its fragment ring: per-tile staging/epilogue is hidden by the co-resident workgroups, a
+// launch costs (tiles on the busiest CU) x (rows per tile) x f + a fixed latency that grows with the tile (first staging and
+// last epilogue of a CU have nothing to overlap with); f = relative MFMA efficiency of the wave layout.
+double plan_cost(const FdnTile& t, int N, int mcap, int cs, const Box& bx, double f) {
     const double tiles = (double)N * t.ntd * t.nth * t.ntw;
     const double rows = (double)(t.td + bx.ta1 - bx.ta0) * (t.th + bx.tb1 - bx.tb0) * (t.tw + bx.tc1 - bx.tc0);
     const double tapfrac = (bx.ta1 - bx.ta0 + 1) * (bx.tb1 - bx.tb0 + 1) * (bx.tc1 - bx.tc0 + 1) / 27.0;
-    const double per_tile = mcap * tapfrac + 0.02 * rows + 3.0 * cs + 4.0;     // MFMA work + staging + barriers + epilogue
+    const double per_tile = mcap * tapfrac * f + 0.005 * rows + 0.5 * cs;
     const double per_cu_max = (double)((long long)((tiles + 255) / 256));
     const double per_cu_avg = tiles / 256.0;
-    // the launch ends when the busiest CU does (measured: 24^3 N=8 runs 11 % faster as 1728 tiles of 64 voxels, 7 per CU,
-    // than as 432 tiles of 256, 2 per CU on 176 CUs and 1 on the rest); the average only breaks ties
-    return (0.95 * per_cu_max + 0.05 * per_cu_avg) * per_tile;
+    // the launch ends when the busiest CU does; the average only breaks ties
+    return (0.95 * per_cu_max + 0.05 * per_cu_avg) * per_tile + 20.0 + 0.18 * mcap;
 }
 
-Plan best_plan(int N, const Box& bx, int mcap, int max_rows, int cs) {
+Plan best_plan(int N, const Box& bx, int mcap, int max_rows, int cs, double f) {
     Plan best{{1, 1, 1, bx.ed, bx.eh, bx.ew}, 1e30};
     const int da = bx.ta1 - bx.ta0, db = bx.tb1 - bx.tb0, dc = bx.tc1 - bx.tc0;
     for (int td = 1; td <= bx.ed && td <= mcap; ++td)
@@ -424,7 +454,7 @@ Plan best_plan(int N, const Box& bx, int mcap, int max_rows, int cs) {
             for (int tw = 1; tw <= bx.ew && td * th * tw <= mcap; ++tw) {
                 if ((td + da) * (th + db) * (tw + dc) > max_rows) continue;
                 FdnTile t{td, th, tw, (bx.ed + td - 1) / td, (bx.eh + th - 1) / th, (bx.ew + tw - 1) / tw};
-                const double c = plan_cost(t, N, mcap, cs, bx);
+                const double c = plan_cost(t, N, mcap, cs, bx, f);
                 if (c < best.cost) best = {t, c};
             }
     return best;
@@ -433,7 +463,9 @@ Plan best_plan(int N, const Box& bx, int mcap, int max_rows, int cs) {
 template <int MT, int NW, int CS>
 Plan plan_for(int N, const Box& bx) {
     using C = Conv64Cfg<MT, NW, CS>;
-    return best_plan(N, bx, C::MCAP, C::MAXROWS, CS);
+    // measured at 48^3 N=8 (same work per CU): <1,1> 1.463 ms, <1,2> 1.506, <2,1> 1.542 per 3456..3584 row units; cs4 +2 %
+    const double f = (MT == 2 ? 1.0 : (NW == 1 ? 0.985 : 1.015)) + (CS == 4 ? 0.02 : 0.0);
+    return best_plan(N, bx, C::MCAP, C::MAXROWS, CS, f);
 }
 
 template <int MT, int NW, int CS>
@@ -485,10 +517,9 @@ int launch_boxes(Conv64Args& a, const Box* boxes, int nbox, hipStream_t s) {
                          1e30, plan_for<1, 2, 2>(a.N, bx).cost, 1e30};
     int v = fdn_conv64_force_layout;
     if (v < 1 || v > 6) {
-        // auto: cheapest of the variants that measured best on MI355X (tools/bench_kernels.py): <2,1,cs2> on large grids
-        // (48^3: 122 TF), <1,2,cs2> or <2,1,cs4> on 24^3, <1,1,cs2> on 26^3
+        // auto: cheapest of the cs2 variants (tools/bench_kernels.py: <1,1,cs2> wins at 48^3 N=8 -- 6912 tiles = 27 per CU
+        // exactly -- <1,2,cs2> at 24^3; the cs4 variants are never ahead)
         v = 1;
-        if (c[2] < c[v]) v = 2;
         if (c[3] < c[v]) v = 3;
         if (c[5] < c[v]) v = 5;
     }
@@ -505,7 +536,7 @@ int launch_boxes(Conv64Args& a, const Box* boxes, int nbox, hipStream_t s) {
 }  // namespace
 
 FdnTile fdn_plan_tile(int N, int OD, int OH, int OW, int max_vox, int max_halo_rows, int) {
-    return best_plan(N, Box{0, 0, 0, OD, OH, OW, 0, 2, 0, 2, 0, 2}, max_vox, max_halo_rows, 2).t;
+    return best_plan(N, Box{0, 0, 0, OD, OH, OW, 0, 2, 0, 2, 0, 2}, max_vox, max_halo_rows, 2, 1.0).t;
 }
 
 int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, const float* residual, float* y,

@@ -1,0 +1,27 @@
+"""K-loop ablations of the fp32 conv64 forward: python tools/abl_conv_f32.py"""
+import importlib, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+fdn = importlib.import_module("4dflownet_amd")
+ops = fdn.ops
+lib = fdn._lib.load()
+def timeit(fn, iters=10):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+for N, P in ((8, 48), (32, 48), (8, 24)):
+    x = torch.randn((N, P, P, P, 64), device="cuda")
+    w = torch.randn((3, 3, 3, 64, 64), device="cuda") * 0.02
+    wf, wd = ops.pack_conv64_weights(w)
+    y = torch.empty_like(x)
+    flop = 2.0 * 27 * 64 * 64 * N * P ** 3
+    lib.fdn_debug_set_conv64_mt(1)
+    for dbg in (0, 13, 13 + 16, 13 + 32, 13 + 48, 13 + 64, 13 + 64 + 16, 13 + 64 + 48, 64):
+        lib.fdn_debug_set_conv64_dbg(dbg)
+        ms = timeit(lambda: ops.conv3d_fwd(x, w, None, ops.ACT_RELU, wpack=wf, out=y))
+        print("N=%d P=%d dbg=%3d: %.3f ms %.1f TF" % (N, P, dbg, ms, flop / ms * 1e-9))
+    lib.fdn_debug_set_conv64_dbg(0)
