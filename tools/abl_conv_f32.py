@@ -19,9 +19,9 @@ for N, P in ((8, 48), (32, 48), (8, 24)):
     wf, wd = ops.pack_conv64_weights(w)
     y = torch.empty_like(x)
     flop = 2.0 * 27 * 64 * 64 * N * P ** 3
-    lib.fdn_debug_set_conv64_mt(1)
-    for dbg in (0, 13, 13 + 16, 13 + 32, 13 + 48, 13 + 64, 13 + 64 + 16, 13 + 64 + 48, 64):
+    for var, dbg in ((0, 0), (0, 1), (0, 4), (0, 8), (0, 13), (1, 0), (1, 13), (5, 0), (5, 13)):
+        lib.fdn_debug_set_conv64_mt(var)
         lib.fdn_debug_set_conv64_dbg(dbg)
         ms = timeit(lambda: ops.conv3d_fwd(x, w, None, ops.ACT_RELU, wpack=wf, out=y))
-        print("N=%d P=%d dbg=%3d: %.3f ms %.1f TF" % (N, P, dbg, ms, flop / ms * 1e-9))
+        print("N=%d P=%d var=%d dbg=%3d: %.3f ms %.1f TF" % (N, P, var, dbg, ms, flop / ms * 1e-9))
     lib.fdn_debug_set_conv64_dbg(0)
