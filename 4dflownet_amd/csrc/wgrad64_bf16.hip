@@ -255,7 +255,7 @@ int fdn_wgrad64_bf16_launch(const uint16_t* x, const uint16_t* dz, float* dw, vo
     }
     hipLaunchKernelGGL(wgrad64_bf16_kernel, dim3(3 * a.S), dim3(256), LDS_BYTES, s, a);
     FDN_CHECK_LAUNCH("wgrad64_bf16_kernel");
-    hipLaunchKernelGGL(wgrad64_reduce_kernel, dim3((27 * 1024 + 255) / 256), dim3(256), 0, s, (const float*)ws, dw, a.S);
+    hipLaunchKernelGGL(wgrad64_reduce_kernel, dim3(27 * 1024 / 64), dim3(256), 0, s, (const float*)ws, dw, a.S);
     FDN_CHECK_LAUNCH("wgrad64_reduce_kernel");
     return FDN_OK;
 }

@@ -150,21 +150,28 @@ __global__ __launch_bounds__(256, 2) void wgrad64_mfma_kernel(Wgrad64Args p) {
         }
 }
 
-// dw[e] = sum_s partial[s][e]   (e over 27*64*64, float4 per thread)
-__global__ void wgrad64_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int S) {
-    const int e4 = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e4 >= 27 * 4096 / 4) return;
+// dw[e] = sum_s partial[s][e]   (e over 27*64*64).  Block = 64 float4 columns x 4 quarters of S (combined through LDS in a
+// fixed order): 432 blocks / 1728 waves keep enough loads in flight to stream the 75 MB of partials; the first version
+// (108 blocks, one thread per column over all S) left more than half of the CUs idle.
+__global__ __launch_bounds__(256) void wgrad64_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int S) {
+    __shared__ f32x4 red[3][64];
+    const int col = threadIdx.x & 63, qtr = threadIdx.x >> 6;
+    const int e4 = blockIdx.x * 64 + col;                       // 27*1024 float4 columns, a multiple of 64
     const f32x4* p = (const f32x4*)partial + e4;
+    const int s0q = (S * qtr) >> 2, s1q = (S * (qtr + 1)) >> 2;
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
-    int s = 0;
-    for (; s + 4 <= S; s += 4) {
+    int s = s0q;
+    for (; s + 4 <= s1q; s += 4) {
         s0 += p[(size_t)(s + 0) * (27 * 1024)];
         s1 += p[(size_t)(s + 1) * (27 * 1024)];
         s2 += p[(size_t)(s + 2) * (27 * 1024)];
         s3 += p[(size_t)(s + 3) * (27 * 1024)];
     }
-    for (; s < S; ++s) s0 += p[(size_t)s * (27 * 1024)];
-    ((f32x4*)dw)[e4] = (s0 + s1) + (s2 + s3);
+    for (; s < s1q; ++s) s0 += p[(size_t)s * (27 * 1024)];
+    const f32x4 t = (s0 + s1) + (s2 + s3);
+    if (qtr) red[qtr - 1][col] = t;
+    __syncthreads();
+    if (qtr == 0) ((f32x4*)dw)[e4] = (t + red[0][col]) + (red[1][col] + red[2][col]);
 }
 
 namespace {
@@ -193,7 +200,7 @@ int fdn_wgrad64_launch(const float* x, const float* dz, float* dw, void* ws, siz
     const size_t lds = (size_t)(kTD * (kTH + 2) * (kTW + 2) + kTD * kTH * kTW) * 256;
     hipLaunchKernelGGL((wgrad64_mfma_kernel<kTD, kTH, kTW>), dim3(a.S, 3), dim3(256), lds, s, a);
     FDN_CHECK_LAUNCH("wgrad64_mfma_kernel");
-    hipLaunchKernelGGL(wgrad64_reduce_kernel, dim3((27 * 1024 + 255) / 256), dim3(256), 0, s, (const float*)ws, dw, a.S);
+    hipLaunchKernelGGL(wgrad64_reduce_kernel, dim3(27 * 1024 / 64), dim3(256), 0, s, (const float*)ws, dw, a.S);
     FDN_CHECK_LAUNCH("wgrad64_reduce_kernel");
     return FDN_OK;
 }
