@@ -150,6 +150,170 @@ __global__ __launch_bounds__(256, 2) void wgrad64_mfma_kernel(Wgrad64Args p) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Pipelined variant (the default): tiles of 1 x TH x TW voxels through THREE LDS buffers, so that nothing but one barrier
+// per tile interrupts the MFMA stream of a wave.  While tile k is contracted out of buffer k%3:
+//   pairs 0..2   the registers holding tile k+1 (loaded during tile k-1) are written to buffer (k+1)%3,
+//   pairs 3..9   the rows of tile k+2 are loaded into those registers (address arithmetic in the MFMA shadow),
+//   pair  8      one barrier: every wave has written its part of tile k+1 (and finished tile k-1, so buffer (k+2)%3 may be
+//                overwritten during tile k+1) -- with two buffers a wave running at twice the speed of a sibling (its SIMD
+//                partner idle) could overwrite rows the sibling still reads,
+//   pair  15     the first LDS reads of tile k+1 are issued: the read-ahead ring crosses tile boundaries.
+// Measured on MI355X: the two-barrier version above spent ~8 % of the launch between its barriers (ablation: 1.445 ->
+// 1.342 ms at 8x48^3 without staging); co-resident workgroups do not fill those bubbles.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int TH, int TW>
+__global__ __launch_bounds__(256, 2) void wgrad64_pipe_kernel(Wgrad64Args p) {
+    constexpr int XH = TH + 2, XW = TW + 2;
+    constexpr int XROWS = XH * XW, ZROWS = TH * TW;
+    constexpr int BUFB = (XROWS + ZROWS) * 256;
+    constexpr int XP = (XROWS + 15) / 16, ZP = (ZROWS + 15) / 16;
+    constexpr int NPAIR = TH * TW / 2, PPR = TW / 2;
+    static_assert(NPAIR % 2 == 0 && NPAIR >= 12, "two register sets; the pipeline stages are pinned to pairs 0..10");
+    static_assert(XP <= 4 && ZP <= 2, "stage placement below");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 31;
+    const int kh = lane >> 5;
+    const int mq = wave & 1, nq = wave >> 1;
+    const int a = blockIdx.y;        // kernel-depth tap
+    const int split = blockIdx.x;
+    const int c16 = tid & 15;        // 16-B chunk within a 256-B row
+    const int rsub = tid >> 4;       // 0..15
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // per-thread staged rows: (h,w) inside the halo box / the tile do not depend on the tile
+    int xh[XP], xw[XP], zh[ZP], zw[ZP];
+#pragma unroll
+    for (int u = 0; u < XP; ++u) { const int r = min(u * 16 + rsub, XROWS - 1); xh[u] = r / XW; xw[u] = r - xh[u] * XW; }
+#pragma unroll
+    for (int u = 0; u < ZP; ++u) { const int r = min(u * 16 + rsub, ZROWS - 1); zh[u] = r / TW; zw[u] = r - zh[u] * TW; }
+
+    // tile walk: tile = split + k*S, decoded incrementally (n, d, th, tw) with S pre-split the same way -- scalar work only
+    const int per_d = p.nth * p.ntw, per_n = p.D * per_d;
+    int tn, td, th, tw;
+    {
+        int b = split;
+        tn = b / per_n; b -= tn * per_n;
+        td = b / per_d; b -= td * per_d;
+        th = b / p.ntw; tw = b - th * p.ntw;
+    }
+    int sn, sd, sh, sw;
+    {
+        int b = p.S;
+        sn = b / per_n; b -= sn * per_n;
+        sd = b / per_d; b -= sd * per_d;
+        sh = b / p.ntw; sw = b - sh * p.ntw;
+    }
+    const int nk = (p.ntiles - split + p.S - 1) / p.S;      // tiles of this workgroup (>= 1 by construction of S)
+    int kload = 0;                                          // index of the tile the cursor (tn,td,th,tw) points at
+    auto advance = [&]() {                                  // cursor -> next tile of this workgroup (stays on the last one)
+        if (kload + 1 < nk) {
+            ++kload;
+            tw += sw; if (tw >= p.ntw) { tw -= p.ntw; ++th; }
+            th += sh; if (th >= p.nth) { th -= p.nth; ++td; }
+            td += sd; if (td >= p.D) { td -= p.D; ++tn; }
+            tn += sn;
+        }
+    };
+
+    f32x4 xv[XP], zv[ZP];
+    unsigned zok = 0;
+    auto load_x = [&](int u) {                              // x row (edge clamp applied here) of the cursor tile
+        const int qd = min(max(td + a - 1, 0), p.D - 1);
+        const char* plane = (const char*)p.x + ((size_t)(tn * p.D + qd) * p.H * p.W) * 256;
+        const int qh = min(max(th * TH + xh[u] - 1, 0), p.H - 1);
+        const int qw = min(max(tw * TW + xw[u] - 1, 0), p.W - 1);
+        xv[u] = *(const f32x4*)(plane + (unsigned)((qh * p.W + qw) * 256 + c16 * 16));
+    };
+    auto load_z = [&](int u) {                              // dz row, zeroed at the LDS write if outside the volume
+        const char* plane = (const char*)p.dz + ((size_t)(tn * p.D + td) * p.H * p.W) * 256;
+        const int qh = th * TH + zh[u], qw = tw * TW + zw[u];
+        const bool ok = qh < p.H && qw < p.W;
+        zok = ok ? (zok | (1u << u)) : (zok & ~(1u << u));
+        zv[u] = *(const f32x4*)(plane + (unsigned)((min(qh, p.H - 1) * p.W + min(qw, p.W - 1)) * 256 + c16 * 16));
+    };
+    auto write_x = [&](int u, char* buf) {
+        const int r = u * 16 + rsub;
+        if ((u + 1) * 16 <= XROWS || r < XROWS) *(f32x4*)(buf + r * 256 + c16 * 16) = xv[u];      // branch-free for full passes
+    };
+    auto write_z = [&](int u, char* buf) {
+        const int r = u * 16 + rsub;
+        if ((u + 1) * 16 <= ZROWS || r < ZROWS)
+            *(f32x4*)(buf + XROWS * 256 + r * 256 + c16 * 16) = ((zok >> u) & 1) ? zv[u] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+
+    // ---- prologue: tile 0 -> buffer 0, tile 1 -> registers ----
+#pragma unroll
+    for (int u = 0; u < XP; ++u) load_x(u);
+#pragma unroll
+    for (int u = 0; u < ZP; ++u) load_z(u);
+#pragma unroll
+    for (int u = 0; u < XP; ++u) write_x(u, smem);
+#pragma unroll
+    for (int u = 0; u < ZP; ++u) write_z(u, smem);
+    advance();
+#pragma unroll
+    for (int u = 0; u < XP; ++u) load_x(u);
+#pragma unroll
+    for (int u = 0; u < ZP; ++u) load_z(u);
+    __syncthreads();
+
+    const int lane_x = (mq * 32 + li) * 4 + kh * 256;
+    const int lane_z = XROWS * 256 + (nq * 32 + li) * 4 + kh * 256;
+    float bq[2], aq[2][9];
+    auto issue = [&](const char* buf, int q, float& bv, float (&av)[9]) {     // the 10 LDS reads of voxel pair q
+        const int kk = q / PPR, w2 = q % PPR;
+        bv = *(const float*)(buf + lane_z + (kk * TW) * 256 + w2 * 512);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) av[t] = *(const float*)(buf + lane_x + ((kk + t / 3) * XW + (t % 3)) * 256 + w2 * 512);
+    };
+    int bcur = 0;                                           // buffer of tile k
+    issue(smem, 0, bq[0], aq[0]);
+#pragma unroll 1
+    for (int k = 0; k < nk; ++k) {
+        const int bnxt = bcur == 2 ? 0 : bcur + 1;
+        const char* cur = smem + bcur * BUFB;
+        char* nxt = smem + bnxt * BUFB;
+#pragma unroll
+        for (int q = 0; q < NPAIR; ++q) {
+            if (q == 8) __syncthreads();
+            if (q + 1 < NPAIR) issue(cur, q + 1, bq[(q + 1) & 1], aq[(q + 1) & 1]);
+            else issue(nxt, 0, bq[0], aq[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q == 0) { write_x(0, nxt); if (XP > 1) write_x(1, nxt); }
+            if (q == 1) { if (XP > 2) write_x(2, nxt); if (XP > 3) write_x(3, nxt); }
+            if (q == 2) { write_z(0, nxt); if (ZP > 1) write_z(1, nxt); }
+            if (q == 3) advance();
+            if (q >= 4 && q < 4 + XP) load_x(q - 4);
+            if (q >= 9 && q < 9 + ZP) load_z(q - 9);
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[q & 1][t], bq[q & 1], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        bcur = bnxt;
+    }
+
+    // ---- write this workgroup's partial dW for taps (a, b, c) ----
+    float* out = p.partial + ((size_t)split * 27 + a * 9) * 4096;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = mq * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            out[(size_t)t * 4096 + ci * 64 + nq * 32 + li] = acc[t][r];
+        }
+}
+
 // dw[e] = sum_s partial[s][e]   (e over 27*64*64).  Block = 64 float4 columns x 4 quarters of S (combined through LDS in a
 // fixed order): 432 blocks / 1728 waves keep enough loads in flight to stream the 75 MB of partials; the first version
 // (108 blocks, one thread per column over all S) left more than half of the CUs idle.
@@ -175,12 +339,12 @@ __global__ __launch_bounds__(256) void wgrad64_reduce_kernel(const float* __rest
 }
 
 namespace {
-constexpr int kTD = 2, kTH = 4, kTW = 8;
+constexpr int kTH = 4, kTW = 8;          // pipelined kernel: tiles of 1 x 4 x 8 voxels
 int wgrad64_splits(int N, int D, int H, int W) {
-    const long long ntiles = (long long)N * ((D + kTD - 1) / kTD) * ((H + kTH - 1) / kTH) * ((W + kTW - 1) / kTW);
-    // 3 tap groups x S workgroups; two workgroups fit a CU -> aim for ~512 resident, at least 4 tiles each
+    const long long ntiles = (long long)N * D * ((H + kTH - 1) / kTH) * ((W + kTW - 1) / kTW);
+    // 3 tap groups x S workgroups; two workgroups fit a CU -> aim for ~512 resident, at least 8 tiles each
     long long S = 170;                 // 3*170 = 510 workgroups ~ 2 per CU
-    if (ntiles / 4 < S) S = ntiles / 4 > 0 ? ntiles / 4 : 1;
+    if (ntiles / 8 < S) S = ntiles / 8 > 0 ? ntiles / 8 : 1;
     return (int)S;
 }
 }  // namespace
@@ -194,12 +358,19 @@ int fdn_wgrad64_launch(const float* x, const float* dz, float* dw, void* ws, siz
     Wgrad64Args a;
     a.x = x; a.dz = dz; a.partial = (float*)ws;
     a.N = N; a.D = D; a.H = H; a.W = W;
-    a.ntd = (D + kTD - 1) / kTD; a.nth = (H + kTH - 1) / kTH; a.ntw = (W + kTW - 1) / kTW;
+    a.ntd = D; a.nth = (H + kTH - 1) / kTH; a.ntw = (W + kTW - 1) / kTW;
     a.ntiles = N * a.ntd * a.nth * a.ntw;
     a.S = wgrad64_splits(N, D, H, W);
-    const size_t lds = (size_t)(kTD * (kTH + 2) * (kTW + 2) + kTD * kTH * kTW) * 256;
-    hipLaunchKernelGGL((wgrad64_mfma_kernel<kTD, kTH, kTW>), dim3(a.S, 3), dim3(256), lds, s, a);
-    FDN_CHECK_LAUNCH("wgrad64_mfma_kernel");
+    const size_t lds = (size_t)3 * ((kTH + 2) * (kTW + 2) + kTH * kTW) * 256;
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute((const void*)wgrad64_pipe_kernel<kTH, kTW>,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { fdn_set_error("wgrad64: hipFuncSetAttribute: %s", hipGetErrorString(e)); return FDN_ERR_HIP; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wgrad64_pipe_kernel<kTH, kTW>), dim3(a.S, 3), dim3(256), lds, s, a);
+    FDN_CHECK_LAUNCH("wgrad64_pipe_kernel");
     hipLaunchKernelGGL(wgrad64_reduce_kernel, dim3(27 * 1024 / 64), dim3(256), 0, s, (const float*)ws, dw, a.S);
     FDN_CHECK_LAUNCH("wgrad64_reduce_kernel");
     return FDN_OK;
