@@ -4,15 +4,15 @@
 // as 27 GEMMs  (64 ci) x (64 co)  with the reduction running over all N*D*H*W voxels.
 //
 // Decomposition: grid = (S splits of the voxel-tile list) x (3 kernel-depth taps a).
-//   A workgroup (4 waves) walks its share of box tiles (TD x TH x TW voxels).  Per tile it stages
-//   the x rows the 9 taps (a fixed; b,c in 0..2) touch -- TD x (TH+2) x (TW+2) voxel rows with the
+//   A workgroup (4 waves) walks its share of box tiles (1 x TH x TW voxels).  Per tile it stages
+//   the x rows the 9 taps (a fixed; b,c in 0..2) touch -- (TH+2) x (TW+2) voxel rows with the
 //   edge clamp applied while staging -- and the tile's dz rows into LDS, then every wave contracts over
 //   the tile's voxels for its own 32x32 quadrant of (ci,co) and all 9 taps:
 //     v_mfma_f32_32x32x2_f32  A[i=ci][k=voxel] = x row (ds_read_b32, lanes along ci: conflict-free),
 //                             B[k=voxel][j=co] = dz row (shared by the 9 taps).
 //   9 accumulators x 16 VGPRs stay in registers across ALL tiles of the workgroup; partial sums are
 //   written once per workgroup to workspace[S][27][64][64] and a second kernel reduces over S.
-//   x is re-read by the 3 depth-tap groups through L2; per tile a wave issues 9*TD*TH*TW/2 MFMAs
+//   x is re-read by the 3 depth-tap groups through L2; per tile a wave issues 9*TH*TW/2 MFMAs
 //   (64 cyc each) against 10 LDS reads per k-step, so the matrix pipe is the bottleneck by construction.
 #include "fdn_common.h"
 
@@ -24,143 +24,18 @@ struct Wgrad64Args {
     int ntd, nth, ntw, ntiles, S;
 };
 
-template <int TD, int TH, int TW>
-__global__ __launch_bounds__(256, 2) void wgrad64_mfma_kernel(Wgrad64Args p) {
-    constexpr int XH = TH + 2, XW = TW + 2;
-    constexpr int XROWS = TD * XH * XW;
-    constexpr int ZROWS = TD * TH * TW;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* xs = smem;
-    char* zs = smem + XROWS * 256;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int li = lane & 31;
-    const int kh = lane >> 5;
-    const int mq = wave & 1, nq = wave >> 1;
-    const int a = blockIdx.y;        // kernel-depth tap
-    const int split = blockIdx.x;
-
-    f32x16 acc[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-    const int tiles_per_n = p.ntd * p.nth * p.ntw;
-    const int c16 = tid & 15;   // 16-B chunk within a 256-B row
-    const int rsub = tid >> 4;  // 0..15
-
-    // Tile staging is software-pipelined through registers: the K loop below reads only LDS (no vector-memory waits), so
-    // the global loads of tile t+1 issued before it stay in flight under tile t's MFMAs and are written to LDS afterwards.
-    constexpr int XP = (XROWS + 15) / 16, ZP = (ZROWS + 15) / 16;     // float4 per thread for the x rows / dz rows
-    f32x4 xv[XP], zv[ZP];
-    auto prefetch = [&](int tile) {
-        int b = tile;
-        const int n = b / tiles_per_n;
-        b -= n * tiles_per_n;
-        const int tdi = b / (p.nth * p.ntw);
-        b -= tdi * (p.nth * p.ntw);
-        const int thi = b / p.ntw;
-        const int p0d = tdi * TD, p0h = thi * TH, p0w = (b - thi * p.ntw) * TW;
-        const size_t vox_n = (size_t)n * p.D * p.H * p.W;
-#pragma unroll
-        for (int u = 0; u < XP; ++u) {          // x rows, edge clamp applied here
-            const int r = u * 16 + rsub;
-            xv[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (r < XROWS) {
-                const int zd = r / (XH * XW);
-                const int r2 = r - zd * (XH * XW);
-                const int zh = r2 / XW;
-                const int qd = min(max(p0d + zd + a - 1, 0), p.D - 1);
-                const int qh = min(max(p0h + zh - 1, 0), p.H - 1);
-                const int qw = min(max(p0w + (r2 - zh * XW) - 1, 0), p.W - 1);
-                xv[u] = *(const f32x4*)(p.x + (vox_n + ((size_t)qd * p.H + qh) * p.W + qw) * 64 + c16 * 4);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < ZP; ++u) {          // dz rows, zero outside the volume
-            const int r = u * 16 + rsub;
-            zv[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (r < ZROWS) {
-                const int zd = r / (TH * TW);
-                const int r2 = r - zd * (TH * TW);
-                const int zh = r2 / TW;
-                const int qd = p0d + zd, qh = p0h + zh, qw = p0w + (r2 - zh * TW);
-                if (qd < p.D && qh < p.H && qw < p.W)
-                    zv[u] = *(const f32x4*)(p.dz + (vox_n + ((size_t)qd * p.H + qh) * p.W + qw) * 64 + c16 * 4);
-            }
-        }
-    };
-    if (split < p.ntiles) prefetch(split);
-    for (int tile = split; tile < p.ntiles; tile += p.S) {
-        __syncthreads();   // previous tile fully consumed
-#pragma unroll
-        for (int u = 0; u < XP; ++u) {
-            const int r = u * 16 + rsub;
-            if (r < XROWS) *(f32x4*)(xs + r * 256 + c16 * 16) = xv[u];
-        }
-#pragma unroll
-        for (int u = 0; u < ZP; ++u) {
-            const int r = u * 16 + rsub;
-            if (r < ZROWS) *(f32x4*)(zs + r * 256 + c16 * 16) = zv[u];
-        }
-        __syncthreads();
-        if (tile + p.S < p.ntiles) prefetch(tile + p.S);
-
-        // ---- contract over the tile's voxels, two per MFMA (lane half kh picks the voxel of the pair) ----
-        const char* xa = xs + (mq * 32 + li) * 4 + kh * 256;
-        const char* zb = zs + (nq * 32 + li) * 4 + kh * 256;
-#pragma unroll 1
-        for (int kd = 0; kd < TD; ++kd) {
-#pragma unroll 1
-            for (int kk = 0; kk < TH; ++kk) {
-                const char* xr = xa + ((kd * XH + kk) * XW) * 256;
-                const char* zr = zb + ((kd * TH + kk) * TW) * 256;
-                // the 10 LDS reads of voxel pair w2 + 1 are issued before the 9 MFMAs of pair w2 (pinned: hipcc would sink them)
-                float bq[2], aq[2][9];
-                auto issue = [&](int w2, float& bv, float (&av)[9]) {
-                    bv = *(const float*)(zr + w2 * 512);
-#pragma unroll
-                    for (int t = 0; t < 9; ++t) av[t] = *(const float*)(xr + w2 * 512 + ((t / 3) * XW + (t % 3)) * 256);
-                };
-                issue(0, bq[0], aq[0]);
-#pragma unroll
-                for (int w2 = 0; w2 < TW / 2; ++w2) {
-                    if (w2 + 1 < TW / 2) issue(w2 + 1, bq[(w2 + 1) & 1], aq[(w2 + 1) & 1]);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int t = 0; t < 9; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[w2 & 1][t], bq[w2 & 1], acc[t], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-    }
-
-    // ---- write this workgroup's partial dW for taps (a, b, c) ----
-    float* out = p.partial + ((size_t)split * 27 + a * 9) * 4096;
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ci = mq * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            out[(size_t)t * 4096 + ci * 64 + nq * 32 + li] = acc[t][r];
-        }
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
-// Pipelined variant (the default): tiles of 1 x TH x TW voxels through THREE LDS buffers, so that nothing but one barrier
-// per tile interrupts the MFMA stream of a wave.  While tile k is contracted out of buffer k%3:
+// Tile pipeline: tiles of 1 x TH x TW voxels go through THREE LDS buffers, so that nothing but one barrier per tile
+// interrupts the MFMA stream of a wave.  While tile k is contracted out of buffer k%3:
 //   pairs 0..2   the registers holding tile k+1 (loaded during tile k-1) are written to buffer (k+1)%3,
 //   pairs 3..9   the rows of tile k+2 are loaded into those registers (address arithmetic in the MFMA shadow),
 //   pair  8      one barrier: every wave has written its part of tile k+1 (and finished tile k-1, so buffer (k+2)%3 may be
 //                overwritten during tile k+1) -- with two buffers a wave running at twice the speed of a sibling (its SIMD
 //                partner idle) could overwrite rows the sibling still reads,
 //   pair  15     the first LDS reads of tile k+1 are issued: the read-ahead ring crosses tile boundaries.
-// Measured on MI355X: the two-barrier version above spent ~8 % of the launch between its barriers (ablation: 1.445 ->
-// 1.342 ms at 8x48^3 without staging); co-resident workgroups do not fill those bubbles.
+// Measured on MI355X: the first version (2x4x8 tiles, one buffer, barrier / LDS write / barrier / prefetch between the K
+// loops of consecutive tiles) spent ~8 % of the launch there (ablation: 1.445 -> 1.342 ms at 8x48^3 without staging) and
+// co-resident workgroups did not fill those bubbles; this pipeline runs 1.393 ms (0.210 -> 0.196 ms at 8x24^3).
 // ---------------------------------------------------------------------------------------------------------------------
 template <int TH, int TW>
 __global__ __launch_bounds__(256, 2) void wgrad64_pipe_kernel(Wgrad64Args p) {
