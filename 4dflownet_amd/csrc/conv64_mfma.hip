@@ -6,8 +6,9 @@
 //
 // Work decomposition: M = output voxels of a box tile, N = 64 cout, K = 27 taps x 64 cin.
 //   * One workgroup (4 waves) per box tile.  The tile's input box + 1-voxel halo is staged in CS slices of
-//     64/CS input channels into LDS (256/CS bytes per voxel row, 16-B chunks XOR-swizzled by row so the A-fragment
-//     ds_read_b128 spreads over all banks).  The boundary rule (edge clamp for forward == SYMMETRIC p=1, zero for
+//     64/CS input channels into LDS (256/CS bytes per voxel row + a 16-B pad: with a row stride of 144 B / 80 B the 16 rows
+//     a ds_read_b128 lane group touches fall on 16 different 4-bank groups, so no XOR swizzle -- and no per-read vector
+//     address arithmetic -- is needed: the A-fragment address is lane base + tap offset (one v_add) + an immediate).  The boundary rule (edge clamp for forward == SYMMETRIC p=1, zero for
 //     dgrad) is applied while staging, so the K loop is branch-free.
 //   * Latency hiding is by co-resident workgroups, not by software pipelining across phases: 2 workgroups per CU with
 //     CS=2 (<= 80 KB LDS each; the variant that measures best on large grids), up to 4-6 with CS=4 / the small layouts;
@@ -41,13 +42,14 @@ struct Conv64Cfg {
     static constexpr int NT = 2 / NW;                 // 32-wide cout tiles per wave
     static constexpr int MCAP = WM * MT * 32;         // voxels per tile
     static constexpr int ROWB = 256 / CS;             // bytes per staged voxel row
+    static constexpr int LROW = ROWB + 16;            // LDS row stride: one 16-B pad per row (see the kernel header)
     static constexpr int CH = ROWB / 16;              // 16-B chunks per row
     static constexpr int KG = 8 / CS;                 // k-groups (8 cin) per staged slice
     // workgroups per CU the variant is sized for (VGPR cap via launch bounds, LDS via MAXROWS)
     static constexpr int WG_PER_CU = MT == 2 ? (CS == 4 ? 4 : 2) : (NW == 1 ? (CS == 4 ? 5 : 3) : (CS == 4 ? 6 : 4));
-    static constexpr int MAXROWS = ((160 * 1024 / WG_PER_CU) - MCAP * 4 - 256) / ROWB > 1000
-                                       ? 1000 : ((160 * 1024 / WG_PER_CU) - MCAP * 4 - 256) / ROWB;
-    static constexpr int LDS_BYTES = MAXROWS * ROWB + MCAP * 4;
+    static constexpr int MAXROWS = ((160 * 1024 / WG_PER_CU) - MCAP * 4 - 256) / LROW > 1000
+                                       ? 1000 : ((160 * 1024 / WG_PER_CU) - MCAP * 4 - 256) / LROW;
+    static constexpr int LDS_BYTES = MAXROWS * LROW + MCAP * 4;
 };
 
 // GEN = false: a single region with all 27 taps (every forward launch) -- tap ranges are compile-time constants.
@@ -55,7 +57,7 @@ template <int MT, int NW, int CS, bool GEN>
 __global__ __launch_bounds__(256, (Conv64Cfg<MT, NW, CS>::WG_PER_CU > 8 ? 8 : Conv64Cfg<MT, NW, CS>::WG_PER_CU))
 void conv64_mfma_kernel(Conv64Args p) {
     using C = Conv64Cfg<MT, NW, CS>;
-    constexpr int NT = C::NT, ROWB = C::ROWB, CH = C::CH, KG = C::KG;
+    constexpr int NT = C::NT, LROW = C::LROW, CH = C::CH, KG = C::KG;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -82,7 +84,7 @@ void conv64_mfma_kernel(Conv64Args p) {
     const int tdi = b / (R.nth * R.ntw);
     b -= tdi * (R.nth * R.ntw);
     const int thi = b / R.ntw;
-    int* mtab = (int*)(smem + R.rows * ROWB);          // output voxel index of each tile row, -1 if unused
+    int* mtab = (int*)(smem + R.rows * LROW);          // output voxel index of each tile row, -1 if unused
     const int p0d = R.obd + tdi * R.td, p0h = R.obh + thi * R.th, p0w = R.obw + (b - thi * R.ntw) * R.tw;
 
     const int nv = R.td * R.th * R.tw;
@@ -120,6 +122,9 @@ void conv64_mfma_kernel(Conv64Args p) {
         const int mh = r2 / R.tw;
         row0[mi] = (md * R.hh + mh) * R.hw + (r2 - mh * R.tw);
     }
+    int abase[MT];                                      // LDS byte offset of this lane's A fragment at tap (0,0,0), k-group 0
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) abase[mi] = row0[mi] * LROW + kh * 16;
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -156,8 +161,7 @@ void conv64_mfma_kernel(Conv64Args p) {
     auto lda = [&](int g, int tapoff_) {
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) {
-            const int row = row0[mi] + tapoff_;
-            A[g][mi] = *(const f32x4*)(smem + row * ROWB + ((((g * 2 + kh) ^ (row / CS)) & (CH - 1)) << 4));
+            A[g][mi] = *(const f32x4*)(smem + abase[mi] + tapoff_ * LROW + g * 32);
         }
     };
 
@@ -194,7 +198,7 @@ void conv64_mfma_kernel(Conv64Args p) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int r = r0 + u * RPP + rsub;
-                if (r < rows_eff) *(f32x4*)(smem + r * ROWB + ((chunk ^ ((r / CS) & (CH - 1))) << 4)) = v[u];
+                if (r < rows_eff) *(f32x4*)(smem + r * LROW + (chunk << 4)) = v[u];
             }
         }
         __syncthreads();
@@ -214,15 +218,8 @@ void conv64_mfma_kernel(Conv64Args p) {
 #pragma unroll
             for (int g = 0; g < KG - 1; ++g) lda(g, 0);
             const int sln = sl + 1 < CS ? sl + 1 : sl;            // harmless reload after the last slice
-#pragma unroll 1
-            for (int it = 0; it < ntap; ++it) {
-                int na = ta, nb = tb, nc = tc;
-                if (++nc > tc1) { nc = tc0; if (++nb > tb1) { nb = tb0; ++na; } }
-                const bool last = it + 1 == ntap;
-                const int tapoff_n = last ? tapoff : ((na - ta0) * R.hh + (nb - tb0)) * R.hw + (nc - tc0);
-                const int tap_cur = (ta * 3 + tb) * 3 + tc;
-                const int tap_nxt = last ? tap_first : (na * 3 + nb) * 3 + nc;
-                const int sl_nxt = last ? sln : sl;
+            // one tap = KG steps; (tapoff, tap) of this tap and of the next one (for the refills) come in as scalars
+            auto tap_body = [&](int tapoff, int tapoff_n, int tap_cur, int tap_nxt, int sl_nxt) {
 #pragma unroll
                 for (int g = 0; g < KG; ++g) {
 #pragma unroll
@@ -248,7 +245,17 @@ void conv64_mfma_kernel(Conv64Args p) {
                                 acc[mi][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[g][mi][s], B[g][nn][s], acc[mi][nn], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                ta = na; tb = nb; tc = nc; tapoff = tapoff_n;
+            };
+            {
+#pragma unroll 1
+                for (int it = 0; it < ntap; ++it) {
+                    int na = ta, nb = tb, nc = tc;
+                    if (++nc > tc1) { nc = tc0; if (++nb > tb1) { nb = tb0; ++na; } }
+                    const bool last = it + 1 == ntap;
+                    const int tapoff_n = last ? tapoff : ((na - ta0) * R.hh + (nb - tb0)) * R.hw + (nc - tc0);
+                    tap_body(tapoff, tapoff_n, (ta * 3 + tb) * 3 + tc, last ? tap_first : (na * 3 + nb) * 3 + nc, last ? sln : sl);
+                    ta = na; tb = nb; tc = nc; tapoff = tapoff_n;
+                }
             }
         }
     }
@@ -500,7 +507,7 @@ int launch_conv64(Conv64Args& a, const Box* boxes, int nbox, hipStream_t s) {
         if (e != hipSuccess) { fdn_set_error("conv64: hipFuncSetAttribute: %s", hipGetErrorString(e)); return FDN_ERR_HIP; }
         attr_set = true;
     }
-    const size_t lds = (size_t)max_rows * C::ROWB + C::MCAP * 4;
+    const size_t lds = (size_t)max_rows * C::LROW + C::MCAP * 4;
     const Conv64Region& r0 = a.reg[0];
     const bool simple = a.nreg == 1 && r0.ta0 == 0 && r0.ta1 == 2 && r0.tb0 == 0 && r0.tb1 == 2 && r0.tc0 == 0 && r0.tc1 == 2;
     if (simple) hipLaunchKernelGGL((conv64_mfma_kernel<MT, NW, CS, false>), dim3((unsigned)first), dim3(256), lds, s, a);
