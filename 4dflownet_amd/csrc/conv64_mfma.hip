@@ -165,41 +165,53 @@ void conv64_mfma_kernel(Conv64Args p) {
         }
     };
 
+    // ---- staging plan, once per tile: byte offset (from the sample's first voxel) of each halo row this thread stages, with the
+    // boundary rule applied -- edge clamp, or 0xffffffff for rows the dgrad mode reads as zero (a buffer load past
+    // num_records returns 0) and for rows past the box.  The slices then cost one buffer load per row and no vector ALU
+    // work: on this part every VALU instruction of every wave takes its cycles from the fp32 MFMA stream. ----
+    constexpr int UA = (C::MAXROWS + RPP - 1) / RPP;
+    unsigned soff[UA];
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+        const int r = u * RPP + rsub;
+        const int zd = fdn_div20(r, R.mg_hhhw);
+        const int r2 = r - zd * R.hh * R.hw;
+        const int zh = fdn_div20(r2, R.mg_hw);
+        int qd = q0d + zd, qh = q0h + zh, qw = q0w + (r2 - zh * R.hw);
+        bool ok = r < rows_eff;
+        if (p.zero_mode) {
+            ok = ok && (unsigned)qd < (unsigned)p.ID && (unsigned)qh < (unsigned)p.IH && (unsigned)qw < (unsigned)p.IW;
+        } else {
+            qd = min(max(qd, 0), p.ID - 1);
+            qh = min(max(qh, 0), p.IH - 1);
+            qw = min(max(qw, 0), p.IW - 1);
+        }
+        soff[u] = ok ? (unsigned)(((qd * p.IH + qh) * p.IW + qw) * 256 + chunk * 16) : 0xffffffffu;
+    }
+    const int nfull = rows_eff / RPP;                       // passes in which every thread has a row
+    const bool tail = rsub < rows_eff - nfull * RPP;        // this thread has a row in the last, partial pass
+    const unsigned sample_bytes = (unsigned)(p.ID * p.IH * p.IW) * 256u;
+
 #pragma unroll 1
     for (int sl = 0; sl < CS; ++sl) {
         if (sl) __syncthreads();  // everyone finished reading the previous slice
         // ---- stage input box + halo, cin [sl*64/CS, (sl+1)*64/CS) ----
-        const float* xh = p.x + sl * (64 / CS) + chunk * 4;
+        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.x + in_n * 64 + sl * (64 / CS)), 0, sample_bytes - sl * (256 / CS), 0x00020000);
         // loads per thread issued before the first LDS write: the whole slice (one memory round trip) when the variant runs
         // at 2 workgroups per CU (256-VGPR budget), 4 otherwise
-        constexpr int U = C::WG_PER_CU <= 2 ? (C::MAXROWS + RPP - 1) / RPP : 4;
-        for (int r0 = 0; r0 < rows_eff; r0 += RPP * U) {
+        constexpr int U = C::WG_PER_CU <= 2 ? UA : 4;
+#pragma unroll
+        for (int u0 = 0; u0 < UA; u0 += U) {
+            if (u0 * RPP >= rows_eff) break;
             f32x4 v[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int r = r0 + u * RPP + rsub;
-                v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (r < rows_eff) {
-                    const int zd = fdn_div20(r, R.mg_hhhw);
-                    const int r2 = r - zd * R.hh * R.hw;
-                    const int zh = fdn_div20(r2, R.mg_hw);
-                    int qd = q0d + zd, qh = q0h + zh, qw = q0w + (r2 - zh * R.hw);
-                    bool ok = true;
-                    if (p.zero_mode) {
-                        ok = (unsigned)qd < (unsigned)p.ID && (unsigned)qh < (unsigned)p.IH && (unsigned)qw < (unsigned)p.IW;
-                    } else {
-                        qd = min(max(qd, 0), p.ID - 1);
-                        qh = min(max(qh, 0), p.IH - 1);
-                        qw = min(max(qw, 0), p.IW - 1);
-                    }
-                    if (ok) v[u] = *(const f32x4*)(xh + (in_n + ((size_t)qd * p.IH + qh) * p.IW + qw) * 64);
-                }
-            }
+            for (int u = 0; u < U; ++u)
+                if (u0 + u < UA) v[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, soff[u0 + u], 0, 0));
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int r = r0 + u * RPP + rsub;
-                if (r < rows_eff) *(f32x4*)(smem + r * LROW + (chunk << 4)) = v[u];
-            }
+            for (int u = 0; u < U; ++u)
+                if (u0 + u < UA && (u0 + u < nfull || (u0 + u == nfull && tail)))
+                    *(f32x4*)(smem + ((u0 + u) * RPP + rsub) * LROW + (chunk << 4)) = v[u];
         }
         __syncthreads();
 
@@ -549,6 +561,8 @@ FdnTile fdn_plan_tile(int N, int OD, int OH, int OW, int max_vox, int max_halo_r
 int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, const float* residual, float* y,
                          const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
                          int OW, int off, int zero_mode, int act, float alpha, hipStream_t s) {
+    // staged rows are addressed with 32-bit byte offsets from the sample's first voxel (256 B per voxel)
+    FDN_REQUIRE((long long)ID * IH * IW < (1ll << 24), "conv64: a sample of %dx%dx%d voxels exceeds the 32-bit row addressing", ID, IH, IW);
     Conv64Args a;
     a.x = x; a.wp = wpack; a.bias = bias; a.res = residual; a.y = y;
     a.fskip = fskip; a.fy = fy; a.fout = fout;
