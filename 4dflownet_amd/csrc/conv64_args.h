@@ -19,6 +19,8 @@ struct Conv64Region {
     int hh, hw;                 // staged box dims: th + (tb1-tb0), tw + (tc1-tc0)   (depth: td + (ta1-ta0))
     int rows;                   // staged rows
     unsigned mg_hhhw, mg_hw;    // magic divisors for staged-row decomposition
+    unsigned mg_thtw, mg_tw;    // ... for tile-row -> (d,h,w) (fp32 kernel)
+    unsigned mg_tpn_hi, mg_tpn_lo, mg_thw_hi, mg_thw_lo, mg_ntw_hi, mg_ntw_lo;   // 40-bit magics: block -> (n, td, th, tw)
     // bf16 kernel only: LDS image geometry.  Staged voxel (zd,zh,zw) lives in LDS row (zd*hh + zh)*hs + zw (hs >= hw,
     // hs = 4 mod 8 so that the two 4-row runs a ds_read_b128 lane group takes from rows zh, zh+1 fall on the same bank
     // rows), its two 16-B chunks swapped when ((zh >> swz_hs) + ((zw >> 2) & swz_wm)) & 1.

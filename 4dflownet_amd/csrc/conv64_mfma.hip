@@ -77,13 +77,15 @@ void conv64_mfma_kernel(Conv64Args p) {
     const Conv64Region R = p.reg[ri];
     const int ta0 = GEN ? R.ta0 : 0, ta1 = GEN ? R.ta1 : 2, tb0 = GEN ? R.tb0 : 0, tb1 = GEN ? R.tb1 : 2;
     const int tc0 = GEN ? R.tc0 : 0, tc1 = GEN ? R.tc1 : 2;
+    // tile coordinates by multiply-shift with host-made magics: runtime integer division costs ~20 VALU instructions, and
+    // on this part every one of them takes its cycles from the fp32 MFMA stream of the SIMD
     const int tiles_per_n = R.ntd * R.nth * R.ntw;
     int b = (int)blockIdx.x - R.first_block;
-    const int n = b / tiles_per_n;
+    const int n = fdn_udiv40(b, R.mg_tpn_hi, R.mg_tpn_lo);
     b -= n * tiles_per_n;
-    const int tdi = b / (R.nth * R.ntw);
+    const int tdi = fdn_udiv40(b, R.mg_thw_hi, R.mg_thw_lo);
     b -= tdi * (R.nth * R.ntw);
-    const int thi = b / R.ntw;
+    const int thi = fdn_udiv40(b, R.mg_ntw_hi, R.mg_ntw_lo);
     int* mtab = (int*)(smem + R.rows * LROW);          // output voxel index of each tile row, -1 if unused
     const int p0d = R.obd + tdi * R.td, p0h = R.obh + thi * R.th, p0w = R.obw + (b - thi * R.ntw) * R.tw;
 
@@ -94,9 +96,9 @@ void conv64_mfma_kernel(Conv64Args p) {
     for (int m = tid; m < C::MCAP; m += 256) {
         int g = -1;
         if (m < nv) {
-            const int md = m / thtw;
+            const int md = fdn_div20(m, R.mg_thtw);
             const int r2 = m - md * thtw;
-            const int mh = r2 / R.tw;
+            const int mh = fdn_div20(r2, R.mg_tw);
             const int pd = p0d + md, ph = p0h + mh, pw = p0w + (r2 - mh * R.tw);
             if (pd < R.obd + R.ebd && ph < R.obh + R.ebh && pw < R.obw + R.ebw) {
                 g = ((n * p.OD + pd) * p.OH + ph) * p.OW + pw;
@@ -117,9 +119,9 @@ void conv64_mfma_kernel(Conv64Args p) {
     for (int mi = 0; mi < MT; ++mi) {
         int m = (wave_m * MT + mi) * 32 + li;
         m = m < nv ? m : nv - 1;
-        const int md = m / thtw;
+        const int md = fdn_div20(m, R.mg_thtw);
         const int r2 = m - md * thtw;
-        const int mh = r2 / R.tw;
+        const int mh = fdn_div20(r2, R.mg_tw);
         row0[mi] = (md * R.hh + mh) * R.hw + (r2 - mh * R.tw);
     }
     int abase[MT];                                      // LDS byte offset of this lane's A fragment at tap (0,0,0), k-group 0
@@ -198,9 +200,8 @@ void conv64_mfma_kernel(Conv64Args p) {
         // ---- stage input box + halo, cin [sl*64/CS, (sl+1)*64/CS) ----
         const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(p.x + in_n * 64 + sl * (64 / CS)), 0, sample_bytes - sl * (256 / CS), 0x00020000);
-        // loads per thread issued before the first LDS write: the whole slice (one memory round trip) when the variant runs
-        // at 2 workgroups per CU (256-VGPR budget), 4 otherwise
-        constexpr int U = C::WG_PER_CU <= 2 ? UA : 4;
+        // all loads of the slice are issued before the first LDS write (one memory round trip)
+        constexpr int U = UA;
 #pragma unroll
         for (int u0 = 0; u0 < UA; u0 += U) {
             if (u0 * RPP >= rows_eff) break;
@@ -505,6 +506,11 @@ int launch_conv64(Conv64Args& a, const Box* boxes, int nbox, hipStream_t s) {
         r.rows = (t.td + (bx.ta1 - bx.ta0)) * r.hh * r.hw;
         r.mg_hhhw = fdn_magic20(r.hh * r.hw);
         r.mg_hw = fdn_magic20(r.hw);
+        r.mg_thtw = fdn_magic20(t.th * t.tw);
+        r.mg_tw = fdn_magic20(t.tw);
+        fdn_magic40(t.ntd * t.nth * t.ntw, &r.mg_tpn_hi, &r.mg_tpn_lo);
+        fdn_magic40(t.nth * t.ntw, &r.mg_thw_hi, &r.mg_thw_lo);
+        fdn_magic40(t.ntw, &r.mg_ntw_hi, &r.mg_ntw_lo);
         first += a.N * t.ntd * t.nth * t.ntw;
         if (r.rows > max_rows) max_rows = r.rows;
     }

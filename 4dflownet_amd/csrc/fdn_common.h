@@ -89,6 +89,15 @@ void fdn_set_error(const char* fmt, ...);
 // floor(r/d) for 0 <= r < 1024 and 1 <= d <= 1024, with magic = ceil(2^20/d).
 __host__ __device__ inline unsigned fdn_magic20(unsigned d) { return ((1u << 20) + d - 1) / d; }
 __device__ __forceinline__ int fdn_div20(int r, unsigned magic) { return (int)(((unsigned)r * magic) >> 20); }
+// floor(n/d) for n*d < 2^40 with M = ceil(2^40/d) = hi*2^32 + lo:  (n*M) >> 40 = (n*hi + mulhi(n, lo)) >> 8.
+// For wave-uniform n this is four scalar instructions.
+inline void fdn_magic40(unsigned d, unsigned* hi, unsigned* lo) {
+    const unsigned long long m = ((1ull << 40) + d - 1) / d;
+    *hi = (unsigned)(m >> 32); *lo = (unsigned)m;
+}
+__device__ __forceinline__ int fdn_udiv40(int n, unsigned hi, unsigned lo) {
+    return (int)(((unsigned)n * hi + __umulhi((unsigned)n, lo)) >> 8);
+}
 
 __device__ __forceinline__ float fdn_act(float z, int act, float alpha) {
     if (act == FDN_ACT_RELU) return z > 0.f ? z : 0.f;
