@@ -22,6 +22,7 @@ struct Wgrad64Args {
     float* partial;
     int N, D, H, W;
     int ntd, nth, ntw, ntiles, S;
+    unsigned bytes;              // size of x (= of dz) in bytes; < 4 GB (checked by the launcher)
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -100,21 +101,42 @@ __global__ __launch_bounds__(256, 2) void wgrad64_pipe_kernel(Wgrad64Args p) {
         }
     };
 
+    // Staged rows come in through buffer loads: the tensor is the buffer, the (sample, depth plane, tile origin) part of the
+    // address is a scalar offset and the row part a per-thread constant, so a tile whose halo box lies inside its plane costs
+    // NO vector ALU work (on this part every VALU instruction takes its cycles from the fp32 MFMA stream); only tiles on the
+    // plane border compute clamped per-thread offsets.  dz rows outside the volume read 0 through the range check.
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.dz, 0, p.bytes, 0x00020000);
+    unsigned xc[XP], zc[ZP];
+#pragma unroll
+    for (int u = 0; u < XP; ++u) xc[u] = (unsigned)((xh[u] * p.W + xw[u]) * 256 + c16 * 16);
+#pragma unroll
+    for (int u = 0; u < ZP; ++u) zc[u] = (unsigned)((zh[u] * p.W + zw[u]) * 256 + c16 * 16);
     f32x4 xv[XP], zv[ZP];
-    unsigned zok = 0;
+    auto bload = [&](__amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)vo, (int)so, 0));
+    };
     auto load_x = [&](int u) {                              // x row (edge clamp applied here) of the cursor tile
         const int qd = min(max(td + a - 1, 0), p.D - 1);
-        const char* plane = (const char*)p.x + ((size_t)(tn * p.D + qd) * p.H * p.W) * 256;
-        const int qh = min(max(th * TH + xh[u] - 1, 0), p.H - 1);
-        const int qw = min(max(tw * TW + xw[u] - 1, 0), p.W - 1);
-        xv[u] = *(const f32x4*)(plane + (unsigned)((qh * p.W + qw) * 256 + c16 * 16));
+        const unsigned plane = (unsigned)((tn * p.D + qd) * p.H * p.W) * 256u;
+        const int h0 = th * TH - 1, w0 = tw * TW - 1;
+        if (h0 >= 0 && h0 + XH <= p.H && w0 >= 0 && w0 + XW <= p.W) {
+            xv[u] = bload(xrs, xc[u], plane + (unsigned)((h0 * p.W + w0) * 256));
+        } else {
+            const int qh = min(max(h0 + xh[u], 0), p.H - 1);
+            const int qw = min(max(w0 + xw[u], 0), p.W - 1);
+            xv[u] = bload(xrs, (unsigned)((qh * p.W + qw) * 256 + c16 * 16), plane);
+        }
     };
-    auto load_z = [&](int u) {                              // dz row, zeroed at the LDS write if outside the volume
-        const char* plane = (const char*)p.dz + ((size_t)(tn * p.D + td) * p.H * p.W) * 256;
-        const int qh = th * TH + zh[u], qw = tw * TW + zw[u];
-        const bool ok = qh < p.H && qw < p.W;
-        zok = ok ? (zok | (1u << u)) : (zok & ~(1u << u));
-        zv[u] = *(const f32x4*)(plane + (unsigned)((min(qh, p.H - 1) * p.W + min(qw, p.W - 1)) * 256 + c16 * 16));
+    auto load_z = [&](int u) {                              // dz row, zero outside the volume
+        const unsigned plane = (unsigned)((tn * p.D + td) * p.H * p.W) * 256u;
+        const int h0 = th * TH, w0 = tw * TW;
+        if (h0 + TH <= p.H && w0 + TW <= p.W) {
+            zv[u] = bload(zrs, zc[u], plane + (unsigned)((h0 * p.W + w0) * 256));
+        } else {
+            const int qh = h0 + zh[u], qw = w0 + zw[u];
+            zv[u] = bload(zrs, qh < p.H && qw < p.W ? (unsigned)((qh * p.W + qw) * 256 + c16 * 16) : 0xffffffffu, plane);
+        }
     };
     auto write_x = [&](int u, char* buf) {
         const int r = u * 16 + rsub;
@@ -122,8 +144,7 @@ __global__ __launch_bounds__(256, 2) void wgrad64_pipe_kernel(Wgrad64Args p) {
     };
     auto write_z = [&](int u, char* buf) {
         const int r = u * 16 + rsub;
-        if ((u + 1) * 16 <= ZROWS || r < ZROWS)
-            *(f32x4*)(buf + XROWS * 256 + r * 256 + c16 * 16) = ((zok >> u) & 1) ? zv[u] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        if ((u + 1) * 16 <= ZROWS || r < ZROWS) *(f32x4*)(buf + XROWS * 256 + r * 256 + c16 * 16) = zv[u];
     };
 
     // ---- prologue: tile 0 -> buffer 0, tile 1 -> registers ----
@@ -236,6 +257,8 @@ int fdn_wgrad64_launch(const float* x, const float* dz, float* dw, void* ws, siz
     a.ntd = D; a.nth = (H + kTH - 1) / kTH; a.ntw = (W + kTW - 1) / kTW;
     a.ntiles = N * a.ntd * a.nth * a.ntw;
     a.S = wgrad64_splits(N, D, H, W);
+    FDN_REQUIRE((long long)N * D * H * W * 256 < (1ll << 32), "wgrad64: x of %dx%dx%dx%dx64 floats exceeds the 32-bit buffer addressing", N, D, H, W);
+    a.bytes = (unsigned)((long long)N * D * H * W * 256);
     const size_t lds = (size_t)3 * ((kTH + 2) * (kTW + 2) + kTH * kTW) * 256;
     static bool attr_set = false;
     if (!attr_set) {
