@@ -16,7 +16,8 @@ __global__ __launch_bounds__(64 * WAVES) void k(float* out, const float* in, int
     float av = a + threadIdx.x * 1e-6f, bv = b;
     const unsigned laddr = (threadIdx.x & 63) * 16;
     const f32x4* gp = (const f32x4*)in + (threadIdx.x & 63);
-    f32x4 r4[16]; float r1[16];
+    f32x4 r4[16]; float r1[16]; unsigned sc[8] = {0, 1, 2, 3, 4, 5, 6, 7}; unsigned va[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, 1 << 24, 0x00020000);
     for (int it = 0; it < iters; ++it) {
         acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[0], 0, 0, 0);
 #pragma unroll
@@ -25,15 +26,20 @@ __global__ __launch_bounds__(64 * WAVES) void k(float* out, const float* in, int
             if (KIND == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r4[q]) : "v"(laddr), "n"(q * 1024));
             if (KIND == 3) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(r4[q]) : "v"(gp), "n"(q * 1024 % 4096));
             if (KIND == 4) asm volatile("global_load_dword %0, %1, off offset:%2" : "=v"(r1[q]) : "v"(gp), "n"(q * 1024 % 4096));
+            if (KIND == 5) asm volatile("s_add_u32 %0, %0, 3" : "+s"(sc[q & 7]) :: "scc");
+            if (KIND == 6) asm volatile("s_mul_i32 %0, %0, 3" : "+s"(sc[q & 7]));
+            if (KIND == 7) { unsigned lo = laddr; asm volatile("" : "+v"(lo)); r4[q & 15] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lo + (q * 256 % 4096), 0, 0)); }
+            if (KIND == 8) asm volatile("v_add_u32 %0, %0, %1" : "+v"(va[q & 7]) : "v"(laddr));
         }
 #pragma unroll
         for (int u = 1; u < 15; ++u) acc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[u & 3], 0, 0, 0);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
 #pragma unroll
-        for (int q = 0; q < K; ++q) { if (KIND == 1 || KIND == 4) asm volatile("" :: "v"(r1[q])); else asm volatile("" :: "v"(r4[q])); }
+        for (int q = 0; q < K && q < 16; ++q) { if (KIND == 1 || KIND == 4) asm volatile("" :: "v"(r1[q])); else if (KIND == 2 || KIND == 3 || KIND == 7) asm volatile("" :: "v"(r4[q])); }
         acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[3], 0, 0, 0);
     }
     float s = 0.f;
+    for (int i = 0; i < 8; ++i) s += sc[i] + va[i];
     for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
     out[blockIdx.x * 64 * WAVES + threadIdx.x] = s;
 }
@@ -61,9 +67,11 @@ void table(float* d, float* in) {
 #define ROW(KIND, K, name) { float t = run<KIND, K, WAVES>(d, in, IT); printf("  + %2d %-20s %.3f ms  -> %.1f cycles per load\n", K, name, t, (t / base - 1.0) * cyc / K / (WAVES / 4)); }
     ROW(1, 8, "ds_read_b32") ROW(1, 16, "ds_read_b32") ROW(2, 4, "ds_read_b128") ROW(2, 8, "ds_read_b128")
     ROW(4, 8, "global_load_dword") ROW(3, 4, "global_load_dwordx4") ROW(3, 8, "global_load_dwordx4")
+    ROW(7, 4, "buffer_load_dwordx4") ROW(7, 8, "buffer_load_dwordx4") ROW(5, 32, "s_add_u32") ROW(5, 64, "s_add_u32") ROW(6, 32, "s_mul_i32") ROW(8, 32, "v_add_u32") ROW(8, 64, "v_add_u32")
 }
 
 int main() {
+    setvbuf(stdout, nullptr, _IONBF, 0);
     float *d, *in; hipMalloc(&d, 1 << 24); hipMalloc(&in, 1 << 24); hipMemset(in, 0, 1 << 24);
     table<4>(d, in);
     table<8>(d, in);
