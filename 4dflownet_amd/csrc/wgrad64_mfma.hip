@@ -29,7 +29,7 @@ struct Wgrad64Args {
 // Tile pipeline: tiles of 1 x TH x TW voxels go through THREE LDS buffers, so that nothing but one barrier per tile
 // interrupts the MFMA stream of a wave.  While tile k is contracted out of buffer k%3:
 //   pairs 0..2   the registers holding tile k+1 (loaded during tile k-1) are written to buffer (k+1)%3,
-//   pairs 3..9   the rows of tile k+2 are loaded into those registers (address arithmetic in the MFMA shadow),
+//   pairs 3..10  the rows of tile k+2 are loaded into those registers (buffer loads, scalar tile offsets),
 //   pair  8      one barrier: every wave has written its part of tile k+1 (and finished tile k-1, so buffer (k+2)%3 may be
 //                overwritten during tile k+1) -- with two buffers a wave running at twice the speed of a sibling (its SIMD
 //                partner idle) could overwrite rows the sibling still reads,
