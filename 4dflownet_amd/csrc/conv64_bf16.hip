@@ -92,12 +92,14 @@ __global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
     const int na = GEN ? R.ta1 - R.ta0 + 1 : 3;          // depth taps: 3, or 1 on the d-face slabs
     const int nb = GEN ? R.tb1 - R.tb0 + 1 : 3, nc = GEN ? R.tc1 - R.tc0 + 1 : 3;
     const int tiles_per_n = R.ntd * R.nth * R.ntw;
+    // (multiply-shift with host-made magics: a runtime integer division is ~25 VALU instructions, and everything outside the K
+    // loop of this kernel is issue-bound work no co-resident wave can hide -- DESIGN.md, machine model)
     int b = bid - R.first_block;
-    const int n = b / tiles_per_n;
+    const int n = fdn_udiv40(b, R.mg_tpn_hi, R.mg_tpn_lo);
     b -= n * tiles_per_n;
-    const int tdi = b / (R.nth * R.ntw);
+    const int tdi = fdn_udiv40(b, R.mg_thw_hi, R.mg_thw_lo);
     b -= tdi * (R.nth * R.ntw);
-    const int thi = b / R.ntw;
+    const int thi = fdn_udiv40(b, R.mg_ntw_hi, R.mg_ntw_lo);
     const int bufB = R.lrows * ROWB;
     int* mtab = (int*)(smem + 2 * bufB);
     const int p0d = R.obd + tdi * R.td, p0h = R.obh + thi * R.th, p0w = R.obw + (b - thi * R.ntw) * R.tw;
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
         int g = -1;
         const int md = m >> 6, pr = m & 63;
         if (md < R.td && pr < prn) {
-            const int mh = pr / R.tw;
+            const int mh = fdn_div20(pr, R.mg_tw);
             const int pd = p0d + md, ph = p0h + mh, pw = p0w + (pr - mh * R.tw);
             if (pd < R.obd + R.ebd && ph < R.obh + R.ebh && pw < R.obw + R.ebw) {
                 g = ((n * p.OD + pd) * p.OH + ph) * p.OW + pw;
@@ -187,18 +189,29 @@ __global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
     {
         int pr = wm * 32 + j;
         pr = pr < prn ? pr : prn - 1;
-        mh0 = pr / R.tw;
+        mh0 = fdn_div20(pr, R.mg_tw);
         mw0 = pr - mh0 * R.tw;
     }
     const int lrow0 = mh0 * R.hs + mw0;
     const int pstrideB = R.hh * R.hs * ROWB;              // LDS bytes per staged plane
     const int npl = R.td + na - 1;                        // staged planes
 
+    // accumulators start from the bias (lane (j,kh) holds cout [wn*32 + kh*16, +16) of its voxels): no add in the epilogue
     f32x16 acc[MT];
+    {
+        f32x16 bv16;
 #pragma unroll
-    for (int mi = 0; mi < MT; ++mi)
+        for (int r = 0; r < 16; ++r) bv16[r] = 0.f;
+        if (p.bias) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+            for (int r = 0; r < 16; r += 4) {
+                const f32x4 t = *(const f32x4*)(p.bias + wn * 32 + kh * 16 + r);
+                bv16[r] = t.x; bv16[r + 1] = t.y; bv16[r + 2] = t.z; bv16[r + 3] = t.w;
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) acc[mi] = bv16;
+    }
 
     // one (b,c) step on buffer `buf`: FULL = every plane and depth tap present (no predicates)
     auto kstep = [&](auto fullc, const char* buf, int db, int dc, const u32x4 (&wsrc)[3]) {
@@ -275,16 +288,7 @@ __global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
     // ---- epilogue: lane (j,kh) holds cout [wn*32 + kh*16, +16) of the voxel at position wm*32 + j of every plane ----
     const float slope = p.act == FDN_ACT_RELU ? 0.f : (p.act == FDN_ACT_LEAKY ? p.alpha : 1.f);
     const int cofs = wn * 32 + kh * 16;
-    float bv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) bv[r] = 0.f;
-    if (p.bias) {
-#pragma unroll
-        for (int r = 0; r < 16; r += 4) {
-            const f32x4 t = *(const f32x4*)(p.bias + cofs + r);
-            bv[r] = t.x; bv[r + 1] = t.y; bv[r + 2] = t.z; bv[r + 3] = t.w;
-        }
-    }
+    const bool act_max = slope <= 1.f;          // act(t) = max(t, slope*t) for slope in [0,1] (relu, leaky, none): 2 VALU, not 3
 #pragma unroll
     for (int md = 0; md < MT; ++md) {
         const int g = mtab[md * 64 + wm * 32 + j];
@@ -309,14 +313,21 @@ __global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
             }
         } else {
             const size_t o = (size_t)g * 64 + cofs;
-            float rv[16];
+            if (p.res) {
+                float rv[16];
+                ld_bf16x16(p.res + o, rv);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) rv[r] = 0.f;
-            if (p.res) ld_bf16x16(p.res + o, rv);
+                for (int r = 0; r < 16; ++r) z[r] = acc[md][r] + rv[r];
+            } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float t = acc[md][r] + bv[r] + rv[r];
-                z[r] = t > 0.f ? t : slope * t;
+                for (int r = 0; r < 16; ++r) z[r] = acc[md][r];
+            }
+            if (act_max) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = fmaxf(z[r], slope * z[r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = z[r] > 0.f ? z[r] : slope * z[r];
             }
             st_bf16x16(p.y + o, z);
         }
@@ -495,6 +506,11 @@ int launch_bf16(Conv64BfArgs& a, const Box* boxes, int nbox, hipStream_t s) {
         r.lrows = (t.td + (bx.ta1 - bx.ta0)) * r.hh * r.hs;
         r.mg_hhhw = fdn_magic20(r.hh * r.hw);
         r.mg_hw = fdn_magic20(r.hw);
+        r.mg_thtw = fdn_magic20(t.th * t.tw);
+        r.mg_tw = fdn_magic20(t.tw);
+        fdn_magic40(t.ntd * t.nth * t.ntw, &r.mg_tpn_hi, &r.mg_tpn_lo);
+        fdn_magic40(t.nth * t.ntw, &r.mg_thw_hi, &r.mg_thw_lo);
+        fdn_magic40(t.ntw, &r.mg_ntw_hi, &r.mg_ntw_lo);
         // swizzle mode by tile shape: rows of >= 4 h values per 32 positions -> by zh; one long w row -> by w quad;
         // a column (tw <= 2) -> by h quad
         r.swz_hs = t.tw <= 2 ? 2 : 0;
