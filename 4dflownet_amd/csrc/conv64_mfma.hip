@@ -128,6 +128,10 @@ void conv64_mfma_kernel(Conv64Args p) {
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) abase[mi] = row0[mi] * LROW + kh * 16;
 
+    // The MFMAs run as D[cout][voxel] (the weights are the row operand) and the packed stream permutes the cout rows so that
+    // the 16 accumulator registers of lane (li, kh) are 16 CONSECUTIVE output channels of voxel li: cout = 32 nn + 16 kh + r
+    // (+ 32 NT wave_n).
+    const int cofs = wave_n * (NT * 32) + kh * 16;
     f32x16 acc[MT][NT];
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
@@ -242,7 +246,7 @@ void conv64_mfma_kernel(Conv64Args p) {
                     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
                         for (int nn = 0; nn < NT; ++nn)
-                            acc[mi][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[g][mi][0], B[g][nn][0], acc[mi][nn], 0, 0, 0);
+                            acc[mi][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(B[g][nn][0], A[g][mi][0], acc[mi][nn], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                     if (g == 0) {
                         ldb(KG - 1, wsoff(sl, tap_cur, KG - 1));
@@ -258,7 +262,7 @@ void conv64_mfma_kernel(Conv64Args p) {
                         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
                             for (int nn = 0; nn < NT; ++nn)
-                                acc[mi][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[g][mi][s], B[g][nn][s], acc[mi][nn], 0, 0, 0);
+                                acc[mi][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(B[g][nn][s], A[g][mi][s], acc[mi][nn], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
@@ -277,87 +281,88 @@ void conv64_mfma_kernel(Conv64Args p) {
     }
     if (p.dbg & 8) return;
 
-    // ---- epilogue: 128-B row segments per half-wave.  Branch-free activation: act(z) = z > 0 ? z : slope*z with
-    // slope 1 (none) / 0 (relu) / alpha (leaky).  Rows are handled RB at a time; the uniform "is there a residual / skip /
-    // mask tensor" tests sit OUTSIDE the per-row loops so each batch's loads are issued back to back (one latency). ----
+    // ---- epilogue: every lane owns ONE output voxel per M tile (see the accumulator layout above): one index lookup, 16-B
+    // vector loads / stores, and the activation as max(z, slope*z) for slope in [0,1] (relu / leaky / none).  Everything
+    // here is paid in MFMA cycles (machine model), so it is kept to ~3 VALU instructions per element. ----
     const float slope = p.act == FDN_ACT_RELU ? 0.f : (p.act == FDN_ACT_LEAKY ? p.alpha : 1.f);
-    const int cofs = wave_n * (NT * 32) + li;
-    constexpr int RB = C::WG_PER_CU <= 2 ? 16 : (C::WG_PER_CU == 3 ? 8 : 4);    // batch size by VGPR budget
-    float bvs[NT];
-#pragma unroll
-    for (int nn = 0; nn < NT; ++nn) bvs[nn] = 0.f;
-    if (p.bias) {
-#pragma unroll
-        for (int nn = 0; nn < NT; ++nn) bvs[nn] = p.bias[cofs + nn * 32];
-    }
+    const bool act_max = slope <= 1.f;
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
+        const int g = mtab[(wave_m * MT + mi) * 32 + li];
+        if (g < 0) continue;
+        if (p.fout) {
+            // dgrad with fused fold: tagged voxels (strictly inside the volume, exactly one contribution) are finished
+            // here into dz_prev; everything else goes to the padded scratch for the border fold.
+            const size_t o = (size_t)(g & ~(1 << 30)) * 64 + cofs;
+            if (g & (1 << 30)) {
+                f32x4 sk[NT][4], ym[NT][4];
 #pragma unroll
-        for (int r0 = 0; r0 < 16; r0 += RB) {
-            int g[RB];
+                for (int nn = 0; nn < NT; ++nn)
 #pragma unroll
-            for (int j = 0; j < RB; ++j) g[j] = mtab[(wave_m * MT + mi) * 32 + ((r0 + j) & 3) + 8 * ((r0 + j) >> 2) + 4 * kh];
-            if (p.fout) {
-                // dgrad with fused fold: tagged rows (voxels strictly inside the volume, exactly one contribution)
-                // are finished here into dz_prev; everything else goes to the padded scratch for the border fold.
-                float sk[RB][NT], ym[RB][NT];
-                size_t oi[RB];
-#pragma unroll
-                for (int j = 0; j < RB; ++j) {
-                    const bool inner = g[j] >= 0 && (g[j] & (1 << 30));
-                    oi[j] = (size_t)(inner ? (g[j] & ~(1 << 30)) : 0) * 64 + cofs;
-#pragma unroll
-                    for (int nn = 0; nn < NT; ++nn) { sk[j][nn] = 0.f; ym[j][nn] = 1.f; }
-                }
-                if (p.fskip) {
-#pragma unroll
-                    for (int j = 0; j < RB; ++j)
-#pragma unroll
-                        for (int nn = 0; nn < NT; ++nn) sk[j][nn] = p.fskip[oi[j] + nn * 32];
-                }
-                if (p.fy) {
-#pragma unroll
-                    for (int j = 0; j < RB; ++j)
-#pragma unroll
-                        for (int nn = 0; nn < NT; ++nn) ym[j][nn] = p.fy[oi[j] + nn * 32];
-                }
-#pragma unroll
-                for (int j = 0; j < RB; ++j) {
-                    if (g[j] < 0) continue;
-                    const bool inner = g[j] & (1 << 30);
-                    const size_t o = (size_t)(g[j] & ~(1 << 30)) * 64 + cofs;
-#pragma unroll
-                    for (int nn = 0; nn < NT; ++nn) {
-                        const float a = acc[mi][nn][r0 + j];
-                        if (inner) p.fout[o + nn * 32] = (a + sk[j][nn]) * (ym[j][nn] > 0.f ? 1.f : slope);
-                        else p.y[o + nn * 32] = a;
+                    for (int q = 0; q < 4; ++q) {
+                        sk[nn][q] = p.fskip ? *(const f32x4*)(p.fskip + o + nn * 32 + q * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                        ym[nn][q] = p.fy ? *(const f32x4*)(p.fy + o + nn * 32 + q * 4) : (f32x4){1.f, 1.f, 1.f, 1.f};
                     }
-                }
+#pragma unroll
+                for (int nn = 0; nn < NT; ++nn)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            v[e] = (acc[mi][nn][q * 4 + e] + sk[nn][q][e]) * (ym[nn][q][e] > 0.f ? 1.f : slope);
+                        *(f32x4*)(p.fout + o + nn * 32 + q * 4) = v;
+                    }
             } else {
-                float rv[RB][NT];
 #pragma unroll
-                for (int j = 0; j < RB; ++j)
+                for (int nn = 0; nn < NT; ++nn)
 #pragma unroll
-                    for (int nn = 0; nn < NT; ++nn) rv[j][nn] = 0.f;
-                if (p.res) {
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v;
 #pragma unroll
-                    for (int j = 0; j < RB; ++j) {
-                        const size_t o = (size_t)(g[j] >= 0 ? g[j] : 0) * 64 + cofs;
-#pragma unroll
-                        for (int nn = 0; nn < NT; ++nn) rv[j][nn] = p.res[o + nn * 32];
+                        for (int e = 0; e < 4; ++e) v[e] = acc[mi][nn][q * 4 + e];
+                        *(f32x4*)(p.y + o + nn * 32 + q * 4) = v;
                     }
-                }
-#pragma unroll
-                for (int j = 0; j < RB; ++j) {
-                    if (g[j] < 0) continue;
-                    const size_t o = (size_t)g[j] * 64 + cofs;
-#pragma unroll
-                    for (int nn = 0; nn < NT; ++nn) {
-                        const float z = acc[mi][nn][r0 + j] + bvs[nn] + rv[j][nn];
-                        p.y[o + nn * 32] = z > 0.f ? z : slope * z;
-                    }
-                }
             }
+        } else {
+            const size_t o = (size_t)g * 64 + cofs;
+            f32x4 z[NT][4];
+            if (p.res) {
+#pragma unroll
+                for (int nn = 0; nn < NT; ++nn)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) z[nn][q] = *(const f32x4*)(p.res + o + nn * 32 + q * 4);
+#pragma unroll
+                for (int nn = 0; nn < NT; ++nn)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) z[nn][q][e] += acc[mi][nn][q * 4 + e];
+            } else {
+#pragma unroll
+                for (int nn = 0; nn < NT; ++nn)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) z[nn][q][e] = acc[mi][nn][q * 4 + e];
+            }
+            if (p.bias) {             // 4 of the 30 layers; dword loads: the bias lives in the flat parameter buffer, 4-B aligned
+#pragma unroll
+                for (int nn = 0; nn < NT; ++nn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z[nn][r >> 2][r & 3] += p.bias[cofs + nn * 32 + r];
+            }
+#pragma unroll
+            for (int nn = 0; nn < NT; ++nn)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = z[nn][q][e];
+                        z[nn][q][e] = act_max ? fmaxf(t, slope * t) : (t > 0.f ? t : slope * t);
+                    }
+                    *(f32x4*)(p.y + o + nn * 32 + q * 4) = z[nn][q];
+                }
         }
     }
 }
@@ -418,9 +423,12 @@ __global__ __launch_bounds__(256) void fold_halo_border_kernel(const float* __re
 }
 
 // --------------------------------------------------------------------------------------------
-// weight packing: Keras (27,64,64)[tap][cin][cout] -> operand streams [half][tap][g][kh][cout][s]
-//   fwd  : cin = 32*half + 8g + 4kh + s, same tap
-//   dgrad: contraction runs over cout of the layer, taps flipped: stream[..][ci][s] = w[26-tap][ci][co = 32*half+8g+4kh+s]
+// weight packing: Keras (27,64,64)[tap][cin][cout] -> operand streams [half][tap][g][kh][row j][s]
+//   row j of a 32-row tile is MFMA row i = j & 31, which lands in accumulator register r = (i&3) + 4(i>>3) of lane half
+//   kh' = (i>>2)&1; the stream stores output channel c(j) = (j & 32) + 16 kh' + r there, so that a lane's 16 registers are
+//   16 consecutive channels (see the kernel)
+//   fwd  : cin = 32*half + 8g + 4kh + s, same tap, cout = c(j)
+//   dgrad: contraction runs over cout of the layer, taps flipped: stream[..][j][s] = w[26-tap][ci = c(j)][co = 32*half+8g+4kh+s]
 // --------------------------------------------------------------------------------------------
 __global__ void pack_conv64_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wd) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over 27*64*64 packed elements
@@ -433,8 +441,9 @@ __global__ void pack_conv64_kernel(const float* __restrict__ w, float* __restric
     const int half = rest / 27;
     const int tap = rest - half * 27;
     const int k = half * 32 + g * 8 + kh * 4 + s;
-    if (wf) wf[idx] = w[(tap * 64 + k) * 64 + j];
-    if (wd) wd[idx] = w[((26 - tap) * 64 + j) * 64 + k];
+    const int cj = (j & 32) + 16 * ((j >> 2) & 1) + (j & 3) + 4 * ((j & 31) >> 3);
+    if (wf) wf[idx] = w[(tap * 64 + k) * 64 + cj];
+    if (wd) wd[idx] = w[((26 - tap) * 64 + cj) * 64 + k];
 }
 
 extern "C" int fdn_pack_conv64_weights(const float* w, float* wp_fwd, float* wp_dgrad, void* stream) {
