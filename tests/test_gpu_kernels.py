@@ -105,7 +105,7 @@ def test_conv64_dgrad_fused_fold(ops, fdn, shape, layout):
         fdn._lib.load().fdn_debug_set_conv64_shell_slabs(1)
 
 
-@pytest.mark.parametrize("shape", SHAPES + [(2, 16, 16, 16)])
+@pytest.mark.parametrize("shape", SHAPES + [(2, 16, 16, 16), (1, 1, 1, 1), (1, 2, 3, 1), (1, 3, 20, 33), (5, 9, 8, 24)])
 def test_conv64_wgrad(ops, shape):
     rng = np.random.default_rng(3)
     N, D, H, W = shape
