@@ -192,7 +192,7 @@ void conv64_mfma_kernel(Conv64Args p) {
             qh = min(max(qh, 0), p.IH - 1);
             qw = min(max(qw, 0), p.IW - 1);
         }
-        soff[u] = ok ? (unsigned)(((qd * p.IH + qh) * p.IW + qw) * 256 + chunk * 16) : 0xffffffffu;
+        soff[u] = ok ? (unsigned)((qd * p.IH + qh) * p.IW + qw) * 256u + (unsigned)(chunk * 16) : 0xffffffffu;
     }
     const int nfull = rows_eff / RPP;                       // passes in which every thread has a row
     const bool tail = rsub < rows_eff - nfull * RPP;        // this thread has a row in the last, partial pass
