@@ -41,11 +41,49 @@ def init_from_env(backend=None):
     return rk, ws, lrk
 
 
+def _host_staged():
+    """True when device tensors have to travel through host memory: the process group is gloo (CPU tests, and the
+    single-GPU test harness that runs two ranks on ONE device, where RCCL refuses duplicate GPUs)."""
+    return dist.get_backend() == "gloo"
+
+
 def allreduce_sum_(flat):
-    """In-place SUM all-reduce of one flat buffer (the 13.4 MB gradient vector at cfg2)."""
+    """In-place SUM all-reduce of one flat buffer (the 13.4 MB gradient vector at cfg2).  nccl (= RCCL): straight on
+    the device buffer over xGMI.  gloo: device tensors are staged through host memory."""
     if is_dist() and world_size() > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if flat.is_cuda and _host_staged():
+            h = flat.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            flat.copy_(h)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
+
+
+def all_gather_equal(t):
+    """all_gather of equally shaped tensors -> list of world tensors on t's device (host-staged under gloo)."""
+    if not is_dist() or world_size() == 1:
+        return [t]
+    if t.is_cuda and _host_staged():
+        h = t.cpu()
+        out = [torch.empty_like(h) for _ in range(world_size())]
+        dist.all_gather(out, h)
+        return [o.to(t.device) for o in out]
+    out = [torch.empty_like(t) for _ in range(world_size())]
+    dist.all_gather(out, t)
+    return out
+
+
+def allreduce_sum_host(values, op="sum"):
+    """SUM (or "max") all-reduce of a few host scalars (epoch metrics: totals and counts; bench: step time).
+    Returns a list of floats."""
+    if not is_dist() or world_size() == 1:
+        return [float(v) for v in values]
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64)
+    if not _host_staged():
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
+    return t.cpu().tolist()
 
 
 def global_batch_size(local_b, device=None):

@@ -44,8 +44,7 @@ def predict_patches(network, velocities, magnitudes, batch_size):
     if world > 1:
         pad = torch.zeros((per, S, S, S, 3), device=network.device)
         pad[:mine.shape[0]] = mine
-        gathered = [torch.empty_like(pad) for _ in range(world)]
-        torch.distributed.all_gather(gathered, pad)
+        gathered = parallel.all_gather_equal(pad)
         mine = torch.cat([g[:max(0, min((r + 1) * per, n) - min(r * per, n))] for r, g in enumerate(gathered)], 0)
     return mine.cpu().numpy().astype(np.float64)
 

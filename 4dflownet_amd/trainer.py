@@ -46,6 +46,11 @@ class Mean:
     def result(self):
         return float(self._total.item()) / self._count if self._count else 0.0
 
+    def result_global(self):
+        """Mean over every rank's elements (collective: every rank must call it).  Single process == result()."""
+        total, count = parallel.allreduce_sum_host([float(self._total.item()), float(self._count)])
+        return total / count if count else 0.0
+
 
 class _Optimizer:
     """Keras-Adam state on one flat buffer.  `weights` mirrors optimizer.weights = [iterations, m..., v...]."""
@@ -142,6 +147,8 @@ class TrainerController:
     def test_step(self, data_pairs):
         """TrainerController.py:227-239: forward + metrics, no L2, no update."""
         inputs, hires, venc, mask = self._unpack(data_pairs)
+        if inputs[0].shape[0] == 0:             # ragged tail on this rank (data parallel): nothing to evaluate
+            return None
         pred = self.model.forward(inputs, training=False)
         self.calculate_and_update_metrics(hires, pred, mask, 'val', False)
         return pred
@@ -210,7 +217,9 @@ class TrainerController:
                     print("\rEpoch %d Validation batch %d/%d | loss: %.5f (%.1f %%) - %.1f secs" % (
                         epoch + 1, i + 1, total_batch_val, self.loss_metrics['val_loss'].result(),
                         self.loss_metrics['val_accuracy'].result(), time.time() - start_loop), end='')
-            res = dict((k, v.result()) for k, v in self.loss_metrics.items())
+            # data parallel: every rank saw a shard of each global batch -> combine (total, count) over ranks, so
+            # loss.csv and the best-model decision do not depend on the world size
+            res = dict((k, v.result_global()) for k, v in self.loss_metrics.items())
             message = "\rEpoch %d Train loss: %.5f (%.1f %%), Val loss: %.5f (%.1f %%) - %.1f secs" % (
                 epoch + 1, res['train_loss'], res['train_accuracy'], res['val_loss'], res['val_accuracy'],
                 time.time() - start_loop)

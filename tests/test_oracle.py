@@ -7,55 +7,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import flownet_oracle as O
-
-
-def t_conv(x, w, b=None):
-    """torch: replicate pad + valid conv, NDHWC in/out."""
-    k = w.shape[0]
-    p = (k - 1) // 2
-    xt = x.permute(0, 4, 1, 2, 3)
-    if p:
-        xt = F.pad(xt, (p,) * 6, mode="replicate")
-    wt = w.permute(4, 3, 0, 1, 2)
-    y = F.conv3d(xt, wt, b)
-    return y.permute(0, 2, 3, 4, 1)
-
-
-def t_forward(params, inputs, R, LB, HB):
-    u, v, w, mu, mv, mw = inputs
-    speed = (u ** 2 + v ** 2 + w ** 2) ** 0.5
-    mag = (mu ** 2 + mv ** 2 + mw ** 2) ** 0.5
-    pcmr = mag * speed
-    phase = torch.cat([u, v, w], -1)
-    pc = torch.cat([pcmr, mag, speed], -1)
-    P = params
-    pc = F.relu(t_conv(pc, *P[0])); pc = F.relu(t_conv(pc, *P[1]))
-    ph = F.relu(t_conv(phase, *P[2])); ph = F.relu(t_conv(ph, *P[3]))
-    x = F.relu(t_conv(torch.cat([ph, pc], -1), *P[4]))
-    x = F.relu(t_conv(x, *P[5]))
-    li = 6
-    for i in range(LB + HB):
-        if i == LB and R > 1:
-            x = F.interpolate(x.permute(0, 4, 1, 2, 3), scale_factor=R, mode="trilinear", align_corners=True).permute(0, 2, 3, 4, 1)
-        h = F.leaky_relu(t_conv(x, P[li][0]), 0.2)
-        x = F.leaky_relu(x + t_conv(h, P[li + 1][0]), 0.2)
-        li += 2
-    if HB == 0 and R > 1:
-        x = F.interpolate(x.permute(0, 4, 1, 2, 3), scale_factor=R, mode="trilinear", align_corners=True).permute(0, 2, 3, 4, 1)
-    outs = []
-    for _ in range(3):
-        g = F.relu(t_conv(x, *P[li]))
-        outs.append(t_conv(g, *P[li + 1]))
-        li += 2
-    return torch.cat(outs, -1)
-
-
-def t_loss(pred, hires, mask):
-    mse = ((pred - hires) ** 2).sum(-1)
-    nf = (mask < 0.5).to(pred.dtype)
-    fluid = (mse * mask).sum((1, 2, 3)) / (mask.sum((1, 2, 3)) + 1)
-    nonfluid = (mse * nf).sum((1, 2, 3)) / (nf.sum((1, 2, 3)) + 1)
-    return fluid + nonfluid
+from oracle.torch_cpu import t_forward, t_loss
 
 
 def _rand_params(LB, HB, seed=0):

@@ -50,3 +50,26 @@ def test_all_rotations_and_coverage_budget(tmp_path):
     one = pi.generate_patch_index(DATA, "example_data.h5", "example_data_HR.h5", str(tmp_path / "o.csv"), patch_size=16,
                                   n_patch=2, minimum_coverage=1.1, n_empty_patch_allowed=1, seed=1)
     assert len(one) == 2
+
+
+def test_pinned_to_reference_generator(tmp_path):
+    """byte-for-byte the CSV the reference's PatchData.generate_random_patches writes after random.seed(s)
+    (tests/golden/patch_index_golden.json, produced by tests/golden/make_golden_patch_index.py importing
+    /root/reference/src/prepare_data/PatchData.py): acceptance / skip / not_found > 100 state machine, empty-patch budget,
+    all-rotation expansion, the single random rotation, and the 3-decimal coverage rounding (PatchData.py:12-68,97-102)."""
+    import json
+    gold = json.load(open(os.path.join(HERE, "golden", "patch_index_golden.json")))
+    assert len(gold["cases"]) >= 8
+    with h5io.H5File(os.path.join(DATA, gold["lr_file"])) as f:
+        mask = f["mask"].read()[0]
+    for i, case in enumerate(gold["cases"]):
+        p = case["params"]
+        out = str(tmp_path / ("g%d.csv" % i))
+        rows = pi.generate_patch_index(DATA, gold["lr_file"], gold["hr_file"], out, patch_size=p["patch_size"], n_patch=p["n_patch"],
+                                       n_empty_patch_allowed=p["n_empty_patch_allowed"], all_rotation=p["all_rotation"],
+                                       mask_threshold=p["mask_threshold"], minimum_coverage=p["minimum_coverage"], seed=p["seed"])
+        assert open(out, newline="").read() == case["csv"], p
+        assert len(rows) == case["csv"].count("\n") - 1
+        bm = (mask >= p["mask_threshold"]) * 1
+        for c in case["coverage"]:
+            assert pi.patch_coverage(bm, tuple(c["start"]), p["patch_size"]) == c["coverage"]
