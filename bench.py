@@ -3,15 +3,23 @@ gradient all-reduce + Adam) at the paper-default configuration (BASELINE.json co
 patch 24, res x2, per-GPU batch 8, 8 low-res + 4 hi-res ResBlocks, fp32, synthetic inputs resident in HBM.
 
     python bench.py --gpus N --steps K --warmup W
-(N > 1: launched by torch.distributed.run, one rank per GPU, RCCL sum-all-reduce of the flat gradient.)
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the 64->64 3x3x3 MFMA conv, shared by
-forward and dgrad), with its launch durations measured live by HIP events on the launch stream inside the
-timed region; `cpu_baseline` times the CPU oracle (numpy restatement, kind "port") on a bounded sample."""
+N > 1: one rank per GPU, RCCL sum-all-reduce of the flat gradient.  Either launched by torch.distributed.run (RANK /
+WORLD_SIZE in the environment) or -- when those are absent -- bench.py re-executes itself under torch.distributed.run
+with N ranks.  Asking for more ranks than GPUs is a hard error (unless --oversubscribe, a launcher self-test that puts
+several ranks on one device over gloo and marks the line as such).
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the 64->64 3x3x3 MFMA conv, shared by forward and
+dgrad), `roofline_wgrad` for the second one (the 64->64 weight-gradient kernel); both from launch durations measured
+live by HIP events on the launch stream inside the timed region.  At N=1, after the timed region: `cpu_baseline` (the same
+train step on the host cores: torch-CPU/oneDNN, plus the numpy oracle as a second figure) and `secondary` (a loader-fed
+cfg2 run with the on-device input pipeline inside the timed loop, and a short cfg4 bf16 run)."""
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,7 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
-PEAK_BF16_MFMA_TFLOPS = 2516.6       # dense bf16: 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz (tools/mfma_peak_bf16.hip sustains 1895)
+PEAK_BF16_MFMA_TFLOPS = 2516.6       # dense bf16: 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz
 FLOP_PER_VOXEL_CONV64 = 2.0 * 27 * 64 * 64   # 3.0576 GFLOP per 24^3 patch = 221 184 FLOP/voxel
 
 
@@ -40,86 +48,238 @@ def synthetic_batch(B, P, R, seed, device):
     return (u, v, w, mu, mv, mw, uh, vh, wh, venc, mask)
 
 
-class ConvTimer:
-    """Brackets every 64->64 MFMA conv launch (forward and dgrad) with HIP events on the launch stream."""
+class LaunchTimer:
+    """Brackets every 64->64 3x3x3 launch (forward, dgrad, wgrad) with HIP events on the launch stream (torch's current
+    stream is the stream handed through the C-ABI)."""
 
     def __init__(self, ops):
         self.ops = ops
-        self.records = []
+        self.records = {"conv": [], "wgrad": []}
         self.enabled = False
-        self._fwd, self._dgrad, self._dgrad_fused = ops.conv3d_fwd, getattr(ops, "conv3d_dgrad", None), ops.conv3d_dgrad_fused
+        self._orig = {}
+
+    def _wrap(self, name, kind, vox_of, is64):
+        orig = getattr(self.ops, name, None)
+        if orig is None:
+            return
+        self._orig[name] = orig
+        rec = self.records[kind]
+
+        def f(*a, **k):
+            if not self.enabled or not is64(*a, **k):
+                return orig(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); out = orig(*a, **k); e1.record()
+            rec.append((vox_of(*a, **k), e0, e1))
+            return out
+        setattr(self.ops, name, f)
 
     def install(self):
-        ops, rec = self.ops, self.records
+        vox = lambda t: t.shape[0] * t.shape[1] * t.shape[2] * t.shape[3]
+        self._wrap("conv3d_fwd", "conv", lambda x, w, *a, **k: vox(x), lambda x, w, *a, **k: tuple(w.shape) == (3, 3, 3, 64, 64))
+        self._wrap("conv3d_dgrad_fused", "conv", lambda dz, *a, **k: vox(dz), lambda *a, **k: True)
+        self._wrap("conv3d_wgrad", "wgrad", lambda x, dz, K, Cin, Cout, *a, **k: vox(x),
+                   lambda x, dz, K, Cin, Cout, *a, **k: (K, Cin, Cout) == (3, 64, 64))
 
-        def fwd(x, w, *a, **k):
-            if not self.enabled or tuple(w.shape) != (3, 3, 3, 64, 64):
-                return self._fwd(x, w, *a, **k)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); out = self._fwd(x, w, *a, **k); e1.record()
-            rec.append(("fwd", x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3], e0, e1))
-            return out
+    def uninstall(self):
+        for name, orig in self._orig.items():
+            setattr(self.ops, name, orig)
 
-        def dgrad(dz, w, *a, **k):
-            if not self.enabled or tuple(w.shape) != (3, 3, 3, 64, 64):
-                return self._dgrad(dz, w, *a, **k)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); out = self._dgrad(dz, w, *a, **k); e1.record()
-            rec.append(("dgrad", dz.shape[0] * dz.shape[1] * dz.shape[2] * dz.shape[3], e0, e1))
-            return out
-
-        def dgrad_fused(dz, *a, **k):
-            if not self.enabled:
-                return self._dgrad_fused(dz, *a, **k)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); out = self._dgrad_fused(dz, *a, **k); e1.record()
-            rec.append(("dgrad", dz.shape[0] * dz.shape[1] * dz.shape[2] * dz.shape[3], e0, e1))
-            return out
-
-        ops.conv3d_fwd, ops.conv3d_dgrad_fused = fwd, dgrad_fused
-        if self._dgrad is not None:
-            ops.conv3d_dgrad = dgrad
-
-    def summary(self):
-        n = len(self.records)
+    def summary(self, kind):
+        recs = self.records[kind]
+        n = len(recs)
         if n == 0:
             return None
-        total_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in self.records)
-        total_flop = sum(vox * FLOP_PER_VOXEL_CONV64 for _, vox, _, _ in self.records)
+        total_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in recs)
+        total_flop = sum(vox * FLOP_PER_VOXEL_CONV64 for vox, _, _ in recs)
         return n, total_ms / n, total_flop / n
 
 
-def pmc_traffic_bytes(fname="r1_pmc_traffic.json", kernel="conv64_mfma_kernel"):
-    """HBM bytes per conv64 launch from the committed rocprofv3 PMC passes (profiles/r1_pmc_traffic.json for the fp32
-    workload, r1_cfg4_pmc_traffic.json for cfg4; produced by tools/pmc_traffic.py from separate --pmc FETCH_SIZE / --pmc
-    WRITE_SIZE runs of this same command, read side doubled as MI355X_MICROARCH.md prescribes for gfx950).
-    Launch-weighted over the conv64 variants; None if the file is absent."""
-    path = os.path.join(ROOT, "profiles", fname)
-    if not os.path.exists(path):
-        return None
-    d = json.load(open(path))
-    rows = [(v["launches"], v["hbm_bytes_per_launch"]) for k, v in d.items() if kernel in k]
-    n = sum(r[0] for r in rows)
-    return sum(r[0] * r[1] for r in rows) / n if n else None
+def pmc_traffic_bytes(fname, kernel):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json, produced by
+    tools/pmc_traffic.py from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command, read side doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  Launch-weighted over the kernel's variants; None if the file is absent."""
+    for f in ([fname] if isinstance(fname, str) else fname):
+        path = os.path.join(ROOT, "profiles", f)
+        if os.path.exists(path):
+            d = json.load(open(path))
+            rows = [(v["launches"], v["hbm_bytes_per_launch"]) for k, v in d.items() if kernel in k]
+            n = sum(r[0] for r in rows)
+            if n:
+                return sum(r[0] * r[1] for r in rows) / n, f
+    return None, None
+
+
+def host_cpu_model():
+    try:
+        for l in open("/proc/cpuinfo"):
+            if l.startswith("model name"):
+                return l.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(P, R, LB, HB):
-    """Time the CPU oracle (numpy float32 restatement of the same train step) on ONE patch: forward + loss +
-    backward + Adam at the benchmark's network configuration.  Returns the cpu_baseline object."""
+    """The same train step (forward + loss + backward + Adam) on the GPU box's host cores, on a bounded sample.
+    Primary figure: torch-CPU (oneDNN conv3d + autograd, float32, all cores torch uses) -- the closest available stand-in
+    for the reference's TensorFlow CPU path, which cannot run here (TensorFlow absent).  Second figure: the numpy oracle."""
     from oracle import flownet_oracle as O          # checker / baseline only, never on the product path
+    from oracle import torch_cpu as TC
+    out = {"unit": "patches/s", "kind": "port", "cpu_model": host_cpu_model(), "logical_cpus": os.cpu_count()}
+    # torch-CPU: warm-up step (oneDNN primitive creation), then the timed one; 1 patch per step
+    dt_warm, threads = TC.time_train_step(P, R, LB, HB, B=1)
+    reps = 2 if dt_warm < 8 else 1
+    dt, threads = TC.time_train_step(P, R, LB, HB, B=1, repeats=reps)
+    out.update({"value": 1.0 / dt, "cores": int(threads),
+                "sample": "1 train step (fwd+loss+bwd+Adam) of 1 patch, P%d/R%d/LB%d/HB%d fp32, torch-CPU %s (oneDNN conv3d + autograd), "
+                          "%d threads, best of %d after one warm-up step: %.2f s" % (P, R, LB, HB, torch.__version__, threads, reps, dt)})
     try:
         from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        blas = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
-        cores = os.cpu_count() or 1
+        blas = os.cpu_count() or 1
     params = O.init_params(0, LB, HB, np.float32)
     batch = O.synthetic_batch(1, P, R, seed=1234, dtype=np.float32)
-    state = {}
     t0 = time.time()
-    O.train_step(params, state, batch, 1e-4, R, LB, HB)
-    dt = time.time() - t0
-    return {"value": 1.0 / dt, "unit": "patches/s", "cores": int(cores), "kind": "port",
-            "sample": "1 train step (fwd+loss+bwd+Adam) of 1 patch, P%d/R%d/LB%d/HB%d fp32, numpy oracle, %.1f s" % (P, R, LB, HB, dt)}
+    O.train_step(params, {}, batch, 1e-4, R, LB, HB)
+    dn = time.time() - t0
+    out["numpy_oracle"] = {"value": 1.0 / dn, "unit": "patches/s", "cores": int(blas),
+                           "sample": "same step, numpy float32 restatement (oracle/flownet_oracle.py), %d BLAS threads: %.1f s" % (blas, dn)}
+    return out
+
+
+def fwd_flop_per_patch(specs, P, R, LB):
+    """Forward FLOPs per patch from the layer list (SURVEY.md 8d: 328.83 GFLOP at cfg2); a train step is 3x."""
+    f = 0.0
+    hr_from = 6 + 2 * LB
+    for i, (_, k, ci, co, _) in enumerate(specs):
+        vox = P ** 3 * (R ** 3 if i >= hr_from else 1)
+        f += 2.0 * k ** 3 * ci * co * vox
+    return f
+
+
+def roofline_obj(timer, kind, bf16, kernel, traffic_files):
+    s = timer.summary(kind)
+    if s is None:
+        return None
+    n_launch, avg_ms, avg_flop = s
+    achieved = avg_flop / (avg_ms * 1e-3) / 1e12
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+    traffic, tfile = pmc_traffic_bytes(traffic_files, kernel.split(" ")[0])
+    vox = avg_flop / FLOP_PER_VOXEL_CONV64
+    esz = 2.0 if bf16 else 4.0
+    # conv: in + out rows + the weight stream; wgrad: x + dz rows + the dW it writes (fp32)
+    alg = vox * 64 * esz * 2 + 27 * 64 * 64 * (4.0 if kind == "wgrad" else esz)
+    return {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+            "traffic": traffic,
+            "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/%s)" % tfile if tfile else None,
+            "algorithmic_bytes_per_launch": alg, "launches_timed": n_launch, "avg_launch_ms": avg_ms,
+            "avg_launch_gflop": avg_flop / 1e9}
+
+
+def timed_steps(step_fn, steps, warmup, parallel):
+    for _ in range(warmup):
+        step_fn()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    torch.cuda.synchronize()
+    parallel.barrier()
+    return time.perf_counter() - t0
+
+
+def secondary_runs(trainer, parallel, device, P, R, B, LB, HB):
+    """Short extra measurements at N=1 (VERDICT r1 #5/#6), outside the headline timed region."""
+    sec = {}
+    # (1) cfg2 with the on-device input pipeline inside the timed loop: CSV rows -> fdn_gather_patches -> train_step
+    try:
+        data_device = importlib.import_module("4dflownet_amd.data_device")
+        patch_index = importlib.import_module("4dflownet_amd.patch_index")
+        data = importlib.import_module("4dflownet_amd.data")
+        ddir = os.path.join(ROOT, "tests", "golden", "data")
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            csv_path = os.path.join(td, "bench%d.csv" % P)
+            import contextlib, io
+            with contextlib.redirect_stdout(io.StringIO()):
+                patch_index.generate_patch_index(ddir, "example_data.h5", "example_data_HR.h5", csv_path, patch_size=P, n_patch=8 * B,
+                                                 minimum_coverage=0.05, seed=0)
+                rows = data.load_indexes(csv_path)
+                ph = data_device.DevicePatchHandler3D(ddir, P, R, B, 0.6, device=device)
+                ds = ph.initialize_dataset(rows, shuffle=True, shard=(0, 1))
+        tc = trainer.TrainerController(P, R, initial_learning_rate=1e-4, quicksave_enable=False, low_resblock=LB, hi_resblock=HB,
+                                       device=device, seed=0)
+        n_full = [0]
+
+        def epoch():
+            for batch in ds:
+                if batch[0].shape[0] == B:
+                    tc.train_step(batch)
+                    n_full[0] += 1
+        epoch()                                            # warm-up epoch (uploads the volumes once)
+        torch.cuda.synchronize()
+        n_full[0] = 0
+        t0 = time.perf_counter()
+        epoch()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        sec["cfg2_loader_fed"] = {"value": n_full[0] * B / dt, "unit": "patches/s", "ms_per_step": dt / n_full[0] * 1e3, "steps": n_full[0],
+                                  "workload": "cfg2 train_step fed by DevicePatchHandler3D (example_data*.h5 resident in HBM, %d rows with "
+                                              "random rotations, shuffle, fdn_gather_patches inside the timed loop)" % len(rows)}
+        del tc, ds, ph
+    except Exception as e:                                 # secondary figures must never take the headline line down
+        sec["cfg2_loader_fed"] = {"error": repr(e)}
+    torch.cuda.empty_cache()
+    # (2) cfg4: patch 32, res x4, batch 4, bf16 activations (BASELINE.json configs[3])
+    try:
+        P4, R4, B4 = 32, 4, 4
+        tc = trainer.TrainerController(P4, R4, initial_learning_rate=1e-4, quicksave_enable=False, low_resblock=LB, hi_resblock=HB,
+                                       device=device, seed=0, dtype="bfloat16")
+        batch = synthetic_batch(B4, P4, R4, 1234, device)
+        timer = LaunchTimer(tc.model.ops)
+        timer.install()
+        for _ in range(2):
+            tc.train_step(batch)
+        torch.cuda.synchronize()
+        timer.enabled = True
+        steps = 5
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tc.train_step(batch)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        timer.enabled = False
+        timer.uninstall()
+        f4 = fwd_flop_per_patch(tc.model.specs, P4, R4, LB)
+        sec["cfg4_bf16"] = {"value": steps * B4 / dt, "unit": "patches/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+                            "workload": "cfg4 train_step: patch_size=32 res_increase=4 batch=4 bf16 activations, fp32 accumulation/parameters",
+                            "train_step_tflops": steps * B4 / dt * 3.0 * f4 / 1e12,
+                            "roofline": roofline_obj(timer, "conv", True, "conv64_bf16_kernel (3x3x3 64->64 fwd + dgrad launches)",
+                                                     ["r2_cfg4_pmc_traffic.json", "r1_cfg4_pmc_traffic.json"]),
+                            "roofline_wgrad": roofline_obj(timer, "wgrad", True, "wgrad64_bf16_kernel (3x3x3 64->64 weight gradient)",
+                                                           ["r2_cfg4_pmc_traffic.json", "r1_cfg4_pmc_traffic.json"])}
+        del tc, batch
+    except Exception as e:
+        sec["cfg4_bf16"] = {"error": repr(e)}
+    torch.cuda.empty_cache()
+    return sec
+
+
+def self_spawn(args):
+    """--gpus N > 1 without a torch.distributed.run environment: launch N ranks of this script."""
+    ngpu = torch.cuda.device_count()
+    if ngpu < args.gpus and not args.oversubscribe:
+        raise SystemExit("bench.py: --gpus %d requested but only %d GPU(s) are visible; refusing to run fewer ranks silently "
+                         "(use --oversubscribe only to self-test the launcher)" % (args.gpus, ngpu))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -137,16 +297,30 @@ def main():
     ap.add_argument("--config", choices=["cfg2", "cfg4"], default="cfg2",
                     help="cfg2 = the headline workload (defaults above); cfg4 = patch 32, res x4, batch 4, bf16 (secondary metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="launcher self-test: allow more ranks than GPUs (ranks share devices, gloo with host staging); not a scaling number")
     args = ap.parse_args()
     if args.config == "cfg4":
         args.patch, args.res, args.batch, args.dtype = 32, 4, 4, "bf16"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_spawn(args)
 
     parallel = importlib.import_module("4dflownet_amd.parallel")
-    rank, world, local_rank = parallel.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    ngpu = torch.cuda.device_count()
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if env_world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, env_world))
+    oversub = env_world > ngpu
+    if oversub and not args.oversubscribe:
+        raise SystemExit("bench.py: %d ranks but only %d GPU(s) visible" % (env_world, ngpu))
+    if oversub:
+        os.environ["LOCAL_RANK"] = str(int(os.environ.get("LOCAL_RANK", "0")) % max(ngpu, 1))
+    rank, world, local_rank = parallel.init_from_env(backend="gloo" if oversub else None)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    # the world size the collective actually sees: all-reduce a one per rank
+    rccl_ranks = int(round(parallel.allreduce_sum_(torch.ones(1, device=device)).item()))
 
     fdn = importlib.import_module("4dflownet_amd")
     trainer = importlib.import_module("4dflownet_amd.trainer")
@@ -156,7 +330,7 @@ def main():
     tc = trainer.TrainerController(P, R, initial_learning_rate=1e-4, quicksave_enable=False, low_resblock=LB,
                                    hi_resblock=HB, device=device, seed=0, dtype="bfloat16" if bf16 else "float32")
     batch = synthetic_batch(B, P, R, 1234 + rank, device)
-    timer = ConvTimer(tc.model.ops)
+    timer = LaunchTimer(tc.model.ops)
     timer.install()
 
     for _ in range(args.warmup):
@@ -171,27 +345,22 @@ def main():
     parallel.barrier()
     dt = time.perf_counter() - t0
     timer.enabled = False
+    timer.uninstall()
 
-    t = torch.tensor([dt], device=device, dtype=torch.float64)
-    if world > 1:
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    dt = float(t.item())
+    dt = parallel.allreduce_sum_host([dt], op="max")[0]
     if rank != 0:
+        if parallel.is_dist():
+            parallel.barrier()
         return
-    n_launch, avg_ms, avg_flop = timer.summary()
-    achieved = avg_flop / (avg_ms * 1e-3) / 1e12
-    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
-    # forward FLOPs per patch from the layer list (328.83 GFLOP at cfg2), train step = 3x
-    fwd_flop = 0.0
-    hr_from = 6 + 2 * LB
-    for i, (_, k, ci, co, _) in enumerate(tc.model.specs):
-        vox = P ** 3 * (R ** 3 if i >= hr_from else 1)
-        fwd_flop += 2.0 * k ** 3 * ci * co * vox
+    fwd_flop = fwd_flop_per_patch(tc.model.specs, P, R, LB)
+    tr = ["r2_cfg4_pmc_traffic.json", "r1_cfg4_pmc_traffic.json"] if args.config == "cfg4" else (
+        [] if bf16 else ["r2_pmc_traffic.json", "r1_pmc_traffic.json"])
     line = {
         "metric": "3D patches/sec (train step, patch=%d, res×%d)" % (P, R),
         "value": args.steps * B * world / dt,
         "unit": "patches/s",
-        "n_gpus": world,
+        "n_gpus": rccl_ranks,
+        "rccl_ranks": rccl_ranks,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
@@ -202,20 +371,27 @@ def main():
         "data": "synthetic (SURVEY 8d: default_rng(1234+rank) inputs, Glorot-uniform default_rng(0) weights)",
         "config": {"workload": "%s train_step: patch_size=%d res_increase=%d batch=%d/GPU low_resblock=%d hi_resblock=%d %s"
                                % (args.config, P, R, B, LB, HB, "bf16 activations, fp32 accumulation/parameters" if bf16 else "fp32"),
-                   "global_batch": B * world, "parallelism": "dp%d" % world},
-        "roofline": {"bound": "mfma", "kernel": "%s (3x3x3 64->64 fwd + dgrad launches)" % ("conv64_bf16_kernel" if bf16 else "conv64_mfma_kernel"),
-                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                     "frac": achieved / peak,
-                     "traffic": (pmc_traffic_bytes("r1_cfg4_pmc_traffic.json", "conv64_bf16_kernel") if args.config == "cfg4" else None)
-                                if bf16 else pmc_traffic_bytes(),
-                     "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r1%s_pmc_traffic.json)" % ("_cfg4" if bf16 else ""),
-                     "algorithmic_bytes_per_launch": avg_flop / FLOP_PER_VOXEL_CONV64 * (256.0 if bf16 else 512.0) + (221184.0 if bf16 else 442368.0),
-                     "launches_timed": n_launch, "avg_launch_ms": avg_ms, "avg_launch_gflop": avg_flop / 1e9},
+                   "global_batch": B * world, "parallelism": "dp%d" % world,
+                   "collective": ("none" if world == 1 else
+                                  "gloo, host-staged (OVERSUBSCRIBED launcher self-test: %d ranks on %d GPU -- not a scaling number)" % (world, ngpu)
+                                  if oversub else "RCCL sum all-reduce of the flat fp32 gradient (%d B) per step" % (4 * (tc.model.n_params + 1)))},
+        "roofline": roofline_obj(timer, "conv", bf16, "%s (3x3x3 64->64 fwd + dgrad launches)" % ("conv64_bf16_kernel" if bf16 else "conv64_mfma_kernel"), tr),
+        "roofline_wgrad": roofline_obj(timer, "wgrad", bf16, "%s (3x3x3 64->64 weight gradient + partial reduction)"
+                                       % ("wgrad64_bf16_kernel" if bf16 else "wgrad64_pipe_kernel"), tr),
         "train_step_tflops": args.steps * B * world / dt * 3.0 * fwd_flop / 1e12,
     }
-    if world == 1 and not args.no_cpu_baseline and not bf16:
-        line["cpu_baseline"] = cpu_baseline(P, R, LB, HB)
-    print(json.dumps(line))
+    if oversub:
+        line["oversubscribed"] = True
+    del tc, batch
+    torch.cuda.empty_cache()
+    if world == 1 and not bf16 and args.config == "cfg2":
+        if not args.no_secondary:
+            line["secondary"] = secondary_runs(trainer, parallel, device, P, R, B, LB, HB)
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(P, R, LB, HB)
+    print(json.dumps(line), flush=True)
+    if parallel.is_dist():
+        parallel.barrier()
 
 
 if __name__ == "__main__":
