@@ -1,10 +1,12 @@
 """ctypes binding of lib4dflow_hip.so (include/fdn.h).  There is NO fallback: if the library is missing or a
 call fails, an exception is raised."""
+import contextlib
 import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib4dflow_hip.so")
+TEST_LIB_PATH = os.path.join(_HERE, "lib4dflow_hip_test.so")     # same sources + fdn_debug_* hooks (tests / tools only)
 
 c_fp = ctypes.c_void_p      # device pointer to float
 c_i = ctypes.c_int
@@ -49,28 +51,65 @@ SIGNATURES = {
 }
 
 
+# test-build-only entry points (csrc: #ifdef FDN_TEST_HOOKS); NOT part of include/fdn.h
+DEBUG_SIGNATURES = {
+    "fdn_debug_set_conv64_mt": (c_i, [c_i]),
+    "fdn_debug_set_conv64_dbg": (c_i, [c_i]),
+    "fdn_debug_set_conv64_shell_slabs": (c_i, [c_i]),
+    "fdn_debug_set_conv64_bf16_mt": (c_i, [c_i]),
+    "fdn_debug_set_conv64_bf16_dbg": (c_i, [c_i]),
+    "fdn_debug_set_heads_mfma": (c_i, [c_i]),
+}
+
+
 class FdnError(RuntimeError):
     pass
 
 
-_lib = None
+_product = None
+_test = None
+_lib = None          # the library load() hands out: the product build, except inside `with test_build():`
+
+
+def _open(path, sigs):
+    if not os.path.exists(path):
+        raise FdnError("%s is not built (%s).  Run `python __graft_entry__.py` or "
+                       "`python 4dflownet_amd/build.py`; there is no CPU fallback." % (os.path.basename(path), path))
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)          # AttributeError if an export is missing
+        fn.restype = res
+        fn.argtypes = args
+    return lib
 
 
 def load():
     """Load the shared library (once) and attach the prototypes.  Raises FdnError if it is not built."""
-    global _lib
+    global _lib, _product
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise FdnError("lib4dflow_hip.so is not built (%s).  Run `python __graft_entry__.py` or "
-                       "`python 4dflownet_amd/build.py`; there is no CPU fallback." % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)          # AttributeError if an export is missing
-        fn.restype = res
-        fn.argtypes = args
-    _lib = lib
-    return lib
+    if _product is None:
+        _product = _open(LIB_PATH, SIGNATURES)
+    _lib = _product
+    return _lib
+
+
+@contextlib.contextmanager
+def test_build():
+    """Tests / tools only: route every call of the operator layer through lib4dflow_hip_test.so -- the same sources
+    compiled with -DFDN_TEST_HOOKS -- so kernel variants the planner would not pick at a given size can be forced
+    (fdn_debug_*).  Yields the test library; restores the product library on exit."""
+    global _lib, _test
+    if _test is None:
+        sigs = dict(SIGNATURES)
+        sigs.update(DEBUG_SIGNATURES)
+        _test = _open(TEST_LIB_PATH, sigs)
+    prev = _lib
+    _lib = _test
+    try:
+        yield _test
+    finally:
+        _lib = prev
 
 
 def check(rc, what):

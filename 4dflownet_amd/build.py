@@ -9,6 +9,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib4dflow_hip.so")
+# Test build: the same sources with -DFDN_TEST_HOOKS, which adds the fdn_debug_* variant-forcing / ablation entry points
+# (process-global switches).  Loaded only by tests/ and tools/ through _lib.test_build(); the product library has none.
+LIB_TEST = os.path.join(HERE, "lib4dflow_hip_test.so")
 SOURCES = ["api.hip", "conv64_mfma.hip", "conv64_bf16.hip", "wgrad64_mfma.hip", "wgrad64_bf16.hip", "small_convs.hip", "heads_mfma.hip", "elementwise.hip", "patch_gather.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-I", os.path.join(ROOT, "include"), "-I", CSRC]
@@ -30,19 +33,22 @@ def _stamp():
     return h.hexdigest()
 
 
-def build_library(force=False, verbose=False):
-    """Compile every HIP translation unit for gfx950 and link the shared library.  Returns its path."""
-    stamp_file = LIB + ".stamp"
-    stamp = _stamp()
-    if not force and os.path.exists(LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
-        return LIB
+def build_library(force=False, verbose=False, test_hooks=False):
+    """Compile every HIP translation unit for gfx950 and link the shared library.  Returns its path.
+    test_hooks=True builds lib4dflow_hip_test.so (adds the fdn_debug_* entry points)."""
+    lib = LIB_TEST if test_hooks else LIB
+    extra = ["-DFDN_TEST_HOOKS"] if test_hooks else []
+    stamp_file = lib + ".stamp"
+    stamp = _stamp() + "".join(extra)
+    if not force and os.path.exists(lib) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+        return lib
     hipcc = _hipcc()
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build", "test" if test_hooks else "product")
     os.makedirs(objdir, exist_ok=True)
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj] + FLAGS
+        cmd = [hipcc, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj] + FLAGS + extra
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
@@ -52,13 +58,14 @@ def build_library(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    r = subprocess.run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs, capture_output=True, text=True)
+    r = subprocess.run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", lib] + objs, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
     with open(stamp_file, "w") as f:
         f.write(stamp)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
     print(build_library(force="--force" in sys.argv, verbose=True))
+    print(build_library(force="--force" in sys.argv, verbose=True, test_hooks=True))

@@ -2,6 +2,9 @@
 // See include/fdn.h for the contract and the reference call sites each entry point replaces.
 #include <stdarg.h>
 #include <stdio.h>
+#include <mutex>
+#include <set>
+#include <utility>
 #include "fdn_common.h"
 
 static thread_local char g_err[512] = "";
@@ -13,7 +16,20 @@ void fdn_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int fdn_version(void) { return 100; }
+int fdn_func_max_lds(const void* fn, int bytes, const char* who) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;       // (device, kernel) pairs whose attribute is set
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({dev, fn})) return FDN_OK;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) { fdn_set_error("%s: hipFuncSetAttribute(%d B of LDS): %s", who, bytes, hipGetErrorString(e)); return FDN_ERR_HIP; }
+    done.insert({dev, fn});
+    return FDN_OK;
+}
+
+extern "C" int fdn_version(void) { return 110; }
 extern "C" const char* fdn_last_error(void) { return g_err; }
 
 // small-channel kernels (small_convs.hip), templated on the activation storage type (float / uint16_t = bf16 bits)

@@ -30,8 +30,8 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-static int fdn_conv64bf_force_mt = 0;    // test/bench hook: 0 = auto, 4 / 8 = force the variant, +16 = full-depth tiles only
-static int fdn_conv64bf_dbg = 0;         // ablation bits: 1 = weight stride 0, 2 = no XCD remap, 4 = staging loads from a cache-resident 32 KB, 8 = no epilogue
+FDN_HOOK_VAR(int, fdn_conv64bf_force_mt, 0);    // test/bench hook: 0 = auto, 4 / 8 = force the variant, +16 = full-depth tiles only
+FDN_HOOK_VAR(int, fdn_conv64bf_dbg, 0);         // ablation bits: 1 = weight stride 0, 2 = no XCD remap, 4 = staging loads from a cache-resident 32 KB, 8 = no epilogue
 
 template <int MT>
 struct Conv64BfCfg {
@@ -463,13 +463,7 @@ template <int MT, bool FAST>
 int launch_regions(Conv64BfArgs& a, hipStream_t s) {
     using C = Conv64BfCfg<MT>;
     if (a.nreg == 0) return FDN_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv64_bf16_kernel<MT, FAST>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BUDGET);
-        if (e != hipSuccess) { fdn_set_error("conv64_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return FDN_ERR_HIP; }
-        attr_set = true;
-    }
+    if (int rc = fdn_func_max_lds((const void*)conv64_bf16_kernel<MT, FAST>, C::LDS_BUDGET, "conv64_bf16")) return rc;
     int blocks = 0, max_lrows = 0;
     for (int i = 0; i < a.nreg; ++i) {
         Conv64Region& r = a.reg[i];
@@ -569,5 +563,9 @@ int fdn_fold_halo_border_bf16_launch(const float* s0, const float* s1, const flo
     return FDN_OK;
 }
 
+#ifdef FDN_TEST_HOOKS
+#ifdef FDN_TEST_HOOKS
 extern "C" int fdn_debug_set_conv64_bf16_mt(int mt) { fdn_conv64bf_force_mt = mt; return FDN_OK; }
 extern "C" int fdn_debug_set_conv64_bf16_dbg(int bits) { fdn_conv64bf_dbg = bits; return FDN_OK; }
+#endif
+#endif

@@ -31,10 +31,10 @@
 #include "fdn_common.h"
 #include "conv64_args.h"
 
-// test/bench hooks (set through fdn_debug_* entry points; not part of include/fdn.h)
-static int fdn_conv64_force_layout = 0;   // 0 = auto, 1..6 = index into the variant table below
-static int fdn_conv64_dbg = 0;            // ablation bits, see Conv64Args::dbg
-static int fdn_conv64_shell_slabs = 1;    // fused dgrad: 1 = inner box + 6 shell slabs, 0 = one launch over the padded grid
+// test/bench hooks: compile-time constants in the product library, settable through fdn_debug_* in the test build only
+FDN_HOOK_VAR(int, fdn_conv64_force_layout, 0);   // 0 = auto, 1..6 = index into the variant table below
+FDN_HOOK_VAR(int, fdn_conv64_dbg, 0);            // ablation bits, see Conv64Args::dbg
+FDN_HOOK_VAR(int, fdn_conv64_shell_slabs, 1);    // fused dgrad: 1 = inner box + 6 shell slabs, 0 = one launch over the padded grid
 
 template <int MT, int NW, int CS>
 struct Conv64Cfg {
@@ -527,16 +527,8 @@ int launch_conv64(Conv64Args& a, const Box* boxes, int nbox, hipStream_t s) {
         if (r.rows > max_rows) max_rows = r.rows;
     }
     if (a.nreg == 0) return FDN_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv64_mfma_kernel<MT, NW, CS, true>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)conv64_mfma_kernel<MT, NW, CS, false>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        if (e != hipSuccess) { fdn_set_error("conv64: hipFuncSetAttribute: %s", hipGetErrorString(e)); return FDN_ERR_HIP; }
-        attr_set = true;
-    }
+    if (int rc = fdn_func_max_lds((const void*)conv64_mfma_kernel<MT, NW, CS, true>, C::LDS_BYTES, "conv64")) return rc;
+    if (int rc = fdn_func_max_lds((const void*)conv64_mfma_kernel<MT, NW, CS, false>, C::LDS_BYTES, "conv64")) return rc;
     const size_t lds = (size_t)max_rows * C::LROW + C::MCAP * 4;
     const Conv64Region& r0 = a.reg[0];
     const bool simple = a.nreg == 1 && r0.ta0 == 0 && r0.ta1 == 2 && r0.tb0 == 0 && r0.tb1 == 2 && r0.tc0 == 0 && r0.tc1 == 2;
@@ -623,6 +615,8 @@ int fdn_fold_halo_border_launch(const float* s0, const float* s1, const float* s
     return FDN_OK;
 }
 
+#ifdef FDN_TEST_HOOKS
 extern "C" int fdn_debug_set_conv64_mt(int layout) { fdn_conv64_force_layout = layout; return FDN_OK; }
 extern "C" int fdn_debug_set_conv64_dbg(int bits) { fdn_conv64_dbg = bits; return FDN_OK; }
 extern "C" int fdn_debug_set_conv64_shell_slabs(int on) { fdn_conv64_shell_slabs = on; return FDN_OK; }
+#endif

@@ -390,12 +390,7 @@ static int upsample_bwd_t(const T* dy, const T* y_prev, int act, float alpha, T*
     const size_t lds = (size_t)W * R * C * sizeof(float);
     FDN_REQUIRE(rows < (1ll << 31) && lds <= 160 * 1024, "fdn_upsample_trilinear_bwd: row of %d x %d channels does not fit the LDS stage", W * R, C);
     if (lds > 48 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)upsample_bwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) { fdn_set_error("upsample_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return FDN_ERR_HIP; }
-            attr_set = true;
-        }
+        if (int rc = fdn_func_max_lds((const void*)upsample_bwd_kernel<T>, 160 * 1024, "upsample_bwd")) return rc;
     }
     hipLaunchKernelGGL(upsample_bwd_kernel<T>, dim3((unsigned)(rows < 65536 ? rows : 65536)), dim3(256), lds, (hipStream_t)stream, dy,
                        y_prev, act, alpha, dx, N, D, H, W, C / E, R, axis_scale(D, R), axis_scale(H, R), axis_scale(W, R));

@@ -69,6 +69,18 @@ template <> struct FdnVec<uint16_t> {
 
 void fdn_set_error(const char* fmt, ...);
 
+// hipFuncAttributeMaxDynamicSharedMemorySize, set once per (device, kernel) under a lock: the C-ABI is re-entrant per
+// (device, stream) from any host thread (api.hip).  Returns FDN_OK or FDN_ERR_HIP (message set).
+int fdn_func_max_lds(const void* fn, int bytes, const char* who);
+
+// Variant-forcing / ablation hooks (fdn_debug_*) exist only in the TEST build of the library (lib4dflow_hip_test.so,
+// compiled with -DFDN_TEST_HOOKS by 4dflownet_amd/build.py); the product library has no mutable global state.
+#ifdef FDN_TEST_HOOKS
+#define FDN_HOOK_VAR(type, name, init) static type name = init
+#else
+#define FDN_HOOK_VAR(type, name, init) static constexpr type name = init
+#endif
+
 #define FDN_CHECK_LAUNCH(name)                                                         \
     do {                                                                               \
         hipError_t e_ = hipGetLastError();                                             \

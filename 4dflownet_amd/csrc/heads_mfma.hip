@@ -176,12 +176,7 @@ int fdn_head_fwd_launch(const T* x, const float* w, const float* bias, float* y,
                         int act, float alpha, hipStream_t s) {
     const int ntd = (D + H_TD - 1) / H_TD, nth = (H + H_TH - 1) / H_TH, ntw = (W + H_TW - 1) / H_TW;
     const size_t lds = (size_t)27 * H_HVP * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)head_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { fdn_set_error("head_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return FDN_ERR_HIP; }
-        attr_set = true;
-    }
+    if (int rc = fdn_func_max_lds((const void*)head_fwd_kernel<T>, (int)lds, "head_fwd")) return rc;
     // persistent grid: every workgroup runs `iters` (a multiple of 3, see the kernel) tiles, at most 2 workgroups per CU
     const int ntiles = N * ntd * nth * ntw;
     const int iters = 3 * ((ntiles + 3 * 512 - 1) / (3 * 512));

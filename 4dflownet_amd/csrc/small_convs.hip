@@ -575,8 +575,10 @@ int fdn_head_dgrad_blocks(int N, int D, int H, int W);
 template <typename T> int fdn_head_wgrad_launch(const T* x, const float* dz, float* partial, int N, int D, int H, int W, int lddz,
                                                 int dz_coff, hipStream_t s);
 int fdn_head_wgrad_blocks(int N, int D, int H, int W);
-static int fdn_heads_use_mfma = 1;
+FDN_HOOK_VAR(int, fdn_heads_use_mfma, 1);
+#ifdef FDN_TEST_HOOKS
 extern "C" int fdn_debug_set_heads_mfma(int on) { fdn_heads_use_mfma = on; return FDN_OK; }
+#endif
 
 template <typename T>
 int fdn_conv_cout1_fwd_launch(const T* x, const float* w, const float* bias, float* y, int N, int D, int H, int W, int ldy,

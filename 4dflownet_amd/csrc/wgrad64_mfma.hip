@@ -260,13 +260,7 @@ int fdn_wgrad64_launch(const float* x, const float* dz, float* dw, void* ws, siz
     FDN_REQUIRE((long long)N * D * H * W * 256 < (1ll << 32), "wgrad64: x of %dx%dx%dx%dx64 floats exceeds the 32-bit buffer addressing", N, D, H, W);
     a.bytes = (unsigned)((long long)N * D * H * W * 256);
     const size_t lds = (size_t)3 * ((kTH + 2) * (kTW + 2) + kTH * kTW) * 256;
-    static bool attr_set = false;
-    if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute((const void*)wgrad64_pipe_kernel<kTH, kTW>,
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { fdn_set_error("wgrad64: hipFuncSetAttribute: %s", hipGetErrorString(e)); return FDN_ERR_HIP; }
-        attr_set = true;
-    }
+    if (int rc = fdn_func_max_lds((const void*)wgrad64_pipe_kernel<kTH, kTW>, (int)lds, "wgrad64")) return rc;
     hipLaunchKernelGGL((wgrad64_pipe_kernel<kTH, kTW>), dim3(a.S, 3), dim3(256), lds, s, a);
     FDN_CHECK_LAUNCH("wgrad64_pipe_kernel");
     hipLaunchKernelGGL(wgrad64_reduce_kernel, dim3(27 * 1024 / 64), dim3(256), 0, s, (const float*)ws, dw, a.S);

@@ -9,7 +9,7 @@ import numpy as np
 
 from . import fft_downsampling as fft
 from . import h5io
-from .h5util import save_to_h5
+from .h5io import append_dataset
 
 MAG_VALUES = np.asarray([60, 80, 120, 180, 240])                      # px values [0-4095]   (:33)
 VENC_VALUES = np.asarray([0.3, 0.6, 1.0, 1.5, 2.0, 2.5, 3.0, 3.5])    # m/s                  (:34)
@@ -38,7 +38,7 @@ def pick_vencs(max_u, max_v, max_w, venc_choice):
 
 def save_row(output_filepath, col_name, dataset):
     """prepare_data/h5functions.save_to_h5: one row appended along a new leading axis, float64 stored as float32."""
-    save_to_h5(output_filepath, col_name, np.expand_dims(np.asarray(dataset), axis=0))
+    append_dataset(output_filepath, col_name, np.expand_dims(np.asarray(dataset), axis=0))
 
 
 def zoom_mask(mask, factor):

@@ -2,6 +2,7 @@
 import ctypes
 import os
 import re
+import subprocess
 
 import pytest
 
@@ -21,6 +22,14 @@ def test_library_builds_and_exports_every_declared_symbol(fdn):
     # the ctypes table covers exactly the declared API
     assert declared == set(fdn._lib.SIGNATURES), declared ^ set(fdn._lib.SIGNATURES)
     assert fdn._lib.load().fdn_version() >= 100
+    # the product library carries no process-global switches (include/fdn.h: "no global mutable state"); the variant-forcing
+    # hooks live in the test build only, which exports the full API as well
+    exported = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
+    assert "fdn_debug" not in exported and "fdn_conv3d_fwd" in exported
+    tpath = build.build_library(test_hooks=True)
+    tlib = ctypes.CDLL(tpath)
+    for name in sorted(declared) + sorted(fdn._lib.DEBUG_SIGNATURES):
+        assert hasattr(tlib, name), "test build misses %s" % name
 
 
 def test_no_cpu_fallback(fdn):

@@ -146,18 +146,7 @@ def test_written_files_are_readable_by_real_h5py(tmp_path):
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr
 
 
-def test_small_api_parity_helpers(tmp_path):
-    h5util = importlib.import_module("4dflownet_amd.h5util")
-    utility = importlib.import_module("4dflownet_amd.utility")
-    preds = np.arange(2 * 3 * 4 * 5 * 3, dtype=np.float64).reshape(2, 3, 4, 5, 3)
-    h5util.save_prediction_columns(str(tmp_path / "o"), "p.h5", ["u", "v", "w"], preds, compression="gzip")
-    h5util.save_predictions(str(tmp_path / "o"), "p.h5", "u", preds[..., 0])
-    back = h5io.read_all(str(tmp_path / "o" / "p.h5"))
-    assert back["u"].shape == (4, 3, 4, 5) and back["w"].dtype == np.float32 and np.array_equal(back["v"], preds[..., 1].astype(np.float32))
-    utility.log_to_file(str(tmp_path / "l.txt"), "a\n"); utility.log_to_file(str(tmp_path / "l.txt"), "b\n")
-    assert open(str(tmp_path / "l.txt")).read() == "a\nb\n"
-    h, m, s = utility.calculate_time_elapsed(__import__("time").time() - 3725)
-    assert (h, m) == (1, 2) and 4 <= s <= 6
+def test_py_function_bridge_alias():
     ph = data.PatchHandler3D(DATA, 16, 2, 4, 0.6)
     row = G["loader"][0]["csv_row"]
     a = ph.load_data_using_patch_index(row); b = ph.load_patches_from_index_file(row)

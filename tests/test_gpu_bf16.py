@@ -9,6 +9,7 @@ import pytest
 import torch
 
 from oracle import flownet_oracle as O
+from test_gpu_kernels import variant_lib
 
 pytestmark = pytest.mark.gpu
 
@@ -69,16 +70,18 @@ def test_conv64_fwd_bf16(bops, fdn, shape, mt):
     b = rng.normal(size=64).astype(np.float32)
     res = rb(rng.normal(size=(N, D, H, W, 64)))
     wf, _ = bops.pack_conv64_weights(dev(w))
-    lib = fdn._lib.load()
-    lib.fdn_debug_set_conv64_bf16_mt(mt)
-    try:
-        for act, bias, r in [(O.ACT_RELU, b, None), (O.ACT_LEAKY, None, res), (O.ACT_NONE, None, None)]:
-            ref = O.conv3d_fwd(x, rb(w), None if bias is None else bias.astype(np.float64), act, 0.2, r)
-            got = bops.conv64_fwd(devb(x), wf, None if bias is None else dev(bias), act, 0.2,
-                                  None if r is None else devb(r))
-            close_bf16(got, ref, name="conv64 bf16 fwd act=%d" % act)
-    finally:
-        lib.fdn_debug_set_conv64_bf16_mt(0)
+    with variant_lib(fdn, mt) as lib:
+        if lib is not None:
+            lib.fdn_debug_set_conv64_bf16_mt(mt)
+        try:
+            for act, bias, r in [(O.ACT_RELU, b, None), (O.ACT_LEAKY, None, res), (O.ACT_NONE, None, None)]:
+                ref = O.conv3d_fwd(x, rb(w), None if bias is None else bias.astype(np.float64), act, 0.2, r)
+                got = bops.conv64_fwd(devb(x), wf, None if bias is None else dev(bias), act, 0.2,
+                                      None if r is None else devb(r))
+                close_bf16(got, ref, name="conv64 bf16 fwd act=%d" % act)
+        finally:
+            if lib is not None:
+                lib.fdn_debug_set_conv64_bf16_mt(0)
 
 
 @pytest.mark.parametrize("shape", SHAPES + [(1, 2, 3, 1)])
@@ -92,16 +95,18 @@ def test_conv64_dgrad_fused_bf16(bops, fdn, shape, mt):
     skip = rb(rng.normal(size=(N, D, H, W, 64)))
     dx = O.conv3d_dgrad(dz, rb(w), (N, D, H, W, 64))
     _, wd = bops.pack_conv64_weights(dev(w))
-    lib = fdn._lib.load()
-    lib.fdn_debug_set_conv64_bf16_mt(mt)
-    try:
-        pad = torch.full((N, D + 2, H + 2, W + 2, 64), float("nan"), device="cuda")
-        out = torch.full((N, D, H, W, 64), float("nan"), device="cuda", dtype=torch.bfloat16)
-        bops.conv64_dgrad_fused(devb(dz), wd, pad, out, skip=devb(skip), y_prev=devb(y), act=O.ACT_LEAKY)
-        bops.fold_halo_border([pad], out, devb(skip), devb(y), O.ACT_LEAKY)
-        close_bf16(out, O.act_bwd_from_output(dx + skip, y, O.ACT_LEAKY), name="bf16 fused dgrad+border")
-    finally:
-        lib.fdn_debug_set_conv64_bf16_mt(0)
+    with variant_lib(fdn, mt) as lib:
+        if lib is not None:
+            lib.fdn_debug_set_conv64_bf16_mt(mt)
+        try:
+            pad = torch.full((N, D + 2, H + 2, W + 2, 64), float("nan"), device="cuda")
+            out = torch.full((N, D, H, W, 64), float("nan"), device="cuda", dtype=torch.bfloat16)
+            bops.conv64_dgrad_fused(devb(dz), wd, pad, out, skip=devb(skip), y_prev=devb(y), act=O.ACT_LEAKY)
+            bops.fold_halo_border([pad], out, devb(skip), devb(y), O.ACT_LEAKY)
+            close_bf16(out, O.act_bwd_from_output(dx + skip, y, O.ACT_LEAKY), name="bf16 fused dgrad+border")
+        finally:
+            if lib is not None:
+                lib.fdn_debug_set_conv64_bf16_mt(0)
 
 
 @pytest.mark.parametrize("shape", [(2, 8, 8, 8), (1, 5, 7, 9), (1, 10, 12, 16), (3, 4, 4, 2), (2, 16, 16, 16), (1, 1, 1, 1)])

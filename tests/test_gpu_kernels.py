@@ -1,6 +1,8 @@
 """Parity of every HIP entry point against the CPU oracle, called through the C-ABI (ctypes) on a real MI355X.
 Tolerance: north_star asks <= 1e-3 relative fp32; the kernels are exact-fp32 FMA chains, so we check 2e-5
 of the output scale (max |ref|)."""
+import contextlib
+
 import numpy as np
 import pytest
 import torch
@@ -33,6 +35,18 @@ def ops(fdn):
 SHAPES = [(2, 8, 8, 8), (1, 5, 7, 9), (1, 10, 12, 16), (3, 4, 4, 2)]
 
 
+@contextlib.contextmanager
+def variant_lib(fdn, variant):
+    """variant == 0: run on the product library (yields None).  Otherwise route the operator layer through the TEST build
+    (lib4dflow_hip_test.so: same sources + fdn_debug_* hooks) so a kernel variant the planner would not pick at this size
+    can be forced; the product library exports no such switches."""
+    if not variant:
+        yield None
+    else:
+        with fdn._lib.test_build() as lib:
+            yield lib
+
+
 @pytest.mark.parametrize("shape", SHAPES)
 @pytest.mark.parametrize("mt", [0, 1, 2, 3, 4, 5, 6])   # 0 = planner, 1..6 = forced <MT,NW,CS> variant
 def test_conv64_fwd(ops, fdn, shape, mt):
@@ -42,16 +56,19 @@ def test_conv64_fwd(ops, fdn, shape, mt):
     w = (rng.normal(size=(3, 3, 3, 64, 64)) * 0.05).astype(np.float32)
     b = rng.normal(size=64).astype(np.float32)
     res = rng.normal(size=(N, D, H, W, 64)).astype(np.float32)
-    fdn._lib.load().fdn_debug_set_conv64_mt(mt)
-    try:
-        for act, bias, r in [(O.ACT_RELU, b, None), (O.ACT_LEAKY, None, res), (O.ACT_NONE, None, None)]:
-            ref = O.conv3d_fwd(x.astype(np.float64), w.astype(np.float64), None if bias is None else bias.astype(np.float64),
-                               act, 0.2, None if r is None else r.astype(np.float64))
-            got = ops.conv3d_fwd(dev(x), dev(w), None if bias is None else dev(bias), act, 0.2,
-                                 None if r is None else dev(r))
-            close(got, ref, name="conv64 fwd act=%d" % act)
-    finally:
-        fdn._lib.load().fdn_debug_set_conv64_mt(0)
+    with variant_lib(fdn, mt) as lib:              # mt == 0: the product library, planner's choice
+        if lib is not None:
+            lib.fdn_debug_set_conv64_mt(mt)
+        try:
+            for act, bias, r in [(O.ACT_RELU, b, None), (O.ACT_LEAKY, None, res), (O.ACT_NONE, None, None)]:
+                ref = O.conv3d_fwd(x.astype(np.float64), w.astype(np.float64), None if bias is None else bias.astype(np.float64),
+                                   act, 0.2, None if r is None else r.astype(np.float64))
+                got = ops.conv3d_fwd(dev(x), dev(w), None if bias is None else dev(bias), act, 0.2,
+                                     None if r is None else dev(r))
+                close(got, ref, name="conv64 fwd act=%d" % act)
+        finally:
+            if lib is not None:
+                lib.fdn_debug_set_conv64_mt(0)
 
 
 @pytest.mark.parametrize("shape", SHAPES)
@@ -83,26 +100,29 @@ def test_conv64_dgrad_fused_fold(ops, fdn, shape, layout):
     skip = rng.normal(size=(N, D, H, W, 64)).astype(np.float32)
     dx = O.conv3d_dgrad(dz.astype(np.float64), w.astype(np.float64), (N, D, H, W, 64))
     _, wd = ops.pack_conv64_weights(dev(w))
-    fdn._lib.load().fdn_debug_set_conv64_mt(layout)
-    # odd layouts also exercise the single padded-grid launch; the default is inner box + six 9-tap shell slabs
-    fdn._lib.load().fdn_debug_set_conv64_shell_slabs(0 if layout in (1, 3, 5) else 1)
-    try:
-        pad = torch.full((N, D + 2, H + 2, W + 2, 64), float("nan"), device="cuda")
-        out = torch.full((N, D, H, W, 64), float("nan"), device="cuda")
-        ops.conv3d_dgrad_fused(dev(dz), wd, pad, out, skip=dev(skip), y_prev=dev(y), act=O.ACT_LEAKY)
-        ops.fold_halo_border([pad], out, dev(skip), dev(y), O.ACT_LEAKY)
-        close(out, O.act_bwd_from_output(dx + skip, y, O.ACT_LEAKY), name="fused dgrad+border")
-        # fan-in of three consumers chained through the output buffer (skip aliases out), mask on the last
-        acc = torch.full((N, D, H, W, 64), float("nan"), device="cuda")
-        pads = [torch.empty_like(pad) for _ in range(3)]
-        for k in range(3):
-            ops.conv3d_dgrad_fused(dev(dz * (k + 1)), wd, pads[k], acc, skip=acc if k else None,
-                                   y_prev=dev(y) if k == 2 else None, act=O.ACT_RELU if k == 2 else O.ACT_NONE)
-        ops.fold_halo_border(pads, acc, None, dev(y), O.ACT_RELU)
-        close(acc, O.act_bwd_from_output(6 * dx, y, O.ACT_RELU), name="fused fan-in of 3")
-    finally:
-        fdn._lib.load().fdn_debug_set_conv64_mt(0)
-        fdn._lib.load().fdn_debug_set_conv64_shell_slabs(1)
+    with variant_lib(fdn, layout) as lib:          # layout == 0: the product library (planner, shell slabs)
+        if lib is not None:
+            lib.fdn_debug_set_conv64_mt(layout)
+            # odd layouts also exercise the single padded-grid launch; the default is inner box + six 9-tap shell slabs
+            lib.fdn_debug_set_conv64_shell_slabs(0 if layout in (1, 3, 5) else 1)
+        try:
+            pad = torch.full((N, D + 2, H + 2, W + 2, 64), float("nan"), device="cuda")
+            out = torch.full((N, D, H, W, 64), float("nan"), device="cuda")
+            ops.conv3d_dgrad_fused(dev(dz), wd, pad, out, skip=dev(skip), y_prev=dev(y), act=O.ACT_LEAKY)
+            ops.fold_halo_border([pad], out, dev(skip), dev(y), O.ACT_LEAKY)
+            close(out, O.act_bwd_from_output(dx + skip, y, O.ACT_LEAKY), name="fused dgrad+border")
+            # fan-in of three consumers chained through the output buffer (skip aliases out), mask on the last
+            acc = torch.full((N, D, H, W, 64), float("nan"), device="cuda")
+            pads = [torch.empty_like(pad) for _ in range(3)]
+            for k in range(3):
+                ops.conv3d_dgrad_fused(dev(dz * (k + 1)), wd, pads[k], acc, skip=acc if k else None,
+                                       y_prev=dev(y) if k == 2 else None, act=O.ACT_RELU if k == 2 else O.ACT_NONE)
+            ops.fold_halo_border(pads, acc, None, dev(y), O.ACT_RELU)
+            close(acc, O.act_bwd_from_output(6 * dx, y, O.ACT_RELU), name="fused fan-in of 3")
+        finally:
+            if lib is not None:
+                lib.fdn_debug_set_conv64_mt(0)
+                lib.fdn_debug_set_conv64_shell_slabs(1)
 
 
 @pytest.mark.parametrize("shape", SHAPES + [(2, 16, 16, 16), (1, 1, 1, 1), (1, 2, 3, 1), (1, 3, 20, 33), (5, 9, 8, 24)])

@@ -4,7 +4,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 fdn = importlib.import_module("4dflownet_amd")
 ops = fdn.ops
-lib = fdn._lib.load()
+lib = fdn._lib.test_build().__enter__()     # test build: the fdn_debug_* hooks are not in the product library
 def timeit(fn, iters=10):
     for _ in range(3): fn()
     torch.cuda.synchronize()

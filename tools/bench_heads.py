@@ -3,8 +3,8 @@ import importlib, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 fdn = importlib.import_module("4dflownet_amd")
-lib = fdn._lib.load()
-lib_dbg = __import__("ctypes").CDLL(fdn._lib.LIB_PATH)
+lib = fdn._lib.test_build().__enter__()     # test build: the fdn_debug_* hooks are not in the product library
+lib_dbg = lib
 
 
 def timeit(fn, iters=10):

@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--ablate", action="store_true")
     args = ap.parse_args()
     torch.manual_seed(0)
-    lib = fdn._lib.load()
+    lib = fdn._lib.test_build().__enter__()     # test build: the fdn_debug_* hooks are not in the product library
     for P in args.sizes:
         N = args.n
         x = torch.randn((N, P, P, P, 64), device="cuda")

@@ -3,7 +3,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 fdn = importlib.import_module("4dflownet_amd")
 import ctypes
-dbg = ctypes.CDLL(fdn._lib.LIB_PATH)
+dbg = fdn._lib.test_build().__enter__()
 torch.manual_seed(0)
 for dtype in ("f32", "bf16"):
     ops = fdn.ops if dtype == "f32" else importlib.import_module("4dflownet_amd.ops_bf16")
