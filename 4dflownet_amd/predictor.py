@@ -64,7 +64,7 @@ def predict_file(network, input_filepath, output_filepath, patch_size, res_incre
         results = predict_patches(network, velocities, magnitudes, batch_size)
         if verbose and is0:
             print("Processed row %d/%d: %d patches in %.2f secs." % (nrow + 1, nr_rows, len(results), time.time() - t0))
-        vols = []
+        vols, cols = [], []
         for i in range(3):
             v = pgen._patchup_with_overlap(results[:, :, :, :, i], pgen.nr_x, pgen.nr_y, pgen.nr_z)
             v = v * dataset.venc                                   # de-normalise (:103)
@@ -72,10 +72,11 @@ def predict_file(network, input_filepath, output_filepath, patch_size, res_incre
                 v[np.abs(v) < dataset.velocity_per_px] = 0        # (:104-107)
             v = np.expand_dims(v, axis=0)
             vols.append(v)
-            if is0:
-                save_to_h5(output_filepath, dataset.velocity_colnames[i], v, compression='gzip')
-        if dataset.dx is not None and is0:
-            save_to_h5(output_filepath, dataset.dx_colname, np.expand_dims(dataset.dx / res_increase, axis=0), compression='gzip')
+            cols.append((dataset.velocity_colnames[i], v))
+        if dataset.dx is not None:
+            cols.append((dataset.dx_colname, np.expand_dims(dataset.dx / res_increase, axis=0)))
+        if is0:
+            h5io.append_datasets(output_filepath, cols, compression='gzip')     # u, v, w (+ dx/R): one pass over the file
         written.append(tuple(vols))
     return written
 

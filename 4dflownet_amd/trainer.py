@@ -255,7 +255,14 @@ class TrainerController:
             print('Saving current model - %s\n' % time.ctime())
 
     def save_best_model(self):
-        """TrainerController.py:347-363: '<dir>/<name>-best.h5' + optimizer.pkl = [iterations, m..., v...]."""
+        """TrainerController.py:347-363: '<dir>/<name>-best.h5' + optimizer.pkl = [iterations, m..., v...].
+
+        ORDER of the m / v arrays: layer CREATION order (conv3d, conv3d_1, ... kernel then bias), the order of this
+        model's trainable_variables.  Keras writes optimizer.weights in `model.trainable_variables` order, which for a
+        functional model is its depth-sorted layer list: the parallel pc / phase branches and the three heads interleave
+        there ([TF], unverifiable here: TensorFlow is absent).  Several of those layers share a shape, so a pickle written
+        by the reference cannot be told apart from ours by shapes alone: optimizer.pkl is a restart file for THIS
+        implementation, not an interchange format (the .h5 weights, keyed by layer name, are)."""
         self.model.save('%s-best.h5' % self.model_path)
         tv = self.model.trainable_variables
         sizes = [t.numel() for t in tv]
@@ -273,6 +280,11 @@ class TrainerController:
         n = len(self.model.trainable_variables)
         if len(opt_weights) != 1 + 2 * n:
             raise ValueError("optimizer.pkl holds %d arrays, expected %d" % (len(opt_weights), 1 + 2 * n))
+        shapes = [tuple(t.shape) for t in self.model.trainable_variables]
+        for k, (a, shp) in enumerate(zip(list(opt_weights[1:1 + n]) + list(opt_weights[1 + n:]), shapes + shapes)):
+            if tuple(np.shape(a)) != shp:
+                raise ValueError("optimizer.pkl: array %d has shape %s, expected %s (slot order = layer creation order, "
+                                 "see save_best_model)" % (k + 1, tuple(np.shape(a)), shp))
         self.optimizer.iterations = int(opt_weights[0])
         flat = lambda arrs: torch.from_numpy(np.concatenate([np.asarray(a, np.float32).reshape(-1) for a in arrs]))
         self.optimizer.m.copy_(flat(opt_weights[1:1 + n]))
@@ -290,7 +302,8 @@ class TrainerController:
         out = out.cpu().numpy()
         preds = preds_t.cpu().numpy()
         path = os.path.join(self.model_dir, "quicksave_%s.h5" % self.network_name)
-        sv = lambda name, arr: h5io.append_dataset(path, name, np.asarray(arr), compression='gzip')
+        cols = []
+        sv = lambda name, arr: cols.append((name, np.asarray(arr)))
         sv("epoch", np.asarray([epoch_nr]))
         pe = np.expand_dims(preds, 0)
         sv("u", pe[..., 0]); sv("v", pe[..., 1]); sv("w", pe[..., 2])
@@ -300,4 +313,5 @@ class TrainerController:
             sv("hr_u", np.squeeze(cpu(hires[0]), -1)); sv("hr_v", np.squeeze(cpu(hires[1]), -1))
             sv("hr_w", np.squeeze(cpu(hires[2]), -1))
             sv("venc", cpu(venc)); sv("mask", cpu(mask))
+        h5io.append_datasets(path, cols, compression='gzip')      # one pass over the file for all columns
         return out[:, 0], out[:, 1], out[:, 0], np.zeros_like(out[:, 0])

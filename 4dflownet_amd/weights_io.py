@@ -30,12 +30,32 @@ def load_model_weights(model, path):
         return
     from . import h5io
     by_layer = h5io.read_keras_weights(path)
+    names = [L.name for L in model.layers]
+    if not all(n in by_layer for n in names):
+        # Keras' load_weights matches layers by position, not by name: a model built second in a process is saved as
+        # conv3d_36 ... conv3d_71.  Fall back to the file's conv layers in creation order (numeric suffix) -- the shapes
+        # are then checked one by one by set_weights.
+        conv = sorted((n for n in by_layer if _suffix(n) is not None), key=_suffix)
+        if len(conv) != len(names):
+            raise KeyError("%s holds %d conv3d layers (%s ...), the model has %d: cannot match by name or by position"
+                           % (path, len(conv), ", ".join(conv[:3]), len(names)))
+        names = conv
     arrays = []
-    for L in model.layers:
-        if L.name not in by_layer:
-            raise KeyError("layer %s not found in %s" % (L.name, path))
-        k, b = by_layer[L.name]
+    for L, n in zip(model.layers, names):
+        k, b = by_layer[n]
+        if (b is None) != (L.b is None):
+            raise ValueError("%s: layer %s %s a bias but the model's %s %s" % (path, n, "has" if b is not None else "lacks", L.name,
+                                                                               "has none" if L.b is None else "expects one"))
         arrays.append(k)
         if L.b is not None:
             arrays.append(b)
     model.set_weights(arrays)
+
+
+def _suffix(name):
+    """conv3d -> 0, conv3d_<k> -> k, anything else -> None."""
+    if name == "conv3d":
+        return 0
+    if name.startswith("conv3d_") and name[7:].isdigit():
+        return int(name[7:])
+    return None

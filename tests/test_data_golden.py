@@ -134,6 +134,40 @@ def test_keras_weight_file_roundtrip(tmp_path):
     assert back["conv3d_1"][1] is None
 
 
+def test_keras_weight_file_with_shifted_layer_names_loads_by_position(tmp_path):
+    """Keras load_weights matches by topological position: a model built second in a process is saved as conv3d_36...;
+    such files must load, while a wrong layer count or a bias mismatch must raise."""
+    weights_io = importlib.import_module("4dflownet_amd.weights_io")
+    rng = np.random.default_rng(1)
+    shapes = [((3, 3, 3, 3, 64), True), ((3, 3, 3, 64, 64), False), ((3, 3, 3, 64, 1), True)]
+
+    class L:
+        def __init__(self, name, shp, bias):
+            self.name, self.w, self.b = name, np.zeros(shp, np.float32), (np.zeros(shp[-1], np.float32) if bias else None)
+
+    class M:
+        layers = [L("conv3d" if i == 0 else "conv3d_%d" % i, shp, b) for i, (shp, b) in enumerate(shapes)]
+
+        def set_weights(self, arrays):
+            self.got = arrays
+
+    file_layers = [("conv3d_%d" % (36 + i), rng.normal(size=shp).astype(np.float32), rng.normal(size=shp[-1]).astype(np.float32) if b else None)
+                   for i, (shp, b) in enumerate(shapes)]
+    p = str(tmp_path / "shifted.h5")
+    h5io.write_keras_weights(p, file_layers)
+    m = M()
+    weights_io.load_model_weights(m, p)
+    exp = [a for _, k, b in file_layers for a in ((k,) if b is None else (k, b))]
+    assert len(m.got) == len(exp) and all(np.array_equal(x, y) for x, y in zip(m.got, exp))
+    h5io.write_keras_weights(str(tmp_path / "short.h5"), file_layers[:2])
+    with pytest.raises(KeyError):
+        weights_io.load_model_weights(M(), str(tmp_path / "short.h5"))
+    bad = [file_layers[0], (file_layers[1][0], file_layers[1][1], np.zeros(64, np.float32)), file_layers[2]]
+    h5io.write_keras_weights(str(tmp_path / "bias.h5"), bad)
+    with pytest.raises(ValueError):
+        weights_io.load_model_weights(M(), str(tmp_path / "bias.h5"))
+
+
 @pytest.mark.skipif(not os.path.exists("/opt/conda/bin/python3.9"), reason="h5py interpreter only exists in the build container")
 def test_written_files_are_readable_by_real_h5py(tmp_path):
     import subprocess
