@@ -446,12 +446,16 @@ __global__ void pack_conv64_kernel(const float* __restrict__ w, float* __restric
     if (wd) wd[idx] = w[((26 - tap) * 64 + cj) * 64 + k];
 }
 
+// pack = [direct stream, 27*64*64 floats | Winograd F(4,3) stream, 54*64*64 floats]  (FDN_CONV64_PACK_FLOATS in fdn.h)
+constexpr int kDirectPackFloats = 27 * 64 * 64;
+
 extern "C" int fdn_pack_conv64_weights(const float* w, float* wp_fwd, float* wp_dgrad, void* stream) {
     FDN_REQUIRE(w != nullptr, "fdn_pack_conv64_weights: w is NULL");
     hipLaunchKernelGGL(pack_conv64_kernel, dim3((27 * 64 * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w,
                        wp_fwd, wp_dgrad);
     FDN_CHECK_LAUNCH("fdn_pack_conv64_weights");
-    return FDN_OK;
+    return fdn_pack_conv64_wino_launch(w, wp_fwd ? wp_fwd + kDirectPackFloats : nullptr,
+                                       wp_dgrad ? wp_dgrad + kDirectPackFloats : nullptr, (hipStream_t)stream);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -579,7 +583,16 @@ int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, 
     a.N = N; a.ID = ID; a.IH = IH; a.IW = IW; a.OD = OD; a.OH = OH; a.OW = OW;
     a.off = off; a.zero_mode = zero_mode; a.act = act; a.alpha = alpha; a.dbg = fdn_conv64_dbg;
     const Box full{0, 0, 0, OD, OH, OW, 0, 2, 0, 2, 0, 2};
-    if (!(fout && zero_mode && off == -1 && fdn_conv64_shell_slabs)) return launch_boxes(a, &full, 1, s);
+    // Winograd F(4,3) along W (conv64_wino.hip) whenever the W extent is a multiple of 4: half the MFMA work.  A forced
+    // direct layout (test build) selects the direct kernel below.
+    const bool wino = fdn_conv64_force_layout == 0 || fdn_conv64_force_layout == 7;
+    const float* upack = wpack + kDirectPackFloats;
+    if (!(fout && zero_mode && off == -1 && fdn_conv64_shell_slabs)) {
+        if (wino && fdn_conv64_wino_ok(OD, OH, OW))
+            return fdn_conv64_wino_launch(x, upack, bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, 0, 0, 0, OD, OH,
+                                          OW, off, zero_mode, act, alpha, s);
+        return launch_boxes(a, &full, 1, s);
+    }
     // Fused dgrad on the padded grid (OD = ID+2): padded index p <-> position P = p-1 reads dz[p - 2 + tap], zero outside.
     // The inner box p in [1,ID]^3 needs all 27 taps.  Every shell position has at least one coordinate at 0 or ID+1, where
     // only tap 2 (resp. tap 0) of that dimension can reach a real voxel: six disjoint 1-voxel slabs with 9 taps each
@@ -590,6 +603,13 @@ int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, 
         {0, 0, 0, 1, OH, OW, 2, 2, 0, 2, 0, 2},       {ID + 1, 0, 0, 1, OH, OW, 0, 0, 0, 2, 0, 2},     // d faces, full (h,w)
         {1, 0, 0, ID, 1, OW, 0, 2, 2, 2, 0, 2},       {1, IH + 1, 0, ID, 1, OW, 0, 2, 0, 0, 0, 2},     // h faces, d inner
         {1, 1, 0, ID, IH, 1, 0, 2, 0, 2, 2, 2},       {1, 1, IW + 1, ID, IH, 1, 0, 2, 0, 2, 0, 0}};    // w faces, d,h inner
+    if (wino && fdn_conv64_wino_ok(ID, IH, IW)) {
+        // inner box through the Winograd kernel (fused-fold epilogue), the six 9-tap shell slabs as one direct launch
+        if (int rc = fdn_conv64_wino_launch(x, upack, bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, 1, 1, 1, ID, IH,
+                                            IW, off, zero_mode, act, alpha, s))
+            return rc;
+        return launch_boxes(a, boxes + 1, 6, s);
+    }
     return launch_boxes(a, boxes, 7, s);
 }
 

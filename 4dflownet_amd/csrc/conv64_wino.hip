@@ -1,0 +1,416 @@
+// conv3d 3x3x3, 64 -> 64 channels, fp32, NDHWC: Winograd F(4,3) along W + direct taps along D,H, on v_mfma_f32_32x32x2_f32.
+//
+// Same contract as conv64_mfma.hip (tf.pad(SYMMETRIC) + Conv3D + bias + activation + residual of
+// src/Network/SR4DFlowNet.py:93-120 in clamp mode; Conv3DBackpropInputV2 of the same layers in zero mode with the
+// interior MirrorPadGrad fused into the epilogue), but with HALF the multiplies: on MI355X the fp32 matrix rate equals
+// the fp32 vector rate (157.3 TFLOP/s both), so the only way past the fp32 MFMA roofline is to execute fewer FLOPs.
+//
+// A run of 4 consecutive output voxels along W (a "group") is computed from 6 input voxels x[4p-1 .. 4p+4] as
+//     Y = A^T [ (G g) .* (B^T x) ]                      (Lavin & Gray, F(4,3); interpolation points 0, +-1, +-2, inf)
+// per (depth tap a, height tap b, cin): 6 multiplies instead of 12.  In implicit-GEMM terms the 27-tap K loop of the direct
+// kernel becomes 9 (a,b) taps x 6 Winograd coordinates xi, each a [groups x 64 cin] x [64 cin x 64 cout] GEMM into its OWN
+// accumulator M_xi; the output transform A^T runs once, in the epilogue.  MFMA work per voxel: 9*6/4 = 13.5 tap-equivalents
+// instead of 27.  fp32 error: ~3x the direct kernel's (5e-7 vs 1.7e-7 relative, tools/wino_numerics.py) -- three orders of
+// magnitude inside the 1e-3 parity tolerance.
+//
+// Work decomposition:
+//   * M = groups.  One workgroup (4 waves) = a box tile of td x th x tg groups (<= 64 groups = 256 voxels) x 64 cout;
+//     wave (wm, wn) owns 32 groups x 32 cout x 6 xi = 6 accumulator tiles of 32x32 (96 VGPRs).
+//   * Input transform while staging: for every (halo line, group, 16-B channel chunk) one thread loads the 6 input chunks
+//     (boundary rule applied: edge clamp == SYMMETRIC p=1, or zero for dgrad, through the buffer range check), forms the 6
+//     transformed chunks V_xi = B^T x (14 VALU per float) and writes them to LDS as 6 planes [xi][line][group] of rows with
+//     64/CS channels (+16-B pad: conflict-free ds_read_b128, see conv64_mfma.hip).  CS = 4 slices of 16 cin: 48 KB of LDS for an
+//     8x8x1 tile, 2 workgroups per CU; while one transforms, the other keeps the matrix pipe busy.
+//   * Weights: the packed stream U = G g per (a,b) tap, [cin/32][tap*6+xi][k-group][lane-half][cout row][4], read straight from
+//     L1/L2 (885 KB per layer and direction, shared by every workgroup), cout rows permuted so a lane's 16 accumulator
+//     registers are 16 consecutive channels (as in the direct kernel).
+//   * K loop: one step = one k-group (8 cin) of one (tap, xi): 1 ds_read_b128 + 1 buffer_load_b128 feed 4 MFMAs.  Fragments
+//     live in a ring of 4 slots; the slot consumed by step s-1 is refilled with the operands of step s+3 right after the first
+//     MFMA of step s (scalar address arithmetic, one v_add per LDS read) -- the same in-stream pipeline as the direct kernel.
+//   * Epilogue: Y = A^T M per lane (12 VALU per output element quartet), then bias / residual / activation, or the fused
+//     MirrorPadGrad + skip + act' of the dgrad mode, and 16-B stores: a lane owns 4 voxels x 16 consecutive channels.
+#include "fdn_common.h"
+
+namespace {
+
+struct WinoArgs {
+    const float* x;
+    const float* up;        // Winograd-domain operand stream (fdn_pack_conv64_weights, second part of the pack)
+    const float* bias;
+    const float* res;
+    float* y;
+    const float* fskip;     // fused fold (dgrad mode): see conv64_args.h
+    const float* fy;
+    float* fout;
+    int N, ID, IH, IW, OD, OH, OW;
+    int obd, obh, obw, ebd, ebh, ebw;     // output box (ebw a multiple of 4), all 27 taps
+    int off, zero_mode, act;
+    float alpha;
+    int td, th, tg, ntd, nth, ntg;        // tile in (d, h, groups) and tile counts
+    int hh, lines, ltg, items;            // th+2, (td+2)*hh, lines*tg, lines*tg*CH
+    unsigned mg_tg, mg_thtg, mg_itg, mg_ihh;
+    unsigned mg_tpn_hi, mg_tpn_lo, mg_thg_hi, mg_thg_lo, mg_ntg_hi, mg_ntg_lo;
+};
+
+constexpr int kWinoCS = 4;                 // cin slices
+constexpr int kWinoMaxLtg = 160;           // LDS: 6 planes x ltg rows x 80 B + tables <= 80 KB -> 2 workgroups per CU
+constexpr int kWinoUA = 3;                 // transform items per thread (<= 768 items = 192 (line, group) pairs x 4 chunks)
+
+template <int CS>
+__global__ __launch_bounds__(256, 2) void conv64_wino_kernel(WinoArgs p) {
+    constexpr int ROWB = 256 / CS, LROW = ROWB + 16, CH = ROWB / 16, KG = 8 / CS;
+    constexpr int SPT = 6 * KG;            // K steps per (a,b) tap
+    constexpr int RD = 4;                  // fragment ring depth
+    constexpr int UA = kWinoUA;
+    static_assert(SPT % RD == 0, "ring slots must be compile-time");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 31;
+    const int kh = lane >> 5;
+    const int wave_m = wave & 1;
+    const int wave_n = wave >> 1;
+    const int planeb = p.ltg * LROW;                       // bytes per xi plane
+    int* mtab = (int*)(smem + 6 * planeb);                 // [0,64): output index of the group's first voxel; [64,128): fused
+                                                           // index (interior d,h) or -1; [128,192): iw of the first voxel
+
+    // ---- tile coordinates (scalar multiply-shift divisions, host-made magics) ----
+    const int tiles_per_n = p.ntd * p.nth * p.ntg;
+    int b = (int)blockIdx.x;
+    const int n = fdn_udiv40(b, p.mg_tpn_hi, p.mg_tpn_lo);
+    b -= n * tiles_per_n;
+    const int tdi = fdn_udiv40(b, p.mg_thg_hi, p.mg_thg_lo);
+    b -= tdi * (p.nth * p.ntg);
+    const int thi = fdn_udiv40(b, p.mg_ntg_hi, p.mg_ntg_lo);
+    const int p0d = p.obd + tdi * p.td, p0h = p.obh + thi * p.th, p0w = p.obw + (b - thi * p.ntg) * p.tg * 4;
+    const int ng = p.td * p.th * p.tg;
+    const int thtg = p.th * p.tg;
+
+    if (tid < 64) {
+        int g = -1, gf = -1, iw0 = 0;
+        if (tid < ng) {
+            const int md = fdn_div20(tid, p.mg_thtg);
+            const int r2 = tid - md * thtg;
+            const int mh = fdn_div20(r2, p.mg_tg);
+            const int pd = p0d + md, ph = p0h + mh, pw = p0w + 4 * (r2 - mh * p.tg);
+            if (pd < p.obd + p.ebd && ph < p.obh + p.ebh && pw < p.obw + p.ebw) {
+                g = ((n * p.OD + pd) * p.OH + ph) * p.OW + pw;
+                if (p.fout) {
+                    const int id = pd - 1, ih = ph - 1;
+                    iw0 = pw - 1;
+                    if (id >= 1 && id <= p.ID - 2 && ih >= 1 && ih <= p.IH - 2) gf = ((n * p.ID + id) * p.IH + ih) * p.IW + iw0;
+                }
+            }
+        }
+        mtab[tid] = g; mtab[64 + tid] = gf; mtab[128 + tid] = iw0;
+    }
+
+    // ---- this lane's A row: (line of its group at tap (0,0)) * tg + group-in-line, plane xi = 0 ----
+    int abase;
+    {
+        int m = wave_m * 32 + li;
+        m = m < ng ? m : ng - 1;
+        const int md = fdn_div20(m, p.mg_thtg);
+        const int r2 = m - md * thtg;
+        const int mh = fdn_div20(r2, p.mg_tg);
+        abase = ((md * p.hh + mh) * p.tg + (r2 - mh * p.tg)) * LROW + kh * 16;
+    }
+    const int cofs = wave_n * 32 + kh * 16;                // first of this lane's 16 consecutive output channels
+
+    f32x16 acc[6];
+#pragma unroll
+    for (int xi = 0; xi < 6; ++xi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
+
+    // ---- transform plan, once per tile: for each of this thread's (line, group, chunk) items the byte offsets (from the
+    // sample's first voxel) of the 6 input rows with the boundary rule applied (0xffffffff = reads zero) and the LDS offset ----
+    const int q0d = p0d - 1 + p.off, q0h = p0h - 1 + p.off, q0w = p0w - 1 + p.off;
+    unsigned soff[UA][6];
+    int vrow[UA];
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+        const int i = u * 256 + tid;
+        const bool oki = i < p.items;
+        const int chunk = i & (CH - 1);
+        const int r = i / CH;
+        const int line = fdn_div20(r, p.mg_itg);
+        const int pg = r - line * p.tg;
+        const int zd = fdn_div20(line, p.mg_ihh);
+        int qd = q0d + zd, qh = q0h + (line - zd * p.hh);
+        const int qw0 = q0w + 4 * pg;
+        bool okl = oki;
+        if (p.zero_mode) okl = okl && (unsigned)qd < (unsigned)p.ID && (unsigned)qh < (unsigned)p.IH;
+        else { qd = min(max(qd, 0), p.ID - 1); qh = min(max(qh, 0), p.IH - 1); }
+        const int lbase = (qd * p.IH + qh) * p.IW;
+#pragma unroll
+        for (int nn = 0; nn < 6; ++nn) {
+            int qw = qw0 + nn;
+            bool ok = okl;
+            if (p.zero_mode) ok = ok && (unsigned)qw < (unsigned)p.IW;
+            else qw = min(max(qw, 0), p.IW - 1);
+            soff[u][nn] = ok ? (unsigned)(lbase + qw) * 256u + (unsigned)(chunk * 16) : 0xffffffffu;
+        }
+        vrow[u] = oki ? r * LROW + chunk * 16 : -1;
+    }
+    const size_t in_n = (size_t)n * p.ID * p.IH * p.IW;
+    const unsigned sample_bytes = (unsigned)(p.ID * p.IH * p.IW) * 256u;
+
+    // weight stream: unit (2048 B) index = half*216 + (tap*6 + xi)*4 + k-group-in-half
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.up, 0, 54 * 64 * 64 * 4, 0x00020000);
+    const int wvoff = (kh * 64 + wave_n * 32 + li) * 16;
+    f32x4 A[RD], B[RD];
+    auto wsoff = [&](int sl_, int tap, int jj) -> int {      // jj = xi*KG + g within the tap
+        return ((((sl_ * KG) >> 2) * 216) + tap * 24 + ((sl_ * KG) & 3) + (jj / KG) * 4 + (jj % KG)) * 2048;
+    };
+    auto ldb = [&](int slot, int so) {
+        B[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, so, 0));
+    };
+    auto lda = [&](int slot, int tapb, int jj) {             // tapb: byte offset of the (a,b) tap's line
+        A[slot] = *(const f32x4*)(smem + abase + tapb + (jj / KG) * planeb + (jj % KG) * 32);
+    };
+
+#pragma unroll 1
+    for (int sl = 0; sl < CS; ++sl) {
+        if (sl) __syncthreads();                             // everyone finished reading the previous slice
+        // ---- stage + transform cin [sl*64/CS, (sl+1)*64/CS): all loads in flight before the first use ----
+        {
+            const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(p.x + in_n * 64 + sl * (64 / CS)), 0, sample_bytes - sl * (256 / CS), 0x00020000);
+            f32x4 xv[UA][6];
+#pragma unroll
+            for (int u = 0; u < UA; ++u) {
+                if (u * 256 >= p.items) break;
+#pragma unroll
+                for (int nn = 0; nn < 6; ++nn)
+                    xv[u][nn] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, soff[u][nn], 0, 0));
+            }
+#pragma unroll
+            for (int u = 0; u < UA; ++u) {
+                if (u * 256 >= p.items) break;
+                if (vrow[u] < 0) continue;
+                // B^T of F(4,3): rows (4,0,-5,0,1,0) (0,-4,-4,1,1,0) (0,4,-4,-1,1,0) (0,-2,-1,2,1,0) (0,2,-1,-2,1,0) (0,4,0,-5,0,1)
+                const f32x4 x0 = xv[u][0], x1 = xv[u][1], x2 = xv[u][2], x3 = xv[u][3], x4 = xv[u][4], x5 = xv[u][5];
+                const f32x4 t1 = x4 - 4.f * x2, t2 = x3 - 4.f * x1;
+                const f32x4 t3 = x4 - x2, t4 = 2.f * (x3 - x1);
+                char* vp = smem + vrow[u];
+                *(f32x4*)(vp) = 4.f * x0 - 5.f * x2 + x4;
+                *(f32x4*)(vp + planeb) = t1 + t2;
+                *(f32x4*)(vp + 2 * planeb) = t1 - t2;
+                *(f32x4*)(vp + 3 * planeb) = t3 + t4;
+                *(f32x4*)(vp + 4 * planeb) = t3 - t4;
+                *(f32x4*)(vp + 5 * planeb) = 4.f * x1 - 5.f * x3 + x5;
+            }
+        }
+        __syncthreads();
+
+        // ---- K loop: 9 (a,b) taps x 6 xi x KG k-groups ----
+        {
+            if (sl == 0) {
+#pragma unroll
+                for (int j = 0; j < RD - 1; ++j) ldb(j, wsoff(0, 0, j));
+            }
+#pragma unroll
+            for (int j = 0; j < RD - 1; ++j) lda(j, 0, j);
+            const int sln = sl + 1 < CS ? sl + 1 : sl;       // harmless reload after the last slice
+            int ta = 0, tb = 0, tapb = 0;
+#pragma unroll 1
+            for (int it = 0; it < 9; ++it) {
+                int na = ta, nb = tb + 1;
+                if (nb > 2) { nb = 0; ++na; }
+                const bool last = it == 8;
+                const int tapb_n = last ? tapb : (na * p.hh + nb) * p.tg * LROW;
+                const int tap_n = last ? 0 : it + 1;
+                const int sl_n = last ? sln : sl;
+#pragma unroll
+                for (int j = 0; j < SPT; ++j) {
+                    const int slot = j % RD;
+                    const int xi = j / KG;
+                    acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(B[slot][0], A[slot][0], acc[xi], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    {
+                        const int jj = j + RD - 1;           // the step whose operands go into the slot step j-1 just freed
+                        const int slotr = jj % RD;
+                        if (jj < SPT) { ldb(slotr, wsoff(sl, it, jj)); lda(slotr, tapb, jj); }
+                        else { ldb(slotr, wsoff(sl_n, tap_n, jj - SPT)); lda(slotr, tapb_n, jj - SPT); }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int s = 1; s < 4; ++s)
+                        acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(B[slot][s], A[slot][s], acc[xi], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                ta = na; tb = nb; tapb = tapb_n;
+            }
+        }
+    }
+
+    // ---- epilogue: Y = A^T M, A^T = (1,1,1,1,1,0) (0,1,-1,2,-2,0) (0,1,1,4,4,0) (0,1,-1,8,-8,1); lane = one group x 16 cout ----
+    const int m = wave_m * 32 + li;
+    const int g0 = mtab[m];
+    if (g0 < 0) return;
+    const int gf0 = mtab[64 + m];
+    const int iw0 = mtab[128 + m];
+    const float slope = p.act == FDN_ACT_RELU ? 0.f : (p.act == FDN_ACT_LEAKY ? p.alpha : 1.f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f32x4 z[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = q * 4 + e;
+                const float s12 = acc[1][r] + acc[2][r], d12 = acc[1][r] - acc[2][r];
+                const float s34 = acc[3][r] + acc[4][r], d34 = acc[3][r] - acc[4][r];
+                float v;
+                if (i == 0) v = acc[0][r] + s12 + s34;
+                else if (i == 1) v = d12 + 2.f * d34;
+                else if (i == 2) v = s12 + 4.f * s34;
+                else v = d12 + 8.f * d34 + acc[5][r];
+                z[q][e] = v;
+            }
+        if (p.fout) {
+            const int iw = iw0 + i;
+            if (gf0 >= 0 && iw >= 1 && iw <= p.IW - 2) {
+                // strictly inside the volume: exactly one contribution -> finish dz_prev = (dgrad + skip) * act'(y) here
+                const size_t o = (size_t)(gf0 + i) * 64 + cofs;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 sk = p.fskip ? *(const f32x4*)(p.fskip + o + q * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    const f32x4 ym = p.fy ? *(const f32x4*)(p.fy + o + q * 4) : (f32x4){1.f, 1.f, 1.f, 1.f};
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (z[q][e] + sk[e]) * (ym[e] > 0.f ? 1.f : slope);
+                    *(f32x4*)(p.fout + o + q * 4) = v;
+                }
+            } else {
+                const size_t o = (size_t)(g0 + i) * 64 + cofs;     // surface voxel: padded scratch, finished by the border fold
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *(f32x4*)(p.y + o + q * 4) = z[q];
+            }
+        } else {
+            const size_t o = (size_t)(g0 + i) * 64 + cofs;
+            if (p.res) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) z[q] += *(const f32x4*)(p.res + o + q * 4);
+            }
+            if (p.bias) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r >> 2][r & 3] += p.bias[cofs + r];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = z[q][e];
+                    z[q][e] = fmaxf(t, slope * t);             // relu / leaky / none: slope in [0,1]
+                }
+                *(f32x4*)(p.y + o + q * 4) = z[q];
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Winograd-domain weight stream U = G g along the W taps, G of F(4,3):
+//   (1/4,0,0) (-1/6,-1/6,-1/6) (-1/6,1/6,-1/6) (1/24,1/12,1/6) (1/24,-1/12,1/6) (0,0,1)
+// layout [half][vt = (a*3+b)*6 + xi][k-group][kh][row j][s], row permutation c(j) as in pack_conv64_kernel.
+//   fwd  : cin = 32*half + 8g + 4kh + s, cout = c(j):  U = sum_t G[xi][t] w[a][b][t][cin][cout]
+//   dgrad: contraction over the layer's cout, taps flipped:  U = sum_t G[xi][t] w[2-a][2-b][2-t][ci = c(j)][co = 32*half+8g+4kh+s]
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wino_pack_one(const float* __restrict__ w, float* __restrict__ uf, float* __restrict__ ud, int idx) {
+    const int s = idx & 3;
+    const int j = (idx >> 2) & 63;
+    const int kh = (idx >> 8) & 1;
+    const int g = (idx >> 9) & 3;
+    const int rest = idx >> 11;          // half*54 + vt
+    const int half = rest / 54;
+    const int vt = rest - half * 54;
+    const int tap9 = vt / 6;
+    const int xi = vt - tap9 * 6;
+    const int k = half * 32 + g * 8 + kh * 4 + s;
+    const int cj = (j & 32) + 16 * ((j >> 2) & 1) + (j & 3) + 4 * ((j & 31) >> 3);
+    const float G[6][3] = {{0.25f, 0.f, 0.f}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
+                           {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
+    if (uf) {
+        float v = 0.f;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) v += G[xi][t] * w[((tap9 * 3 + t) * 64 + k) * 64 + cj];
+        uf[idx] = v;
+    }
+    if (ud) {
+        float v = 0.f;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) v += G[xi][t] * w[((26 - (tap9 * 3 + t)) * 64 + cj) * 64 + k];
+        ud[idx] = v;
+    }
+}
+
+__global__ void pack_conv64_wino_kernel(const float* __restrict__ w, float* __restrict__ uf, float* __restrict__ ud) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < 54 * 64 * 64) wino_pack_one(w, uf, ud, idx);
+}
+
+struct WinoPlan { int td, th, tg; double cost; };
+
+// tile choice: every tile costs the MFMA time of 64 groups whatever its fill, plus the transform work of its halo lines;
+// the launch ends with the busiest CU (2 co-resident workgroups per CU share the matrix pipe, so work per CU = its tiles).
+WinoPlan wino_plan(int N, int ebd, int ebh, int ebg) {
+    WinoPlan best{1, 1, 1, 1e30};
+    for (int td = 1; td <= ebd && td <= 64; ++td)
+        for (int th = 1; th <= ebh && td * th <= 64; ++th)
+            for (int tg = 1; tg <= ebg && td * th * tg <= 64; ++tg) {
+                const int ltg = (td + 2) * (th + 2) * tg;
+                if (ltg > kWinoMaxLtg || ltg * (64 / kWinoCS / 4) > kWinoUA * 256) continue;
+                const double tiles = (double)N * ((ebd + td - 1) / td) * ((ebh + th - 1) / th) * ((ebg + tg - 1) / tg);
+                const double per_tile = 64.0 + 0.12 * ltg;
+                const double rounds = 0.9 * (double)((long long)((tiles + 255) / 256)) + 0.1 * tiles / 256.0;
+                const double c = rounds * per_tile;
+                if (c < best.cost) best = {td, th, tg, c};
+            }
+    return best;
+}
+
+}  // namespace
+
+// Is the Winograd kernel applicable to this output box?  (W extent a multiple of 4; everything else falls to the direct kernel.)
+bool fdn_conv64_wino_ok(int ebd, int ebh, int ebw) { return ebd > 0 && ebh > 0 && ebw >= 4 && (ebw & 3) == 0; }
+
+int fdn_conv64_wino_launch(const float* x, const float* upack, const float* bias, const float* residual, float* y,
+                           const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
+                           int OW, int obd, int obh, int obw, int ebd, int ebh, int ebw, int off, int zero_mode, int act,
+                           float alpha, hipStream_t s) {
+    FDN_REQUIRE((long long)ID * IH * IW < (1ll << 24), "conv64 (winograd): a sample of %dx%dx%d voxels exceeds the 32-bit row addressing", ID, IH, IW);
+    FDN_REQUIRE(fdn_conv64_wino_ok(ebd, ebh, ebw), "conv64 (winograd): W extent %d is not a multiple of 4", ebw);
+    constexpr int CS = kWinoCS, LROW = 256 / CS + 16, CH = 256 / CS / 16;
+    const int ebg = ebw / 4;
+    const WinoPlan pl = wino_plan(N, ebd, ebh, ebg);
+    WinoArgs a;
+    a.x = x; a.up = upack; a.bias = bias; a.res = residual; a.y = y; a.fskip = fskip; a.fy = fy; a.fout = fout;
+    a.N = N; a.ID = ID; a.IH = IH; a.IW = IW; a.OD = OD; a.OH = OH; a.OW = OW;
+    a.obd = obd; a.obh = obh; a.obw = obw; a.ebd = ebd; a.ebh = ebh; a.ebw = ebw;
+    a.off = off; a.zero_mode = zero_mode; a.act = act; a.alpha = alpha;
+    a.td = pl.td; a.th = pl.th; a.tg = pl.tg;
+    a.ntd = (ebd + pl.td - 1) / pl.td; a.nth = (ebh + pl.th - 1) / pl.th; a.ntg = (ebg + pl.tg - 1) / pl.tg;
+    a.hh = pl.th + 2; a.lines = (pl.td + 2) * a.hh; a.ltg = a.lines * pl.tg; a.items = a.ltg * CH;
+    a.mg_tg = fdn_magic20(pl.tg); a.mg_thtg = fdn_magic20(pl.th * pl.tg);
+    a.mg_itg = fdn_magic20(pl.tg); a.mg_ihh = fdn_magic20(a.hh);
+    fdn_magic40(a.ntd * a.nth * a.ntg, &a.mg_tpn_hi, &a.mg_tpn_lo);
+    fdn_magic40(a.nth * a.ntg, &a.mg_thg_hi, &a.mg_thg_lo);
+    fdn_magic40(a.ntg, &a.mg_ntg_hi, &a.mg_ntg_lo);
+    const long long blocks = (long long)N * a.ntd * a.nth * a.ntg;
+    FDN_REQUIRE(blocks < (1ll << 31), "conv64 (winograd): too many tiles");
+    const size_t lds = (size_t)6 * a.ltg * LROW + 192 * 4;
+    if (int rc = fdn_func_max_lds((const void*)conv64_wino_kernel<CS>, 6 * kWinoMaxLtg * LROW + 192 * 4, "conv64_wino")) return rc;
+    hipLaunchKernelGGL((conv64_wino_kernel<CS>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+    FDN_CHECK_LAUNCH("conv64_wino_kernel");
+    return FDN_OK;
+}
+
+int fdn_pack_conv64_wino_launch(const float* w, float* uf, float* ud, hipStream_t s) {
+    hipLaunchKernelGGL(pack_conv64_wino_kernel, dim3((54 * 64 * 64 + 255) / 256), dim3(256), 0, s, w, uf, ud);
+    FDN_CHECK_LAUNCH("pack_conv64_wino_kernel");
+    return FDN_OK;
+}

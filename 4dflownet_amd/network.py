@@ -86,7 +86,8 @@ class FlowNetModel:
         self.layers = []
         off = 0
         n64 = sum(1 for _, k, ci, co, _ in self.specs if (k, ci, co) == (3, 64, 64))
-        self._packs = torch.empty((n64, 2, 27 * 64 * 64), device=self.device, dtype=self.act_dtype)
+        pack_elems = ops.CONV64_PACK_FLOATS if dtype == "float32" else 27 * 64 * 64
+        self._packs = torch.empty((n64, 2, pack_elems), device=self.device, dtype=self.act_dtype)
         i64 = 0
         for name, k, ci, co, ub in self.specs:
             L = _Layer()

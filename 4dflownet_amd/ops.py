@@ -9,6 +9,7 @@ from ._lib import FdnError, check
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 LEAKY_ALPHA = 0.2
+CONV64_PACK_FLOATS = 81 * 64 * 64     # FDN_CONV64_PACK_FLOATS: direct stream (27 taps) + Winograd F(4,3) stream (54)
 
 
 def _p(t, name="tensor", allow_none=False):
@@ -45,9 +46,9 @@ def pack_conv64_weights(w, wp_fwd=None, wp_dgrad=None, want_dgrad=True):
     if tuple(w.shape) != (3, 3, 3, 64, 64):
         raise FdnError("pack_conv64_weights: expected (3,3,3,64,64), got %s" % (tuple(w.shape),))
     if wp_fwd is None:
-        wp_fwd = torch.empty(27 * 64 * 64, device=w.device, dtype=torch.float32)
+        wp_fwd = torch.empty(CONV64_PACK_FLOATS, device=w.device, dtype=torch.float32)
     if wp_dgrad is None and want_dgrad:
-        wp_dgrad = torch.empty(27 * 64 * 64, device=w.device, dtype=torch.float32)
+        wp_dgrad = torch.empty(CONV64_PACK_FLOATS, device=w.device, dtype=torch.float32)
     check(_lib.load().fdn_pack_conv64_weights(_p(w), _p(wp_fwd), _p(wp_dgrad, allow_none=True), _stream()),
           "fdn_pack_conv64_weights")
     return wp_fwd, wp_dgrad

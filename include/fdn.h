@@ -51,8 +51,12 @@ int fdn_input_features(const float* u, const float* v, const float* w, const flo
                        const float* mw, float* phase, float* pc, int64_t nvox, void* stream);
 
 /* Re-layout one 3x3x3 64->64 Keras kernel (27,64,64) into the MFMA operand streams used by
- * fdn_conv3d_fwd (wp_fwd) and fdn_conv3d_dgrad (wp_dgrad: taps flipped, Cin/Cout swapped).
- * Each output is 27*64*64 floats.  Either output may be NULL. */
+ * fdn_conv3d_fwd (wp_fwd) and fdn_conv3d_dgrad / fdn_conv3d_dgrad_fused (wp_dgrad: taps flipped,
+ * Cin/Cout swapped).  Each output is FDN_CONV64_PACK_FLOATS floats: the direct-convolution stream
+ * (27 taps) followed by the Winograd F(4,3)-along-W stream U = G g (9 (kd,kh) taps x 6 transform
+ * coordinates), which the conv entry points select when the W extent is a multiple of 4.
+ * Either output may be NULL. */
+#define FDN_CONV64_PACK_FLOATS (81 * 64 * 64)
 int fdn_pack_conv64_weights(const float* w, float* wp_fwd, float* wp_dgrad, void* stream);
 
 /* y = act(conv3d(sym_pad(x), w) + bias + residual).

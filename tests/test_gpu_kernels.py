@@ -33,6 +33,10 @@ def ops(fdn):
 
 
 SHAPES = [(2, 8, 8, 8), (1, 5, 7, 9), (1, 10, 12, 16), (3, 4, 4, 2)]
+# W a multiple of 4 -> the planner (variant 0) takes the Winograd F(4,3) kernel; forced variants 1..6 stay on the direct
+# kernel, 7 forces Winograd.  Shapes cover a single partial tile, ragged tile grids in every dimension, W = 4, and a
+# multi-tile launch (24^3, the cfg2 low-res grid).
+WINO_SHAPES = [(1, 5, 7, 12), (3, 4, 4, 4), (2, 9, 3, 24), (1, 1, 1, 4), (1, 17, 10, 8), (2, 24, 24, 24)]
 
 
 @contextlib.contextmanager
@@ -47,8 +51,8 @@ def variant_lib(fdn, variant):
             yield lib
 
 
-@pytest.mark.parametrize("shape", SHAPES)
-@pytest.mark.parametrize("mt", [0, 1, 2, 3, 4, 5, 6])   # 0 = planner, 1..6 = forced <MT,NW,CS> variant
+@pytest.mark.parametrize("shape,mt", [(sh, mt) for sh in SHAPES for mt in (0, 1, 2, 3, 4, 5, 6)] +
+                         [(sh, mt) for sh in WINO_SHAPES for mt in (0, 7, 3)])   # 0 = planner, 1..6 = forced <MT,NW,CS>, 7 = Winograd
 def test_conv64_fwd(ops, fdn, shape, mt):
     rng = np.random.default_rng(1)
     N, D, H, W = shape
@@ -88,8 +92,8 @@ def test_conv64_dgrad_and_fold(ops, shape):
     close(ops.fold_halo([pad, pad, pad], None, dev(y), O.ACT_RELU), ref3, name="fold 3 src+relu")
 
 
-@pytest.mark.parametrize("shape", SHAPES + [(1, 1, 1, 1), (1, 2, 3, 1)])
-@pytest.mark.parametrize("layout", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("shape,layout", [(sh, lo) for sh in SHAPES + [(1, 1, 1, 1), (1, 2, 3, 1)] for lo in (0, 1, 2, 3, 4, 5, 6)] +
+                         [(sh, lo) for sh in WINO_SHAPES for lo in (0, 7, 5)])
 def test_conv64_dgrad_fused_fold(ops, fdn, shape, layout):
     """dgrad with the interior fold in the conv epilogue + border kernel == oracle dgrad (+ skip, * act')."""
     rng = np.random.default_rng(6)

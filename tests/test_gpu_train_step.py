@@ -104,7 +104,7 @@ def test_train_step_matches_oracle(fdn, P, R, LB, HB, B):
                     assert rel_err(g_total[sb], gref[sb]) < tol_g, (L.name, "bias grad", flips)
             # now the real step on both sides.  Adam's update is ~ lr*sign(g) on the first steps, so an element whose
             # gradient is rounding noise may move by +-lr in either direction: bound those by 2.5*lr*steps, and hold
-            # the well-conditioned elements (|g| >= 1e-3 max|g| of their layer) to 1e-2*lr at the first step.
+            # the well-conditioned elements (|g| >= 1e-3 max|g| of their layer) to 3e-2*lr at the first step.
             w_before = tc.model.flat_w.cpu().numpy().astype(np.float64)
             loss = tc.train_step(batch)
             O.train_step(params, state, b64, 1e-3, R, LB, HB, f32_coeffs=True)
@@ -117,7 +117,9 @@ def test_train_step_matches_oracle(fdn, P, R, LB, HB, B):
                 for L in tc.model.layers:
                     sl = slice(L.w_off, L.w_off + L.w.numel())
                     good = np.abs(gref[sl]) >= 1e-3 * np.abs(gref[sl]).max()
-                    assert np.abs(w_gpu[sl] - w_ref[sl])[good].max() <= 1e-5, (L.name, "adam update")
+                    # 3e-2*lr: the Winograd F(4,3) conv kernels carry ~3x the rounding noise of the direct kernels (5e-7 vs
+                    # 1.7e-7 relative), and lr*g/(|g|+eps') amplifies gradient noise where |g| approaches eps' = 3e-6
+                    assert np.abs(w_gpu[sl] - w_ref[sl])[good].max() <= 3e-5, (L.name, "adam update")
         assert tc.loss_metrics["train_loss"].result() > 0
         assert abs(tc.loss_metrics["l2_reg_loss"].result() - O.l2_regularizer(params)) / O.l2_regularizer(params) < 1e-2
         if flips_total == 0:

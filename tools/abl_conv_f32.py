@@ -4,7 +4,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 fdn = importlib.import_module("4dflownet_amd")
 ops = fdn.ops
-lib = fdn._lib.test_build().__enter__()     # test build: the fdn_debug_* hooks are not in the product library
+_tb = fdn._lib.test_build()                     # test build: the fdn_debug_* hooks are not in the product library
+lib = _tb.__enter__()                          # (keep _tb alive: closing it restores the product library)
 def timeit(fn, iters=10):
     for _ in range(3): fn()
     torch.cuda.synchronize()

@@ -8,7 +8,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 fdn = importlib.import_module("4dflownet_amd")
 bops = importlib.import_module("4dflownet_amd.ops_bf16")
-lib = fdn._lib.test_build().__enter__()     # test build: the fdn_debug_* hooks are not in the product library
+_tb = fdn._lib.test_build()                     # test build: the fdn_debug_* hooks are not in the product library
+lib = _tb.__enter__()                          # (keep _tb alive: closing it restores the product library)
 PEAK = 2516.6   # TFLOP/s dense bf16: 256 CU x 4 SIMD x 1024 flop/clk x 2.4 GHz
 
 

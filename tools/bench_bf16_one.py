@@ -6,7 +6,8 @@ bops = importlib.import_module("4dflownet_amd.ops_bf16")
 N, P = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (4, 128)
 dbg = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 fdn = importlib.import_module("4dflownet_amd")
-fdn._lib.test_build().__enter__().fdn_debug_set_conv64_bf16_dbg(dbg)
+_tb = fdn._lib.test_build()
+_tb.__enter__().fdn_debug_set_conv64_bf16_dbg(dbg)
 w = torch.randn(3, 3, 3, 64, 64, device="cuda") * 0.05
 wf, wd = bops.pack_conv64_weights(w)
 x = torch.randn(N, P, P, P, 64, device="cuda").to(torch.bfloat16)

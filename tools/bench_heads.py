@@ -3,7 +3,8 @@ import importlib, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 fdn = importlib.import_module("4dflownet_amd")
-lib = fdn._lib.test_build().__enter__()     # test build: the fdn_debug_* hooks are not in the product library
+_tb = fdn._lib.test_build()                     # test build: the fdn_debug_* hooks are not in the product library
+lib = _tb.__enter__()                          # (keep _tb alive: closing it restores the product library)
 lib_dbg = lib
 
 

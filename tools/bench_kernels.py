@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 fdn = importlib.import_module("4dflownet_amd")
 ops = fdn.ops
 PEAK = 157.3
-VARIANTS = {0: "auto", 1: "<2,1,cs2>", 2: "<2,1,cs4>", 3: "<1,1,cs2>", 4: "<1,1,cs4>", 5: "<1,2,cs2>", 6: "<1,2,cs4>"}
+VARIANTS = {0: "auto", 7: "winograd F(4,3)", 1: "<2,1,cs2>", 2: "<2,1,cs4>", 3: "<1,1,cs2>", 4: "<1,1,cs4>", 5: "<1,2,cs2>", 6: "<1,2,cs4>"}
 
 
 def timeit(fn, iters, warmup=3):
@@ -35,9 +35,11 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--sizes", type=int, nargs="*", default=[24, 48])
     ap.add_argument("--ablate", action="store_true")
+    ap.add_argument("--variants", type=int, nargs="*", default=[1, 2, 3, 4, 5, 6, 7, 0])
     args = ap.parse_args()
     torch.manual_seed(0)
-    lib = fdn._lib.test_build().__enter__()     # test build: the fdn_debug_* hooks are not in the product library
+    _tb = fdn._lib.test_build()                     # test build: the fdn_debug_* hooks are not in the product library
+    lib = _tb.__enter__()                          # (keep _tb alive: closing it restores the product library)
     for P in args.sizes:
         N = args.n
         x = torch.randn((N, P, P, P, 64), device="cuda")
@@ -49,7 +51,7 @@ def main():
         dxo = torch.empty_like(x)
         flop = 2.0 * 27 * 64 * 64 * N * P ** 3
         rep = lambda name, ms: print("%-34s N=%d P=%d : %8.3f ms  %7.2f TF  %5.1f %% of peak" % (name, N, P, ms, flop / ms * 1e-9, flop / ms * 1e-9 / PEAK * 100))
-        for v in (1, 2, 3, 4, 5, 6, 0):
+        for v in args.variants:
             lib.fdn_debug_set_conv64_mt(v)
             rep("conv64 fwd %s" % VARIANTS[v], timeit(lambda: ops.conv3d_fwd(x, w, None, ops.ACT_RELU, wpack=wf, out=y), args.iters))
             rep("conv64 fwd+res+leaky %s" % VARIANTS[v], timeit(lambda: ops.conv3d_fwd(x, w, None, ops.ACT_LEAKY, 0.2, dz, wpack=wf, out=y), args.iters))

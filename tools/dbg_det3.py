@@ -3,7 +3,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 fdn = importlib.import_module("4dflownet_amd")
 bops = importlib.import_module("4dflownet_amd.ops_bf16")
-lib = fdn._lib.test_build().__enter__()     # test build: the fdn_debug_* hooks are not in the product library
+_tb = fdn._lib.test_build()                     # test build: the fdn_debug_* hooks are not in the product library
+lib = _tb.__enter__()                          # (keep _tb alive: closing it restores the product library)
 torch.manual_seed(0)
 w = torch.randn(3, 3, 3, 64, 64, device="cuda") * 0.05
 wf, wd = bops.pack_conv64_weights(w)

@@ -3,7 +3,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 fdn = importlib.import_module("4dflownet_amd")
 import ctypes
-dbg = fdn._lib.test_build().__enter__()
+_tb = fdn._lib.test_build()
+dbg = _tb.__enter__()
 torch.manual_seed(0)
 for dtype in ("f32", "bf16"):
     ops = fdn.ops if dtype == "f32" else importlib.import_module("4dflownet_amd.ops_bf16")

@@ -8,7 +8,8 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 48
 dbg = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 var = int(sys.argv[4]) if len(sys.argv) > 4 else 0
-lib = fdn._lib.test_build().__enter__()     # test build: the fdn_debug_* hooks are not in the product library
+_tb = fdn._lib.test_build()                     # test build: the fdn_debug_* hooks are not in the product library
+lib = _tb.__enter__()                          # (keep _tb alive: closing it restores the product library)
 x = torch.randn((N, P, P, P, 64), device="cuda")
 w = torch.randn((3, 3, 3, 64, 64), device="cuda") * 0.02
 wf, wd = ops.pack_conv64_weights(w)
