@@ -29,7 +29,12 @@ int fdn_func_max_lds(const void* fn, int bytes, const char* who) {
     return FDN_OK;
 }
 
-extern "C" int fdn_version(void) { return 110; }
+FDN_HOOK_VAR(int, fdn_wgrad64_force_direct, 0);
+#ifdef FDN_TEST_HOOKS
+extern "C" int fdn_debug_set_wgrad64_direct(int on) { fdn_wgrad64_force_direct = on; return FDN_OK; }
+#endif
+
+extern "C" int fdn_version(void) { return 120; }
 extern "C" const char* fdn_last_error(void) { return g_err; }
 
 // small-channel kernels (small_convs.hip), templated on the activation storage type (float / uint16_t = bf16 bits)
@@ -128,7 +133,10 @@ extern "C" int fdn_fold_halo_border(const float* dxpad0, const float* dxpad1, co
 }
 
 extern "C" size_t fdn_conv3d_wgrad_workspace_bytes(int N, int D, int H, int W, int Cin, int Cout, int K) {
-    if (Cin == 64 && Cout == 64 && K == 3) return fdn_wgrad64_workspace_bytes(N, D, H, W);
+    if (Cin == 64 && Cout == 64 && K == 3) {
+        const size_t wd = fdn_wgrad64_workspace_bytes(N, D, H, W), ww = fdn_wgrad64_wino_workspace_bytes(N, D, H, W);
+        return wd > ww ? wd : ww;
+    }
     return fdn_small_wgrad_workspace_bytes(Cin, Cout, K);
 }
 
@@ -147,7 +155,9 @@ extern "C" int fdn_conv3d_wgrad(const float* x, const float* x2, const float* dz
     int rc;
     if (Cin == 64 && Cout == 64 && K == 3) {
         FDN_REQUIRE(lddz == 64 && dz_coff == 0, "fdn_conv3d_wgrad: 64->64 path reads dense dz rows");
-        rc = fdn_wgrad64_launch(x, dz, dw, workspace, workspace_bytes, N, D, H, W, s);
+        // Winograd F(3,4) along W (wgrad64_wino.hip): half the multiplies of the direct kernel (kept for the test build's A/B runs)
+        rc = fdn_wgrad64_force_direct ? fdn_wgrad64_launch(x, dz, dw, workspace, workspace_bytes, N, D, H, W, s)
+                                      : fdn_wgrad64_wino_launch(x, dz, dw, workspace, workspace_bytes, N, D, H, W, s);
     } else if (Cin == 3 && Cout == 64 && K == 3) {
         FDN_REQUIRE(lddz == 64 && dz_coff == 0, "fdn_conv3d_wgrad(3->64): dense dz rows");
         rc = fdn_wgrad_cin3_launch(x, dz, dw, workspace, workspace_bytes, N, D, H, W, s);

@@ -148,6 +148,9 @@ int fdn_fold_halo_border_launch(const float* s0, const float* s1, const float* s
 int fdn_wgrad64_launch(const float* x, const float* dz, float* dw, void* ws, size_t ws_bytes, int N, int D, int H,
                        int W, hipStream_t s);
 size_t fdn_wgrad64_workspace_bytes(int N, int D, int H, int W);
+int fdn_wgrad64_wino_launch(const float* x, const float* dz, float* dw, void* ws, size_t ws_bytes, int N, int D, int H,
+                            int W, hipStream_t s);
+size_t fdn_wgrad64_wino_workspace_bytes(int N, int D, int H, int W);
 
 // bf16 activation path (conv64_bf16.hip)
 int fdn_conv64_bf16_launch(const uint16_t* x, const uint16_t* wpack, const float* bias, const uint16_t* residual, uint16_t* y,
