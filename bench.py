@@ -11,7 +11,8 @@ several ranks on one device over gloo and marks the line as such).
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the 64->64 3x3x3 MFMA conv, shared by forward and
 dgrad), `roofline_wgrad` for the second one (the 64->64 weight-gradient kernel); both from launch durations measured
-live by HIP events on the launch stream inside the timed region.  At N=1, after the timed region: `cpu_baseline` (the same
+live by HIP events on the launch stream inside the timed region.  `achieved`/`frac` count ALGORITHMIC FLOPs; the
+fp32 kernels are Winograd kernels that execute half of them, so `frac` may exceed 1 -- `executed_frac` is the MFMA utilisation.  At N=1, after the timed region: `cpu_baseline` (the same
 train step on the host cores: torch-CPU/oneDNN, plus the numpy oracle as a second figure) and `secondary` (a loader-fed
 cfg2 run with the on-device input pipeline inside the timed loop, and a short cfg4 bf16 run)."""
 import argparse
@@ -58,7 +59,7 @@ class LaunchTimer:
         self.enabled = False
         self._orig = {}
 
-    def _wrap(self, name, kind, vox_of, is64):
+    def _wrap(self, name, kind, shape_of, is64, shell):
         orig = getattr(self.ops, name, None)
         if orig is None:
             return
@@ -70,16 +71,19 @@ class LaunchTimer:
                 return orig(*a, **k)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); out = orig(*a, **k); e1.record()
-            rec.append((vox_of(*a, **k), e0, e1))
+            N, D, H, W = shape_of(*a, **k)
+            # positions of the padded grid outside the volume: the fused dgrad computes them with 9 of the 27 taps (shell slabs)
+            extra = N * ((D + 2) * (H + 2) * (W + 2) - D * H * W) if shell else 0
+            rec.append((N * D * H * W, e0, e1, extra))
             return out
         setattr(self.ops, name, f)
 
     def install(self):
-        vox = lambda t: t.shape[0] * t.shape[1] * t.shape[2] * t.shape[3]
-        self._wrap("conv3d_fwd", "conv", lambda x, w, *a, **k: vox(x), lambda x, w, *a, **k: tuple(w.shape) == (3, 3, 3, 64, 64))
-        self._wrap("conv3d_dgrad_fused", "conv", lambda dz, *a, **k: vox(dz), lambda *a, **k: True)
-        self._wrap("conv3d_wgrad", "wgrad", lambda x, dz, K, Cin, Cout, *a, **k: vox(x),
-                   lambda x, dz, K, Cin, Cout, *a, **k: (K, Cin, Cout) == (3, 64, 64))
+        shp = lambda t: tuple(t.shape[:4])
+        self._wrap("conv3d_fwd", "conv", lambda x, w, *a, **k: shp(x), lambda x, w, *a, **k: tuple(w.shape) == (3, 3, 3, 64, 64), False)
+        self._wrap("conv3d_dgrad_fused", "conv", lambda dz, *a, **k: shp(dz), lambda *a, **k: True, True)
+        self._wrap("conv3d_wgrad", "wgrad", lambda x, dz, K, Cin, Cout, *a, **k: shp(x),
+                   lambda x, dz, K, Cin, Cout, *a, **k: (K, Cin, Cout) == (3, 64, 64), False)
 
     def uninstall(self):
         for name, orig in self._orig.items():
@@ -90,9 +94,12 @@ class LaunchTimer:
         n = len(recs)
         if n == 0:
             return None
-        total_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in recs)
-        total_flop = sum(vox * FLOP_PER_VOXEL_CONV64 for vox, _, _ in recs)
-        return n, total_ms / n, total_flop / n
+        total_ms = sum(e0.elapsed_time(e1) for _, e0, e1, _ in recs)
+        total_flop = sum(vox * FLOP_PER_VOXEL_CONV64 for vox, _, _, _ in recs)
+        # FLOPs the MFMA pipe actually executes: Winograd F(4,3)/F(3,4) along W needs 13.5 tap-equivalents per voxel instead of
+        # 27 (W extents here are multiples of 4); the dgrad shell positions run 9 direct taps each
+        exec_flop = sum(0.5 * vox * FLOP_PER_VOXEL_CONV64 + extra * 9 * 2.0 * 64 * 64 for vox, _, _, extra in recs)
+        return n, total_ms / n, total_flop / n, exec_flop / n
 
 
 def pmc_traffic_bytes(fname, kernel):
@@ -163,7 +170,9 @@ def roofline_obj(timer, kind, bf16, kernel, traffic_files):
     s = timer.summary(kind)
     if s is None:
         return None
-    n_launch, avg_ms, avg_flop = s
+    n_launch, avg_ms, avg_flop, avg_exec = s
+    if bf16:
+        avg_exec = avg_flop                                   # the bf16 kernels are direct convolutions
     achieved = avg_flop / (avg_ms * 1e-3) / 1e12
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
     traffic, tfile = pmc_traffic_bytes(traffic_files, kernel.split(" ")[0])
@@ -175,7 +184,10 @@ def roofline_obj(timer, kind, bf16, kernel, traffic_files):
             "traffic": traffic,
             "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/%s)" % tfile if tfile else None,
             "algorithmic_bytes_per_launch": alg, "launches_timed": n_launch, "avg_launch_ms": avg_ms,
-            "avg_launch_gflop": avg_flop / 1e9}
+            "avg_launch_gflop": avg_flop / 1e9,
+            # frac is ALGORITHMIC FLOPs (221 184 per voxel) over the MFMA peak and exceeds 1 when the kernel executes
+            # fewer multiplies than the direct algorithm (fp32: Winograd along W); executed_frac is the matrix-pipe utilisation
+            "executed_gflop_per_launch": avg_exec / 1e9, "executed_frac": avg_exec / (avg_ms * 1e-3) / 1e12 / peak}
 
 
 def timed_steps(step_fn, steps, warmup, parallel):
@@ -375,9 +387,10 @@ def main():
                    "collective": ("none" if world == 1 else
                                   "gloo, host-staged (OVERSUBSCRIBED launcher self-test: %d ranks on %d GPU -- not a scaling number)" % (world, ngpu)
                                   if oversub else "RCCL sum all-reduce of the flat fp32 gradient (%d B) per step" % (4 * (tc.model.n_params + 1)))},
-        "roofline": roofline_obj(timer, "conv", bf16, "%s (3x3x3 64->64 fwd + dgrad launches)" % ("conv64_bf16_kernel" if bf16 else "conv64_mfma_kernel"), tr),
-        "roofline_wgrad": roofline_obj(timer, "wgrad", bf16, "%s (3x3x3 64->64 weight gradient + partial reduction)"
-                                       % ("wgrad64_bf16_kernel" if bf16 else "wgrad64_pipe_kernel"), tr),
+        "roofline": roofline_obj(timer, "conv", bf16, "%s (3x3x3 64->64 fwd + dgrad launches%s)"
+                                 % (("conv64_bf16_kernel", "") if bf16 else ("conv64_wino_kernel", "; Winograd F(4,3) along W, dgrad shell slabs on conv64_mfma_kernel")), tr),
+        "roofline_wgrad": roofline_obj(timer, "wgrad", bf16, "%s (3x3x3 64->64 weight gradient + partial reduction%s)"
+                                       % (("wgrad64_bf16_kernel", "") if bf16 else ("wgrad64_wino_kernel", "; Winograd F(3,4) along W")), tr),
         "train_step_tflops": args.steps * B * world / dt * 3.0 * fwd_flop / 1e12,
     }
     if oversub:
