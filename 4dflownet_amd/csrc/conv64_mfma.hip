@@ -30,6 +30,7 @@
 //   2/NW global loads, so the matrix pipe is the only busy resource by construction.
 #include "fdn_common.h"
 #include "conv64_args.h"
+#include "conv64_pack.h"
 
 // test/bench hooks: compile-time constants in the product library, settable through fdn_debug_* in the test build only
 FDN_HOOK_VAR(int, fdn_conv64_force_layout, 0);   // 0 = auto, 1..6 = index into the variant table below
@@ -423,27 +424,21 @@ __global__ __launch_bounds__(256) void fold_halo_border_kernel(const float* __re
 }
 
 // --------------------------------------------------------------------------------------------
-// weight packing: Keras (27,64,64)[tap][cin][cout] -> operand streams [half][tap][g][kh][row j][s]
-//   row j of a 32-row tile is MFMA row i = j & 31, which lands in accumulator register r = (i&3) + 4(i>>3) of lane half
-//   kh' = (i>>2)&1; the stream stores output channel c(j) = (j & 32) + 16 kh' + r there, so that a lane's 16 registers are
-//   16 consecutive channels (see the kernel)
-//   fwd  : cin = 32*half + 8g + 4kh + s, same tap, cout = c(j)
-//   dgrad: contraction runs over cout of the layer, taps flipped: stream[..][j][s] = w[26-tap][ci = c(j)][co = 32*half+8g+4kh+s]
+// weight packing (layouts: conv64_pack.h)
 // --------------------------------------------------------------------------------------------
 __global__ void pack_conv64_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wd) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over 27*64*64 packed elements
-    if (idx >= 27 * 64 * 64) return;
-    const int s = idx & 3;
-    const int j = (idx >> 2) & 63;
-    const int kh = (idx >> 8) & 1;
-    const int g = (idx >> 9) & 3;
-    const int rest = idx >> 11;          // half*27 + tap
-    const int half = rest / 27;
-    const int tap = rest - half * 27;
-    const int k = half * 32 + g * 8 + kh * 4 + s;
-    const int cj = (j & 32) + 16 * ((j >> 2) & 1) + (j & 3) + 4 * ((j & 31) >> 3);
-    if (wf) wf[idx] = w[(tap * 64 + k) * 64 + cj];
-    if (wd) wd[idx] = w[((26 - tap) * 64 + cj) * 64 + k];
+    if (idx < 27 * 64 * 64) fdn_pack_direct_one(w, wf, wd, idx);
+}
+
+// every 64->64 layer of the network in ONE launch: blockIdx.y = layer, packs[layer][fwd|dgrad][direct | winograd]
+__global__ void pack_conv64_batch_kernel(const float* __restrict__ w_base, const int64_t* __restrict__ w_offsets, float* __restrict__ packs) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over 81*64*64 packed elements per direction
+    const float* w = w_base + w_offsets[blockIdx.y];
+    float* pf = packs + (size_t)blockIdx.y * 2 * (81 * 64 * 64);
+    float* pd = pf + 81 * 64 * 64;
+    if (idx < 27 * 64 * 64) fdn_pack_direct_one(w, pf, pd, idx);
+    else if (idx < 81 * 64 * 64) fdn_pack_wino_one(w, pf + 27 * 64 * 64, pd + 27 * 64 * 64, idx - 27 * 64 * 64);
 }
 
 // pack = [direct stream, 27*64*64 floats | Winograd F(4,3) stream, 54*64*64 floats]  (FDN_CONV64_PACK_FLOATS in fdn.h)
@@ -456,6 +451,14 @@ extern "C" int fdn_pack_conv64_weights(const float* w, float* wp_fwd, float* wp_
     FDN_CHECK_LAUNCH("fdn_pack_conv64_weights");
     return fdn_pack_conv64_wino_launch(w, wp_fwd ? wp_fwd + kDirectPackFloats : nullptr,
                                        wp_dgrad ? wp_dgrad + kDirectPackFloats : nullptr, (hipStream_t)stream);
+}
+
+extern "C" int fdn_pack_conv64_weights_batch(const float* w_base, const int64_t* w_offsets, int n_layers, float* packs, void* stream) {
+    FDN_REQUIRE(w_base && w_offsets && packs && n_layers > 0, "fdn_pack_conv64_weights_batch: NULL argument or n_layers<=0");
+    hipLaunchKernelGGL(pack_conv64_batch_kernel, dim3((81 * 64 * 64 + 255) / 256, (unsigned)n_layers), dim3(256), 0, (hipStream_t)stream,
+                       w_base, w_offsets, packs);
+    FDN_CHECK_LAUNCH("fdn_pack_conv64_weights_batch");
+    return FDN_OK;
 }
 
 // --------------------------------------------------------------------------------------------

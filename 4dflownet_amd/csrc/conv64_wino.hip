@@ -30,6 +30,7 @@
 //   * Epilogue: Y = A^T M per lane (12 VALU per output element quartet), then bias / residual / activation, or the fused
 //     MirrorPadGrad + skip + act' of the dgrad mode, and 16-B stores: a lane owns 4 voxels x 16 consecutive channels.
 #include "fdn_common.h"
+#include "conv64_pack.h"
 
 namespace {
 
@@ -313,44 +314,9 @@ __global__ __launch_bounds__(256, 2) void conv64_wino_kernel(WinoArgs p) {
     }
 }
 
-// --------------------------------------------------------------------------------------------
-// Winograd-domain weight stream U = G g along the W taps, G of F(4,3):
-//   (1/4,0,0) (-1/6,-1/6,-1/6) (-1/6,1/6,-1/6) (1/24,1/12,1/6) (1/24,-1/12,1/6) (0,0,1)
-// layout [half][vt = (a*3+b)*6 + xi][k-group][kh][row j][s], row permutation c(j) as in pack_conv64_kernel.
-//   fwd  : cin = 32*half + 8g + 4kh + s, cout = c(j):  U = sum_t G[xi][t] w[a][b][t][cin][cout]
-//   dgrad: contraction over the layer's cout, taps flipped:  U = sum_t G[xi][t] w[2-a][2-b][2-t][ci = c(j)][co = 32*half+8g+4kh+s]
-// --------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wino_pack_one(const float* __restrict__ w, float* __restrict__ uf, float* __restrict__ ud, int idx) {
-    const int s = idx & 3;
-    const int j = (idx >> 2) & 63;
-    const int kh = (idx >> 8) & 1;
-    const int g = (idx >> 9) & 3;
-    const int rest = idx >> 11;          // half*54 + vt
-    const int half = rest / 54;
-    const int vt = rest - half * 54;
-    const int tap9 = vt / 6;
-    const int xi = vt - tap9 * 6;
-    const int k = half * 32 + g * 8 + kh * 4 + s;
-    const int cj = (j & 32) + 16 * ((j >> 2) & 1) + (j & 3) + 4 * ((j & 31) >> 3);
-    const float G[6][3] = {{0.25f, 0.f, 0.f}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
-                           {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
-    if (uf) {
-        float v = 0.f;
-#pragma unroll
-        for (int t = 0; t < 3; ++t) v += G[xi][t] * w[((tap9 * 3 + t) * 64 + k) * 64 + cj];
-        uf[idx] = v;
-    }
-    if (ud) {
-        float v = 0.f;
-#pragma unroll
-        for (int t = 0; t < 3; ++t) v += G[xi][t] * w[((26 - (tap9 * 3 + t)) * 64 + cj) * 64 + k];
-        ud[idx] = v;
-    }
-}
-
 __global__ void pack_conv64_wino_kernel(const float* __restrict__ w, float* __restrict__ uf, float* __restrict__ ud) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < 54 * 64 * 64) wino_pack_one(w, uf, ud, idx);
+    if (idx < 54 * 64 * 64) fdn_pack_wino_one(w, uf, ud, idx);
 }
 
 struct WinoPlan { int td, th, tg; double cost; };

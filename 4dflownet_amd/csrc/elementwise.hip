@@ -309,20 +309,47 @@ __global__ __launch_bounds__(256) void l2_sumsq_kernel(const float* __restrict__
     if (threadIdx.x == 0) atomicAdd(out, a);
 }
 
-__global__ void adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            const uint8_t* __restrict__ isk, int64_t n, float lr_t, float b1, float b2, float eps,
-                            float l2s_host, const float* __restrict__ l2s_dev) {
+// sumsq != null: block b also writes sum(w_new^2) over its kernel (non-bias) elements to sumsq[b] (fixed order: the
+// regulariser value of the NEXT step's loss, so fdn_l2_sumsq does not have to stream the parameters again).
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, const uint8_t* __restrict__ isk, int64_t n, float lr_t,
+                                                   float b1, float b2, float eps, float l2s_host,
+                                                   const float* __restrict__ l2s_dev, float* __restrict__ sumsq) {
     const float l2s = l2s_dev ? l2s_host * l2s_dev[0] : l2s_host;
+    float ss = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float wi = w[i];
         float gi = g[i];
-        if (isk[i]) gi += l2s * wi;
+        const bool k = isk[i] != 0;
+        if (k) gi += l2s * wi;
         const float mi = b1 * m[i] + (1.f - b1) * gi;
         const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
         m[i] = mi;
         v[i] = vi;
-        w[i] = wi - lr_t * mi / (sqrtf(vi) + eps);
+        const float wn = wi - lr_t * mi / (sqrtf(vi) + eps);
+        w[i] = wn;
+        if (k) ss += wn * wn;
     }
+    if (sumsq) {
+        __shared__ float red[4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+        __syncthreads();
+        if (threadIdx.x == 0) sumsq[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
+
+// out[0] = sum of n partials, one block, fixed order (deterministic)
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 int grid_for(int64_t items, int cap = 4096) {
@@ -440,10 +467,20 @@ extern "C" int fdn_l2_sumsq(const float* w, const uint8_t* is_kernel, int64_t n,
 }
 
 extern "C" int fdn_adam_step(float* w, const float* g, float* m, float* v, const uint8_t* is_kernel, int64_t n, float lr_t,
-                             float b1, float b2, float eps, float l2_grad_scale, const float* l2_scale_dev, void* stream) {
+                             float b1, float b2, float eps, float l2_grad_scale, const float* l2_scale_dev,
+                             float* sumsq_partials, void* stream) {
     FDN_REQUIRE(w && g && m && v && is_kernel && n > 0, "fdn_adam_step: bad argument");
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, (hipStream_t)stream, w, g, m, v, is_kernel, n,
-                       lr_t, b1, b2, eps, l2_grad_scale, l2_scale_dev);
+    // fixed grid of FDN_ADAM_PARTIALS blocks when partials are requested (blocks beyond the data write 0)
+    const int grid = sumsq_partials ? FDN_ADAM_PARTIALS : grid_for(n, 2048);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, g, m, v, is_kernel, n,
+                       lr_t, b1, b2, eps, l2_grad_scale, l2_scale_dev, sumsq_partials);
     FDN_CHECK_LAUNCH("adam_kernel");
+    return FDN_OK;
+}
+
+extern "C" int fdn_sum_partials(const float* partials, int n, float* out, void* stream) {
+    FDN_REQUIRE(partials && out && n > 0, "fdn_sum_partials: bad argument");
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, n, out);
+    FDN_CHECK_LAUNCH("sum_partials_kernel");
     return FDN_OK;
 }

@@ -15,7 +15,8 @@
 //   waves with all 18 quadrant accumulators = 288 registers exceed the 256 AGPRs: hipcc then shuttles ~60 accumulator tiles
 //   per tile between the register files, 980 v_accvgpr moves per loop body -- measured no faster than the direct kernel.)
 //   K = groups: one v_mfma_f32_32x32x2_f32 contracts the two groups of a line; its operands are single floats per lane, stored
-//   in LDS as [line][group][xi pair][channel][parity] (conflict-free ds_read_b32: 12 reads per 9 MFMAs; the direct kernel 10).
+//   in LDS per (line, group) and parity as a pair plane + a single plane (one ds_read_b64 + one ds_read_b32 fetch a wave's
+//   three coordinates: 8 reads per 9 MFMAs; the direct kernel needs 10).
 //   Transform on the way in: waves 0-3: thread (halo line, group, 16-B channel chunk) loads the 6 x chunks (edge clamp applied),
 //   waves 4-6: thread (line, group, chunk) the 4 dz chunks (zero outside the volume); each forms its 6 transformed chunks and
 //   writes them to LDS.
@@ -36,7 +37,7 @@ struct WgWinoArgs {
 };
 
 constexpr int WTH = 6, WTG = 2, WTW = 4 * WTG;          // tile: 1 x 6 x 8 voxels
-constexpr int GROWB = 1536;                             // bytes per (line, group): 3 xi pairs x 64 channels x 2 floats
+constexpr int GROWB = 1536;                             // bytes per (line, group): 2 parities x (64 ch x 2 floats + 64 ch x 1 float)
 constexpr int VBYTES = (WTH + 2) * WTG * GROWB;         // transformed x: 8 halo lines
 constexpr int ZBYTES = WTH * WTG * GROWB;               // transformed dz
 constexpr int WBUFB = VBYTES + ZBYTES;                  // 43 008 B; three buffers = 126 KB
@@ -96,57 +97,82 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
 
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.dz, 0, p.bytes, 0x00020000);
-    f32x4 xr[6], zr[4];
-    auto bload = [&](__amdgpu_buffer_rsrc_t r, unsigned vo) {
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)vo, 0, 0));
+    f32x4 raw[6];                         // this thread's raw rows: 6 x chunks (waves 0-3) or 4 dz chunks (waves 4-6)
+    auto bload = [&](__amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)vo, (int)so, 0));
     };
-    // raw rows of the cursor tile: x voxels 4g-1 .. 4g+4 of halo line il (edge clamp == SYMMETRIC p=1), dz voxels 4g .. 4g+3
+    // Raw rows of the cursor tile: x voxels 4g-1 .. 4g+4 of halo line il (edge clamp == SYMMETRIC p=1), dz voxels 4g .. 4g+3
+    // (zero outside the volume).  The (sample, plane, tile origin) part of an address is a scalar offset and the (line, voxel,
+    // chunk) part a per-thread constant, so a tile whose halo box lies inside its plane costs NO vector ALU work (every VALU
+    // instruction takes its cycles from the fp32 MFMA stream of its SIMD); border tiles clamp per thread.
+    unsigned tc[6];                       // per-thread constant part, relative to the tile's halo origin (x) / origin (dz)
+#pragma unroll
+    for (int nn = 0; nn < 6; ++nn) tc[nn] = (unsigned)((il * p.W + 4 * ig + nn) * 256 + c16 * 16);
+    unsigned rowoff = 0;                  // border tiles: byte offset of this thread's (clamped) line, chunk included
+    bool x_in = false, z_in = false;
+    unsigned x_so = 0, z_so = 0;
+    auto locate = [&]() {                 // once per tile, after advance(): scalar unless the tile touches the plane border
+        const int qd = min(max(td + a - 1, 0), p.D - 1);
+        const int h0 = th * WTH - 1, w0 = tw * WTW - 1;
+        const unsigned xplane = (unsigned)((tn * p.D + qd) * p.H * p.W) * 256u;
+        const unsigned zplane = (unsigned)((tn * p.D + td) * p.H * p.W) * 256u;
+        x_in = h0 >= 0 && h0 + WTH + 2 <= p.H && w0 >= 0 && w0 + WTW + 2 <= p.W;
+        z_in = h0 + 1 + WTH <= p.H && w0 + 1 + WTW <= p.W;
+        x_so = xplane + (unsigned)((h0 * p.W + w0) * 256);
+        z_so = zplane + (unsigned)(((h0 + 1) * p.W + w0 + 1) * 256);
+        if (!x_in && xitem) rowoff = xplane + (unsigned)(min(max(h0 + il, 0), p.H - 1) * p.W * 256 + c16 * 16);
+        if (!z_in && zitem) rowoff = h0 + 1 + il < p.H ? zplane + (unsigned)((h0 + 1 + il) * p.W * 256 + c16 * 16) : 0xffffffffu;
+    };
     auto load_x = [&](int nn) {
         if (!xitem) return;
-        const int qd = min(max(td + a - 1, 0), p.D - 1);
-        const int qh = min(max(th * WTH - 1 + il, 0), p.H - 1);
-        const int qw = min(max(tw * WTW + 4 * ig - 1 + nn, 0), p.W - 1);
-        xr[nn] = bload(xrs, (unsigned)((((tn * p.D + qd) * p.H + qh) * p.W + qw) * 256 + c16 * 16));
+        if (x_in) raw[nn] = bload(xrs, tc[nn], x_so);
+        else raw[nn] = bload(xrs, rowoff + (unsigned)(min(max(tw * WTW + 4 * ig - 1 + nn, 0), p.W - 1) * 256), 0);
     };
     auto load_z = [&](int j) {
         if (!zitem) return;
-        const int qh = th * WTH + il, qw = tw * WTW + 4 * ig + j;
-        const bool ok = qh < p.H && qw < p.W;
-        zr[j] = bload(zrs, ok ? (unsigned)((((tn * p.D + td) * p.H + qh) * p.W + qw) * 256 + c16 * 16) : 0xffffffffu);
+        if (z_in) raw[j] = bload(zrs, tc[j], z_so);
+        else {
+            const int qw = tw * WTW + 4 * ig + j;
+            raw[j] = bload(zrs, (rowoff != 0xffffffffu && qw < p.W) ? rowoff + (unsigned)(qw * 256) : 0xffffffffu, 0);
+        }
     };
-    // transformed pairs (xi = 2 xp, 2 xp + 1) of this thread's 4 channels -> [line][group][xp][channel][2]
-    auto put = [&](char* dst, f32x4 va, f32x4 vb) {
-        *(f32x4*)dst = (f32x4){va.x, vb.x, va.y, vb.y};
-        *(f32x4*)(dst + 16) = (f32x4){va.z, vb.z, va.w, vb.w};
+    // LDS image of a (line, group): [parity e][ (xp0,xp1) pairs: 64 ch x 2 | xp2: 64 ch ]  (xi = 2 xp + e): a wave reads its three
+    // coordinates with one ds_read_b64 + one ds_read_b32
+    auto put = [&](char* dst, f32x4 v0, f32x4 v1, f32x4 v2) {
+        *(f32x4*)(dst + c16 * 32) = (f32x4){v0.x, v1.x, v0.y, v1.y};
+        *(f32x4*)(dst + c16 * 32 + 16) = (f32x4){v0.z, v1.z, v0.w, v1.w};
+        *(f32x4*)(dst + 512 + c16 * 16) = v2;
     };
-    auto write_v = [&](int xp, char* buf) {
+    auto write_v = [&](int e, char* buf) {
         // B^T of F(4,3)/F(3,4): (4,0,-5,0,1,0) (0,-4,-4,1,1,0) (0,4,-4,-1,1,0) (0,-2,-1,2,1,0) (0,2,-1,-2,1,0) (0,4,0,-5,0,1)
         if (!xitem) return;
-        char* dst = buf + (il * WTG + ig) * GROWB + xp * 512 + c16 * 32;
-        const f32x4 x0 = xr[0], x1 = xr[1], x2 = xr[2], x3 = xr[3], x4 = xr[4], x5 = xr[5];
-        if (xp == 0) put(dst, 4.f * x0 - 5.f * x2 + x4, (x4 - 4.f * x2) + (x3 - 4.f * x1));
-        else if (xp == 1) put(dst, (x4 - 4.f * x2) - (x3 - 4.f * x1), (x4 - x2) + 2.f * (x3 - x1));
-        else put(dst, (x4 - x2) - 2.f * (x3 - x1), 4.f * x1 - 5.f * x3 + x5);
+        char* dst = buf + (il * WTG + ig) * GROWB + e * 768;
+        const f32x4 x0 = raw[0], x1 = raw[1], x2 = raw[2], x3 = raw[3], x4 = raw[4], x5 = raw[5];
+        const f32x4 t1 = x4 - 4.f * x2, t2 = x3 - 4.f * x1, t3 = x4 - x2, t4 = 2.f * (x3 - x1);
+        if (e == 0) put(dst, 4.f * x0 - 5.f * x2 + x4, t1 - t2, t3 - t4);          // xi = 0, 2, 4
+        else put(dst, t1 + t2, t3 + t4, 4.f * x1 - 5.f * x3 + x5);                  // xi = 1, 3, 5
     };
-    auto write_z = [&](int xp, char* buf) {
+    auto write_z = [&](int e, char* buf) {
         // G' of F(3,4): (1/4,0,0,0) -1/6(1,1,1,1) -1/6(1,-1,1,-1) 1/24(1,2,4,8) 1/24(1,-2,4,-8) (0,0,0,1)
         if (!zitem) return;
-        char* dst = buf + VBYTES + (il * WTG + ig) * GROWB + xp * 512 + c16 * 32;
-        const f32x4 z0 = zr[0], z1 = zr[1], z2 = zr[2], z3 = zr[3];
+        char* dst = buf + VBYTES + (il * WTG + ig) * GROWB + e * 768;
+        const f32x4 z0 = raw[0], z1 = raw[1], z2 = raw[2], z3 = raw[3];
         const float s6 = -1.f / 6, s24 = 1.f / 24;
-        if (xp == 0) put(dst, 0.25f * z0, s6 * ((z0 + z2) + (z1 + z3)));
-        else if (xp == 1) put(dst, s6 * ((z0 + z2) - (z1 + z3)), s24 * ((z0 + 4.f * z2) + (2.f * z1 + 8.f * z3)));
-        else put(dst, s24 * ((z0 + 4.f * z2) - (2.f * z1 + 8.f * z3)), z3);
+        const f32x4 e1 = z0 + z2, o1 = z1 + z3, e2 = z0 + 4.f * z2, o2 = 2.f * z1 + 8.f * z3;
+        if (e == 0) put(dst, 0.25f * z0, s6 * (e1 - o1), s24 * (e2 - o2));          // xi = 0, 2, 4
+        else put(dst, s6 * (e1 + o1), s24 * (e2 + o2), z3);                          // xi = 1, 3, 5
     };
 
     // ---- prologue: tile 0 -> buffer 0, tile 1 -> registers ----
+    locate();
 #pragma unroll
     for (int nn = 0; nn < 6; ++nn) load_x(nn);
 #pragma unroll
     for (int j = 0; j < 4; ++j) load_z(j);
 #pragma unroll
-    for (int xp = 0; xp < 3; ++xp) { write_v(xp, smem); write_z(xp, smem); }
+    for (int e = 0; e < 2; ++e) { write_v(e, smem); write_z(e, smem); }
     advance();
+    locate();
 #pragma unroll
     for (int nn = 0; nn < 6; ++nn) load_x(nn);
 #pragma unroll
@@ -154,20 +180,23 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
     __syncthreads();
 
     // operands: lane (li, kh) = channel (mq*32 + li) resp. (nq*32 + li) of group kh, coordinate parity eh
-    const int lane_v = kh * GROWB + (mq * 32 + li) * 8 + eh * 4;
-    const int lane_z = VBYTES + kh * GROWB + (nq * 32 + li) * 8 + eh * 4;
-    float V[2][3], Z[2][3];
-    auto issue_v = [&](const char* buf, int line, float (&v)[3]) {
-#pragma unroll
-        for (int xp = 0; xp < 3; ++xp) v[xp] = *(const float*)(buf + lane_v + line * (WTG * GROWB) + xp * 512);
+    const int lane_v = kh * GROWB + eh * 768 + (mq * 32 + li) * 8;
+    const int lane_z = VBYTES + kh * GROWB + eh * 768 + (nq * 32 + li) * 8;
+    const int lane_v1 = kh * GROWB + eh * 768 + 512 + (mq * 32 + li) * 4;
+    const int lane_z1 = VBYTES + kh * GROWB + eh * 768 + 512 + (nq * 32 + li) * 4;
+    f32x2 Vp[2], Zp[2];
+    float Vs[2], Zs[2];
+    auto issue_v = [&](const char* buf, int line, int slot) {
+        Vp[slot] = *(const f32x2*)(buf + lane_v + line * (WTG * GROWB));
+        Vs[slot] = *(const float*)(buf + lane_v1 + line * (WTG * GROWB));
     };
-    auto issue_z = [&](const char* buf, int line, float (&z)[3]) {
-#pragma unroll
-        for (int xp = 0; xp < 3; ++xp) z[xp] = *(const float*)(buf + lane_z + line * (WTG * GROWB) + xp * 512);
+    auto issue_z = [&](const char* buf, int line, int slot) {
+        Zp[slot] = *(const f32x2*)(buf + lane_z + line * (WTG * GROWB));
+        Zs[slot] = *(const float*)(buf + lane_z1 + line * (WTG * GROWB));
     };
     int bcur = 0;
-    issue_z(smem, 0, Z[0]);
-    issue_v(smem, 0, V[0]);
+    issue_z(smem, 0, 0);
+    issue_v(smem, 0, 0);
 #pragma unroll 1
     for (int k = 0; k < nk; ++k) {
         const int bnxt = bcur == 2 ? 0 : bcur + 1;
@@ -180,22 +209,22 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
             if (s == 12) __syncthreads();       // tile k+1 is complete in `nxt`; every wave is done with tile k-1's buffer
             // read-ahead: operands of the next slot (the first slot of tile k+1 at the end)
             if (s + 1 < 18) {
-                issue_v(cur, (s + 1) / 3 + (s + 1) % 3, V[(s + 1) & 1]);
-                if ((s + 1) % 3 == 0) issue_z(cur, (s + 1) / 3, Z[((s + 1) / 3) & 1]);
+                issue_v(cur, (s + 1) / 3 + (s + 1) % 3, (s + 1) & 1);
+                if ((s + 1) % 3 == 0) issue_z(cur, (s + 1) / 3, ((s + 1) / 3) & 1);
             } else {
-                issue_v(nxt, 0, V[0]);
-                issue_z(nxt, 0, Z[0]);
+                issue_v(nxt, 0, 0);
+                issue_z(nxt, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
             // pipeline stages, pinned to slots: transform + write tile k+1, then load the raw rows of tile k+2
-            if (s < 3) write_v(s, nxt);
-            else if (s < 6) write_z(s - 3, nxt);
-            else if (s == 6) advance();
-            else if (s < 13) load_x(s - 7);
-            else if (s < 17) load_z(s - 13);
-#pragma unroll
-            for (int xp = 0; xp < 3; ++xp)
-                acc[b][xp] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[s & 1][xp], Z[q & 1][xp], acc[b][xp], 0, 0, 0);
+            if (s < 2) write_v(s, nxt);
+            else if (s < 4) write_z(s - 2, nxt);
+            else if (s == 5) { advance(); locate(); }
+            else if (s >= 6 && s < 12) load_x(s - 6);
+            else if (s >= 13 && s < 17) load_z(s - 13);
+            acc[b][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vp[s & 1].x, Zp[q & 1].x, acc[b][0], 0, 0, 0);
+            acc[b][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vp[s & 1].y, Zp[q & 1].y, acc[b][1], 0, 0, 0);
+            acc[b][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[s & 1], Zs[q & 1], acc[b][2], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         bcur = bnxt;

@@ -114,6 +114,8 @@ class FlowNetModel:
             self.layers.append(L)
         assert off == n
         self.is_kernel = torch.tensor(is_kernel, device=self.device)
+        self._w64_offsets = torch.tensor([L.w_off for L in self.layers if L.wp_f is not None], device=self.device, dtype=torch.int64)
+        self.weights_version = 0       # bumped by weights_changed(): lets the trainer know whether Adam's sum-of-squares is current
         self._ws = None
         self._ws_bias = None
         self._side = None              # second HIP stream for the weight-gradient launches
@@ -137,6 +139,10 @@ class FlowNetModel:
 
     def weights_changed(self):
         """Re-derive the MFMA operand streams after any parameter update (Adam step, load_weights)."""
+        self.weights_version += 1
+        if self.dtype == "float32":
+            ops.pack_conv64_weights_batch(self.flat_w, self._w64_offsets, self._packs)      # all 64->64 layers, one launch
+            return
         for L in self.layers:
             if L.wp_f is not None:
                 self.ops.pack_conv64_weights(L.w, L.wp_f, L.wp_d)

@@ -211,7 +211,32 @@ def l2_sumsq(w_flat, is_kernel, out=None):
     return out
 
 
-def adam_step(w, g, m, v, is_kernel, lr_t, b1, b2, eps, l2_grad_scale, l2_scale_dev=None):
+ADAM_PARTIALS = 2048                  # FDN_ADAM_PARTIALS
+
+
+def adam_step(w, g, m, v, is_kernel, lr_t, b1, b2, eps, l2_grad_scale, l2_scale_dev=None, sumsq_partials=None):
+    """sumsq_partials (ADAM_PARTIALS floats): also receive per-block sums of the updated kernel parameters' squares."""
+    if sumsq_partials is not None and sumsq_partials.numel() < ADAM_PARTIALS:
+        raise FdnError("adam_step: sumsq_partials needs %d floats" % ADAM_PARTIALS)
     check(_lib.load().fdn_adam_step(_p(w), _p(g), _p(m), _p(v), _p(is_kernel), w.numel(), float(lr_t), float(b1), float(b2),
-                                    float(eps), float(l2_grad_scale), _p(l2_scale_dev, allow_none=True), _stream()),
+                                    float(eps), float(l2_grad_scale), _p(l2_scale_dev, allow_none=True),
+                                    _p(sumsq_partials, allow_none=True), _stream()),
           "fdn_adam_step")
+
+
+def sum_partials(partials, out=None):
+    if out is None:
+        out = torch.empty((1,), device=partials.device, dtype=torch.float32)
+    check(_lib.load().fdn_sum_partials(_p(partials), partials.numel(), _p(out), _stream()), "fdn_sum_partials")
+    return out
+
+
+def pack_conv64_weights_batch(w_flat, w_offsets, packs):
+    """Every 64->64 kernel of the flat parameter buffer in one launch.  w_offsets: int64 DEVICE tensor of float offsets;
+    packs: (n_layers, 2, CONV64_PACK_FLOATS)."""
+    n = w_offsets.numel()
+    if w_offsets.dtype != torch.int64 or not w_offsets.is_cuda or packs.numel() != n * 2 * CONV64_PACK_FLOATS:
+        raise FdnError("pack_conv64_weights_batch: bad offsets / packs")
+    check(_lib.load().fdn_pack_conv64_weights_batch(_p(w_flat), w_offsets.data_ptr(), n, _p(packs), _stream()),
+          "fdn_pack_conv64_weights_batch")
+    return packs

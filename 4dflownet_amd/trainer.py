@@ -91,6 +91,8 @@ class TrainerController:
         self.learning_rate = initial_learning_rate
         self.optimizer = _Optimizer(self.model, initial_learning_rate)
         self._l2_buf = torch.zeros(1, device=self.device)
+        self._l2_partials = torch.zeros(ops.ADAM_PARTIALS, device=self.device)   # sum(w^2) blocks left by the last Adam step
+        self._l2_version = -1          # model.weights_version those partials belong to
         self.unique_model_name = network_name
         self.model_dir = None
 
@@ -102,7 +104,10 @@ class TrainerController:
 
     def calculate_regularizer_loss(self):
         """5e-7 * sum(kernel^2) as a 0-d device tensor (TrainerController.py:129-141)."""
-        ops.l2_sumsq(self.model.flat_w, self.model.is_kernel, self._l2_buf)
+        if self._l2_version == self.model.weights_version:
+            ops.sum_partials(self._l2_partials, self._l2_buf)      # the Adam kernel already streamed the parameters
+        else:                                                      # first step, or weights were loaded / re-initialised
+            ops.l2_sumsq(self.model.flat_w, self.model.is_kernel, self._l2_buf)
         return self._l2_buf[0] * L2_LAMBDA
 
     def calculate_and_update_metrics(self, hires, predictions, mask, metric_set, want_grad):
@@ -140,8 +145,9 @@ class TrainerController:
         opt.iterations += 1
         # L2 regulariser gradient: the (B,) loss vector carries the scalar L2 term B times (:249) -> B_global * 2*lambda*w
         ops.adam_step(m.flat_w, m.flat_g, opt.m, opt.v, m.is_kernel, opt.lr_t(), ADAM_B1, ADAM_B2, ADAM_EPS,
-                      2.0 * L2_LAMBDA, m.batch_slot)
+                      2.0 * L2_LAMBDA, m.batch_slot, sumsq_partials=self._l2_partials)
         m.weights_changed()
+        self._l2_version = m.weights_version
         return loss
 
     def test_step(self, data_pairs):

@@ -58,6 +58,11 @@ int fdn_input_features(const float* u, const float* v, const float* w, const flo
  * Either output may be NULL. */
 #define FDN_CONV64_PACK_FLOATS (81 * 64 * 64)
 int fdn_pack_conv64_weights(const float* w, float* wp_fwd, float* wp_dgrad, void* stream);
+/* The same for n_layers kernels in ONE launch (after every optimizer step): layer i lives at
+ * w_base + w_offsets[i] (w_offsets: DEVICE array of n_layers float offsets), its two streams at
+ * packs + i * 2 * FDN_CONV64_PACK_FLOATS (forward stream first, dgrad stream second). */
+int fdn_pack_conv64_weights_batch(const float* w_base, const int64_t* w_offsets, int n_layers, float* packs,
+                                  void* stream);
 
 /* y = act(conv3d(sym_pad(x), w) + bias + residual).
  * Replaces tf.pad(SYMMETRIC,p=(K-1)/2) + Conv3D(valid) + BiasAdd + activation, and the
@@ -150,7 +155,13 @@ int fdn_l2_sumsq(const float* w, const uint8_t* is_kernel, int64_t n, float* out
  * all-reduced gradient buffer, so no host synchronisation is needed).  TrainerController.py:73,225. */
 int fdn_adam_step(float* w, const float* g, float* m, float* v, const uint8_t* is_kernel, int64_t n,
                   float lr_t, float b1, float b2, float eps, float l2_grad_scale, const float* l2_scale_dev,
-                  void* stream);
+                  float* sumsq_partials, void* stream);
+/* If sumsq_partials != NULL (FDN_ADAM_PARTIALS floats) the step also leaves per-block sums of the UPDATED
+ * kernel parameters' squares there; fdn_sum_partials adds them up in a fixed order (deterministic):
+ * 5e-7 * that sum is the regulariser value of the next step's loss, so fdn_l2_sumsq need not stream the
+ * parameters again.  src/Network/TrainerController.py:129-141. */
+#define FDN_ADAM_PARTIALS 2048
+int fdn_sum_partials(const float* partials, int n, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * bf16 activation path (BASELINE.json configs[3]: patch 32, res x4, bf16).  The reference has no bf16

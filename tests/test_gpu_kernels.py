@@ -257,8 +257,36 @@ def test_adam_and_l2(ops):
             ops.adam_step(dw, dev(g), dm, dv, dk, lr_t, 0.9, 0.999, 1e-7, 2 * O.L2_LAMBDA, torch.tensor([8.0], device="cuda"))
         else:
             ops.adam_step(dw, dev(g), dm, dv, dk, lr_t, 0.9, 0.999, 1e-7, l2s)
+    # the step can leave sum(w_new^2) of the kernel parameters behind (per-block partials, summed in a fixed order): equal to a
+    # fresh fdn_l2_sumsq pass over the updated parameters, and run-to-run identical
+    part = torch.full((ops.ADAM_PARTIALS,), float("nan"), device="cuda")
+    w_before = dw.clone()
+    ops.adam_step(dw, dev(g), dm.clone(), dv.clone(), dk, 1e-3, 0.9, 0.999, 1e-7, l2s, sumsq_partials=part)
+    s1 = ops.sum_partials(part).clone()
+    close(s1, ops.l2_sumsq(dw, dk).cpu().numpy(), tol=1e-6, name="adam sumsq partials")
+    part2 = torch.zeros_like(part)
+    dw2 = w_before.clone()
+    ops.adam_step(dw2, dev(g), dm.clone(), dv.clone(), dk, 1e-3, 0.9, 0.999, 1e-7, l2s, sumsq_partials=part2)
+    assert torch.equal(ops.sum_partials(part2), s1) and torch.equal(dw2, dw)
+    dw = w_before
     # (1-b2) evaluated in fp32 (as Keras does for fp32 variables) is off by 1.3e-5 relative from the float64 oracle
     close(dw, wr, tol=5e-5, name="adam w"); close(dm, m, tol=1e-5, name="adam m"); close(dv, v, tol=5e-5, name="adam v")
+
+
+def test_pack_batch_equals_per_layer_pack(ops):
+    """fdn_pack_conv64_weights_batch (all 64->64 layers of the flat parameter buffer in one launch) == per-layer packing."""
+    rng = np.random.default_rng(17)
+    nl, sz = 3, 27 * 64 * 64
+    gaps = [5, 64, 0]                                   # biases / other layers between the kernels in the flat buffer
+    offs, pos = [], 7
+    for gp in gaps:
+        offs.append(pos); pos += sz + gp
+    flat = dev(rng.normal(size=pos).astype(np.float32))
+    packs = torch.full((nl, 2, ops.CONV64_PACK_FLOATS), float("nan"), device="cuda")
+    ops.pack_conv64_weights_batch(flat, torch.tensor(offs, device="cuda", dtype=torch.int64), packs)
+    for i, o in enumerate(offs):
+        wf, wd = ops.pack_conv64_weights(flat[o:o + sz].view(3, 3, 3, 64, 64))
+        assert torch.equal(packs[i, 0], wf) and torch.equal(packs[i, 1], wd)
 
 
 def test_errors_are_loud(ops, fdn):

@@ -71,6 +71,7 @@ def test_train_step_matches_oracle(fdn, P, R, LB, HB, B):
         batch = O.synthetic_batch(B, P, R, seed=21 + seed)
         b64 = tuple(a.astype(np.float64) for a in batch)
         state = {}
+        ad_state = {}
         flips_total = 0
         for step in range(2):
             # every step starts from identical parameters: the oracle adopts the GPU's fp32 weights (the +-lr
@@ -103,8 +104,7 @@ def test_train_step_matches_oracle(fdn, P, R, LB, HB, B):
                     sb = slice(L.b_off, L.b_off + L.cout)
                     assert rel_err(g_total[sb], gref[sb]) < tol_g, (L.name, "bias grad", flips)
             # now the real step on both sides.  Adam's update is ~ lr*sign(g) on the first steps, so an element whose
-            # gradient is rounding noise may move by +-lr in either direction: bound those by 2.5*lr*steps, and hold
-            # the well-conditioned elements (|g| >= 1e-3 max|g| of their layer) to 3e-2*lr at the first step.
+            # gradient is rounding noise may move by +-lr in either direction: bound those by 2.5*lr*steps.
             w_before = tc.model.flat_w.cpu().numpy().astype(np.float64)
             loss = tc.train_step(batch)
             O.train_step(params, state, b64, 1e-3, R, LB, HB, f32_coeffs=True)
@@ -113,13 +113,13 @@ def test_train_step_matches_oracle(fdn, P, R, LB, HB, B):
             w_ref = O.flatten(params)
             assert np.abs(w_gpu - w_ref).max() <= 2.5e-3
             assert np.abs(w_gpu - w_before).max() <= 1.05e-3          # |Adam update| <= lr while m/sqrt(v) <= 1
-            if flips == 0:
-                for L in tc.model.layers:
-                    sl = slice(L.w_off, L.w_off + L.w.numel())
-                    good = np.abs(gref[sl]) >= 1e-3 * np.abs(gref[sl]).max()
-                    # 3e-2*lr: the Winograd F(4,3) conv kernels carry ~3x the rounding noise of the direct kernels (5e-7 vs
-                    # 1.7e-7 relative), and lr*g/(|g|+eps') amplifies gradient noise where |g| approaches eps' = 3e-6
-                    assert np.abs(w_gpu[sl] - w_ref[sl])[good].max() <= 3e-5, (L.name, "adam update")
+            # The optimizer arithmetic itself, decoupled from gradient noise: Keras-Adam in float64 driven by the GPU's OWN gradient
+            # (g_total above; train_step recomputes the identical, deterministic gradient) must land on the GPU's weights.  (Comparing
+            # against the oracle's gradient instead amplifies its ~1e-6 rounding noise by lr/eps' = 316 wherever |g| ~ eps' = 3e-6.)
+            ad_m = ad_state.setdefault("m", np.zeros_like(w_before)); ad_v = ad_state.setdefault("v", np.zeros_like(w_before))
+            w_exp = w_before.copy()
+            O.adam_step_tf(w_exp, g_total, ad_m, ad_v, step + 1, 1e-3)
+            assert np.abs(w_gpu - w_exp).max() <= 2e-6, "adam update vs float64 Keras-Adam on the same gradient"
         assert tc.loss_metrics["train_loss"].result() > 0
         assert abs(tc.loss_metrics["l2_reg_loss"].result() - O.l2_regularizer(params)) / O.l2_regularizer(params) < 1e-2
         if flips_total == 0:
