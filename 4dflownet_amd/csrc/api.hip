@@ -122,6 +122,17 @@ extern "C" int fdn_conv3d_dgrad_fused(const float* dz, const float* wpack, float
                                 -1, 1, act, alpha, (hipStream_t)stream);
 }
 
+extern "C" int fdn_conv3d_dgrad_fused_part(const float* dz, const float* wpack, float* dxpad, const float* skip,
+                                           const float* y_prev, int act, float alpha, float* dz_prev, int N, int D, int H,
+                                           int W, int parts, void* stream) {
+    FDN_REQUIRE(dz && wpack && dxpad && dz_prev, "fdn_conv3d_dgrad_fused_part: NULL argument");
+    FDN_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && D <= 1020 && H <= 1020 && W <= 1020, "fdn_conv3d_dgrad_fused_part: bad dims");
+    FDN_REQUIRE(act >= FDN_ACT_NONE && act <= FDN_ACT_LEAKY, "fdn_conv3d_dgrad_fused_part: bad act %d", act);
+    FDN_REQUIRE(parts >= 1 && parts <= 3, "fdn_conv3d_dgrad_fused_part: parts must be FDN_DGRAD_INNER | FDN_DGRAD_SHELL");
+    return fdn_conv64_launch_ex(dz, wpack, nullptr, nullptr, dxpad, skip, y_prev, dz_prev, N, D, H, W, D + 2, H + 2, W + 2,
+                                -1, 1, act, alpha, (hipStream_t)stream, parts);
+}
+
 extern "C" int fdn_fold_halo_border(const float* dxpad0, const float* dxpad1, const float* dxpad2, int nsrc,
                                     const float* skip, const float* y_prev, int act, float alpha, float* dz_prev, int N,
                                     int D, int H, int W, void* stream) {

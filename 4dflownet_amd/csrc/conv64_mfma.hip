@@ -577,7 +577,7 @@ FdnTile fdn_plan_tile(int N, int OD, int OH, int OW, int max_vox, int max_halo_r
 
 int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, const float* residual, float* y,
                          const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
-                         int OW, int off, int zero_mode, int act, float alpha, hipStream_t s) {
+                         int OW, int off, int zero_mode, int act, float alpha, hipStream_t s, int parts) {
     // staged rows are addressed with 32-bit byte offsets from the sample's first voxel (256 B per voxel)
     FDN_REQUIRE((long long)ID * IH * IW < (1ll << 24), "conv64: a sample of %dx%dx%d voxels exceeds the 32-bit row addressing", ID, IH, IW);
     Conv64Args a;
@@ -606,21 +606,26 @@ int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, 
         {0, 0, 0, 1, OH, OW, 2, 2, 0, 2, 0, 2},       {ID + 1, 0, 0, 1, OH, OW, 0, 0, 0, 2, 0, 2},     // d faces, full (h,w)
         {1, 0, 0, ID, 1, OW, 0, 2, 2, 2, 0, 2},       {1, IH + 1, 0, ID, 1, OW, 0, 2, 0, 0, 0, 2},     // h faces, d inner
         {1, 1, 0, ID, IH, 1, 0, 2, 0, 2, 2, 2},       {1, 1, IW + 1, ID, IH, 1, 0, 2, 0, 2, 0, 0}};    // w faces, d,h inner
+    // parts: bit 0 = the inner box (finishes the interior of dz_prev), bit 1 = the six shell slabs (padded scratch only).  The two
+    // write disjoint positions, so a caller may issue them on different streams and join before the border fold.
     if (wino && fdn_conv64_wino_ok(ID, IH, IW)) {
         // inner box through the Winograd kernel (fused-fold epilogue), the six 9-tap shell slabs as one direct launch
-        if (int rc = fdn_conv64_wino_launch(x, upack, bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, 1, 1, 1, ID, IH,
-                                            IW, off, zero_mode, act, alpha, s))
-            return rc;
-        return launch_boxes(a, boxes + 1, 6, s);
+        if (parts & 1)
+            if (int rc = fdn_conv64_wino_launch(x, upack, bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, 1, 1, 1, ID,
+                                                IH, IW, off, zero_mode, act, alpha, s))
+                return rc;
+        return (parts & 2) ? launch_boxes(a, boxes + 1, 6, s) : FDN_OK;
     }
-    return launch_boxes(a, boxes, 7, s);
+    if (parts == 3) return launch_boxes(a, boxes, 7, s);
+    if (parts & 1) return launch_boxes(a, boxes, 1, s);
+    return (parts & 2) ? launch_boxes(a, boxes + 1, 6, s) : FDN_OK;
 }
 
 int fdn_conv64_launch(const float* x, const float* wpack, const float* bias, const float* residual, float* y, int N,
                       int ID, int IH, int IW, int OD, int OH, int OW, int off, int zero_mode, int act, float alpha,
                       hipStream_t s) {
     return fdn_conv64_launch_ex(x, wpack, bias, residual, y, nullptr, nullptr, nullptr, N, ID, IH, IW, OD, OH, OW, off,
-                                zero_mode, act, alpha, s);
+                                zero_mode, act, alpha, s, 3);
 }
 
 int fdn_fold_halo_border_launch(const float* s0, const float* s1, const float* s2, int nsrc, const float* skip,

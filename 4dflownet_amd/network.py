@@ -119,6 +119,8 @@ class FlowNetModel:
         self._ws = None
         self._ws_bias = None
         self._side = None              # second HIP stream for the weight-gradient launches
+        self.overlap_shell = False     # dgrad shell slabs on a side stream: measured 38.6 -> 39.3 ms per cfg2 step (the two stream joins per
+                                       # layer cost more than the tail the slabs fill), so off
         self.overlap_wgrad = False     # measured +0.7 % at cfg2 (kernels already fill the chip); off so per-kernel timings stay clean
         self._cache = None
         self.glorot_uniform_init(seed)
@@ -284,7 +286,21 @@ class FlowNetModel:
         are finished by the conv epilogue, the surface by one small border kernel."""
         out = torch.empty_like(dz)
         pad = self._pad_like(dz)
-        self.ops.conv3d_dgrad_fused(dz, L.wp_d, pad, out, skip=skip, y_prev=y_prev, act=act)
+        if self.overlap_shell and self.dtype == "float32":
+            # the six 9-tap shell slabs (a short direct-conv launch) run on a second stream next to the Winograd launch of the
+            # inner box and fill its tail; both only read dz and write disjoint positions
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
+            main = torch.cuda.current_stream()
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                self.ops.conv3d_dgrad_fused(dz, L.wp_d, pad, out, parts=ops.DGRAD_SHELL)
+            self.ops.conv3d_dgrad_fused(dz, L.wp_d, pad, out, skip=skip, y_prev=y_prev, act=act, parts=ops.DGRAD_INNER)
+            main.wait_stream(self._side)
+            for t in (dz, pad):
+                t.record_stream(self._side)
+        else:
+            self.ops.conv3d_dgrad_fused(dz, L.wp_d, pad, out, skip=skip, y_prev=y_prev, act=act)
         self.ops.fold_halo_border([pad], out, skip, y_prev, act)
         return out
 

@@ -117,13 +117,23 @@ def fold_halo(dxpads, skip=None, y_prev=None, act=ACT_NONE, alpha=LEAKY_ALPHA, o
     return out
 
 
-def conv3d_dgrad_fused(dz, wpack_dgrad, dxpad, out, skip=None, y_prev=None, act=ACT_NONE, alpha=LEAKY_ALPHA):
+DGRAD_INNER, DGRAD_SHELL = 1, 2
+
+
+def conv3d_dgrad_fused(dz, wpack_dgrad, dxpad, out, skip=None, y_prev=None, act=ACT_NONE, alpha=LEAKY_ALPHA, parts=3):
     """64->64 dgrad; interior voxels of `out` are finished in the conv epilogue (skip may alias out), the rest lands
-    in the padded scratch `dxpad` for fold_halo_border."""
+    in the padded scratch `dxpad` for fold_halo_border.  parts: DGRAD_INNER | DGRAD_SHELL -- the two pieces write disjoint
+    positions and may run on different streams."""
     N, D, H, W = dz.shape[:4]
-    check(_lib.load().fdn_conv3d_dgrad_fused(_p(dz, "dz"), _p(wpack_dgrad, "wpack"), _p(dxpad, "dxpad"),
-                                             _p(skip, allow_none=True), _p(y_prev, allow_none=True), act, float(alpha),
-                                             _p(out, "out"), N, D, H, W, _stream()), "fdn_conv3d_dgrad_fused")
+    if parts == 3:
+        check(_lib.load().fdn_conv3d_dgrad_fused(_p(dz, "dz"), _p(wpack_dgrad, "wpack"), _p(dxpad, "dxpad"),
+                                                 _p(skip, allow_none=True), _p(y_prev, allow_none=True), act, float(alpha),
+                                                 _p(out, "out"), N, D, H, W, _stream()), "fdn_conv3d_dgrad_fused")
+    else:
+        check(_lib.load().fdn_conv3d_dgrad_fused_part(_p(dz, "dz"), _p(wpack_dgrad, "wpack"), _p(dxpad, "dxpad"),
+                                                      _p(skip, allow_none=True), _p(y_prev, allow_none=True), act, float(alpha),
+                                                      _p(out, "out"), N, D, H, W, int(parts), _stream()),
+              "fdn_conv3d_dgrad_fused_part")
     return out
 
 

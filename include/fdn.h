@@ -105,6 +105,13 @@ int fdn_fold_halo(const float* dxpad0, const float* dxpad1, const float* dxpad2,
  * (gradient fan-in over several consumers: call with y_prev=NULL for all but the last).  wpack = wp_dgrad. */
 int fdn_conv3d_dgrad_fused(const float* dz, const float* wpack, float* dxpad, const float* skip, const float* y_prev,
                            int act, float alpha, float* dz_prev, int N, int D, int H, int W, void* stream);
+/* The same in two independent pieces, for callers that overlap them on two streams (they write disjoint positions; both must
+ * have completed before fdn_fold_halo_border): FDN_DGRAD_INNER = the D x H x W box (finishes the interior of dz_prev, writes its
+ * surface voxels to dxpad), FDN_DGRAD_SHELL = the one-voxel shell of the padded grid (dxpad only; ignores skip / y_prev). */
+#define FDN_DGRAD_INNER 1
+#define FDN_DGRAD_SHELL 2
+int fdn_conv3d_dgrad_fused_part(const float* dz, const float* wpack, float* dxpad, const float* skip, const float* y_prev,
+                                int act, float alpha, float* dz_prev, int N, int D, int H, int W, int parts, void* stream);
 int fdn_fold_halo_border(const float* dxpad0, const float* dxpad1, const float* dxpad2, int nsrc, const float* skip,
                          const float* y_prev, int act, float alpha, float* dz_prev, int N, int D, int H, int W,
                          void* stream);

@@ -273,6 +273,27 @@ def test_adam_and_l2(ops):
     close(dw, wr, tol=5e-5, name="adam w"); close(dm, m, tol=1e-5, name="adam m"); close(dv, v, tol=5e-5, name="adam v")
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 8, 8), (1, 5, 7, 9), (1, 6, 4, 12)])
+def test_conv64_dgrad_fused_parts_equal_whole(ops, shape):
+    """FDN_DGRAD_INNER and FDN_DGRAD_SHELL issued separately (on two streams) write exactly what the single call writes."""
+    rng = np.random.default_rng(8)
+    N, D, H, W = shape
+    dz = dev(rng.normal(size=(N, D, H, W, 64)).astype(np.float32))
+    y = dev(rng.normal(size=(N, D, H, W, 64)).astype(np.float32))
+    skip = dev(rng.normal(size=(N, D, H, W, 64)).astype(np.float32))
+    _, wd = ops.pack_conv64_weights(dev((rng.normal(size=(3, 3, 3, 64, 64)) * 0.05).astype(np.float32)))
+    pad0 = torch.zeros((N, D + 2, H + 2, W + 2, 64), device="cuda"); out0 = torch.zeros((N, D, H, W, 64), device="cuda")
+    ops.conv3d_dgrad_fused(dz, wd, pad0, out0, skip=skip, y_prev=y, act=O.ACT_LEAKY)
+    pad1 = torch.zeros_like(pad0); out1 = torch.zeros_like(out0)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.conv3d_dgrad_fused(dz, wd, pad1, out1, parts=ops.DGRAD_SHELL)
+    ops.conv3d_dgrad_fused(dz, wd, pad1, out1, skip=skip, y_prev=y, act=O.ACT_LEAKY, parts=ops.DGRAD_INNER)
+    torch.cuda.current_stream().wait_stream(side)
+    assert torch.equal(pad0, pad1) and torch.equal(out0, out1)
+
+
 def test_pack_batch_equals_per_layer_pack(ops):
     """fdn_pack_conv64_weights_batch (all 64->64 layers of the flat parameter buffer in one launch) == per-layer packing."""
     rng = np.random.default_rng(17)
