@@ -282,31 +282,37 @@ __global__ __launch_bounds__(256) void loss_main_kernel(const float* __restrict_
     const float a = block_sum(sf, red);
     const float b = block_sum(snf, red);
     const float c = block_sum(srel, red);
+    // per-block partials, summed by loss_finalize_kernel in block order: the reported loss / metric is run-to-run identical
+    // (the mask counts above are integers < 2^24, so their atomic sums are exact in any order)
     if (threadIdx.x == 0) {
-        atomicAdd(&scratch[n * 8 + 2], a);
-        atomicAdd(&scratch[n * 8 + 3], b);
-        atomicAdd(&scratch[n * 8 + 4], c);
+        float* part = scratch + (size_t)gridDim.y * 8 + ((size_t)n * gridDim.x + blockIdx.x) * 3;
+        part[0] = a; part[1] = b; part[2] = c;
     }
 }
 
-__global__ void loss_finalize_kernel(const float* __restrict__ scratch, float* __restrict__ out, int N) {
+__global__ void loss_finalize_kernel(const float* __restrict__ scratch, float* __restrict__ out, int N, int nblk) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     const float sm = scratch[n * 8 + 0], snf = scratch[n * 8 + 1];
-    out[n * 4 + 0] = scratch[n * 8 + 2] / (sm + 1.f) + scratch[n * 8 + 3] / (snf + 1.f);
-    out[n * 4 + 1] = scratch[n * 8 + 4] / (sm + 1.f) * 100.f;
+    const float* part = scratch + (size_t)N * 8 + (size_t)n * nblk * 3;
+    float sf = 0.f, sn = 0.f, sr = 0.f;
+    for (int b = 0; b < nblk; ++b) { sf += part[b * 3]; sn += part[b * 3 + 1]; sr += part[b * 3 + 2]; }
+    out[n * 4 + 0] = sf / (sm + 1.f) + sn / (snf + 1.f);
+    out[n * 4 + 1] = sr / (sm + 1.f) * 100.f;
     out[n * 4 + 2] = sm;
     out[n * 4 + 3] = snf;
 }
 
-__global__ __launch_bounds__(256) void l2_sumsq_kernel(const float* __restrict__ w, const uint8_t* __restrict__ isk,
-                                                        int64_t n, float* __restrict__ out) {
-    __shared__ float red[4];
+// ONE block (fixed summation order, no atomics): this pass only runs when the parameters changed outside the optimizer
+// (first step, load_weights); afterwards the Adam kernel supplies the sum
+__global__ __launch_bounds__(1024) void l2_sumsq_kernel(const float* __restrict__ w, const uint8_t* __restrict__ isk,
+                                                         int64_t n, float* __restrict__ out) {
+    __shared__ float red[16];
     float s = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    for (int64_t i = threadIdx.x; i < n; i += 1024)
         if (isk[i]) s += w[i] * w[i];
     const float a = block_sum(s, red);
-    if (threadIdx.x == 0) atomicAdd(out, a);
+    if (threadIdx.x == 0) out[0] = a;
 }
 
 // sumsq != null: block b also writes sum(w_new^2) over its kernel (non-bias) elements to sumsq[b] (fixed order: the
@@ -446,12 +452,12 @@ extern "C" int fdn_loss_metrics(const float* pred, const float* uh, const float*
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(scratch, 0, (size_t)N * 8 * sizeof(float), s);
     if (e != hipSuccess) { fdn_set_error("fdn_loss_metrics: memset: %s", hipGetErrorString(e)); return FDN_ERR_HIP; }
-    const int gx = grid_for(V, 256);
+    const int gx = grid_for(V, FDN_LOSS_BLOCKS);
     hipLaunchKernelGGL(mask_sums_kernel, dim3(gx, N), dim3(256), 0, s, mask, scratch, V);
     FDN_CHECK_LAUNCH("mask_sums_kernel");
     hipLaunchKernelGGL(loss_main_kernel, dim3(gx, N), dim3(256), 0, s, pred, uh, vh, wh, mask, scratch, dpred, V);
     FDN_CHECK_LAUNCH("loss_main_kernel");
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3((N + 63) / 64), dim3(64), 0, s, (const float*)scratch, out, N);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3((N + 63) / 64), dim3(64), 0, s, (const float*)scratch, out, N, gx);
     FDN_CHECK_LAUNCH("loss_finalize_kernel");
     return FDN_OK;
 }
@@ -459,9 +465,7 @@ extern "C" int fdn_loss_metrics(const float* pred, const float* uh, const float*
 extern "C" int fdn_l2_sumsq(const float* w, const uint8_t* is_kernel, int64_t n, float* out, void* stream) {
     FDN_REQUIRE(w && is_kernel && out && n > 0, "fdn_l2_sumsq: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(out, 0, sizeof(float), s);
-    if (e != hipSuccess) { fdn_set_error("fdn_l2_sumsq: memset: %s", hipGetErrorString(e)); return FDN_ERR_HIP; }
-    hipLaunchKernelGGL(l2_sumsq_kernel, dim3(grid_for(n, 512)), dim3(256), 0, s, w, is_kernel, n, out);
+    hipLaunchKernelGGL(l2_sumsq_kernel, dim3(1), dim3(1024), 0, s, w, is_kernel, n, out);
     FDN_CHECK_LAUNCH("l2_sumsq_kernel");
     return FDN_OK;
 }

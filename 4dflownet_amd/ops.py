@@ -205,7 +205,7 @@ def loss_metrics(pred, uh, vh, wh, mask, want_grad=True, out=None, dpred=None, s
     if out is None:
         out = torch.empty((N, 4), device=pred.device, dtype=torch.float32)
     if scratch is None:
-        scratch = torch.empty((N * 8,), device=pred.device, dtype=torch.float32)
+        scratch = torch.empty((N * (8 + 3 * 256),), device=pred.device, dtype=torch.float32)     # FDN_LOSS_SCRATCH_FLOATS(N)
     if want_grad and dpred is None:
         dpred = torch.empty_like(pred)
     check(_lib.load().fdn_loss_metrics(_p(pred), _p(uh), _p(vh), _p(wh), _p(mask), _p(out),

@@ -297,8 +297,8 @@ def self_spawn(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--patch", type=int, default=24)
     ap.add_argument("--res", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8)

@@ -139,7 +139,10 @@ int fdn_upsample_trilinear_bwd(const float* dy, const float* y_prev, int act, fl
 /* Loss + metric + dPred in one call.  src/Network/TrainerController.py:84-127,143-156,
  * src/Network/loss_utils.py:64-103.
  * pred (N,V,3); uh,vh,wh (N,V); mask (N,V).  out (N,4) = {mse loss, rel-error %, sum(mask), sum(nonfluid)}.
- * dpred (N,V,3) = d(sum_b loss_b)/dpred, or NULL (test_step).  scratch: N*8 floats. */
+ * dpred (N,V,3) = d(sum_b loss_b)/dpred, or NULL (test_step).  scratch: FDN_LOSS_SCRATCH_FLOATS(N) floats (per-block
+ * partial sums, added up in a fixed order: the reported values are run-to-run identical). */
+#define FDN_LOSS_BLOCKS 256
+#define FDN_LOSS_SCRATCH_FLOATS(N) ((N) * (8 + 3 * FDN_LOSS_BLOCKS))
 int fdn_loss_metrics(const float* pred, const float* uh, const float* vh, const float* wh, const float* mask,
                      float* out, float* dpred, float* scratch, int N, int64_t V, void* stream);
 

@@ -84,7 +84,8 @@ def test_predictor_end_to_end_on_example_volume(tmp_path):
 
 def test_cfg4_grid_sizes_run_in_fp32():
     """BASELINE cfg4 geometry (patch 32, res x4 -> 128^3 HR grid, 130^3 padded) through a shortened network in fp32:
-    exercises the large-grid index paths of every kernel.  (The bf16 variant of cfg4 is not built yet -- DESIGN.md.)"""
+    exercises the large-grid index paths of every fp32 kernel.  (cfg4 proper -- bf16 storage -- is covered by tests/test_gpu_bf16*.py
+    and, at its full launch shape, tests/test_gpu_fullsize.py.)"""
     torch.manual_seed(0)
     tc = trainer.TrainerController(32, 4, initial_learning_rate=1e-3, quicksave_enable=False, low_resblock=1, hi_resblock=1)
     batch = O.synthetic_batch(1, 32, 4, seed=3)

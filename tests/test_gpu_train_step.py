@@ -174,7 +174,9 @@ def test_full_size_cfg2_patch_matches_oracle(fdn):
     g = tc.model.backward(dpred).cpu().numpy().astype(np.float64)
     assert rel_err(pred.cpu().numpy(), ref["pred"]) < 1e-3
     assert rel_err(out[:, 0].cpu().numpy(), ref["mse"]) < 1e-3
-    assert abs(float(out[0, 1]) - float(ref["rel_err"][0])) < 0.5          # metric in percent, 1e-4 rounding steps
+    # metric in percent: mean over ~13 k fluid voxels of values rounded to 1e-4 steps; an fp32-vs-float32-oracle difference can move a
+    # voxel across a rounding step (1e-2 percentage points / 13 k each) -- hold the mean to 2e-3 percentage points
+    assert abs(float(out[0, 1]) - float(ref["rel_err"][0])) < 2e-3
     isk = tc.model.is_kernel.cpu().numpy().astype(np.float64)
     g_total = g + 2 * O.L2_LAMBDA * tc.model.flat_w.cpu().numpy().astype(np.float64) * isk
     gref = O.flatten(ref["grads"]).astype(np.float64)
