@@ -609,12 +609,19 @@ int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, 
     // parts: bit 0 = the inner box (finishes the interior of dz_prev), bit 1 = the six shell slabs (padded scratch only).  The two
     // write disjoint positions, so a caller may issue them on different streams and join before the border fold.
     if (wino && fdn_conv64_wino_ok(ID, IH, IW)) {
-        // inner box through the Winograd kernel (fused-fold epilogue), the six 9-tap shell slabs as one direct launch
-        if (parts & 1)
-            if (int rc = fdn_conv64_wino_launch(x, upack, bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, 1, 1, 1, ID,
-                                                IH, IW, off, zero_mode, act, alpha, s))
-                return rc;
-        return (parts & 2) ? launch_boxes(a, boxes + 1, 6, s) : FDN_OK;
+        // ONE Winograd launch: the inner box (fused-fold epilogue) + the d and h faces of the shell restricted to the inner W
+        // range (one depth resp. height tap each: a third of the work per tile, dispatched last, they fill the tail); the two w
+        // faces -- a single W tap, nothing to transform -- over the full (d,h) range as one short launch of the direct kernel.
+        const FdnWinoBox wb[5] = {
+            {1, 1, 1, ID, IH, IW, 0, 2, 0, 2},
+            {0, 0, 1, 1, OH, IW, 2, 2, 0, 2}, {ID + 1, 0, 1, 1, OH, IW, 0, 0, 0, 2},        // d faces, full h
+            {1, 0, 1, ID, 1, IW, 0, 2, 2, 2}, {1, IH + 1, 1, ID, 1, IW, 0, 2, 0, 0}};       // h faces, d inner
+        const Box wfaces[2] = {{0, 0, 0, OD, OH, 1, 0, 2, 0, 2, 2, 2}, {0, 0, IW + 1, OD, OH, 1, 0, 2, 0, 2, 0, 0}};
+        const int first = (parts & 1) ? 0 : 1, count = (parts & 1) ? ((parts & 2) ? 5 : 1) : 4;
+        if (int rc = fdn_conv64_wino_launch_boxes(x, upack, bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, wb + first,
+                                                  count, off, zero_mode, act, alpha, s))
+            return rc;
+        return (parts & 2) ? launch_boxes(a, wfaces, 2, s) : FDN_OK;
     }
     if (parts == 3) return launch_boxes(a, boxes, 7, s);
     if (parts & 1) return launch_boxes(a, boxes, 1, s);

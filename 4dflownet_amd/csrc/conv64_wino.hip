@@ -34,6 +34,22 @@
 
 namespace {
 
+// One launch covers up to 5 REGIONS of the output grid: a region is an output box (W extent a multiple of 4) with the (kd, kh)
+// tap ranges that can be non-zero for it, tiled with its own tile shape; workgroups [first_block, next region's) belong to it.
+//   forward     : 1 region, all taps.
+//   fused dgrad : the inner D x H x W box of the padded grid with all taps + the two d faces (1 depth tap) and the two h faces
+//                 (1 height tap) of the shell, each W-inner: they cost a third of an inner tile, are dispatched last and fill
+//                 the launch's tail.  (The two w faces have a single W tap -- nothing to transform -- and stay on the direct kernel.)
+struct WinoRegion {
+    int first_block;
+    int obd, obh, obw, ebd, ebh, ebw;
+    int ta0, ta1, tb0, tb1;
+    int td, th, tg, ntd, nth, ntg;        // tile in (d, h, groups) and tile counts
+    int hh, lines, ltg, items;            // th + (tb1-tb0), (td + (ta1-ta0))*hh, lines*tg, lines*tg*CH
+    unsigned mg_tg, mg_thtg, mg_itg, mg_ihh;
+    unsigned mg_tpn_hi, mg_tpn_lo, mg_thg_hi, mg_thg_lo, mg_ntg_hi, mg_ntg_lo;
+};
+
 struct WinoArgs {
     const float* x;
     const float* up;        // Winograd-domain operand stream (fdn_pack_conv64_weights, second part of the pack)
@@ -44,20 +60,18 @@ struct WinoArgs {
     const float* fy;
     float* fout;
     int N, ID, IH, IW, OD, OH, OW;
-    int obd, obh, obw, ebd, ebh, ebw;     // output box (ebw a multiple of 4), all 27 taps
     int off, zero_mode, act;
     float alpha;
-    int td, th, tg, ntd, nth, ntg;        // tile in (d, h, groups) and tile counts
-    int hh, lines, ltg, items;            // th+2, (td+2)*hh, lines*tg, lines*tg*CH
-    unsigned mg_tg, mg_thtg, mg_itg, mg_ihh;
-    unsigned mg_tpn_hi, mg_tpn_lo, mg_thg_hi, mg_thg_lo, mg_ntg_hi, mg_ntg_lo;
+    int nreg;
+    WinoRegion reg[5];
 };
 
 constexpr int kWinoCS = 4;                 // cin slices
 constexpr int kWinoMaxLtg = 160;           // LDS: 6 planes x ltg rows x 80 B + tables <= 80 KB -> 2 workgroups per CU
 constexpr int kWinoUA = 3;                 // transform items per thread (<= 768 items = 192 (line, group) pairs x 4 chunks)
 
-template <int CS>
+// GEN = false: a single region with all 9 (kd,kh) taps (every forward launch) -- tap ranges are compile-time constants.
+template <int CS, bool GEN>
 __global__ __launch_bounds__(256, 2) void conv64_wino_kernel(WinoArgs p) {
     constexpr int ROWB = 256 / CS, LROW = ROWB + 16, CH = ROWB / 16, KG = 8 / CS;
     constexpr int SPT = 6 * KG;            // K steps per (a,b) tap
@@ -73,30 +87,36 @@ __global__ __launch_bounds__(256, 2) void conv64_wino_kernel(WinoArgs p) {
     const int kh = lane >> 5;
     const int wave_m = wave & 1;
     const int wave_n = wave >> 1;
-    const int planeb = p.ltg * LROW;                       // bytes per xi plane
+    // ---- which region, which tile (scalar multiply-shift divisions, host-made magics) ----
+    int ri = 0;
+    if (GEN) {
+        while (ri + 1 < p.nreg && (int)blockIdx.x >= p.reg[ri + 1].first_block) ++ri;
+        ri = __builtin_amdgcn_readfirstlane(ri);
+    }
+    const WinoRegion R = p.reg[ri];
+    const int ta0 = GEN ? R.ta0 : 0, ta1 = GEN ? R.ta1 : 2, tb0 = GEN ? R.tb0 : 0, tb1 = GEN ? R.tb1 : 2;
+    const int planeb = R.ltg * LROW;                       // bytes per xi plane
     int* mtab = (int*)(smem + 6 * planeb);                 // [0,64): output index of the group's first voxel; [64,128): fused
                                                            // index (interior d,h) or -1; [128,192): iw of the first voxel
-
-    // ---- tile coordinates (scalar multiply-shift divisions, host-made magics) ----
-    const int tiles_per_n = p.ntd * p.nth * p.ntg;
-    int b = (int)blockIdx.x;
-    const int n = fdn_udiv40(b, p.mg_tpn_hi, p.mg_tpn_lo);
+    const int tiles_per_n = R.ntd * R.nth * R.ntg;
+    int b = (int)blockIdx.x - R.first_block;
+    const int n = fdn_udiv40(b, R.mg_tpn_hi, R.mg_tpn_lo);
     b -= n * tiles_per_n;
-    const int tdi = fdn_udiv40(b, p.mg_thg_hi, p.mg_thg_lo);
-    b -= tdi * (p.nth * p.ntg);
-    const int thi = fdn_udiv40(b, p.mg_ntg_hi, p.mg_ntg_lo);
-    const int p0d = p.obd + tdi * p.td, p0h = p.obh + thi * p.th, p0w = p.obw + (b - thi * p.ntg) * p.tg * 4;
-    const int ng = p.td * p.th * p.tg;
-    const int thtg = p.th * p.tg;
+    const int tdi = fdn_udiv40(b, R.mg_thg_hi, R.mg_thg_lo);
+    b -= tdi * (R.nth * R.ntg);
+    const int thi = fdn_udiv40(b, R.mg_ntg_hi, R.mg_ntg_lo);
+    const int p0d = R.obd + tdi * R.td, p0h = R.obh + thi * R.th, p0w = R.obw + (b - thi * R.ntg) * R.tg * 4;
+    const int ng = R.td * R.th * R.tg;
+    const int thtg = R.th * R.tg;
 
     if (tid < 64) {
         int g = -1, gf = -1, iw0 = 0;
         if (tid < ng) {
-            const int md = fdn_div20(tid, p.mg_thtg);
+            const int md = fdn_div20(tid, R.mg_thtg);
             const int r2 = tid - md * thtg;
-            const int mh = fdn_div20(r2, p.mg_tg);
-            const int pd = p0d + md, ph = p0h + mh, pw = p0w + 4 * (r2 - mh * p.tg);
-            if (pd < p.obd + p.ebd && ph < p.obh + p.ebh && pw < p.obw + p.ebw) {
+            const int mh = fdn_div20(r2, R.mg_tg);
+            const int pd = p0d + md, ph = p0h + mh, pw = p0w + 4 * (r2 - mh * R.tg);
+            if (pd < R.obd + R.ebd && ph < R.obh + R.ebh && pw < R.obw + R.ebw) {
                 g = ((n * p.OD + pd) * p.OH + ph) * p.OW + pw;
                 if (p.fout) {
                     const int id = pd - 1, ih = ph - 1;
@@ -113,10 +133,10 @@ __global__ __launch_bounds__(256, 2) void conv64_wino_kernel(WinoArgs p) {
     {
         int m = wave_m * 32 + li;
         m = m < ng ? m : ng - 1;
-        const int md = fdn_div20(m, p.mg_thtg);
+        const int md = fdn_div20(m, R.mg_thtg);
         const int r2 = m - md * thtg;
-        const int mh = fdn_div20(r2, p.mg_tg);
-        abase = ((md * p.hh + mh) * p.tg + (r2 - mh * p.tg)) * LROW + kh * 16;
+        const int mh = fdn_div20(r2, R.mg_tg);
+        abase = ((md * R.hh + mh) * R.tg + (r2 - mh * R.tg)) * LROW + kh * 16;
     }
     const int cofs = wave_n * 32 + kh * 16;                // first of this lane's 16 consecutive output channels
 
@@ -128,19 +148,20 @@ __global__ __launch_bounds__(256, 2) void conv64_wino_kernel(WinoArgs p) {
 
     // ---- transform plan, once per tile: for each of this thread's (line, group, chunk) items the byte offsets (from the
     // sample's first voxel) of the 6 input rows with the boundary rule applied (0xffffffff = reads zero) and the LDS offset ----
-    const int q0d = p0d - 1 + p.off, q0h = p0h - 1 + p.off, q0w = p0w - 1 + p.off;
+    // staged box origin in input coordinates: output p reads input p + tap - 1 + off, the first staged (kd,kh) tap is (ta0,tb0)
+    const int q0d = p0d - 1 + p.off + ta0, q0h = p0h - 1 + p.off + tb0, q0w = p0w - 1 + p.off;
     unsigned soff[UA][6];
     int vrow[UA];
 #pragma unroll
     for (int u = 0; u < UA; ++u) {
         const int i = u * 256 + tid;
-        const bool oki = i < p.items;
+        const bool oki = i < R.items;
         const int chunk = i & (CH - 1);
         const int r = i / CH;
-        const int line = fdn_div20(r, p.mg_itg);
-        const int pg = r - line * p.tg;
-        const int zd = fdn_div20(line, p.mg_ihh);
-        int qd = q0d + zd, qh = q0h + (line - zd * p.hh);
+        const int line = fdn_div20(r, R.mg_itg);
+        const int pg = r - line * R.tg;
+        const int zd = fdn_div20(line, R.mg_ihh);
+        int qd = q0d + zd, qh = q0h + (line - zd * R.hh);
         const int qw0 = q0w + 4 * pg;
         bool okl = oki;
         if (p.zero_mode) okl = okl && (unsigned)qd < (unsigned)p.ID && (unsigned)qh < (unsigned)p.IH;
@@ -183,14 +204,14 @@ __global__ __launch_bounds__(256, 2) void conv64_wino_kernel(WinoArgs p) {
             f32x4 xv[UA][6];
 #pragma unroll
             for (int u = 0; u < UA; ++u) {
-                if (u * 256 >= p.items) break;
+                if (u * 256 >= R.items) break;
 #pragma unroll
                 for (int nn = 0; nn < 6; ++nn)
                     xv[u][nn] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, soff[u][nn], 0, 0));
             }
 #pragma unroll
             for (int u = 0; u < UA; ++u) {
-                if (u * 256 >= p.items) break;
+                if (u * 256 >= R.items) break;
                 if (vrow[u] < 0) continue;
                 // B^T of F(4,3): rows (4,0,-5,0,1,0) (0,-4,-4,1,1,0) (0,4,-4,-1,1,0) (0,-2,-1,2,1,0) (0,2,-1,-2,1,0) (0,4,0,-5,0,1)
                 const f32x4 x0 = xv[u][0], x1 = xv[u][1], x2 = xv[u][2], x3 = xv[u][3], x4 = xv[u][4], x5 = xv[u][5];
@@ -207,23 +228,26 @@ __global__ __launch_bounds__(256, 2) void conv64_wino_kernel(WinoArgs p) {
         }
         __syncthreads();
 
-        // ---- K loop: 9 (a,b) taps x 6 xi x KG k-groups ----
+        // ---- K loop: (kd,kh) taps of the region x 6 xi x KG k-groups ----
         {
+            const int tap_first = ta0 * 3 + tb0;
+            const int ntap9 = (ta1 - ta0 + 1) * (tb1 - tb0 + 1);
             if (sl == 0) {
 #pragma unroll
-                for (int j = 0; j < RD - 1; ++j) ldb(j, wsoff(0, 0, j));
+                for (int j = 0; j < RD - 1; ++j) ldb(j, wsoff(0, tap_first, j));
             }
 #pragma unroll
             for (int j = 0; j < RD - 1; ++j) lda(j, 0, j);
             const int sln = sl + 1 < CS ? sl + 1 : sl;       // harmless reload after the last slice
-            int ta = 0, tb = 0, tapb = 0;
+            int ta = ta0, tb = tb0, tapb = 0;
 #pragma unroll 1
-            for (int it = 0; it < 9; ++it) {
+            for (int it = 0; it < ntap9; ++it) {
                 int na = ta, nb = tb + 1;
-                if (nb > 2) { nb = 0; ++na; }
-                const bool last = it == 8;
-                const int tapb_n = last ? tapb : (na * p.hh + nb) * p.tg * LROW;
-                const int tap_n = last ? 0 : it + 1;
+                if (nb > tb1) { nb = tb0; ++na; }
+                const bool last = it + 1 == ntap9;
+                const int tapb_n = last ? tapb : ((na - ta0) * R.hh + (nb - tb0)) * R.tg * LROW;
+                const int tap_c = ta * 3 + tb;
+                const int tap_n = last ? tap_first : na * 3 + nb;
                 const int sl_n = last ? sln : sl;
 #pragma unroll
                 for (int j = 0; j < SPT; ++j) {
@@ -234,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void conv64_wino_kernel(WinoArgs p) {
                     {
                         const int jj = j + RD - 1;           // the step whose operands go into the slot step j-1 just freed
                         const int slotr = jj % RD;
-                        if (jj < SPT) { ldb(slotr, wsoff(sl, it, jj)); lda(slotr, tapb, jj); }
+                        if (jj < SPT) { ldb(slotr, wsoff(sl, tap_c, jj)); lda(slotr, tapb, jj); }
                         else { ldb(slotr, wsoff(sl_n, tap_n, jj - SPT)); lda(slotr, tapb_n, jj - SPT); }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -321,17 +345,20 @@ __global__ void pack_conv64_wino_kernel(const float* __restrict__ w, float* __re
 
 struct WinoPlan { int td, th, tg; double cost; };
 
-// tile choice: every tile costs the MFMA time of 64 groups whatever its fill, plus the transform work of its halo lines;
-// the launch ends with the busiest CU (2 co-resident workgroups per CU share the matrix pipe, so work per CU = its tiles).
-WinoPlan wino_plan(int N, int ebd, int ebh, int ebg) {
+// tile choice: every tile costs the MFMA time of 64 groups (scaled by the region's share of the 9 (kd,kh) taps) whatever its
+// fill, plus the transform work of its halo lines and a fixed prologue / epilogue; the launch ends with the busiest CU
+// (2 co-resident workgroups per CU share the matrix pipe, so work per CU = its tiles).
+WinoPlan wino_plan(int N, const FdnWinoBox& bx) {
+    const int ebg = bx.ew / 4, da = bx.ta1 - bx.ta0, db = bx.tb1 - bx.tb0;
+    const double tapfrac = (da + 1) * (db + 1) / 9.0;
     WinoPlan best{1, 1, 1, 1e30};
-    for (int td = 1; td <= ebd && td <= 64; ++td)
-        for (int th = 1; th <= ebh && td * th <= 64; ++th)
+    for (int td = 1; td <= bx.ed && td <= 64; ++td)
+        for (int th = 1; th <= bx.eh && td * th <= 64; ++th)
             for (int tg = 1; tg <= ebg && td * th * tg <= 64; ++tg) {
-                const int ltg = (td + 2) * (th + 2) * tg;
+                const int ltg = (td + da) * (th + db) * tg;
                 if (ltg > kWinoMaxLtg || ltg * (64 / kWinoCS / 4) > kWinoUA * 256) continue;
-                const double tiles = (double)N * ((ebd + td - 1) / td) * ((ebh + th - 1) / th) * ((ebg + tg - 1) / tg);
-                const double per_tile = 64.0 + 0.12 * ltg;
+                const double tiles = (double)N * ((bx.ed + td - 1) / td) * ((bx.eh + th - 1) / th) * ((ebg + tg - 1) / tg);
+                const double per_tile = 64.0 * tapfrac + 0.12 * ltg + 4.0;
                 const double rounds = 0.9 * (double)((long long)((tiles + 255) / 256)) + 0.1 * tiles / 256.0;
                 const double c = rounds * per_tile;
                 if (c < best.cost) best = {td, th, tg, c};
@@ -344,35 +371,62 @@ WinoPlan wino_plan(int N, int ebd, int ebh, int ebg) {
 // Is the Winograd kernel applicable to this output box?  (W extent a multiple of 4; everything else falls to the direct kernel.)
 bool fdn_conv64_wino_ok(int ebd, int ebh, int ebw) { return ebd > 0 && ebh > 0 && ebw >= 4 && (ebw & 3) == 0; }
 
+int fdn_conv64_wino_launch_boxes(const float* x, const float* upack, const float* bias, const float* residual, float* y,
+                                 const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
+                                 int OW, const FdnWinoBox* boxes, int nbox, int off, int zero_mode, int act, float alpha,
+                                 hipStream_t s) {
+    FDN_REQUIRE((long long)ID * IH * IW < (1ll << 24), "conv64 (winograd): a sample of %dx%dx%d voxels exceeds the 32-bit row addressing", ID, IH, IW);
+    FDN_REQUIRE(nbox >= 1 && nbox <= 5, "conv64 (winograd): %d regions", nbox);
+    constexpr int CS = kWinoCS, LROW = 256 / CS + 16, CH = 256 / CS / 16;
+    WinoArgs a;
+    a.x = x; a.up = upack; a.bias = bias; a.res = residual; a.y = y; a.fskip = fskip; a.fy = fy; a.fout = fout;
+    a.N = N; a.ID = ID; a.IH = IH; a.IW = IW; a.OD = OD; a.OH = OH; a.OW = OW;
+    a.off = off; a.zero_mode = zero_mode; a.act = act; a.alpha = alpha;
+    a.nreg = 0;
+    long long blocks = 0;
+    int max_ltg = 0;
+    for (int i = 0; i < nbox; ++i) {
+        const FdnWinoBox& bx = boxes[i];
+        if (bx.ed <= 0 || bx.eh <= 0 || bx.ew <= 0) continue;
+        FDN_REQUIRE(fdn_conv64_wino_ok(bx.ed, bx.eh, bx.ew), "conv64 (winograd): W extent %d is not a multiple of 4", bx.ew);
+        const WinoPlan pl = wino_plan(N, bx);
+        WinoRegion& r = a.reg[a.nreg++];
+        r.first_block = (int)blocks;
+        r.obd = bx.od; r.obh = bx.oh; r.obw = bx.ow; r.ebd = bx.ed; r.ebh = bx.eh; r.ebw = bx.ew;
+        r.ta0 = bx.ta0; r.ta1 = bx.ta1; r.tb0 = bx.tb0; r.tb1 = bx.tb1;
+        r.td = pl.td; r.th = pl.th; r.tg = pl.tg;
+        const int ebg = bx.ew / 4;
+        r.ntd = (bx.ed + pl.td - 1) / pl.td; r.nth = (bx.eh + pl.th - 1) / pl.th; r.ntg = (ebg + pl.tg - 1) / pl.tg;
+        r.hh = pl.th + (bx.tb1 - bx.tb0); r.lines = (pl.td + (bx.ta1 - bx.ta0)) * r.hh; r.ltg = r.lines * pl.tg; r.items = r.ltg * CH;
+        r.mg_tg = fdn_magic20(pl.tg); r.mg_thtg = fdn_magic20(pl.th * pl.tg);
+        r.mg_itg = fdn_magic20(pl.tg); r.mg_ihh = fdn_magic20(r.hh);
+        fdn_magic40(r.ntd * r.nth * r.ntg, &r.mg_tpn_hi, &r.mg_tpn_lo);
+        fdn_magic40(r.nth * r.ntg, &r.mg_thg_hi, &r.mg_thg_lo);
+        fdn_magic40(r.ntg, &r.mg_ntg_hi, &r.mg_ntg_lo);
+        blocks += (long long)N * r.ntd * r.nth * r.ntg;
+        if (r.ltg > max_ltg) max_ltg = r.ltg;
+    }
+    if (a.nreg == 0) return FDN_OK;
+    FDN_REQUIRE(blocks < (1ll << 31), "conv64 (winograd): too many tiles");
+    const size_t lds = (size_t)6 * max_ltg * LROW + 192 * 4;
+    const int lds_max = 6 * kWinoMaxLtg * LROW + 192 * 4;
+    if (int rc = fdn_func_max_lds((const void*)conv64_wino_kernel<CS, true>, lds_max, "conv64_wino")) return rc;
+    if (int rc = fdn_func_max_lds((const void*)conv64_wino_kernel<CS, false>, lds_max, "conv64_wino")) return rc;
+    const WinoRegion& r0 = a.reg[0];
+    const bool simple = a.nreg == 1 && r0.ta0 == 0 && r0.ta1 == 2 && r0.tb0 == 0 && r0.tb1 == 2;
+    if (simple) hipLaunchKernelGGL((conv64_wino_kernel<CS, false>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((conv64_wino_kernel<CS, true>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+    FDN_CHECK_LAUNCH("conv64_wino_kernel");
+    return FDN_OK;
+}
+
 int fdn_conv64_wino_launch(const float* x, const float* upack, const float* bias, const float* residual, float* y,
                            const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
                            int OW, int obd, int obh, int obw, int ebd, int ebh, int ebw, int off, int zero_mode, int act,
                            float alpha, hipStream_t s) {
-    FDN_REQUIRE((long long)ID * IH * IW < (1ll << 24), "conv64 (winograd): a sample of %dx%dx%d voxels exceeds the 32-bit row addressing", ID, IH, IW);
-    FDN_REQUIRE(fdn_conv64_wino_ok(ebd, ebh, ebw), "conv64 (winograd): W extent %d is not a multiple of 4", ebw);
-    constexpr int CS = kWinoCS, LROW = 256 / CS + 16, CH = 256 / CS / 16;
-    const int ebg = ebw / 4;
-    const WinoPlan pl = wino_plan(N, ebd, ebh, ebg);
-    WinoArgs a;
-    a.x = x; a.up = upack; a.bias = bias; a.res = residual; a.y = y; a.fskip = fskip; a.fy = fy; a.fout = fout;
-    a.N = N; a.ID = ID; a.IH = IH; a.IW = IW; a.OD = OD; a.OH = OH; a.OW = OW;
-    a.obd = obd; a.obh = obh; a.obw = obw; a.ebd = ebd; a.ebh = ebh; a.ebw = ebw;
-    a.off = off; a.zero_mode = zero_mode; a.act = act; a.alpha = alpha;
-    a.td = pl.td; a.th = pl.th; a.tg = pl.tg;
-    a.ntd = (ebd + pl.td - 1) / pl.td; a.nth = (ebh + pl.th - 1) / pl.th; a.ntg = (ebg + pl.tg - 1) / pl.tg;
-    a.hh = pl.th + 2; a.lines = (pl.td + 2) * a.hh; a.ltg = a.lines * pl.tg; a.items = a.ltg * CH;
-    a.mg_tg = fdn_magic20(pl.tg); a.mg_thtg = fdn_magic20(pl.th * pl.tg);
-    a.mg_itg = fdn_magic20(pl.tg); a.mg_ihh = fdn_magic20(a.hh);
-    fdn_magic40(a.ntd * a.nth * a.ntg, &a.mg_tpn_hi, &a.mg_tpn_lo);
-    fdn_magic40(a.nth * a.ntg, &a.mg_thg_hi, &a.mg_thg_lo);
-    fdn_magic40(a.ntg, &a.mg_ntg_hi, &a.mg_ntg_lo);
-    const long long blocks = (long long)N * a.ntd * a.nth * a.ntg;
-    FDN_REQUIRE(blocks < (1ll << 31), "conv64 (winograd): too many tiles");
-    const size_t lds = (size_t)6 * a.ltg * LROW + 192 * 4;
-    if (int rc = fdn_func_max_lds((const void*)conv64_wino_kernel<CS>, 6 * kWinoMaxLtg * LROW + 192 * 4, "conv64_wino")) return rc;
-    hipLaunchKernelGGL((conv64_wino_kernel<CS>), dim3((unsigned)blocks), dim3(256), lds, s, a);
-    FDN_CHECK_LAUNCH("conv64_wino_kernel");
-    return FDN_OK;
+    const FdnWinoBox bx{obd, obh, obw, ebd, ebh, ebw, 0, 2, 0, 2};
+    return fdn_conv64_wino_launch_boxes(x, upack, bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, &bx, 1, off,
+                                        zero_mode, act, alpha, s);
 }
 
 int fdn_pack_conv64_wino_launch(const float* w, float* uf, float* ud, hipStream_t s) {
