@@ -62,9 +62,13 @@ struct WinoArgs {
     int N, ID, IH, IW, OD, OH, OW;
     int off, zero_mode, act;
     float alpha;
+    int dbg;                // ablation bits (test build only): 1 = weight stream stride 0, 4 = no staging, 8 = no epilogue,
+                            // 16 = no transform arithmetic, 32 = epilogue arithmetic without the stores
     int nreg;
     WinoRegion reg[5];
 };
+
+FDN_HOOK_VAR(int, fdn_conv64_wino_dbg, 0);
 
 constexpr int kWinoCS = 4;                 // cin slices
 constexpr int kWinoMaxLtg = 160;           // LDS: 6 planes x ltg rows x 80 B + tables <= 80 KB -> 2 workgroups per CU
@@ -184,8 +188,9 @@ __global__ __launch_bounds__(256, 2) void conv64_wino_kernel(WinoArgs p) {
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.up, 0, 54 * 64 * 64 * 4, 0x00020000);
     const int wvoff = (kh * 64 + wave_n * 32 + li) * 16;
     f32x4 A[RD], B[RD];
+    const int bmul = (p.dbg & 1) ? 0 : 2048;
     auto wsoff = [&](int sl_, int tap, int jj) -> int {      // jj = xi*KG + g within the tap
-        return ((((sl_ * KG) >> 2) * 216) + tap * 24 + ((sl_ * KG) & 3) + (jj / KG) * 4 + (jj % KG)) * 2048;
+        return ((((sl_ * KG) >> 2) * 216) + tap * 24 + ((sl_ * KG) & 3) + (jj / KG) * 4 + (jj % KG)) * bmul;
     };
     auto ldb = [&](int slot, int so) {
         B[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, so, 0));
@@ -202,17 +207,24 @@ __global__ __launch_bounds__(256, 2) void conv64_wino_kernel(WinoArgs p) {
             const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(p.x + in_n * 64 + sl * (64 / CS)), 0, sample_bytes - sl * (256 / CS), 0x00020000);
             f32x4 xv[UA][6];
+            const int items_eff = (p.dbg & 4) ? 0 : R.items;
 #pragma unroll
             for (int u = 0; u < UA; ++u) {
-                if (u * 256 >= R.items) break;
+                if (u * 256 >= items_eff) break;
 #pragma unroll
                 for (int nn = 0; nn < 6; ++nn)
                     xv[u][nn] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, soff[u][nn], 0, 0));
             }
 #pragma unroll
             for (int u = 0; u < UA; ++u) {
-                if (u * 256 >= R.items) break;
+                if (u * 256 >= items_eff) break;
                 if (vrow[u] < 0) continue;
+                if (p.dbg & 16) {                            // ablation: raw rows, no transform arithmetic
+                    char* vq = smem + vrow[u];
+#pragma unroll
+                    for (int nn = 0; nn < 6; ++nn) *(f32x4*)(vq + nn * planeb) = xv[u][nn];
+                    continue;
+                }
                 // B^T of F(4,3): rows (4,0,-5,0,1,0) (0,-4,-4,1,1,0) (0,4,-4,-1,1,0) (0,-2,-1,2,1,0) (0,2,-1,-2,1,0) (0,4,0,-5,0,1)
                 const f32x4 x0 = xv[u][0], x1 = xv[u][1], x2 = xv[u][2], x3 = xv[u][3], x4 = xv[u][4], x5 = xv[u][5];
                 const f32x4 t1 = x4 - 4.f * x2, t2 = x3 - 4.f * x1;
@@ -272,6 +284,7 @@ __global__ __launch_bounds__(256, 2) void conv64_wino_kernel(WinoArgs p) {
         }
     }
 
+    if (p.dbg & 8) return;
     // ---- epilogue: Y = A^T M, A^T = (1,1,1,1,1,0) (0,1,-1,2,-2,0) (0,1,1,4,4,0) (0,1,-1,8,-8,1); lane = one group x 16 cout ----
     const int m = wave_m * 32 + li;
     const int g0 = mtab[m];
@@ -332,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void conv64_wino_kernel(WinoArgs p) {
                     const float t = z[q][e];
                     z[q][e] = fmaxf(t, slope * t);             // relu / leaky / none: slope in [0,1]
                 }
-                *(f32x4*)(p.y + o + q * 4) = z[q];
+                if (!(p.dbg & 32) || z[q][0] == 12345.678f) *(f32x4*)(p.y + o + q * 4) = z[q];
             }
         }
     }
@@ -381,7 +394,7 @@ int fdn_conv64_wino_launch_boxes(const float* x, const float* upack, const float
     WinoArgs a;
     a.x = x; a.up = upack; a.bias = bias; a.res = residual; a.y = y; a.fskip = fskip; a.fy = fy; a.fout = fout;
     a.N = N; a.ID = ID; a.IH = IH; a.IW = IW; a.OD = OD; a.OH = OH; a.OW = OW;
-    a.off = off; a.zero_mode = zero_mode; a.act = act; a.alpha = alpha;
+    a.off = off; a.zero_mode = zero_mode; a.act = act; a.alpha = alpha; a.dbg = fdn_conv64_wino_dbg;
     a.nreg = 0;
     long long blocks = 0;
     int max_ltg = 0;
@@ -428,6 +441,10 @@ int fdn_conv64_wino_launch(const float* x, const float* upack, const float* bias
     return fdn_conv64_wino_launch_boxes(x, upack, bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, &bx, 1, off,
                                         zero_mode, act, alpha, s);
 }
+
+#ifdef FDN_TEST_HOOKS
+extern "C" int fdn_debug_set_conv64_wino_dbg(int bits) { fdn_conv64_wino_dbg = bits; return FDN_OK; }
+#endif
 
 int fdn_pack_conv64_wino_launch(const float* w, float* uf, float* ud, hipStream_t s) {
     hipLaunchKernelGGL(pack_conv64_wino_kernel, dim3((54 * 64 * 64 + 255) / 256), dim3(256), 0, s, w, uf, ud);

@@ -555,9 +555,21 @@ size_t fdn_small_wgrad_workspace_bytes(int Cin, int Cout, int K) {
 
 // Launchers, templated on the activation storage type T (float, or uint16_t = bf16 bits); parameters, parameter
 // gradients, the 64->1 heads' output (the prediction) and its gradient are always fp32.
+// cin3_mfma.hip: the im2col-GEMM formulation of the two 3 -> 64 kernels (default); the VALU kernels of this file stay selectable
+// for A/B runs in the test build (fdn_debug_set_cin3_mfma(0)) and serve odd W in the weight gradient
+template <typename T> int fdn_conv_cin3_fwd_mfma_launch(const T* x, const float* w, const float* bias, T* y, int N, int D, int H,
+                                                        int W, int act, float alpha, hipStream_t s);
+template <typename T> int fdn_wgrad_cin3_mfma_launch(const T* x, const T* dz, float* partial, int nblocks, int N, int D, int H,
+                                                     int W, hipStream_t s);
+FDN_HOOK_VAR(int, fdn_cin3_use_mfma, 1);
+#ifdef FDN_TEST_HOOKS
+extern "C" int fdn_debug_set_cin3_mfma(int on) { fdn_cin3_use_mfma = on; return FDN_OK; }
+#endif
+
 template <typename T>
 int fdn_conv_cin3_fwd_launch(const T* x, const float* w, const float* bias, T* y, int N, int D, int H, int W, int act,
                              float alpha, hipStream_t s) {
+    if (fdn_cin3_use_mfma) return fdn_conv_cin3_fwd_mfma_launch<T>(x, w, bias, y, N, D, H, W, act, alpha, s);
     const int64_t nvox = (int64_t)N * D * H * W;
     hipLaunchKernelGGL(conv_cin3_fwd_kernel<T>, dim3((unsigned)((nvox + 63) / 64)), dim3(256), 0, s, x, w, bias, y, N, D, H,
                        W, act, alpha);
@@ -622,6 +634,10 @@ template <typename T>
 int fdn_wgrad_cin3_launch(const T* x, const T* dz, float* dw, void* ws, size_t, int N, int D, int H, int W, hipStream_t s) {
     const int64_t nvox = (int64_t)N * D * H * W;
     const int nb = nblocks_for(nvox, 4 * 32, kSmallBlocks);
+    if (fdn_cin3_use_mfma && (W & 1) == 0) {
+        if (int rc = fdn_wgrad_cin3_mfma_launch<T>(x, dz, (float*)ws, nb, N, D, H, W, s)) return rc;
+        return reduce_partials((const float*)ws, dw, nb, 81 * 64, s);
+    }
     hipLaunchKernelGGL(wgrad_cin3_kernel<T>, dim3(nb), dim3(256), 0, s, x, dz, (float*)ws, N, D, H, W);
     FDN_CHECK_LAUNCH("wgrad_cin3_kernel");
     return reduce_partials((const float*)ws, dw, nb, 81 * 64, s);

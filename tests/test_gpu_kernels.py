@@ -150,8 +150,21 @@ def test_conv64_wgrad(ops, fdn, shape, direct):
     close(db, O.bias_grad(dz.astype(np.float64)), name="bias grad 64")
 
 
-@pytest.mark.parametrize("shape", [(2, 6, 6, 6), (1, 5, 7, 9), (1, 1, 2, 3)])
-def test_thin_layers(ops, shape):
+@pytest.mark.parametrize("shape,valu", [((2, 6, 6, 6), 0), ((1, 5, 7, 9), 0), ((1, 1, 2, 3), 0), ((1, 4, 5, 8), 0), ((2, 12, 10, 24), 0),
+                                        ((2, 6, 6, 6), 1), ((1, 5, 7, 9), 1)])
+def test_thin_layers(ops, fdn, shape, valu):
+    """valu = 1: the VALU 3 -> 64 kernels (test build); 0: the product library (im2col MFMA kernels)."""
+    with variant_lib(fdn, valu) as lib:
+        if lib is not None:
+            lib.fdn_debug_set_cin3_mfma(0)
+        try:
+            _thin_layers(ops, shape)
+        finally:
+            if lib is not None:
+                lib.fdn_debug_set_cin3_mfma(1)
+
+
+def _thin_layers(ops, shape):
     rng = np.random.default_rng(4)
     N, D, H, W = shape
     f64 = lambda a: a.astype(np.float64)
