@@ -308,9 +308,16 @@ __global__ void loss_finalize_kernel(const float* __restrict__ scratch, float* _
 __global__ __launch_bounds__(1024) void l2_sumsq_kernel(const float* __restrict__ w, const uint8_t* __restrict__ isk,
                                                          int64_t n, float* __restrict__ out) {
     __shared__ float red[16];
-    float s = 0.f;
-    for (int64_t i = threadIdx.x; i < n; i += 1024)
-        if (isk[i]) s += w[i] * w[i];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;           // four independent chains: the loads of a trip overlap
+    int64_t i = threadIdx.x;
+    for (; i + 3 * 1024 < n; i += 4 * 1024) {
+        const float a0 = isk[i] ? w[i] : 0.f, a1 = isk[i + 1024] ? w[i + 1024] : 0.f;
+        const float a2 = isk[i + 2048] ? w[i + 2048] : 0.f, a3 = isk[i + 3072] ? w[i + 3072] : 0.f;
+        s0 += a0 * a0; s1 += a1 * a1; s2 += a2 * a2; s3 += a3 * a3;
+    }
+    for (; i < n; i += 1024)
+        if (isk[i]) s0 += w[i] * w[i];
+    const float s = (s0 + s1) + (s2 + s3);
     const float a = block_sum(s, red);
     if (threadIdx.x == 0) out[0] = a;
 }
