@@ -72,6 +72,8 @@ FDN_HOOK_VAR(int, fdn_conv64_wino_dbg, 0);
 
 constexpr int kWinoCS = 4;                 // cin slices
 constexpr int kWinoMaxLtg = 160;           // LDS: 6 planes x ltg rows x 80 B + tables <= 80 KB -> 2 workgroups per CU
+constexpr int kWinoRDB = 6;                // weight-fragment ring depth (prefetch distance 5 K steps)
+constexpr int kWinoRDA = 3;                // voxel-fragment ring depth (LDS, distance 2)
 constexpr int kWinoUA = 3;                 // transform items per thread (<= 768 items = 192 (line, group) pairs x 4 chunks)
 
 // GEN = false: a single region with all 9 (kd,kh) taps (every forward launch) -- tap ranges are compile-time constants.
@@ -79,9 +81,12 @@ template <int CS, bool GEN>
 __global__ __launch_bounds__(256, 2) void conv64_wino_kernel(WinoArgs p) {
     constexpr int ROWB = 256 / CS, LROW = ROWB + 16, CH = ROWB / 16, KG = 8 / CS;
     constexpr int SPT = 6 * KG;            // K steps per (a,b) tap
-    constexpr int RD = 4;                  // fragment ring depth
+    // fragment rings: the weight fragments come from L2 (a wave that has its SIMD to itself -- its co-resident partner staging or
+    // storing -- runs the K loop at twice the shared rate, so the prefetch distance must cover the L2 latency at THAT rate), the
+    // voxel fragments from LDS
+    constexpr int RDB = kWinoRDB, RDA = kWinoRDA;
     constexpr int UA = kWinoUA;
-    static_assert(SPT % RD == 0, "ring slots must be compile-time");
+    static_assert(SPT % RDB == 0 && SPT % RDA == 0, "ring slots must be compile-time");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void conv64_wino_kernel(WinoArgs p) {
     // weight stream: unit (2048 B) index = half*216 + (tap*6 + xi)*4 + k-group-in-half
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.up, 0, 54 * 64 * 64 * 4, 0x00020000);
     const int wvoff = (kh * 64 + wave_n * 32 + li) * 16;
-    f32x4 A[RD], B[RD];
+    f32x4 A[RDA], B[RDB];
     const int bmul = (p.dbg & 1) ? 0 : 2048;
     auto wsoff = [&](int sl_, int tap, int jj) -> int {      // jj = xi*KG + g within the tap
         return ((((sl_ * KG) >> 2) * 216) + tap * 24 + ((sl_ * KG) & 3) + (jj / KG) * 4 + (jj % KG)) * bmul;
@@ -246,10 +251,10 @@ __global__ __launch_bounds__(256, 2) void conv64_wino_kernel(WinoArgs p) {
             const int ntap9 = (ta1 - ta0 + 1) * (tb1 - tb0 + 1);
             if (sl == 0) {
 #pragma unroll
-                for (int j = 0; j < RD - 1; ++j) ldb(j, wsoff(0, tap_first, j));
+                for (int j = 0; j < RDB - 1; ++j) ldb(j, wsoff(0, tap_first, j));
             }
 #pragma unroll
-            for (int j = 0; j < RD - 1; ++j) lda(j, 0, j);
+            for (int j = 0; j < RDA - 1; ++j) lda(j, 0, j);
             const int sln = sl + 1 < CS ? sl + 1 : sl;       // harmless reload after the last slice
             int ta = ta0, tb = tb0, tapb = 0;
 #pragma unroll 1
@@ -263,20 +268,22 @@ __global__ __launch_bounds__(256, 2) void conv64_wino_kernel(WinoArgs p) {
                 const int sl_n = last ? sln : sl;
 #pragma unroll
                 for (int j = 0; j < SPT; ++j) {
-                    const int slot = j % RD;
+                    const int sb = j % RDB, sa = j % RDA;
                     const int xi = j / KG;
-                    acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(B[slot][0], A[slot][0], acc[xi], 0, 0, 0);
+                    acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(B[sb][0], A[sa][0], acc[xi], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                     {
-                        const int jj = j + RD - 1;           // the step whose operands go into the slot step j-1 just freed
-                        const int slotr = jj % RD;
-                        if (jj < SPT) { ldb(slotr, wsoff(sl, tap_c, jj)); lda(slotr, tapb, jj); }
-                        else { ldb(slotr, wsoff(sl_n, tap_n, jj - SPT)); lda(slotr, tapb_n, jj - SPT); }
+                        // the steps whose operands go into the slots step j-1 just freed
+                        const int jb = j + RDB - 1, ja = j + RDA - 1;
+                        if (jb < SPT) ldb(jb % RDB, wsoff(sl, tap_c, jb));
+                        else ldb(jb % RDB, wsoff(sl_n, tap_n, jb - SPT));
+                        if (ja < SPT) lda(ja % RDA, tapb, ja);
+                        else lda(ja % RDA, tapb_n, ja - SPT);
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int s = 1; s < 4; ++s)
-                        acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(B[slot][s], A[slot][s], acc[xi], 0, 0, 0);
+                        acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(B[sb][s], A[sa][s], acc[xi], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 ta = na; tb = nb; tapb = tapb_n;
@@ -421,8 +428,9 @@ int fdn_conv64_wino_launch_boxes(const float* x, const float* upack, const float
     }
     if (a.nreg == 0) return FDN_OK;
     FDN_REQUIRE(blocks < (1ll << 31), "conv64 (winograd): too many tiles");
-    const size_t lds = (size_t)6 * max_ltg * LROW + 192 * 4;
-    const int lds_max = 6 * kWinoMaxLtg * LROW + 192 * 4;
+    size_t lds = (size_t)6 * max_ltg * LROW + 192 * 4;
+    if (fdn_conv64_wino_dbg & 64) lds = 82 * 1024;             // ablation: only ONE workgroup fits a CU
+    const int lds_max = 84 * 1024;
     if (int rc = fdn_func_max_lds((const void*)conv64_wino_kernel<CS, true>, lds_max, "conv64_wino")) return rc;
     if (int rc = fdn_func_max_lds((const void*)conv64_wino_kernel<CS, false>, lds_max, "conv64_wino")) return rc;
     const WinoRegion& r0 = a.reg[0];

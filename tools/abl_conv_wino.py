@@ -11,7 +11,7 @@ for P in ([int(sys.argv[2])] if len(sys.argv) > 2 else [48, 24]):
     wf, _ = ops.pack_conv64_weights(w); y = torch.empty_like(x)
     flop = 2.0 * 27 * 64 * 64 * N * P ** 3
     for bits, name in ((0, "full kernel"), (1, "weight stream stride 0 (L1-resident)"), (4, "no staging (no loads, no transform, no LDS writes)"),
-                       (16, "staging without transform arithmetic"), (8, "no epilogue"), (32, "epilogue arithmetic without the stores"), (13, "stride 0 + no staging + no epilogue")):
+                       (16, "staging without transform arithmetic"), (8, "no epilogue"), (32, "epilogue arithmetic without the stores"), (13, "stride 0 + no staging + no epilogue"), (64, "ONE workgroup per CU (LDS padded)"), (77, "one workgroup per CU, stride 0 + no staging + no epilogue"), (0, "full kernel again")):
         lib.fdn_debug_set_conv64_wino_dbg(bits)
         for _ in range(3): ops.conv3d_fwd(x, w, None, ops.ACT_RELU, wpack=wf, out=y)
         torch.cuda.synchronize()
