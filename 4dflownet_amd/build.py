@@ -26,7 +26,7 @@ def _hipcc():
 
 def _stamp():
     h = hashlib.sha256()
-    for name in sorted(os.listdir(CSRC)) + ["../../include/fdn.h"]:
+    for name in sorted(n for n in os.listdir(CSRC) if n.endswith((".hip", ".h"))) + ["../../include/fdn.h"]:
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(name.encode()); h.update(f.read())
     h.update(" ".join(FLAGS).encode())

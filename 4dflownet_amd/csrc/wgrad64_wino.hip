@@ -34,7 +34,10 @@ struct WgWinoArgs {
     int N, D, H, W;
     int nth, ntw, ntiles, S;
     unsigned bytes;              // size of x (= of dz) in bytes; < 4 GB (checked by the launcher)
+    int dbg;                     // ablation bits (test build): 1 = no raw loads, 2 = no transform / LDS writes, 4 = no LDS operand reads
 };
+
+FDN_HOOK_VAR(int, fdn_wgrad64_wino_dbg, 0);
 
 constexpr int WTH = 6, WTG = 2, WTW = 4 * WTG;          // tile: 1 x 6 x 8 voxels
 constexpr int GROWB = 1536;                             // bytes per (line, group): 2 parities x (64 ch x 2 floats + 64 ch x 1 float)
@@ -124,12 +127,12 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
         if (!z_in && zitem) rowoff = h0 + 1 + il < p.H ? zplane + (unsigned)((h0 + 1 + il) * p.W * 256 + c16 * 16) : 0xffffffffu;
     };
     auto load_x = [&](int nn) {
-        if (!xitem) return;
+        if (!xitem || (p.dbg & 1)) return;
         if (x_in) raw[nn] = bload(xrs, tc[nn], x_so);
         else raw[nn] = bload(xrs, rowoff + (unsigned)(min(max(tw * WTW + 4 * ig - 1 + nn, 0), p.W - 1) * 256), 0);
     };
     auto load_z = [&](int j) {
-        if (!zitem) return;
+        if (!zitem || (p.dbg & 1)) return;
         if (z_in) raw[j] = bload(zrs, tc[j], z_so);
         else {
             const int qw = tw * WTW + 4 * ig + j;
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
     };
     auto write_v = [&](int e, char* buf) {
         // B^T of F(4,3)/F(3,4): (4,0,-5,0,1,0) (0,-4,-4,1,1,0) (0,4,-4,-1,1,0) (0,-2,-1,2,1,0) (0,2,-1,-2,1,0) (0,4,0,-5,0,1)
-        if (!xitem) return;
+        if (!xitem || (p.dbg & 2)) return;
         char* dst = buf + (il * WTG + ig) * GROWB + e * 768;
         const f32x4 x0 = raw[0], x1 = raw[1], x2 = raw[2], x3 = raw[3], x4 = raw[4], x5 = raw[5];
         const f32x4 t1 = x4 - 4.f * x2, t2 = x3 - 4.f * x1, t3 = x4 - x2, t4 = 2.f * (x3 - x1);
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
     };
     auto write_z = [&](int e, char* buf) {
         // G' of F(3,4): (1/4,0,0,0) -1/6(1,1,1,1) -1/6(1,-1,1,-1) 1/24(1,2,4,8) 1/24(1,-2,4,-8) (0,0,0,1)
-        if (!zitem) return;
+        if (!zitem || (p.dbg & 2)) return;
         char* dst = buf + VBYTES + (il * WTG + ig) * GROWB + e * 768;
         const f32x4 z0 = raw[0], z1 = raw[1], z2 = raw[2], z3 = raw[3];
         const float s6 = -1.f / 6, s24 = 1.f / 24;
@@ -184,13 +187,15 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
     const int lane_z = VBYTES + kh * GROWB + eh * 768 + (nq * 32 + li) * 8;
     const int lane_v1 = kh * GROWB + eh * 768 + 512 + (mq * 32 + li) * 4;
     const int lane_z1 = VBYTES + kh * GROWB + eh * 768 + 512 + (nq * 32 + li) * 4;
-    f32x2 Vp[2], Zp[2];
-    float Vs[2], Zs[2];
+    f32x2 Vp[2] = {{1.f, 1.f}, {1.f, 1.f}}, Zp[2] = {{1.f, 1.f}, {1.f, 1.f}};
+    float Vs[2] = {1.f, 1.f}, Zs[2] = {1.f, 1.f};
     auto issue_v = [&](const char* buf, int line, int slot) {
+        if (p.dbg & 4) return;
         Vp[slot] = *(const f32x2*)(buf + lane_v + line * (WTG * GROWB));
         Vs[slot] = *(const float*)(buf + lane_v1 + line * (WTG * GROWB));
     };
     auto issue_z = [&](const char* buf, int line, int slot) {
+        if (p.dbg & 4) return;
         Zp[slot] = *(const f32x2*)(buf + lane_z + line * (WTG * GROWB));
         Zs[slot] = *(const float*)(buf + lane_z1 + line * (WTG * GROWB));
     };
@@ -283,6 +288,10 @@ int wgrad64_wino_splits(int N, int D, int H, int W) {
 
 }  // namespace
 
+#ifdef FDN_TEST_HOOKS
+extern "C" int fdn_debug_set_wgrad64_wino_dbg(int bits) { fdn_wgrad64_wino_dbg = bits; return FDN_OK; }
+#endif
+
 size_t fdn_wgrad64_wino_workspace_bytes(int N, int D, int H, int W) {
     return (size_t)wgrad64_wino_splits(N, D, H, W) * 54 * 4096 * sizeof(float);
 }
@@ -298,6 +307,7 @@ int fdn_wgrad64_wino_launch(const float* x, const float* dz, float* dw, void* ws
     FDN_REQUIRE((long long)N * D * H * W * 256 < (1ll << 32), "wgrad64: x of %dx%dx%dx%dx64 floats exceeds the 32-bit buffer addressing", N, D, H, W);
     FDN_REQUIRE(ws_bytes >= (size_t)a.S * 54 * 4096 * sizeof(float), "wgrad64 (winograd): workspace too small");
     a.bytes = (unsigned)((long long)N * D * H * W * 256);
+    a.dbg = fdn_wgrad64_wino_dbg;
     const size_t lds = (size_t)3 * WBUFB;
     if (int rc = fdn_func_max_lds((const void*)wgrad64_wino_kernel, (int)lds, "wgrad64_wino")) return rc;
     hipLaunchKernelGGL(wgrad64_wino_kernel, dim3(a.S, 3), dim3(512), lds, s, a);

@@ -132,3 +132,40 @@ def test_cfg5_patch_list_sharded_over_ranks_and_all_gathered():
             got = res[r][1][k]
             assert got.shape == (n, 8, 8, 8, 3) and got.dtype == np.float64
             np.testing.assert_array_equal(got, ref)
+
+
+def _helpers_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    parallel = importlib.import_module("4dflownet_amd.parallel")
+    trainer = importlib.import_module("4dflownet_amd.trainer")
+    parallel.init_from_env(backend="gloo")
+    sums = parallel.allreduce_sum_host([rank + 1.0, 10.0 * (rank + 1)])
+    mx = parallel.allreduce_sum_host([float(rank)], op="max")
+    gathered = parallel.all_gather_equal(torch.full((2, 3), float(rank)))
+    # epoch metrics: (total, count) are combined over ranks -- a rank with an empty shard (count 0) does not dilute the mean
+    m = trainer.Mean("x", torch.device("cpu"))
+    if rank == 0:
+        m.update_state(torch.tensor([1.0, 2.0, 3.0]))
+    glob = m.result_global()
+    parallel.barrier()
+    q.put((rank, sums, mx, [g.tolist() for g in gathered], m.result(), glob))
+    dist.destroy_process_group()
+
+
+def test_host_collectives_and_rank_combined_metrics():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_helpers_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert res[r][1] == [3.0, 30.0] and res[r][2] == [1.0]
+        assert res[r][3] == [[[0.0] * 3] * 2, [[1.0] * 3] * 2]
+        assert res[r][5] == 2.0                        # global mean of rank 0's three values; rank 1 contributed nothing
+    assert res[0][4] == 2.0 and res[1][4] == 0.0
