@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void conv64_wino_kernel(WinoArgs p) {
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.up, 0, 54 * 64 * 64 * 4, 0x00020000);
     const int wvoff = (kh * 64 + wave_n * 32 + li) * 16;
     f32x4 A[RDA], B[RDB];
-    const int bmul = (p.dbg & 1) ? 0 : 2048;
+    const int bmul = (FDN_DBG_BITS(p) & 1) ? 0 : 2048;
     auto wsoff = [&](int sl_, int tap, int jj) -> int {      // jj = xi*KG + g within the tap
         return ((((sl_ * KG) >> 2) * 216) + tap * 24 + ((sl_ * KG) & 3) + (jj / KG) * 4 + (jj % KG)) * bmul;
     };
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void conv64_wino_kernel(WinoArgs p) {
             const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(p.x + in_n * 64 + sl * (64 / CS)), 0, sample_bytes - sl * (256 / CS), 0x00020000);
             f32x4 xv[UA][6];
-            const int items_eff = (p.dbg & 4) ? 0 : R.items;
+            const int items_eff = (FDN_DBG_BITS(p) & 4) ? 0 : R.items;
 #pragma unroll
             for (int u = 0; u < UA; ++u) {
                 if (u * 256 >= items_eff) break;
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void conv64_wino_kernel(WinoArgs p) {
             for (int u = 0; u < UA; ++u) {
                 if (u * 256 >= items_eff) break;
                 if (vrow[u] < 0) continue;
-                if (p.dbg & 16) {                            // ablation: raw rows, no transform arithmetic
+                if (FDN_DBG_BITS(p) & 16) {                            // ablation: raw rows, no transform arithmetic
                     char* vq = smem + vrow[u];
 #pragma unroll
                     for (int nn = 0; nn < 6; ++nn) *(f32x4*)(vq + nn * planeb) = xv[u][nn];
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void conv64_wino_kernel(WinoArgs p) {
         }
     }
 
-    if (p.dbg & 8) return;
+    if (FDN_DBG_BITS(p) & 8) return;
     // ---- epilogue: Y = A^T M, A^T = (1,1,1,1,1,0) (0,1,-1,2,-2,0) (0,1,1,4,4,0) (0,1,-1,8,-8,1); lane = one group x 16 cout ----
     const int m = wave_m * 32 + li;
     const int g0 = mtab[m];
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void conv64_wino_kernel(WinoArgs p) {
                     const float t = z[q][e];
                     z[q][e] = fmaxf(t, slope * t);             // relu / leaky / none: slope in [0,1]
                 }
-                if (!(p.dbg & 32) || z[q][0] == 12345.678f) *(f32x4*)(p.y + o + q * 4) = z[q];
+                if (!(FDN_DBG_BITS(p) & 32) || z[q][0] == 12345.678f) *(f32x4*)(p.y + o + q * 4) = z[q];
             }
         }
     }

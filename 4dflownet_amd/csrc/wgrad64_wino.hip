@@ -127,12 +127,12 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
         if (!z_in && zitem) rowoff = h0 + 1 + il < p.H ? zplane + (unsigned)((h0 + 1 + il) * p.W * 256 + c16 * 16) : 0xffffffffu;
     };
     auto load_x = [&](int nn) {
-        if (!xitem || (p.dbg & 1)) return;
+        if (!xitem || (FDN_DBG_BITS(p) & 1)) return;
         if (x_in) raw[nn] = bload(xrs, tc[nn], x_so);
         else raw[nn] = bload(xrs, rowoff + (unsigned)(min(max(tw * WTW + 4 * ig - 1 + nn, 0), p.W - 1) * 256), 0);
     };
     auto load_z = [&](int j) {
-        if (!zitem || (p.dbg & 1)) return;
+        if (!zitem || (FDN_DBG_BITS(p) & 1)) return;
         if (z_in) raw[j] = bload(zrs, tc[j], z_so);
         else {
             const int qw = tw * WTW + 4 * ig + j;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
     };
     auto write_v = [&](int e, char* buf) {
         // B^T of F(4,3)/F(3,4): (4,0,-5,0,1,0) (0,-4,-4,1,1,0) (0,4,-4,-1,1,0) (0,-2,-1,2,1,0) (0,2,-1,-2,1,0) (0,4,0,-5,0,1)
-        if (!xitem || (p.dbg & 2)) return;
+        if (!xitem || (FDN_DBG_BITS(p) & 2)) return;
         char* dst = buf + (il * WTG + ig) * GROWB + e * 768;
         const f32x4 x0 = raw[0], x1 = raw[1], x2 = raw[2], x3 = raw[3], x4 = raw[4], x5 = raw[5];
         const f32x4 t1 = x4 - 4.f * x2, t2 = x3 - 4.f * x1, t3 = x4 - x2, t4 = 2.f * (x3 - x1);
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
     };
     auto write_z = [&](int e, char* buf) {
         // G' of F(3,4): (1/4,0,0,0) -1/6(1,1,1,1) -1/6(1,-1,1,-1) 1/24(1,2,4,8) 1/24(1,-2,4,-8) (0,0,0,1)
-        if (!zitem || (p.dbg & 2)) return;
+        if (!zitem || (FDN_DBG_BITS(p) & 2)) return;
         char* dst = buf + VBYTES + (il * WTG + ig) * GROWB + e * 768;
         const f32x4 z0 = raw[0], z1 = raw[1], z2 = raw[2], z3 = raw[3];
         const float s6 = -1.f / 6, s24 = 1.f / 24;
@@ -190,12 +190,12 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
     f32x2 Vp[2] = {{1.f, 1.f}, {1.f, 1.f}}, Zp[2] = {{1.f, 1.f}, {1.f, 1.f}};
     float Vs[2] = {1.f, 1.f}, Zs[2] = {1.f, 1.f};
     auto issue_v = [&](const char* buf, int line, int slot) {
-        if (p.dbg & 4) return;
+        if (FDN_DBG_BITS(p) & 4) return;
         Vp[slot] = *(const f32x2*)(buf + lane_v + line * (WTG * GROWB));
         Vs[slot] = *(const float*)(buf + lane_v1 + line * (WTG * GROWB));
     };
     auto issue_z = [&](const char* buf, int line, int slot) {
-        if (p.dbg & 4) return;
+        if (FDN_DBG_BITS(p) & 4) return;
         Zp[slot] = *(const f32x2*)(buf + lane_z + line * (WTG * GROWB));
         Zs[slot] = *(const float*)(buf + lane_z1 + line * (WTG * GROWB));
     };
