@@ -173,18 +173,19 @@ class ImageDataset:
         self.venc_colnames = ['venc_u', 'venc_v', 'venc_w']
         self.mag_colnames = ['mag_u', 'mag_v', 'mag_w']
         self.dx_colname = 'dx'
+        self._cache = _VolumeCache()          # every dataset is decoded once per file, not once per row (ImageDataset.py:19-29 re-opens)
 
     def get_dataset_len(self, filepath):
         with h5io.open_read(filepath) as hl:
             return hl[self.velocity_colnames[0]].shape[0]
 
     def load_vectorfield(self, filepath, idx):
-        with h5io.open_read(filepath) as hl:
-            rd = lambda n: np.asarray(hl[n][...] if hasattr(hl[n], "id") else hl[n].read())
-            dx = rd(self.dx_colname)[idx] if self.dx_colname in hl else None
-            vel = np.asarray([rd(n)[idx] for n in self.velocity_colnames])
-            mag = np.asarray([rd(n)[idx] for n in self.mag_colnames])
-            venc = np.max([rd(n)[idx] for n in self.venc_colnames])
+        rd = lambda n: self._cache.get(filepath, n)
+        dxa = rd(self.dx_colname)
+        dx = dxa[idx] if dxa is not None else None
+        vel = np.asarray([rd(n)[idx] for n in self.velocity_colnames])
+        mag = np.asarray([rd(n)[idx] for n in self.mag_colnames])
+        venc = np.max([rd(n)[idx] for n in self.venc_colnames])
         vel = vel / venc
         mag = mag / 4095.
         self.u, self.v, self.w = (vel[i].astype('float32') for i in range(3))

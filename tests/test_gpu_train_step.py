@@ -207,3 +207,36 @@ def test_linearity_of_conv_at_full_size(fdn):
     dw, _ = ops.conv3d_wgrad(x, g, 3, 64, 64)
     assert abs((x.double() * dx.double()).sum().item() - lhs) < 1e-4 * abs(lhs) + 1e-2
     assert abs((w.double() * dw.double()).sum().item() - lhs) < 1e-4 * abs(lhs) + 1e-2
+
+
+def test_winograd_and_direct_kernels_train_alike(fdn):
+    """The product path (Winograd F(4,3)/F(3,4) kernels for every 64->64 layer) and the round-1 direct MFMA kernels (forced in
+    the test build) run the same 6 training steps from the same weights and batch: per-step losses agree to 1e-5 relative, the
+    first step's gradient to 1e-5 of its scale, and after 6 Adam steps the bulk of the weights has moved identically."""
+    trainer_mod = __import__("importlib").import_module("4dflownet_amd.trainer")
+    P, R, LB, HB, B = 8, 2, 2, 1, 2
+    batch = O.synthetic_batch(B, P, R, seed=77)
+
+    def run(direct):
+        tc = trainer_mod.TrainerController(P, R, initial_learning_rate=1e-4, quicksave_enable=False, low_resblock=LB, hi_resblock=HB, seed=3)
+        losses, g0 = [], None
+        for step in range(6):
+            losses.append(tc.train_step(batch).cpu().numpy().astype(np.float64))
+            if step == 0:
+                g0 = tc.model.flat_g.cpu().numpy().astype(np.float64)
+        return np.asarray(losses), g0, tc.model.flat_w.cpu().numpy().astype(np.float64)
+
+    l_w, g_w, w_w = run(False)
+    with fdn._lib.test_build() as lib:
+        lib.fdn_debug_set_conv64_mt(5)            # direct <1,2,cs2> forward / dgrad kernel
+        lib.fdn_debug_set_wgrad64_direct(1)
+        try:
+            l_d, g_d, w_d = run(True)
+        finally:
+            lib.fdn_debug_set_conv64_mt(0)
+            lib.fdn_debug_set_wgrad64_direct(0)
+    assert np.abs(l_w - l_d).max() <= 1e-5 * np.abs(l_d).max()
+    assert np.abs(g_w - g_d).max() <= 1e-5 * np.abs(g_d).max()
+    # Adam moves noise-level gradients by +-lr either way; everything else must coincide
+    dw = np.abs(w_w - w_d)
+    assert dw.max() <= 6 * 2.1e-4 and np.quantile(dw, 0.99) <= 2e-5 and np.mean(dw > 1e-6) < 0.15
