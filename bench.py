@@ -187,7 +187,10 @@ def roofline_obj(timer, kind, bf16, kernel, traffic_files):
             "avg_launch_gflop": avg_flop / 1e9,
             # frac is ALGORITHMIC FLOPs (221 184 per voxel) over the MFMA peak and exceeds 1 when the kernel executes
             # fewer multiplies than the direct algorithm (fp32: Winograd along W); executed_frac is the matrix-pipe utilisation
-            "executed_gflop_per_launch": avg_exec / 1e9, "executed_frac": avg_exec / (avg_ms * 1e-3) / 1e12 / peak}
+            "executed_gflop_per_launch": avg_exec / 1e9, "executed_frac": avg_exec / (avg_ms * 1e-3) / 1e12 / peak,
+            "note": None if bf16 else "frac > 1 is not a measurement error: achieved counts the ALGORITHMIC FLOPs of a direct 3x3x3 convolution "
+                                      "(SURVEY 8d), the kernel is a Winograd F(4,3)/F(3,4)-along-W kernel that executes half of them on the same "
+                                      "fp32 MFMA pipe; executed_frac is the pipe utilisation (PMC SQ_VALU_MFMA_BUSY_CYCLES agrees, profiles/README.md)"}
 
 
 def timed_steps(step_fn, steps, warmup, parallel):
