@@ -280,6 +280,35 @@ def secondary_runs(trainer, parallel, device, P, R, B, LB, HB):
     except Exception as e:
         sec["cfg4_bf16"] = {"error": repr(e)}
     torch.cuda.empty_cache()
+    # (3) cfg5: sliding-window inference (predictor.py:67-115) -- tiler -> batched forward -> gather, host<->device copies included
+    try:
+        predictor = importlib.import_module("4dflownet_amd.predictor")
+        tiler = importlib.import_module("4dflownet_amd.tiler")
+
+        class _Vol:
+            pass
+        rng = np.random.default_rng(0)
+        vol = _Vol()
+        for n_ in ("u", "v", "w"):
+            setattr(vol, n_, rng.uniform(-1, 1, (100, 100, 100)).astype(np.float32))
+        for n_ in ("mag_u", "mag_v", "mag_w"):
+            setattr(vol, n_, rng.uniform(0, 0.016, (100, 100, 100)).astype(np.float32))
+        net = predictor.prepare_network(P, R, LB, HB, device=device)
+        pg = tiler.PatchGenerator(P, R)
+        vel, mag = pg.patchify(vol)
+        predictor.predict_patches(net, vel, mag, B)                     # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = predictor.predict_patches(net, vel, mag, B)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        sec["cfg5_predictor"] = {"value": len(res) / dt, "unit": "patches/s", "patches": int(len(res)),
+                                 "workload": "predictor.predict_patches on a synthetic 100^3 volume (patch_size=%d res_increase=%d batch=%d, fp32): "
+                                             "forward + gather, host<->device copies included; stitching excluded" % (P, R, B)}
+        del net, res
+    except Exception as e:
+        sec["cfg5_predictor"] = {"error": repr(e)}
+    torch.cuda.empty_cache()
     return sec
 
 
