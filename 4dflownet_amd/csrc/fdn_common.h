@@ -158,6 +158,7 @@ size_t fdn_wgrad64_workspace_bytes(int N, int D, int H, int W);
 int fdn_wgrad64_wino_launch(const float* x, const float* dz, float* dw, void* ws, size_t ws_bytes, int N, int D, int H,
                             int W, hipStream_t s);
 size_t fdn_wgrad64_wino_workspace_bytes(int N, int D, int H, int W);
+int fdn_wgrad64_reduce_launch(const float* partial, float* dw, int S, hipStream_t s);
 
 // bf16 activation path (conv64_bf16.hip)
 int fdn_conv64_bf16_launch(const uint16_t* x, const uint16_t* wpack, const float* bias, const uint16_t* residual, uint16_t* y,

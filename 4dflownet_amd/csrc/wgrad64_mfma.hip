@@ -245,6 +245,13 @@ int wgrad64_splits(int N, int D, int H, int W) {
 }
 }  // namespace
 
+// dw = sum over S of partial[S][27][64][64] (shared with the Winograd kernel, whose workgroups write the same layout)
+int fdn_wgrad64_reduce_launch(const float* partial, float* dw, int S, hipStream_t s) {
+    hipLaunchKernelGGL(wgrad64_reduce_kernel, dim3(27 * 1024 / 64), dim3(256), 0, s, partial, dw, S);
+    FDN_CHECK_LAUNCH("wgrad64_reduce_kernel");
+    return FDN_OK;
+}
+
 size_t fdn_wgrad64_workspace_bytes(int N, int D, int H, int W) {
     return (size_t)wgrad64_splits(N, D, H, W) * 27 * 4096 * sizeof(float);
 }

@@ -22,7 +22,8 @@
 //   writes them to LDS.
 //   Tile pipeline through THREE LDS buffers exactly as in the direct kernel: while tile k is contracted, the raw registers of
 //   tile k+1 are transformed and written to buffer (k+1)%3, the raw rows of tile k+2 are loaded, one barrier per tile.
-//   Partials M[S][a][b][xi] go to the workspace; wgrad64_wino_reduce_kernel sums over S and applies A'^T.
+//   The output transform runs inside the workgroup; partials dW[S][27] go to the workspace and are summed by the direct
+//   kernel's reduction (wgrad64_reduce_kernel: same partial layout).
 #include "fdn_common.h"
 
 namespace {
@@ -235,47 +236,52 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
         bcur = bnxt;
     }
 
-    // ---- this workgroup's partial M[a][b][xi] ----
-    float* out = p.partial + ((size_t)split * 3 + a) * 18 * 4096;
+    // ---- output transform inside the workgroup, then ONE partial dW[a][b][t] per workgroup (half the partial traffic of writing
+    // the 18 Winograd-domain matrices).  dW[t] = sum_xi A'^T[t][xi] M_xi with A'^T = (1,1,1,1,1,0) (0,1,-1,2,-2,0) (0,1,1,4,4,1);
+    // a wave holds one parity of xi, so it forms its share of the three taps in place and the odd-parity wave of each quadrant
+    // hands its share to the even one through LDS (the tile buffers are free now), in two rounds of <= 5 of the 9 (b,t) tiles. ----
 #pragma unroll
-    for (int b = 0; b < 3; ++b)
+    for (int b = 0; b < 3; ++b) {
+        const f32x16 m0 = acc[b][0], m1 = acc[b][1], m2 = acc[b][2];       // xi = eh, 2 + eh, 4 + eh
+        if (eh == 0) {           // xi 0, 2, 4
+            acc[b][0] = m0 + m1 + m2;
+            acc[b][1] = -m1 - 2.f * m2;
+            acc[b][2] = m1 + 4.f * m2;
+        } else {                 // xi 1, 3, 5
+            acc[b][0] = m0 + m1;
+            acc[b][1] = m0 + 2.f * m1;
+            acc[b][2] = m0 + 4.f * m1 + m2;
+        }
+    }
+    float* xch = (float*)smem + (size_t)(wave & 3) * (5 * 16 * 64) + lane;          // per quadrant: [tile 5][r 16][lane 64]
 #pragma unroll
-        for (int xp = 0; xp < 3; ++xp)
+    for (int round = 0; round < 2; ++round) {
+        __syncthreads();                                    // tile buffers / the previous round's exchange are no longer read
+        if (eh == 1) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                if ((k < 5) == (round == 0))
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) xch[((k - 5 * round) * 16 + r) * 64] = acc[k / 3][k % 3][r];
+        }
+        __syncthreads();
+        if (eh == 0) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                if ((k < 5) == (round == 0))
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[k / 3][k % 3][r] += xch[((k - 5 * round) * 16 + r) * 64];
+        }
+    }
+    if (eh == 0) {
+        float* out = p.partial + ((size_t)split * 27 + a * 9) * 4096;
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ci = mq * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                out[(size_t)(b * 6 + 2 * xp + eh) * 4096 + ci * 64 + nq * 32 + li] = acc[b][xp][r];
+                out[(size_t)k * 4096 + ci * 64 + nq * 32 + li] = acc[k / 3][k % 3][r];
             }
-}
-
-// dw[a][b][t][e] = sum_xi A'^T[t][xi] sum_s partial[s][a][b][xi][e],  A'^T = (1,1,1,1,1,0) (0,1,-1,2,-2,0) (0,1,1,4,4,1).
-// Block = 64 float4 columns of one (a,b) x 4 quarters of S, combined through LDS in a fixed order (deterministic).
-__global__ __launch_bounds__(256) void wgrad64_wino_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int S) {
-    __shared__ f32x4 red[3][6][64];
-    const int col = threadIdx.x & 63, qtr = threadIdx.x >> 6;
-    const int ab = blockIdx.x >> 4;                              // 9 (a,b) x 16 blocks of 64 columns
-    const int e4 = (blockIdx.x & 15) * 64 + col;                 // float4 column within the 64x64 matrix
-    const f32x4* p = (const f32x4*)partial + (size_t)ab * 6 * 1024 + e4;
-    const int s0q = (S * qtr) >> 2, s1q = (S * (qtr + 1)) >> 2;
-    f32x4 m[6];
-#pragma unroll
-    for (int xi = 0; xi < 6; ++xi) m[xi] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int s = s0q; s < s1q; ++s)
-#pragma unroll
-        for (int xi = 0; xi < 6; ++xi) m[xi] += p[(size_t)s * (54 * 1024) + xi * 1024];
-    if (qtr) {
-#pragma unroll
-        for (int xi = 0; xi < 6; ++xi) red[qtr - 1][xi][col] = m[xi];
-    }
-    __syncthreads();
-    if (qtr == 0) {
-#pragma unroll
-        for (int xi = 0; xi < 6; ++xi) m[xi] = (m[xi] + red[0][xi][col]) + (red[1][xi][col] + red[2][xi][col]);
-        const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
-        f32x4* o = (f32x4*)dw + (size_t)ab * 3 * 1024 + e4;
-        o[0] = m[0] + s12 + s34;
-        o[1024] = d12 + 2.f * d34;
-        o[2048] = s12 + 4.f * s34 + m[5];
     }
 }
 
@@ -293,7 +299,7 @@ extern "C" int fdn_debug_set_wgrad64_wino_dbg(int bits) { fdn_wgrad64_wino_dbg =
 #endif
 
 size_t fdn_wgrad64_wino_workspace_bytes(int N, int D, int H, int W) {
-    return (size_t)wgrad64_wino_splits(N, D, H, W) * 54 * 4096 * sizeof(float);
+    return (size_t)wgrad64_wino_splits(N, D, H, W) * 27 * 4096 * sizeof(float);
 }
 
 int fdn_wgrad64_wino_launch(const float* x, const float* dz, float* dw, void* ws, size_t ws_bytes, int N, int D, int H,
@@ -305,14 +311,12 @@ int fdn_wgrad64_wino_launch(const float* x, const float* dz, float* dw, void* ws
     a.ntiles = N * D * a.nth * a.ntw;
     a.S = wgrad64_wino_splits(N, D, H, W);
     FDN_REQUIRE((long long)N * D * H * W * 256 < (1ll << 32), "wgrad64: x of %dx%dx%dx%dx64 floats exceeds the 32-bit buffer addressing", N, D, H, W);
-    FDN_REQUIRE(ws_bytes >= (size_t)a.S * 54 * 4096 * sizeof(float), "wgrad64 (winograd): workspace too small");
+    FDN_REQUIRE(ws_bytes >= (size_t)a.S * 27 * 4096 * sizeof(float), "wgrad64 (winograd): workspace too small");
     a.bytes = (unsigned)((long long)N * D * H * W * 256);
     a.dbg = fdn_wgrad64_wino_dbg;
     const size_t lds = (size_t)3 * WBUFB;
     if (int rc = fdn_func_max_lds((const void*)wgrad64_wino_kernel, (int)lds, "wgrad64_wino")) return rc;
     hipLaunchKernelGGL(wgrad64_wino_kernel, dim3(a.S, 3), dim3(512), lds, s, a);
     FDN_CHECK_LAUNCH("wgrad64_wino_kernel");
-    hipLaunchKernelGGL(wgrad64_wino_reduce_kernel, dim3(9 * 16), dim3(256), 0, s, (const float*)ws, dw, a.S);
-    FDN_CHECK_LAUNCH("wgrad64_wino_reduce_kernel");
-    return FDN_OK;
+    return fdn_wgrad64_reduce_launch((const float*)ws, dw, a.S, s);
 }
