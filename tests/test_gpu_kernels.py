@@ -330,3 +330,44 @@ def test_errors_are_loud(ops, fdn):
         ops.conv3d_fwd(x, w)                        # unsupported shape
     with pytest.raises(fdn.FdnError):
         ops.conv3d_fwd(torch.zeros((1, 4, 4, 4, 64)), torch.zeros((3, 3, 3, 64, 64)))   # CPU tensors: no fallback
+
+
+def test_winograd_kernels_equal_direct_kernels_on_random_shapes(ops, fdn):
+    """Tile / region logic sweep: on 24 random shapes (W a multiple of 4 for the conv, any W for the weight gradient) the
+    Winograd kernels of the product library must reproduce the direct MFMA kernels (test build) to fp32 accuracy -- forward
+    with bias + residual + LeakyReLU, fused dgrad + border fold with skip and act', weight gradient."""
+    rng = np.random.default_rng(2024)
+    shapes = [(int(rng.integers(1, 4)), int(rng.integers(1, 21)), int(rng.integers(1, 21)), 4 * int(rng.integers(1, 9))) for _ in range(20)]
+    shapes += [(1, 1, 1, 4), (2, 2, 19, 4), (1, 20, 1, 32), (1, 9, 9, 28)]
+    for (N, D, H, W) in shapes:
+        g = torch.Generator(device="cuda").manual_seed(N * 1000003 + D * 1009 + H * 31 + W)
+        x = torch.randn((N, D, H, W, 64), device="cuda", generator=g)
+        res = torch.randn((N, D, H, W, 64), device="cuda", generator=g)
+        dz = torch.randn((N, D, H, W, 64), device="cuda", generator=g)
+        w = torch.randn((3, 3, 3, 64, 64), device="cuda", generator=g) * 0.05
+        b = torch.randn((64,), device="cuda", generator=g)
+        yfix = torch.randn((N, D, H, W, 64), device="cuda", generator=g)   # act' mask: fixed, so a sign flip of a near-zero forward
+        wf, wd = ops.pack_conv64_weights(w)                               # output cannot leak into the dgrad comparison
+        Wg = W + 3 - int(rng.integers(0, 4))                       # weight gradient: an arbitrary W around it
+        xg = torch.randn((N, D, H, Wg, 64), device="cuda", generator=g)
+        dzg = torch.randn((N, D, H, Wg, 64), device="cuda", generator=g)
+
+        def run():
+            y = ops.conv3d_fwd(x, w, b, ops.ACT_LEAKY, 0.2, res, wpack=wf)
+            pad = torch.zeros((N, D + 2, H + 2, W + 2, 64), device="cuda")
+            out = torch.zeros_like(x)
+            ops.conv3d_dgrad_fused(dz, wd, pad, out, skip=res, y_prev=yfix, act=ops.ACT_LEAKY)
+            ops.fold_halo_border([pad], out, res, yfix, ops.ACT_LEAKY)
+            dw, _ = ops.conv3d_wgrad(xg, dzg, 3, 64, 64)
+            return y, out, dw
+
+        got = run()
+        with fdn._lib.test_build() as lib:
+            lib.fdn_debug_set_conv64_mt(5); lib.fdn_debug_set_wgrad64_direct(1)
+            try:
+                ref = run()
+            finally:
+                lib.fdn_debug_set_conv64_mt(0); lib.fdn_debug_set_wgrad64_direct(0)
+        for name, a, r in zip(("fwd", "dgrad", "wgrad"), got, ref):
+            err = (a - r).abs().max().item() / max(r.abs().max().item(), 1e-30)
+            assert err <= 1e-5, (name, (N, D, H, W, Wg), err)
