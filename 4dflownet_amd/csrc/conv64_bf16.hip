@@ -137,24 +137,26 @@ __global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
         }
     }
     const uint16_t* xchunk = p.x + chunk * 8;
-    u32x4 sv[NP];
-    auto stage_load = [&](int sl) {       // unconditional loads (clamped address), zero selection afterwards
+    // staged in two halves of NP/2 voxels that share four registers (half 0: loaded at step 0, written at step 3; half 1: steps 4, 7)
+    constexpr int NH = NP / 2;
+    u32x4 sv[NH];
+    auto stage_load = [&](int sl, int half) {       // unconditional loads (clamped address), zero selection afterwards
 #pragma unroll
-        for (int u = 0; u < NP; ++u) sv[u] = *(const u32x4*)(xchunk + (size_t)(gv[u] & 0x7fffffff) * 64 + sl * 16);
+        for (int u = 0; u < NH; ++u) sv[u] = *(const u32x4*)(xchunk + (size_t)(gv[half * NH + u] & 0x7fffffff) * 64 + sl * 16);
     };
-    auto stage_write = [&](char* buf) {
+    auto stage_write = [&](char* buf, int half) {
 #pragma unroll
-        for (int u = 0; u < NP; ++u) {
-            if (gv[u] < 0) sv[u] = (u32x4){0u, 0u, 0u, 0u};
-            if (lo[u] >= 0) *(u32x4*)(buf + lo[u]) = sv[u];
+        for (int u = 0; u < NH; ++u) {
+            if (gv[half * NH + u] < 0) sv[u] = (u32x4){0u, 0u, 0u, 0u};
+            if (lo[half * NH + u] >= 0) *(u32x4*)(buf + lo[half * NH + u]) = sv[u];
         }
     };
-    stage_load(0);
+    stage_load(0, 0);
 
     // ---- weight fragments: stream [slice 4][b*3+c][a][kh][cout row 64] x 16 B, two register sets, two steps ahead ----
     const int wstride = (p.dbg & 1) ? 0 : 1;
     const u32x4* wbase = (const u32x4*)p.wp + kh * 64 + wn * 32 + j;
-    u32x4 wq[2][3];
+    u32x4 wq[3][3];                       // three register sets: weights THREE steps ahead (see fast_slice)
     auto load_w = [&](u32x4 (&dst)[3], int sl, int tb, int tc) {
         const int bc = tb * 3 + tc;
 #pragma unroll
@@ -164,6 +166,7 @@ __global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
     // step `it` of a slice -> tap (tb0 + it / nc, tc0 + it % nc); nb * nc is 9 or 3
     load_w(wq[0], 0, tb0, tc0);
     load_w(wq[1], 0, tb0 + (nc == 1 ? 1 : 0), tc0 + (nc == 1 ? 0 : 1));
+    load_w(wq[2], 0, tb0 + (nc == 1 ? 2 : 0), tc0 + (nc == 1 ? 0 : 2));
 
     // ---- output voxel of each (plane, position): output-grid voxel index, tagged (bit 30) if finished by the fused fold ----
     for (int m = tid; m < C::MCAP; m += 256) {
@@ -235,7 +238,8 @@ __global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
         }
     };
 
-    stage_write(smem);
+    stage_write(smem, 0);
+    stage_load(0, 1); stage_write(smem, 1);
     __syncthreads();
     if (FAST) {
         // 9 unrolled steps per slice; weights two steps ahead (running into the next slice) in two register sets; the next
@@ -244,16 +248,21 @@ __global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
         // register set of step `it` alternates from slice to slice (PAR); all four slices are straight-line code.
         auto fast_slice = [&](auto prefetchc, auto parc, int sl) {
             constexpr bool PREFETCH = decltype(prefetchc)::value;
-            constexpr int PAR = decltype(parc)::value;
+            (void)parc;
             const char* cur = smem + (sl & 1) * bufB;
             char* nxt = smem + ((sl + 1) & 1) * bufB;
 #pragma unroll
             for (int it = 0; it < 9; ++it) {
-                kstep(std::true_type{}, cur, it / 3, it % 3, wq[(it + PAR) & 1]);
-                if (PREFETCH || it < 7)
-                    load_w(wq[(it + PAR) & 1], sl + (it + 2) / 9, tb0 + ((it + 2) % 9) / 3, tc0 + ((it + 2) % 9) % 3);
-                if (PREFETCH && it == 0) stage_load((sl + 1) & 3);
-                if (PREFETCH && it == 7) stage_write(nxt);
+                // A wave's vector-memory operations return in order (vmcnt), so the wait for a weight fragment also waits for every
+                // staging load issued before it: fragments three steps ahead and staging loads in two groups of four give those
+                // loads ~70 MFMAs to come back before the first wait that covers them.
+                kstep(std::true_type{}, cur, it / 3, it % 3, wq[it % 3]);
+                if (PREFETCH || it < 6)
+                    load_w(wq[it % 3], sl + (it + 3) / 9, tb0 + ((it + 3) % 9) / 3, tc0 + ((it + 3) % 9) % 3);
+                if (PREFETCH && it == 0) stage_load((sl + 1) & 3, 0);
+                if (PREFETCH && it == 3) stage_write(nxt, 0);
+                if (PREFETCH && it == 4) stage_load((sl + 1) & 3, 1);
+                if (PREFETCH && it == 7) stage_write(nxt, 1);
                 // keep every step's loads inside the step: under register pressure the scheduler otherwise sinks the
                 // weight refills down to their first use, i.e. prefetch distance 0
                 __builtin_amdgcn_sched_barrier(0);
@@ -271,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
             const char* cur = smem + (sl & 1) * bufB;
             char* nxt = smem + ((sl + 1) & 1) * bufB;
             // shell slabs / ragged tiles: rolled loop, predicated planes and taps, weights loaded in step
-            if (sl < 3) stage_load(sl + 1);
+            if (sl < 3) { stage_load(sl + 1, 0); stage_write(nxt, 0); stage_load(sl + 1, 1); }
 #pragma unroll 1
             for (int it = 0; it < nb * nc; ++it) {
                 const int db = it / nc, dc = it - db * nc;
@@ -279,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
                 load_w(w3, sl, tb0 + db, tc0 + dc);
                 kstep(std::false_type{}, cur, db, dc, w3);
             }
-            if (sl < 3) stage_write(nxt);
+            if (sl < 3) stage_write(nxt, 1);
             __syncthreads();
         }
     }
