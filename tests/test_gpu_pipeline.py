@@ -102,3 +102,27 @@ def test_cfg4_grid_sizes_run_in_fp32():
     xs = x[0, :2, :2, :2].double(); idx = [0, 0, 1]
     ref = sum(xs[idx[a], idx[b], idx[c]] @ w[a, b, c].double() for a in range(3) for b in range(3) for c in range(3))
     assert (y1[0, 0, 0, 0].double() - ref).abs().max().item() < 1e-3
+
+
+def test_integration_md_ctypes_stub_runs_as_written():
+    """The reference-side binding shown in INTEGRATION.md section 2 is executed verbatim (a maintainer's first contact with the
+    C-ABI) and must reproduce SR4DFlowNet.conv3d (pad SYMMETRIC + Conv3D + bias + ReLU) of the oracle."""
+    import re
+    root = os.path.dirname(HERE)
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(import ctypes, torch\n.*?)```", md, re.S).group(1)
+    ns = {}
+    cwd = os.getcwd()
+    os.chdir(root)                      # the stub opens the library by its repo-relative path
+    try:
+        exec(code, ns)
+    finally:
+        os.chdir(cwd)
+    rng = np.random.default_rng(4)
+    x = rng.normal(size=(1, 6, 5, 8, 64)).astype(np.float32)
+    w = (rng.normal(size=(3, 3, 3, 64, 64)) * 0.05).astype(np.float32)
+    b = rng.normal(size=64).astype(np.float32)
+    y = ns["conv3d"](torch.tensor(x, device="cuda"), torch.tensor(w, device="cuda"), torch.tensor(b, device="cuda"), 1)
+    torch.cuda.synchronize()
+    ref = O.conv3d_fwd(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64), O.ACT_RELU, 0.2, None)
+    assert np.abs(y.cpu().numpy() - ref).max() <= 2e-5 * np.abs(ref).max()
