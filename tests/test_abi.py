@@ -36,3 +36,36 @@ def test_no_cpu_fallback(fdn):
     import torch
     with pytest.raises(fdn.FdnError):
         fdn.ops.input_features(*[torch.zeros(8) for _ in range(6)])
+
+
+def test_header_is_plain_c_and_links_from_c(fdn, tmp_path):
+    """include/fdn.h must be consumable by a C compiler (the boundary is a C-ABI, not a C++ or Python one): compile a C99
+    translation unit against it with gcc, link it to the shared library and run the two entry points that need no GPU."""
+    import shutil
+    from importlib import import_module
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    build = import_module("4dflownet_amd.build")
+    lib = build.build_library()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "abi_smoke.c"
+    src.write_text('#include <stdio.h>\n#include "fdn.h"\n'
+                   'int main(void) {\n'
+                   '    /* every prototype is visible to C: take the address of a few */\n'
+                   '    int (*f)(const float*, float*, float*, void*) = fdn_pack_conv64_weights;\n'
+                   '    size_t (*g)(int, int, int, int, int, int, int) = fdn_conv3d_wgrad_workspace_bytes;\n'
+                   '    printf("%d %d %d %s\\n", fdn_version(), f != 0, (int)(g(8, 24, 24, 24, 64, 64, 3) > 0), FDN_CONV64_PACK_FLOATS == 81 * 4096 ? "ok" : "bad");\n'
+                   '    /* an argument error comes back as a code + message, not as an exception */\n'
+                   '    int rc = fdn_l2_sumsq(0, 0, 0, 0, 0);\n'
+                   '    printf("%d %s\\n", rc, fdn_last_error());\n'
+                   '    return 0;\n}\n')
+    exe = tmp_path / "abi_smoke"
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), str(src), "-o", str(exe), lib,
+                        "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.splitlines()
+    assert lines[0].split()[1:] == ["1", "1", "ok"] and int(lines[0].split()[0]) >= 100
+    assert lines[1].startswith("-1 ") and "fdn_l2_sumsq" in lines[1]
