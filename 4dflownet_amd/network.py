@@ -123,6 +123,12 @@ class FlowNetModel:
                                        # layer cost more than the tail the slabs fill), so off
         self.overlap_wgrad = False     # measured +0.7 % at cfg2 (kernels already fill the chip); off so per-kernel timings stay clean
         self._cache = None
+        # Gradient buckets in the order backward() completes them: slices [lo, hi) of flat_g_ext that are final when the hi-res part
+        # (heads + hi-res blocks, together with the trailing batch slot), the upper half of the low-res blocks and the rest are done.
+        # The data-parallel trainer starts one all-reduce per bucket as soon as it is final (trainer.train_step).
+        cut_hi = self.layers[6 + 2 * self.low_resblock].w_off
+        cut_mid = self.layers[6 + 2 * (self.low_resblock // 2)].w_off
+        self.grad_buckets = [b for b in ((cut_hi, n + 1), (cut_mid, cut_hi), (0, cut_mid)) if b[1] > b[0]]
         self.glorot_uniform_init(seed)
 
     # ------------------------------------------------------------------ parameters
@@ -304,9 +310,17 @@ class FlowNetModel:
         self.ops.fold_halo_border([pad], out, skip, y_prev, act)
         return out
 
-    def backward(self, dpred):
+    def backward(self, dpred, grad_ready=None):
         """Fill self.flat_g with d(sum_b loss_b)/d(params) given dpred (B,PR,PR,PR,3); L2 is NOT included here
-        (it is folded into the Adam kernel).  Consumes the cache of the last forward(training=True)."""
+        (it is folded into the Adam kernel).  Consumes the cache of the last forward(training=True).
+        grad_ready(lo, hi), if given, is called once per entry of self.grad_buckets, in that order, as soon as every launch that
+        writes flat_g_ext[lo:hi] has been enqueued on the current stream."""
+        def bucket_done(k):
+            if grad_ready is not None and k < len(self.grad_buckets):
+                if self._side is not None:
+                    torch.cuda.current_stream().wait_stream(self._side)
+                grad_ready(*self.grad_buckets[k])
+        done = 0
         c = self._cache
         if c is None:
             raise FdnError("backward() without forward(training=True)")
@@ -347,6 +361,9 @@ class FlowNetModel:
         nb = self.low_resblock + self.hi_resblock
         up = c["up"]
         for i in range(nb, -1, -1):
+            if i == self.low_resblock or (done == 1 and i == self.low_resblock // 2 and len(self.grad_buckets) == 3):
+                bucket_done(done)
+                done += 1
             if up is not None and i == self.low_resblock:
                 # dz currently holds d(up_out) (linear producer): pull it through the upsample
                 y_m, a_m = act_of(up[0])
@@ -376,6 +393,9 @@ class FlowNetModel:
             self._wgrad(c["phase"] if src == "p" else c["pc"], dz0, first)
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)      # all weight gradients have landed in flat_g
+        while done < len(self.grad_buckets):
+            bucket_done(done)
+            done += 1
         return self.flat_g
 
 

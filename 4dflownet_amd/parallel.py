@@ -1,8 +1,8 @@
 """Data-parallel plumbing (new relative to the reference, which is single-process -- SURVEY.md section 8e).
 
 One process per GPU; torch.distributed with backend "nccl" (= RCCL over xGMI on ROCm) for GPU tensors and
-"gloo" for the CPU tests.  The only data-path collective is ONE sum-all-reduce of the flat gradient buffer per
-step: SUM (not mean) reproduces the reference's single-process gradient of sum_b loss_b over the global batch
+"gloo" for the CPU tests.  The only data-path collective is the sum-all-reduce of the flat gradient buffer, issued per
+step as a few contiguous buckets while backward is still running: SUM (not mean) reproduces the reference's single-process gradient of sum_b loss_b over the global batch
 (tape.gradient of a vector target, TrainerController.py:223,249)."""
 import os
 
@@ -58,6 +58,24 @@ def allreduce_sum_(flat):
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
+
+
+def allreduce_sum_start(flat):
+    """Start an in-place SUM all-reduce of a (contiguous slice of a) flat device buffer and return a handle for
+    allreduce_wait().  nccl (= RCCL): asynchronous on the process group's own stream, ordered after everything enqueued on the
+    current stream so far.  gloo (host-staged): done synchronously here, handle None."""
+    if not (is_dist() and world_size() > 1):
+        return None
+    if flat.is_cuda and _host_staged():
+        allreduce_sum_(flat)
+        return None
+    return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+
+
+def allreduce_wait(handle):
+    """Make the current stream wait for an all-reduce started by allreduce_sum_start (no host synchronisation under nccl)."""
+    if handle is not None:
+        handle.wait()
 
 
 def all_gather_equal(t):

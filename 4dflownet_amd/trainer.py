@@ -129,18 +129,29 @@ class TrainerController:
         inputs, hires, venc, mask = self._unpack(data_pairs)
         B = inputs[0].shape[0]
         m = self.model
-        if B > 0:
-            pred = m.forward(inputs, training=True)
-            loss, dpred = self.calculate_and_update_metrics(hires, pred, mask, 'train', True)
-            m.backward(dpred)
-        else:                                   # ragged tail on this rank: contribute a zero gradient
-            m.flat_g.zero_()
-            loss = None
         # The trailing slot of the gradient buffer carries this rank's batch size; after the SUM all-reduce it holds the
         # global batch size, which the Adam kernel reads on the device -- no host synchronisation per step.
         m.batch_slot.fill_(float(B))
+        # Data parallel: one SUM all-reduce per gradient bucket, started as soon as backward() has enqueued the bucket's last
+        # launch (RCCL works on its own stream: the hi-res bucket travels while the low-res layers are still computing).  Every
+        # rank issues the same buckets in the same order, also a rank whose shard of a ragged batch is empty.
+        pending = []
+        reduce_bucket = None
         if parallel.world_size() > 1:
-            parallel.allreduce_sum_(m.flat_g_ext)
+            def reduce_bucket(lo, hi):
+                pending.append(parallel.allreduce_sum_start(m.flat_g_ext[lo:hi]))
+        if B > 0:
+            pred = m.forward(inputs, training=True)
+            loss, dpred = self.calculate_and_update_metrics(hires, pred, mask, 'train', True)
+            m.backward(dpred, grad_ready=reduce_bucket)
+        else:                                   # ragged tail on this rank: contribute a zero gradient
+            m.flat_g.zero_()
+            loss = None
+            if reduce_bucket is not None:
+                for lo, hi in m.grad_buckets:
+                    reduce_bucket(lo, hi)
+        for h in pending:
+            parallel.allreduce_wait(h)
         opt = self.optimizer
         opt.iterations += 1
         # L2 regulariser gradient: the (B,) loss vector carries the scalar L2 term B times (:249) -> B_global * 2*lambda*w

@@ -191,3 +191,47 @@ def test_bench_self_spawns_ranks(tmp_path):
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["config"]["global_batch"] == 4
     assert line["config"]["parallelism"] == "dp2" and line["value"] > 0
+
+
+def _rccl_worker(rank, world, port, q):
+    """ONE rank on cuda:0 in a world-1 nccl (= RCCL) group, with parallel.world_size patched to 2 so that train_step takes the
+    data-parallel branch: every gradient bucket goes through a real asynchronous RCCL all-reduce on the process group's stream
+    (the identity for one rank), started from inside backward() and waited for before the Adam launch."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group(backend="nccl", rank=0, world_size=1)
+    parallel = importlib.import_module("4dflownet_amd.parallel")
+    trainer = importlib.import_module("4dflownet_amd.trainer")
+    parallel.world_size = lambda: 2
+    started = []
+    start = parallel.allreduce_sum_start
+    def counting_start(flat):
+        h = start(flat)
+        started.append((flat.numel(), h is not None))
+        return h
+    parallel.allreduce_sum_start = counting_start
+    tc = trainer.TrainerController(P, R, initial_learning_rate=LR, quicksave_enable=False, low_resblock=2, hi_resblock=HB, seed=0)
+    out = []
+    for seed in (41, 42):
+        tc.train_step(O.synthetic_batch(2, P, R, seed=seed))
+        out.append(tc.model.flat_g_ext.cpu().numpy().copy())
+    torch.cuda.synchronize()
+    q.put((0, out, tc.model.flat_w.cpu().numpy().copy(), started, list(tc.model.grad_buckets)))
+    torch.distributed.destroy_process_group()
+
+
+def test_bucketed_rccl_allreduce_inside_backward_is_transparent(fdn):
+    """The asynchronous per-bucket RCCL path (what 8 GPUs run) on one GPU: same gradient buffer and same weights, bit for bit,
+    as the plain single-process steps; the buckets tile the extended gradient buffer exactly and in completion order."""
+    trainer = importlib.import_module("4dflownet_amd.trainer")
+    (_, grads, w, started, buckets), = _run(_rccl_worker, world=1)
+    tc = trainer.TrainerController(P, R, initial_learning_rate=LR, quicksave_enable=False, low_resblock=2, hi_resblock=HB, seed=0)
+    n = tc.model.n_params
+    assert len(buckets) == 3 and buckets[0][1] == n + 1 and buckets[-1][0] == 0
+    assert all(buckets[i][0] == buckets[i + 1][1] for i in range(2))
+    assert started == [(hi - lo, True) for (lo, hi) in buckets] * 2           # 3 asynchronous collectives per step
+    for k, seed in enumerate((41, 42)):
+        tc.train_step(O.synthetic_batch(2, P, R, seed=seed))
+        assert np.array_equal(tc.model.flat_g_ext.cpu().numpy(), grads[k])
+    assert np.array_equal(tc.model.flat_w.cpu().numpy(), w)
