@@ -8,7 +8,7 @@
 // On MI355X the fp32 matrix rate equals the fp32 vector rate, so halving the multiplies is the only way past the fp32 MFMA
 // roofline of the direct kernel (wgrad64_mfma.hip, 0.88 of peak).
 //
-// Decomposition: grid = (S splits of the tile list) x (3 kernel-depth taps a); ONE workgroup of 8 waves per CU.
+// Decomposition: grid = (S splits of the tile list) x (3 kernel-depth taps a), XCD-aware order; ONE workgroup of 8 waves per CU.
 //   A workgroup walks tiles of 1 x 6 x 8 voxels (6 lines of 2 groups) and accumulates the 18 matrices M[b][xi] (b = height
 //   tap, xi = Winograd coordinate) of its depth tap: wave (quadrant, parity) owns a 32x32 (ci,co) quadrant of the 9 matrices
 //   with xi = 2 xp + parity -- 144 accumulator registers that stay resident across all tiles, two waves per SIMD.  (Four
@@ -35,7 +35,7 @@ struct WgWinoArgs {
     int N, D, H, W;
     int nth, ntw, ntiles, S;
     unsigned bytes;              // size of x (= of dz) in bytes; < 4 GB (checked by the launcher)
-    int dbg;                     // ablation bits (test build): 1 = no raw loads, 2 = no transform / LDS writes, 4 = no LDS operand reads
+    int dbg;                     // ablation bits (test build): 1 = no raw loads, 2 = no transform / LDS writes, 4 = no LDS operand reads, 8 = no XCD placement, 16 = depth-fastest tile order
 };
 
 FDN_HOOK_VAR(int, fdn_wgrad64_wino_dbg, 0);
@@ -55,8 +55,20 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
     const int kh = lane >> 5;
     const int mq = wave & 1, nq = (wave >> 1) & 1;
     const int eh = wave >> 2;        // parity of the Winograd coordinates this wave accumulates: xi = 2 xp + eh
-    const int a = blockIdx.y;        // kernel-depth tap
-    const int split = blockIdx.x;
+    // XCD-aware placement: 1-D grid of 3 S workgroups whose ids are dealt round-robin to the 8 XCDs (each with its own L2).  The
+    // (split, tap) pairs q = 3 split + a are cut into 8 contiguous ranges, one per XCD: the three depth taps of a split (same dz
+    // tile) and ~10 consecutive splits (w / h neighbours: shared halo lines) run on ONE XCD at the same time.  Measured at (8,48^3):
+    // HBM reads 763 -> 553 MB per launch (x + dz = 453 MB), 0.889 -> 0.865 ms.  (A depth-fastest tile order -- the 3 x 10 workgroups of an
+    // XCD then share x planes as well -- cuts the reads to 353 MB but runs 0.90 ms: the concurrent tiles then differ by multiples of
+    // the plane stride, 9 x 64 KB at 48^3, and pile onto the same memory channels.  Test-build bit 16.)
+    int a, split;
+    {
+        const int G = 3 * p.S, qx = G >> 3, rx = G & 7;
+        const int xcd = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+        const int q = (FDN_DBG_BITS(p) & 8) ? (int)blockIdx.x : xcd * qx + min(xcd, rx) + j;
+        split = q / 3;
+        a = q - 3 * split;               // kernel-depth tap
+    }
     const int c16 = tid & 15;        // 16-B chunk (4 channels) of a 256-B row
     const int ig = (tid >> 4) & 1;   // group of this thread's transform item
     const int il = (tid >> 5) & 7;   // line of the item: waves 0-3: x halo lines 0..7; waves 4-6: dz lines 0..5
@@ -71,18 +83,27 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[b][xp][r] = 0.f;
 
-    // tile walk: tile = split + k*S, decoded incrementally (n, d, th, tw) with S pre-split the same way -- scalar work only
-    const int per_d = p.nth * p.ntw, per_n = p.D * per_d;
+    // tile walk: tile = split + k*S in the order (n, d, th, tw), decoded incrementally with S pre-split the same way: scalar work only
+    const bool dfast = (FDN_DBG_BITS(p) & 16) != 0;
+    const int per_c = p.D, per_r = p.ntw * per_c, per_n = p.nth * per_r;
+    const int per_d = p.nth * p.ntw;
     int tn, td, th, tw;
-    {
+    int sn, sd, sh, sw;
+    if (dfast) {
+        int b = split;
+        tn = b / per_n; b -= tn * per_n;
+        th = b / per_r; b -= th * per_r;
+        tw = b / per_c; td = b - tw * per_c;
+        b = p.S;
+        sn = b / per_n; b -= sn * per_n;
+        sh = b / per_r; b -= sh * per_r;
+        sw = b / per_c; sd = b - sw * per_c;
+    } else {
         int b = split;
         tn = b / per_n; b -= tn * per_n;
         td = b / per_d; b -= td * per_d;
         th = b / p.ntw; tw = b - th * p.ntw;
-    }
-    int sn, sd, sh, sw;
-    {
-        int b = p.S;
+        b = p.S;
         sn = b / per_n; b -= sn * per_n;
         sd = b / per_d; b -= sd * per_d;
         sh = b / p.ntw; sw = b - sh * p.ntw;
@@ -92,9 +113,15 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
     auto advance = [&]() {                                  // cursor -> next tile of this workgroup (stays on the last one)
         if (kload + 1 < nk) {
             ++kload;
-            tw += sw; if (tw >= p.ntw) { tw -= p.ntw; ++th; }
-            th += sh; if (th >= p.nth) { th -= p.nth; ++td; }
-            td += sd; if (td >= p.D) { td -= p.D; ++tn; }
+            if (dfast) {
+                td += sd; if (td >= p.D) { td -= p.D; ++tw; }
+                tw += sw; if (tw >= p.ntw) { tw -= p.ntw; ++th; }
+                th += sh; if (th >= p.nth) { th -= p.nth; ++tn; }
+            } else {
+                tw += sw; if (tw >= p.ntw) { tw -= p.ntw; ++th; }
+                th += sh; if (th >= p.nth) { th -= p.nth; ++td; }
+                td += sd; if (td >= p.D) { td -= p.D; ++tn; }
+            }
             tn += sn;
         }
     };
@@ -316,7 +343,7 @@ int fdn_wgrad64_wino_launch(const float* x, const float* dz, float* dw, void* ws
     a.dbg = fdn_wgrad64_wino_dbg;
     const size_t lds = (size_t)3 * WBUFB;
     if (int rc = fdn_func_max_lds((const void*)wgrad64_wino_kernel, (int)lds, "wgrad64_wino")) return rc;
-    hipLaunchKernelGGL(wgrad64_wino_kernel, dim3(a.S, 3), dim3(512), lds, s, a);
+    hipLaunchKernelGGL(wgrad64_wino_kernel, dim3(3 * a.S), dim3(512), lds, s, a);
     FDN_CHECK_LAUNCH("wgrad64_wino_kernel");
     return fdn_wgrad64_reduce_launch((const float*)ws, dw, a.S, s);
 }
