@@ -33,7 +33,7 @@ template <typename T>
 __global__ __launch_bounds__(256, 2) void head_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ y, int N, int D,
                                                           int H, int W, int ntd, int nth, int ntw, int iters, int ldy, int y_coff,
-                                                          int act, float alpha) {
+                                                          int act, float alpha, int xcd_walk) {
     extern __shared__ __attribute__((aligned(16))) float zbuf[];      // [27][H_HVP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, kh = lane >> 5;
@@ -99,6 +99,9 @@ __global__ __launch_bounds__(256, 2) void head_fwd_kernel(const T* __restrict__ 
         for (int g = 0; g < NCH; ++g) av[g] = *(const u32x4*)(xp + g * 2 * E);
     };
     const int G = gridDim.x;
+    // XCD-aware walk: workgroup ids are dealt round-robin to the 8 XCDs; within a generation of G tiles every XCD takes one
+    // contiguous run, so tiles that share halo rows (2.3x over-read per tile) meet in the same L2
+    const int my = xcd_walk ? ((int)blockIdx.x & 7) * (G >> 3) + min((int)blockIdx.x & 7, G & 7) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
     // 32 MFMAs of one M-tile slot into acc
     auto mfma_step = [&](const u32x4 (&src)[NCH], f32x16& acc) {
 #pragma unroll
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void head_fwd_kernel(const T* __restrict__ 
         __syncthreads();               // zbuf is rewritten by the next tile
     };
     u32x4 buf[3][NCH];
-    TileOrg cur = decode(blockIdx.x), nxt = decode(blockIdx.x + G);
+    TileOrg cur = decode(my), nxt = decode(my + G);
     load_tile(cur, 0, buf[0]);
     load_tile(cur, 1, buf[1]);
     auto do_tile = [&](auto basec, int tile) {
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void head_fwd_kernel(const T* __restrict__ 
     };
 #pragma unroll 1
     for (int it = 0; it < iters; it += 3) {
-        const int t0 = blockIdx.x + it * G;
+        const int t0 = my + it * G;
         do_tile(std::integral_constant<int, 0>{}, t0);           // steps 0-4   -> ring 0,1,2,0,1
         do_tile(std::integral_constant<int, 2>{}, t0 + G);       // steps 5-9   -> ring 2,0,1,2,0
         do_tile(std::integral_constant<int, 1>{}, t0 + 2 * G);   // steps 10-14 -> ring 1,2,0,1,2
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void head_fwd_kernel(const T* __restrict__ 
 
 template <typename T>
 int fdn_head_fwd_launch(const T* x, const float* w, const float* bias, float* y, int N, int D, int H, int W, int ldy, int y_coff,
-                        int act, float alpha, hipStream_t s) {
+                        int act, float alpha, hipStream_t s, int xcd_walk) {
     const int ntd = (D + H_TD - 1) / H_TD, nth = (H + H_TH - 1) / H_TH, ntw = (W + H_TW - 1) / H_TW;
     const size_t lds = (size_t)27 * H_HVP * sizeof(float);
     if (int rc = fdn_func_max_lds((const void*)head_fwd_kernel<T>, (int)lds, "head_fwd")) return rc;
@@ -182,12 +185,12 @@ int fdn_head_fwd_launch(const T* x, const float* w, const float* bias, float* y,
     const int iters = 3 * ((ntiles + 3 * 512 - 1) / (3 * 512));
     const int grid = (ntiles + iters - 1) / iters;
     hipLaunchKernelGGL(head_fwd_kernel<T>, dim3((unsigned)grid), dim3(256), lds, s, x, w, bias, y, N, D, H, W, ntd, nth, ntw, iters,
-                       ldy, y_coff, act, alpha);
+                       ldy, y_coff, act, alpha, xcd_walk);
     FDN_CHECK_LAUNCH("head_fwd_kernel");
     return FDN_OK;
 }
-template int fdn_head_fwd_launch<float>(const float*, const float*, const float*, float*, int, int, int, int, int, int, int, float, hipStream_t);
-template int fdn_head_fwd_launch<uint16_t>(const uint16_t*, const float*, const float*, float*, int, int, int, int, int, int, int, float, hipStream_t);
+template int fdn_head_fwd_launch<float>(const float*, const float*, const float*, float*, int, int, int, int, int, int, int, float, hipStream_t, int);
+template int fdn_head_fwd_launch<uint16_t>(const uint16_t*, const float*, const float*, float*, int, int, int, int, int, int, int, float, hipStream_t, int);
 
 // ---------------------------------------------------------------------------------------------------------------
 // input gradient of a head, with MirrorPadGrad and the producer's activation gradient:

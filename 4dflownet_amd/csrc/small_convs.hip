@@ -580,7 +580,7 @@ int fdn_conv_cin3_fwd_launch(const T* x, const float* w, const float* bias, T* y
 // heads_mfma.hip: the MFMA formulation of the three 64 -> 1 head kernels (default); the VALU kernels of this file stay
 // selectable for A/B runs (fdn_debug_set_heads_mfma(0))
 template <typename T> int fdn_head_fwd_launch(const T* x, const float* w, const float* bias, float* y, int N, int D, int H,
-                                              int W, int ldy, int y_coff, int act, float alpha, hipStream_t s);
+                                              int W, int ldy, int y_coff, int act, float alpha, hipStream_t s, int xcd_walk);
 template <typename T> int fdn_head_dgrad_launch(const float* dz, const float* w, const T* y_prev, int act, float alpha, T* dz_prev,
                                                 float* bpart, int N, int D, int H, int W, int lddz, int dz_coff, hipStream_t s);
 int fdn_head_dgrad_blocks(int N, int D, int H, int W);
@@ -595,7 +595,7 @@ extern "C" int fdn_debug_set_heads_mfma(int on) { fdn_heads_use_mfma = on; retur
 template <typename T>
 int fdn_conv_cout1_fwd_launch(const T* x, const float* w, const float* bias, float* y, int N, int D, int H, int W, int ldy,
                               int y_coff, int act, float alpha, hipStream_t s) {
-    if (fdn_heads_use_mfma) return fdn_head_fwd_launch<T>(x, w, bias, y, N, D, H, W, ldy, y_coff, act, alpha, s);
+    if (fdn_heads_use_mfma) return fdn_head_fwd_launch<T>(x, w, bias, y, N, D, H, W, ldy, y_coff, act, alpha, s, !(fdn_heads_use_mfma & 2));
     const int64_t nvox = (int64_t)N * D * H * W;
     hipLaunchKernelGGL(conv_cout1_fwd_kernel<T>, dim3(nblocks_for(nvox, 16, 8192)), dim3(256), 0, s, x, w, bias, y, N, D, H,
                        W, ldy, y_coff, act, alpha);
