@@ -27,11 +27,54 @@ def save_to_h5(output_filepath, col_name, dataset, compression=None):
     h5io.append_dataset(output_filepath, col_name, dataset, compression=compression)
 
 
+def _predict_pipelined(network, velocities, magnitudes, batch_size, lo, hi):
+    """Single-process path: the float64 conversion runs on the device, every batch's result travels to a pinned staging buffer on
+    a copy stream while the next batch computes, and the host moves it into the result array in that shadow -- the loop costs the
+    forward time only."""
+    S = velocities[0].shape[1] * network.res_increase
+    res = np.empty((hi - lo, S, S, S, 3), dtype=np.float64)
+    key = (batch_size, S)
+    st = getattr(network, "_predict_stage", None)
+    if st is None or st[0] != key:
+        st = (key, [torch.empty((batch_size, S, S, S, 3), dtype=torch.float64).pin_memory() for _ in range(2)],
+              torch.cuda.Stream(device=network.device))
+        network._predict_stage = st
+    _, stage, copy_stream = st
+    main = torch.cuda.current_stream(network.device)
+    inflight = [None, None]                      # per staging slot: (event, first row, row count, device tensor kept alive)
+
+    def drain(slot):
+        if inflight[slot] is not None:
+            ev, r0, cnt, _keep = inflight[slot]
+            ev.synchronize()
+            res[r0:r0 + cnt] = stage[slot][:cnt].numpy()
+            inflight[slot] = None
+
+    for k, s in enumerate(range(lo, hi, batch_size)):
+        e = min(s + batch_size, hi)
+        ins = [velocities[i][s:e] for i in range(3)] + [magnitudes[i][s:e] for i in range(3)]
+        out64 = network.forward(ins).double()
+        slot = k & 1
+        drain(slot)                              # the copy issued two batches ago has long finished; frees the staging slot
+        copy_stream.wait_stream(main)
+        with torch.cuda.stream(copy_stream):
+            stage[slot][:e - s].copy_(out64, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(copy_stream)
+        out64.record_stream(copy_stream)
+        inflight[slot] = (ev, s - lo, e - s, out64)
+        drain(slot ^ 1)                          # the previous batch's rows, while this batch computes
+    drain(0); drain(1)
+    return res
+
+
 def predict_patches(network, velocities, magnitudes, batch_size):
     """The batched predict loop of predictor.py:79-94 (results accumulate in float64 like np.zeros + np.append
     there), with the patch list sharded over ranks when running data-parallel."""
     n = len(velocities[0])
     world, rank = parallel.world_size(), parallel.rank()
+    if world == 1:
+        return _predict_pipelined(network, velocities, magnitudes, batch_size, 0, n)
     per = (n + world - 1) // world
     lo, hi = min(rank * per, n), min((rank + 1) * per, n)
     outs = []
@@ -41,11 +84,10 @@ def predict_patches(network, velocities, magnitudes, batch_size):
         outs.append(network.forward(ins))
     S = velocities[0].shape[1] * network.res_increase
     mine = torch.cat(outs, 0) if outs else torch.zeros((0, S, S, S, 3), device=network.device)
-    if world > 1:
-        pad = torch.zeros((per, S, S, S, 3), device=network.device)
-        pad[:mine.shape[0]] = mine
-        gathered = parallel.all_gather_equal(pad)
-        mine = torch.cat([g[:max(0, min((r + 1) * per, n) - min(r * per, n))] for r, g in enumerate(gathered)], 0)
+    pad = torch.zeros((per, S, S, S, 3), device=network.device)
+    pad[:mine.shape[0]] = mine
+    gathered = parallel.all_gather_equal(pad)
+    mine = torch.cat([g[:max(0, min((r + 1) * per, n) - min(r * per, n))] for r, g in enumerate(gathered)], 0)
     return mine.cpu().numpy().astype(np.float64)
 
 
