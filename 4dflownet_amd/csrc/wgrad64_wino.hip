@@ -215,8 +215,10 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
     const int lane_z = VBYTES + kh * GROWB + eh * 768 + (nq * 32 + li) * 8;
     const int lane_v1 = kh * GROWB + eh * 768 + 512 + (mq * 32 + li) * 4;
     const int lane_z1 = VBYTES + kh * GROWB + eh * 768 + 512 + (nq * 32 + li) * 4;
-    f32x2 Vp[2] = {{1.f, 1.f}, {1.f, 1.f}}, Zp[2] = {{1.f, 1.f}, {1.f, 1.f}};
-    float Vs[2] = {1.f, 1.f}, Zs[2] = {1.f, 1.f};
+    // x operands live in a ring of four halo lines (line L in slot L & 3): a line is read once and serves the up to three (q, b)
+    // slots with q + b = L -- 8 + 6 operand fetches per tile instead of 18 + 6
+    f32x2 Vp[4] = {{1.f, 1.f}, {1.f, 1.f}, {1.f, 1.f}, {1.f, 1.f}}, Zp[2] = {{1.f, 1.f}, {1.f, 1.f}};
+    float Vs[4] = {1.f, 1.f, 1.f, 1.f}, Zs[2] = {1.f, 1.f};
     auto issue_v = [&](const char* buf, int line, int slot) {
         if (FDN_DBG_BITS(p) & 4) return;
         Vp[slot] = *(const f32x2*)(buf + lane_v + line * (WTG * GROWB));
@@ -242,7 +244,8 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
             if (s == 12) __syncthreads();       // tile k+1 is complete in `nxt`; every wave is done with tile k-1's buffer
             // read-ahead: operands of the next slot (the first slot of tile k+1 at the end)
             if (s + 1 < 18) {
-                issue_v(cur, (s + 1) / 3 + (s + 1) % 3, (s + 1) & 1);
+                const int ln = (s + 1) / 3 + (s + 1) % 3;                      // x halo line of the next slot: new iff b = 2, or q = 0
+                if ((s + 1) % 3 == 2 || s + 1 < 3) issue_v(cur, ln, ln & 3);
                 if ((s + 1) % 3 == 0) issue_z(cur, (s + 1) / 3, ((s + 1) / 3) & 1);
             } else {
                 issue_v(nxt, 0, 0);
@@ -255,9 +258,9 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
             else if (s == 5) { advance(); locate(); }
             else if (s >= 6 && s < 12) load_x(s - 6);
             else if (s >= 13 && s < 17) load_z(s - 13);
-            acc[b][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vp[s & 1].x, Zp[q & 1].x, acc[b][0], 0, 0, 0);
-            acc[b][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vp[s & 1].y, Zp[q & 1].y, acc[b][1], 0, 0, 0);
-            acc[b][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[s & 1], Zs[q & 1], acc[b][2], 0, 0, 0);
+            acc[b][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vp[(q + b) & 3].x, Zp[q & 1].x, acc[b][0], 0, 0, 0);
+            acc[b][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vp[(q + b) & 3].y, Zp[q & 1].y, acc[b][1], 0, 0, 0);
+            acc[b][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[(q + b) & 3], Zs[q & 1], acc[b][2], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         bcur = bnxt;
