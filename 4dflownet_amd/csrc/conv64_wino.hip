@@ -71,7 +71,7 @@ struct WinoArgs {
 FDN_HOOK_VAR(int, fdn_conv64_wino_dbg, 0);
 
 constexpr int kWinoCS = 4;                 // cin slices
-constexpr int kWinoMaxLtg = 160;           // LDS: 6 planes x ltg rows x 80 B + tables <= 80 KB -> 2 workgroups per CU
+constexpr int kWinoMaxLtg = 160;           // LDS: 6 planes x (160 rows x 80 B + 64) + tables = 76.1 KB -> 2 workgroups per CU
 constexpr int kWinoRDB = 6;                // weight-fragment ring depth (prefetch distance 5 K steps)
 constexpr int kWinoRDA = 3;                // voxel-fragment ring depth (LDS, distance 2)
 constexpr int kWinoUA = 3;                 // transform items per thread (<= 768 items = 192 (line, group) pairs x 4 chunks)
@@ -104,7 +104,11 @@ __global__ __launch_bounds__(256, 2) void conv64_wino_kernel(WinoArgs p) {
     }
     const WinoRegion R = p.reg[ri];
     const int ta0 = GEN ? R.ta0 : 0, ta1 = GEN ? R.ta1 : 2, tb0 = GEN ? R.tb0 : 0, tb1 = GEN ? R.tb1 : 2;
-    const int planeb = R.ltg * LROW;                       // bytes per xi plane
+    // bytes per xi plane: a compile-time stride, so the plane / k-group part of every LDS address is an instruction immediate (2 instead
+    // of 7 VALU adds per tap and wave: forward launch at (8,48^3) 0.771 -> 0.756 ms).  The + 64 matters: with a stride that is a multiple
+    // of the 256-B bank row the six planes alias and the fused dgrad launch runs 2.7 % slower (0.908 vs 0.884 ms); 32 / 128 / 176 are
+    // within 1 % of 64.
+    constexpr int planeb = kWinoMaxLtg * LROW + 64;
     int* mtab = (int*)(smem + 6 * planeb);                 // [0,64): output index of the group's first voxel; [64,128): fused
                                                            // index (interior d,h) or -1; [128,192): iw of the first voxel
     const int tiles_per_n = R.ntd * R.nth * R.ntg;
@@ -437,7 +441,8 @@ int fdn_conv64_wino_launch_boxes(const float* x, const float* upack, const float
     }
     if (a.nreg == 0) return FDN_OK;
     FDN_REQUIRE(blocks < (1ll << 31), "conv64 (winograd): too many tiles");
-    size_t lds = (size_t)6 * max_ltg * LROW + 192 * 4;
+    size_t lds = (size_t)6 * (kWinoMaxLtg * LROW + 64) + 192 * 4;      // fixed plane stride (see the kernel); max_ltg <= kWinoMaxLtg by the planner
+    (void)max_ltg;
     if (fdn_conv64_wino_dbg & 64) lds = 82 * 1024;             // ablation: only ONE workgroup fits a CU
     const int lds_max = 84 * 1024;
     if (int rc = fdn_func_max_lds((const void*)conv64_wino_kernel<CS, true>, lds_max, "conv64_wino")) return rc;
