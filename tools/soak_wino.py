@@ -1,0 +1,39 @@
+"""One-off soak of the tile / region / XCD-order logic: Winograd kernels of the product library vs the direct MFMA kernels (test build) on many
+random shapes (the same comparison as tests/test_gpu_kernels.py::test_winograd_kernels_equal_direct_kernels_on_random_shapes).
+    python tools/soak_wino.py [count] [seed] [max_extent]"""
+import importlib, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+fdn = importlib.import_module("4dflownet_amd"); ops = fdn.ops
+count = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+mx = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+rng = np.random.default_rng(seed)
+worst = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
+for k in range(count):
+    N, D, H, W = int(rng.integers(1, 5)), int(rng.integers(1, mx + 1)), int(rng.integers(1, mx + 1)), 4 * int(rng.integers(1, mx // 4 + 1))
+    if N * D * H * W > 120000: N = 1
+    g = torch.Generator(device="cuda").manual_seed(k + 17 * seed)
+    x = torch.randn((N, D, H, W, 64), device="cuda", generator=g); res = torch.randn((N, D, H, W, 64), device="cuda", generator=g)
+    dz = torch.randn((N, D, H, W, 64), device="cuda", generator=g); w = torch.randn((3, 3, 3, 64, 64), device="cuda", generator=g) * 0.05
+    b = torch.randn((64,), device="cuda", generator=g); yfix = torch.randn((N, D, H, W, 64), device="cuda", generator=g)
+    wf, wd = ops.pack_conv64_weights(w)
+    Wg = max(1, W + 3 - int(rng.integers(0, 4)))
+    xg = torch.randn((N, D, H, Wg, 64), device="cuda", generator=g); dzg = torch.randn((N, D, H, Wg, 64), device="cuda", generator=g)
+    def run():
+        y = ops.conv3d_fwd(x, w, b, ops.ACT_LEAKY, 0.2, res, wpack=wf)
+        pad = torch.full((N, D + 2, H + 2, W + 2, 64), float("nan"), device="cuda"); out = torch.zeros_like(x)
+        ops.conv3d_dgrad_fused(dz, wd, pad, out, skip=res, y_prev=yfix, act=ops.ACT_LEAKY)
+        ops.fold_halo_border([pad], out, res, yfix, ops.ACT_LEAKY)
+        dw, _ = ops.conv3d_wgrad(xg, dzg, 3, 64, 64)
+        return y, out, dw
+    got = run()
+    with fdn._lib.test_build() as lib:
+        lib.fdn_debug_set_conv64_mt(5); lib.fdn_debug_set_wgrad64_direct(1)
+        try: ref = run()
+        finally: lib.fdn_debug_set_conv64_mt(0); lib.fdn_debug_set_wgrad64_direct(0)
+    for name, a, r in zip(("fwd", "dgrad", "wgrad"), got, ref):
+        err = (a - r).abs().max().item() / max(r.abs().max().item(), 1e-30)
+        if not (err <= 1e-5): print("MISMATCH", name, (N, D, H, W, Wg), err, flush=True)
+        worst[name] = max(worst[name], err if err == err else 1e9)
+print("%d shapes, worst relative difference:" % count, worst)
