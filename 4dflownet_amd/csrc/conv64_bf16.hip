@@ -518,10 +518,12 @@ int launch_bf16(Conv64BfArgs& a, const Box* boxes, int nbox, hipStream_t s) {
         // a column (tw <= 2) -> by h quad
         r.swz_hs = t.tw <= 2 ? 2 : 0;
         r.swz_wm = t.tw >= 16 ? 1 : 0;
+#ifdef FDN_TEST_HOOKS                                    // the planner's choices, test build only (the product library reads no environment)
         if (getenv("FDN_DEBUG_PLAN"))
             fprintf(stderr, "conv64_bf16<MT=%d> box %d: out (%d,%d,%d)+(%d,%d,%d) taps a[%d,%d] b[%d,%d] c[%d,%d] tile %dx%dx%d x(%d,%d,%d) rows %d lrows %d hs %d %s\n",
                     MT, i, bx.od, bx.oh, bx.ow, bx.ed, bx.eh, bx.ew, bx.ta0, bx.ta1, bx.tb0, bx.tb1, bx.tc0, bx.tc1, t.td, t.th,
                     t.tw, t.ntd, t.nth, t.ntw, r.rows, r.lrows, r.hs, is_fast ? "FAST" : "general");
+#endif
     }
     const int rc = launch_regions<MT, true>(fast, s);
     if (rc != FDN_OK) return rc;
@@ -573,8 +575,6 @@ int fdn_fold_halo_border_bf16_launch(const float* s0, const float* s1, const flo
 }
 
 #ifdef FDN_TEST_HOOKS
-#ifdef FDN_TEST_HOOKS
 extern "C" int fdn_debug_set_conv64_bf16_mt(int mt) { fdn_conv64bf_force_mt = mt; return FDN_OK; }
 extern "C" int fdn_debug_set_conv64_bf16_dbg(int bits) { fdn_conv64bf_dbg = bits; return FDN_OK; }
-#endif
 #endif
