@@ -221,10 +221,14 @@ __global__ __launch_bounds__(256, 2) void head_dgrad_kernel(const float* __restr
 
     // A operand: W^T rows permuted: row q of channel tile m <-> channel 32 m + 16 ((q>>2)&1) + (q&3) + 4 (q>>3);
     // lane (q = li, kh) holds w[t = 2s + kh][that channel] for the 14 K-steps
+    // fp32 storage (VROW): the product is formed as D[voxel][channel] instead -- lane (li, kh) then holds ONE channel (32 m + li) of 16
+    // voxels, and every mask load / store instruction covers whole 128-B lines (32 lanes x 4 B per voxel) instead of 64 scattered
+    // 16-B pieces.
+    constexpr bool VROW = sizeof(T) == 4;
     float wa[2][14];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-        const int ch = 32 * m + 16 * ((li >> 2) & 1) + (li & 3) + 4 * (li >> 3);
+        const int ch = VROW ? 32 * m + li : 32 * m + 16 * ((li >> 2) & 1) + (li & 3) + 4 * (li >> 3);
 #pragma unroll
         for (int s = 0; s < 14; ++s) wa[m][s] = (2 * s + kh) < 27 ? w[(2 * s + kh) * 64 + ch] : 0.f;
     }
@@ -258,17 +262,75 @@ __global__ __launch_bounds__(256, 2) void head_dgrad_kernel(const float* __restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) bsum[m][r] = 0.f;
 
+    // the next tile's halo is requested before this tile's arithmetic and written to LDS after it (the loads' latency would otherwise
+    // sit between the barrier and the first M-tile)
+    constexpr int NST = (H_HV + 255) / 256;
+    float stv[NST];
+    auto stage_load = [&](const TileOrg& o) {
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int i = tid + 256 * u;
+            const int zd = i / (H_XH * H_XW);
+            const int r2 = i - zd * (H_XH * H_XW);
+            const int zh = r2 / H_XW;
+            const int qd = o.d + zd - 1, qh = o.h + zh - 1, qw = o.w + (r2 - zh * H_XW) - 1;
+            float v = 0.f;
+            if (i < H_HV && (unsigned)qd < (unsigned)D && (unsigned)qh < (unsigned)H && (unsigned)qw < (unsigned)W)
+                v = dz[((size_t)o.n * D * H * W + ((size_t)qd * H + qh) * W + qw) * lddz + dz_coff];
+            stv[u] = v;
+        }
+    };
+    auto stage_store = [&](float* dst) {
+#pragma unroll
+        for (int u = 0; u < NST; ++u)
+            if (tid + 256 * u < H_HV) dst[tid + 256 * u] = stv[u];
+    };
     stage(decode(blockIdx.x), zs[0]);
     int par = 0;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, par ^= 1) {
         __syncthreads();                                         // zs[par] complete; zs[par^1] no longer read
-        if (tile + (int)gridDim.x < ntiles) stage(decode(tile + gridDim.x), zs[par ^ 1]);
+        const bool has_next = tile + (int)gridDim.x < ntiles;
+        if (has_next) stage_load(decode(tile + gridDim.x));
         const TileOrg o = decode(tile);
         const float* z = zs[par];
 #pragma unroll 1
         for (int mt = wave * 2; mt < wave * 2 + 2; ++mt) {       // M-tile: d plane mt >> 1, h rows 4 (mt & 1) .. +3
             const int vd = mt >> 1, vh = 4 * (mt & 1) + (li >> 3), vw = li & 7;
             const int gd = o.d + vd, gh = o.h + vh, gw = o.w + vw;
+            // fp32 storage: the 32 mask values of this lane (one channel of 16 voxels, two channel tiles) are requested NOW, so that
+            // their latency hides behind the fold arithmetic and the MFMAs (loaded one by one next to their stores they serialised
+            // into 32 round trips per M-tile: 192 us per launch at (8,48^3) against 59 us without the mask)
+            float ym[2][16];
+            if constexpr (VROW) {
+                if (yprev) {
+                    const int pw = o.w + 4 * kh, ph0 = o.h + 4 * (mt & 1);
+                    const size_t plane = (size_t)o.n * D * H * W + (size_t)min(gd, D - 1) * H * W;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const size_t e = (plane + (size_t)min(ph0 + (r >> 2), H - 1) * W + min(pw + (r & 3), W - 1)) * 64 + li;
+                        ym[0][r] = fdn_ld1(yprev + e);
+                        ym[1][r] = fdn_ld1(yprev + e + 32);
+                    }
+                }
+            }
+            // bf16 storage: this lane's 32 mask values (16 consecutive channels of its voxel in each channel tile) = four 16-B vectors,
+            // requested here for the same reason
+            constexpr int EVP = FdnVec<T>::E;
+            float yq[VROW ? 1 : 2][VROW ? 1 : 16];
+            if constexpr (!VROW) {
+                if (yprev) {
+                    const size_t voxp = (size_t)o.n * D * H * W + ((size_t)min(gd, D - 1) * H + min(gh, H - 1)) * W + min(gw, W - 1);
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int r0 = 0; r0 < 16; r0 += EVP) {
+                            float t[EVP];
+                            FdnVec<T>::ld(yprev + voxp * 64 + 32 * m + 16 * kh + r0, t);
+#pragma unroll
+                            for (int q = 0; q < EVP; ++q) yq[m][r0 + q] = t[q];
+                        }
+                }
+            }
             // 3x3x3 neighbourhood (halo coordinates vd..vd+2 etc.), then the per-axis fold transforms
             float nb[3][3][3];
 #pragma unroll
@@ -323,8 +385,34 @@ __global__ __launch_bounds__(256, 2) void head_dgrad_kernel(const float* __restr
                 const float e0 = nb[t0 / 9][(t0 / 3) % 3][t0 % 3];
                 const float e1 = t1 < 27 ? nb[t1 / 9][(t1 / 3) % 3][t1 % 3] : 0.f;
                 const float bv = kh ? e1 : e0;
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[0][s], bv, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[1][s], bv, acc[1], 0, 0, 0);
+                if constexpr (VROW) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, wa[0][s], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, wa[1][s], acc[1], 0, 0, 0);
+                } else {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[0][s], bv, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[1][s], bv, acc[1], 0, 0, 0);
+                }
+            }
+            if constexpr (VROW) {
+                // register r of lane (li, kh) = voxel row (r & 3) + 8 (r >> 2) + 4 kh of the M-tile: h row r >> 2, w (r & 3) + 4 kh
+                const int pw = o.w + 4 * kh, ph0 = o.h + 4 * (mt & 1);
+                const size_t plane = (size_t)o.n * D * H * W + (size_t)min(gd, D - 1) * H * W;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int qh = ph0 + (r >> 2), qw = pw + (r & 3);
+                    const bool in2 = gd < D && qh < H && qw < W;
+                    const size_t e = (plane + (size_t)min(qh, H - 1) * W + min(qw, W - 1)) * 64 + li;
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        float v = acc[m][r];
+                        if (yprev) v *= ym[m][r] > 0.f ? 1.f : slope;
+                        if (in2) {
+                            fdn_st1(out + e + 32 * m, v);
+                            bsum[m][0] += v;
+                        }
+                    }
+                }
+                continue;
             }
             // lane (voxel li, half kh) holds channels 32 m + 16 kh + r
             const bool inside = gd < D && gh < H && gw < W;
@@ -339,10 +427,8 @@ __global__ __launch_bounds__(256, 2) void head_dgrad_kernel(const float* __restr
 #pragma unroll
                     for (int q = 0; q < EV; ++q) v[q] = acc[m][r0 + q];
                     if (yprev) {
-                        float yv[EV];
-                        FdnVec<T>::ld(yprev + e + r0, yv);
 #pragma unroll
-                        for (int q = 0; q < EV; ++q) v[q] *= yv[q] > 0.f ? 1.f : slope;
+                        for (int q = 0; q < EV; ++q) v[q] *= yq[VROW ? 0 : m][VROW ? 0 : r0 + q] > 0.f ? 1.f : slope;
                     }
                     if (inside) {
                         FdnVec<T>::st(out + e + r0, v);
@@ -352,8 +438,19 @@ __global__ __launch_bounds__(256, 2) void head_dgrad_kernel(const float* __restr
                 }
             }
         }
+        if (has_next) stage_store(zs[par ^ 1]);
     }
-    if (bpart) {
+    if (bpart && VROW) {
+        // per-channel sums: a lane holds channel 32 m + li; fold the two lane halves, then the 4 waves through LDS
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            float v = bsum[m][0];
+            v += __shfl_xor(v, 32, 64);
+            if (kh == 0) bred[wave][32 * m + li] = v;
+        }
+        __syncthreads();
+        if (tid < 64) bpart[(size_t)blockIdx.x * 64 + tid] = (bred[0][tid] + bred[1][tid]) + (bred[2][tid] + bred[3][tid]);
+    } else if (bpart) {
         // per-channel sums: fold the 32 voxel lanes of each half-wave, then the 4 waves through LDS
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -453,6 +550,27 @@ __global__ __launch_bounds__(256, 2) void head_wgrad_kernel(const T* __restrict_
     float* xw = xs[wave];
     float* aw = as[wave];
 
+    constexpr int NST = (H_HV + 255) / 256;
+    float stv[NST];
+    auto stage_load = [&](const TileOrg& o) {
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int i = tid + 256 * u;
+            const int zd = i / (H_XH * H_XW);
+            const int r2 = i - zd * (H_XH * H_XW);
+            const int zh = r2 / H_XW;
+            const int qd = o.d + zd - 1, qh = o.h + zh - 1, qw = o.w + (r2 - zh * H_XW) - 1;
+            float v = 0.f;
+            if (i < H_HV && (unsigned)qd < (unsigned)D && (unsigned)qh < (unsigned)H && (unsigned)qw < (unsigned)W)
+                v = dz[((size_t)o.n * D * H * W + ((size_t)qd * H + qh) * W + qw) * lddz + dz_coff];
+            stv[u] = v;
+        }
+    };
+    auto stage_store = [&](float* dst) {
+#pragma unroll
+        for (int u = 0; u < NST; ++u)
+            if (tid + 256 * u < H_HV) dst[tid + 256 * u] = stv[u];
+    };
     TileOrg o = decode(blockIdx.x);
     stage(o, zs[0]);
     u32x4 xv[NLD];
@@ -462,7 +580,7 @@ __global__ __launch_bounds__(256, 2) void head_wgrad_kernel(const T* __restrict_
         __syncthreads();
         const bool has_next = tile + (int)gridDim.x < ntiles;
         const TileOrg on = decode(tile + gridDim.x);
-        if (has_next) stage(on, zs[par ^ 1]);
+        if (has_next) stage_load(on);                            // requested now, written to LDS after this tile's arithmetic
         const float* z = zs[par];
 #pragma unroll 1
         for (int q = 0; q < 2; ++q) {
@@ -547,6 +665,7 @@ __global__ __launch_bounds__(256, 2) void head_wgrad_kernel(const T* __restrict_
             }
             __builtin_amdgcn_wave_barrier();         // all reads done before the next chunk overwrites the patches
         }
+        if (has_next) stage_store(zs[par ^ 1]);
         o = on;
     }
     // C[tap][channel]: lane (channel li of tile m, half kh) holds taps (r&3) + 8 (r>>2) + 4 kh; fold the 4 waves through LDS

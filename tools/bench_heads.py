@@ -23,3 +23,10 @@ for v in (3, 1, 3, 1):
 print("head dgrad (folded, + act', + bias grad of the producer) %.1f us" % timeit(
     lambda: ops.conv_cout1_dgrad_folded(dpred, w, (N, P, P, P), g, ops.ACT_RELU, lddz=3, dz_coff=1, dbias_prev=gb, workspace=wsb)))
 print("head wgrad (+reduce) %.1f us" % timeit(lambda: ops.conv3d_wgrad(g, dpred, 3, 64, 1, dw=dw, workspace=ws, lddz=3, dz_coff=1)))
+print("head dgrad without the act' mask (no y_prev loads) %.1f us" % timeit(
+    lambda: ops.conv_cout1_dgrad_folded(dpred, w, (N, P, P, P), None, ops.ACT_NONE, lddz=3, dz_coff=1)))
+print("head dgrad without bias grad %.1f us" % timeit(
+    lambda: ops.conv_cout1_dgrad_folded(dpred, w, (N, P, P, P), g, ops.ACT_RELU, lddz=3, dz_coff=1)))
+d1 = torch.randn((N, P, P, P, 1), device="cuda")
+print("head dgrad, dz contiguous (lddz=1) %.1f us" % timeit(
+    lambda: ops.conv_cout1_dgrad_folded(d1, w, (N, P, P, P), g, ops.ACT_RELU, lddz=1, dz_coff=0)))
