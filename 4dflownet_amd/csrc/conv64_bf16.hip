@@ -376,24 +376,45 @@ __global__ __launch_bounds__(256) void fold_halo_border_bf16_kernel(const float*
         pd[nd++] = d + 1; if (d == 0) pd[nd++] = 0; if (d == D - 1) pd[nd++] = D + 1;
         ph[nh++] = h + 1; if (h == 0) ph[nh++] = 0; if (h == H - 1) ph[nh++] = H + 1;
         pw[nw++] = w + 1; if (w == 0) pw[nw++] = 0; if (w == W - 1) pw[nw++] = W + 1;
-        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
-        for (int a = 0; a < nd; ++a)
-            for (int b = 0; b < nh; ++b)
-                for (int c = 0; c < nw; ++c) {
-                    const int64_t off = (((((int64_t)n * (D + 2) + pd[a]) * PH + ph[b]) * PW + pw[c]) * 16 + c8 * 2);
-                    a0 += ((const f32x4*)s0)[off]; a1 += ((const f32x4*)s0)[off + 1];
-                    if (nsrc > 1) { a0 += ((const f32x4*)s1)[off]; a1 += ((const f32x4*)s1)[off + 1]; }
-                    if (nsrc > 2) { a0 += ((const f32x4*)s2)[off]; a1 += ((const f32x4*)s2)[off + 1]; }
-                }
-        float z[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        // all loads of a voxel are requested before the first use (see fold_halo_border_kernel, conv64_mfma.hip)
         const int64_t o = ((((int64_t)n * D + d) * H + h) * W + w) * 64 + c8 * 8;
+        const u32x4 zero_u = {0u, 0u, 0u, 0u};
+        const u32x4 skr = skip ? *(const u32x4*)(skip + o) : zero_u;
+        const u32x4 ypr = yprev ? *(const u32x4*)(yprev + o) : zero_u;
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+        if (D == 1 || H == 1 || W == 1) {          // an axis of extent 1 folds both padded neighbours onto the voxel: general nest
+            for (int a = 0; a < nd; ++a)
+                for (int b = 0; b < nh; ++b)
+                    for (int c = 0; c < nw; ++c) {
+                        const int64_t off = (((((int64_t)n * (D + 2) + pd[a]) * PH + ph[b]) * PW + pw[c]) * 16 + c8 * 2);
+                        a0 += ((const f32x4*)s0)[off]; a1 += ((const f32x4*)s0)[off + 1];
+                        if (nsrc > 1) { a0 += ((const f32x4*)s1)[off]; a1 += ((const f32x4*)s1)[off + 1]; }
+                        if (nsrc > 2) { a0 += ((const f32x4*)s2)[off]; a1 += ((const f32x4*)s2)[off + 1]; }
+                    }
+        } else
+        for (int sidx = 0; sidx < nsrc; ++sidx) {
+            const f32x4* sp = (const f32x4*)(sidx == 0 ? s0 : (sidx == 1 ? s1 : s2));
+            f32x4 v0[8], v1[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int a = k >> 2, b = (k >> 1) & 1, c = k & 1;
+                v0[k] = v1[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (a < nd && b < nh && c < nw) {
+                    const int64_t off = ((((int64_t)n * (D + 2) + pd[a]) * PH + ph[b]) * PW + pw[c]) * 16 + c8 * 2;
+                    v0[k] = sp[off]; v1[k] = sp[off + 1];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { a0 += v0[k]; a1 += v1[k]; }
+        }
+        float z[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
         if (skip) {
-            const bf16x8 t = ld_bf16x8(skip + o);
+            const bf16x8 t = __builtin_bit_cast(bf16x8, skr);
 #pragma unroll
             for (int r = 0; r < 8; ++r) z[r] += (float)t[r];
         }
         if (yprev) {
-            const bf16x8 t = ld_bf16x8(yprev + o);
+            const bf16x8 t = __builtin_bit_cast(bf16x8, ypr);
 #pragma unroll
             for (int r = 0; r < 8; ++r) z[r] *= fdn_act_grad((float)t[r], act, alpha);
         }

@@ -403,19 +403,40 @@ __global__ __launch_bounds__(256) void fold_halo_border_kernel(const float* __re
         pd[nd++] = d + 1; if (d == 0) pd[nd++] = 0; if (d == D - 1) pd[nd++] = D + 1;
         ph[nh++] = h + 1; if (h == 0) ph[nh++] = 0; if (h == H - 1) ph[nh++] = H + 1;
         pw[nw++] = w + 1; if (w == 0) pw[nw++] = 0; if (w == W - 1) pw[nw++] = W + 1;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int a = 0; a < nd; ++a)
-            for (int b = 0; b < nh; ++b)
-                for (int c = 0; c < nw; ++c) {
-                    const int64_t off = (((((int64_t)n * (D + 2) + pd[a]) * PH + ph[b]) * PW + pw[c]) * 16 + c4);
-                    acc += ((const f32x4*)s0)[off];
-                    if (nsrc > 1) acc += ((const f32x4*)s1)[off];
-                    if (nsrc > 2) acc += ((const f32x4*)s2)[off];
-                }
+        // all loads of a voxel are requested before the first use: the (up to 2 x 2 x 2) padded positions as predicated loads of a
+        // fully unrolled nest (a face voxel has 2, an edge 4, a corner 8), skip and the mask up front -- with runtime loop bounds
+        // they came back one round trip at a time
         const int64_t o = ((((int64_t)n * D + d) * H + h) * W + w) * 16 + c4;
-        if (skip) acc += ((const f32x4*)skip)[o];
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 sk = skip ? ((const f32x4*)skip)[o] : zero4;
+        f32x4 y = {1.f, 1.f, 1.f, 1.f};
+        if (yprev) y = ((const f32x4*)yprev)[o];
+        f32x4 acc = zero4;
+        if (D == 1 || H == 1 || W == 1) {          // an axis of extent 1 folds both of its padded neighbours onto the voxel: general nest
+            for (int a = 0; a < nd; ++a)
+                for (int b = 0; b < nh; ++b)
+                    for (int c = 0; c < nw; ++c) {
+                        const int64_t off = (((((int64_t)n * (D + 2) + pd[a]) * PH + ph[b]) * PW + pw[c]) * 16 + c4);
+                        acc += ((const f32x4*)s0)[off];
+                        if (nsrc > 1) acc += ((const f32x4*)s1)[off];
+                        if (nsrc > 2) acc += ((const f32x4*)s2)[off];
+                    }
+        } else
+        for (int sidx = 0; sidx < nsrc; ++sidx) {
+            const f32x4* sp = (const f32x4*)(sidx == 0 ? s0 : (sidx == 1 ? s1 : s2));
+            f32x4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int a = k >> 2, b = (k >> 1) & 1, c = k & 1;
+                v[k] = zero4;
+                if (a < nd && b < nh && c < nw)
+                    v[k] = sp[((((int64_t)n * (D + 2) + pd[a]) * PH + ph[b]) * PW + pw[c]) * 16 + c4];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += v[k];
+        }
+        acc += sk;
         if (yprev) {
-            const f32x4 y = ((const f32x4*)yprev)[o];
             acc.x *= fdn_act_grad(y.x, act, alpha); acc.y *= fdn_act_grad(y.y, act, alpha);
             acc.z *= fdn_act_grad(y.z, act, alpha); acc.w *= fdn_act_grad(y.w, act, alpha);
         }
