@@ -147,8 +147,14 @@ def _helpers_worker(rank, world, port, q):
     if rank == 0:
         m.update_state(torch.tensor([1.0, 2.0, 3.0]))
     glob = m.result_global()
+    # bucketed gradient all-reduce (trainer.train_step): contiguous slices of one flat buffer, started one after the other, waited for
+    # at the end -- together they must equal ONE all-reduce of the whole buffer
+    flat = torch.arange(10, dtype=torch.float32) * (rank + 1)
+    handles = [parallel.allreduce_sum_start(flat[lo:hi]) for lo, hi in ((6, 10), (2, 6), (0, 2))]
+    for h in handles:
+        parallel.allreduce_wait(h)
     parallel.barrier()
-    q.put((rank, sums, mx, [g.tolist() for g in gathered], m.result(), glob))
+    q.put((rank, sums, mx, [g.tolist() for g in gathered], m.result(), glob, flat.tolist()))
     dist.destroy_process_group()
 
 
@@ -168,4 +174,5 @@ def test_host_collectives_and_rank_combined_metrics():
         assert res[r][1] == [3.0, 30.0] and res[r][2] == [1.0]
         assert res[r][3] == [[[0.0] * 3] * 2, [[1.0] * 3] * 2]
         assert res[r][5] == 2.0                        # global mean of rank 0's three values; rank 1 contributed nothing
+        assert res[r][6] == [3.0 * i for i in range(10)]
     assert res[0][4] == 2.0 and res[1][4] == 0.0
