@@ -69,3 +69,35 @@ def test_header_is_plain_c_and_links_from_c(fdn, tmp_path):
     lines = out.stdout.splitlines()
     assert lines[0].split()[1:] == ["1", "1", "ok"] and int(lines[0].split()[0]) >= 100
     assert lines[1].startswith("-1 ") and "fdn_l2_sumsq" in lines[1]
+
+
+def test_oracle_is_test_infrastructure_only():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/: nothing in the package, scripts/ or tools/
+    imports it, and bench.py / __graft_entry__.py reach it only inside those two functions."""
+    import ast
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for pat in ("4dflownet_amd/**/*.py", "scripts/*.py", "tools/*.py"):
+        for f in glob.glob(os.path.join(root, pat), recursive=True):
+            src = open(f).read()
+            for node in ast.walk(ast.parse(src)):
+                if isinstance(node, ast.Import):
+                    assert not any(a.name.split(".")[0] == "oracle" for a in node.names), f
+                if isinstance(node, ast.ImportFrom):
+                    assert (node.module or "").split(".")[0] != "oracle", f
+                if isinstance(node, ast.Call) and getattr(node.func, "attr", "") == "import_module":
+                    assert not any(isinstance(a, ast.Constant) and str(a.value).startswith("oracle") for a in node.args), f
+    allowed = {"bench.py": {"cpu_baseline"}, "__graft_entry__.py": {"smoke", "build"}}      # build() compiles the checker, never runs it
+    for fname, funcs in allowed.items():
+        tree = ast.parse(open(os.path.join(root, fname)).read())
+        for node in tree.body:                         # module level: no oracle import
+            if isinstance(node, (ast.Import, ast.ImportFrom)):
+                names = [a.name for a in node.names] + [getattr(node, "module", "") or ""]
+                assert not any(n.split(".")[0] == "oracle" for n in names), fname
+        for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
+            uses = any((isinstance(n, ast.ImportFrom) and (n.module or "").split(".")[0] == "oracle") or
+                       (isinstance(n, ast.Import) and any(a.name.split(".")[0] == "oracle" for a in n.names)) or
+                       (isinstance(n, ast.Constant) and isinstance(n.value, str) and n.value.startswith("oracle."))
+                       for n in ast.walk(fn))
+            if uses:
+                assert fn.name in funcs or fn.name.startswith("_cpu"), (fname, fn.name)

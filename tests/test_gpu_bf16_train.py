@@ -4,7 +4,7 @@ Oracle = the float64 restatement with the HIP path's bf16 store points emulated 
 two sides agree to one bf16 ulp (tests/test_gpu_bf16.py, the precise gate).  End to end they cannot agree better than
 the quantisation step: a difference d in a layer's input makes a fraction ~d/ulp of its outputs round the other way, so
 the relative L2 distance grows like sqrt(d*ulp) per layer and saturates near one bf16 ulp (2^-8 = 4e-3) -- measured
-(tools/dbg_bf16.py): 4e-7 after the first conv, 5e-4 after six, 5e-3 at the last residual block, 8e-3 on the
+(tests/tools/dbg_bf16.py): 4e-7 after the first conv, 5e-4 after six, 5e-3 at the last residual block, 8e-3 on the
 prediction, 1-6e-2 on the gradients of the earliest layers (tiny test volumes: 2 x 8^3 voxels per gradient).
 Tolerances: prediction 3e-2, per-layer gradients 1.5e-1 (relative L2); a wrong rounding point or operand layout gives
 O(1).  The distance to the un-rounded fp32 network is reported by the second test."""

@@ -126,3 +126,36 @@ def test_integration_md_ctypes_stub_runs_as_written():
     torch.cuda.synchronize()
     ref = O.conv3d_fwd(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64), O.ACT_RELU, 0.2, None)
     assert np.abs(y.cpu().numpy() - ref).max() <= 2e-5 * np.abs(ref).max()
+
+
+def test_full_depth_network_on_example_patches_matches_float64_reference():
+    """north_star parity statement, end to end: the paper-default architecture (8 low-res + 4 hi-res ResBlocks, 36 convolutions) with
+    identical Glorot weights on real patches of data/example_data*.h5 (loader output, two rows of train.csv incl. a rotated one) --
+    prediction, per-sample loss and the gradient of sum_b loss_b against an independent float64 evaluation of the same graph with stock
+    torch-CPU operators (oracle/torch_cpu.py: replicate pad + conv3d, trilinear align_corners, autograd).  Tolerance of the task:
+    1e-3 relative; asserted an order of magnitude tighter."""
+    TC = importlib.import_module("oracle.torch_cpu")
+    P, R, B, LB, HB = 16, 2, 2, 8, 4
+    rows = data.load_indexes(os.path.join(DATA, "train.csv"))[:2]
+    batch = next(iter(data.PatchHandler3D(DATA, P, R, B, 0.6).initialize_dataset(rows, shuffle=False, shard=(0, 1))))
+    tc = trainer.TrainerController(P, R, initial_learning_rate=1e-4, quicksave_enable=False, low_resblock=LB, hi_resblock=HB, seed=0)
+    m = tc.model
+    inputs, hires, venc, mask = tc._unpack(batch)
+    pred = m.forward(inputs, training=True)
+    loss, dpred = tc.calculate_and_update_metrics(hires, pred, mask, 'train', True)
+    g = m.backward(dpred).double().cpu().numpy()
+    # float64 reference with the same parameters
+    params = O.init_params(0, LB, HB, np.float64)
+    assert np.array_equal(O.flatten(params).astype(np.float32), m.flat_w.cpu().numpy())
+    tp = TC.to_torch_params(params, torch.float64)
+    tb = [torch.tensor(np.asarray(a, np.float64)) for a in batch]
+    tpred = TC.t_forward(tp, tb[:6], R, LB, HB)
+    tloss = TC.t_loss(tpred, torch.cat(tb[6:9], -1), tb[10])
+    leaves = [t for wb in tp for t in wb if t is not None]
+    tg = torch.cat([x.reshape(-1) for x in torch.autograd.grad(tloss.sum(), leaves)]).numpy()
+    rp = tpred.detach().numpy()
+    assert np.abs(pred.double().cpu().numpy() - rp).max() <= 1e-4 * np.abs(rp).max()
+    l2 = float(tc.calculate_regularizer_loss())
+    assert np.abs(loss.double().cpu().numpy() - l2 - tloss.detach().numpy()).max() <= 1e-5 * np.abs(tloss.detach().numpy()).max()
+    assert np.linalg.norm(g - tg) <= 1e-4 * np.linalg.norm(tg)
+    assert np.abs(g - tg).max() <= 1e-4 * np.abs(tg).max()

@@ -1,8 +1,9 @@
 """Per-layer gradient error of the bf16 path vs the bf16-emulating oracle (debug aid)."""
 import importlib, os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))      # tests/tools/ -> repo root
+sys.path.insert(0, _ROOT)
+sys.path.insert(0, os.path.join(_ROOT, "tests"))
 from oracle import flownet_oracle as O
 fdn = importlib.import_module("4dflownet_amd")
 T = importlib.import_module("test_gpu_bf16_train")
