@@ -31,7 +31,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 FDN_HOOK_VAR(int, fdn_conv64bf_force_mt, 0);    // test/bench hook: 0 = auto, 4 / 8 = force the variant, +16 = full-depth tiles only
-FDN_HOOK_VAR(int, fdn_conv64bf_dbg, 0);         // ablation bits: 1 = weight stride 0, 2 = no XCD remap, 4 = staging loads from a cache-resident 32 KB, 8 = no epilogue
+FDN_HOOK_VAR(int, fdn_conv64bf_dbg, 0);         // ablation bits: 1 = weight stride 0, 2 = no XCD remap, 4 = staging loads from a cache-resident 32 KB, 8 = no epilogue, 16 = plan the shell slabs like stand-alone launches
 
 template <int MT>
 struct Conv64BfCfg {
@@ -468,7 +468,8 @@ struct Plan { FdnTile t; double cost; };
 // tile = td planes (<= MT) of th x tw (<= 64) positions; a tile's MFMA time does not depend on how full the plane block is
 int lds_hs(int hw) { int hs = hw; while ((hs & 7) != 4) ++hs; return hs; }
 
-Plan best_plan(int N, const Box& bx, int mt, int max_rows, int max_lrows) {
+// tail: one of several regions sharing a launch (the six shell slabs of a fused dgrad): total work counts, not rounds over a chip of its own
+Plan best_plan(int N, const Box& bx, int mt, int max_rows, int max_lrows, bool tail = false) {
     const bool full_only = (fdn_conv64bf_force_mt & 16) && bx.ed >= mt;
     Plan best{{1, 1, 1, bx.ed, bx.eh, bx.ew}, 1e30};
     const int da = bx.ta1 - bx.ta0, db = bx.tb1 - bx.tb0, dc = bx.tc1 - bx.tc0;
@@ -483,7 +484,7 @@ Plan best_plan(int N, const Box& bx, int mt, int max_rows, int max_lrows) {
                 // tiles with td < mt (or a single depth tap) run the predicated K loop: ~1.5x per MFMA
                 const double slow = (td == mt && da == 2) ? 1.0 : 1.5;
                 const double per_tile = slow * td * ntap * 64.0 / 27.0 + 0.05 * rows + 16.0;
-                const double c = (0.9 * (double)((long long)((tiles + 255) / 256)) + 0.1 * tiles / 256.0) * per_tile;
+                const double c = tail ? tiles * per_tile : (0.9 * (double)((long long)((tiles + 255) / 256)) + 0.1 * tiles / 256.0) * per_tile;
                 if (c < best.cost) best = {t, c};
             }
     return best;
@@ -517,7 +518,10 @@ int launch_bf16(Conv64BfArgs& a, const Box* boxes, int nbox, hipStream_t s) {
     for (int i = 0; i < nbox; ++i) {
         const Box& bx = boxes[i];
         if (bx.ed <= 0 || bx.eh <= 0 || bx.ew <= 0) continue;
-        const FdnTile t = best_plan(a.N, bx, MT, C::MAXROWS, C::MAXLROWS).t;
+        FdnTile t = best_plan(a.N, bx, MT, C::MAXROWS, C::MAXLROWS).t;
+        // a secondary region too small to fill the chip on its own (< 1024 tiles = two rounds of workgroup slots): plan it by total work instead (see best_plan)
+        if (i > 0 && !(fdn_conv64bf_dbg & 16) && (long long)a.N * t.ntd * t.nth * t.ntw < 1024)
+            t = best_plan(a.N, bx, MT, C::MAXROWS, C::MAXLROWS, true).t;
         const bool is_fast = t.td == MT && bx.ta0 == 0 && bx.ta1 == 2 && bx.tb0 == 0 && bx.tb1 == 2 && bx.tc0 == 0 && bx.tc1 == 2;
         Conv64BfArgs& dst = is_fast ? fast : slow;
         Conv64Region& r = dst.reg[dst.nreg++];

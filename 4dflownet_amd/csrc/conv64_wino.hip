@@ -63,7 +63,7 @@ struct WinoArgs {
     int off, zero_mode, act;
     float alpha;
     int dbg;                // ablation bits (test build only): 1 = weight stream stride 0, 4 = no staging, 8 = no epilogue,
-                            // 16 = no transform arithmetic, 32 = epilogue arithmetic without the stores, 128 = no XCD remap
+                            // 16 = no transform arithmetic, 32 = epilogue arithmetic without the stores, 128 = no XCD remap, 256 = plan the shell faces like stand-alone launches
     int nreg;
     WinoRegion reg[5];
 };
@@ -381,7 +381,10 @@ struct WinoPlan { int td, th, tg; double cost; };
 // tile choice: every tile costs the MFMA time of 64 groups (scaled by the region's share of the 9 (kd,kh) taps) whatever its
 // fill, plus the transform work of its halo lines and a fixed prologue / epilogue; the launch ends with the busiest CU
 // (2 co-resident workgroups per CU share the matrix pipe, so work per CU = its tiles).
-WinoPlan wino_plan(int N, const FdnWinoBox& bx) {
+// tail = a secondary region of a multi-region launch (the shell faces of a fused dgrad): its tiles fill the slots the main region
+// leaves free, so what counts is their total work (tiles x per-tile time), not rounds over a chip of their own -- without this the
+// faces were cut into 4x more tiles than needed (13- and 25-group tiles that still pay the K loop of 64 groups).
+WinoPlan wino_plan(int N, const FdnWinoBox& bx, bool tail) {
     const int ebg = bx.ew / 4, da = bx.ta1 - bx.ta0, db = bx.tb1 - bx.tb0;
     const double tapfrac = (da + 1) * (db + 1) / 9.0;
     WinoPlan best{1, 1, 1, 1e30};
@@ -393,7 +396,7 @@ WinoPlan wino_plan(int N, const FdnWinoBox& bx) {
                 const double tiles = (double)N * ((bx.ed + td - 1) / td) * ((bx.eh + th - 1) / th) * ((ebg + tg - 1) / tg);
                 const double per_tile = 64.0 * tapfrac + 0.12 * ltg + 4.0;
                 const double rounds = 0.9 * (double)((long long)((tiles + 255) / 256)) + 0.1 * tiles / 256.0;
-                const double c = rounds * per_tile;
+                const double c = tail ? tiles * per_tile : rounds * per_tile;
                 if (c < best.cost) best = {td, th, tg, c};
             }
     return best;
@@ -422,7 +425,11 @@ int fdn_conv64_wino_launch_boxes(const float* x, const float* upack, const float
         const FdnWinoBox& bx = boxes[i];
         if (bx.ed <= 0 || bx.eh <= 0 || bx.ew <= 0) continue;
         FDN_REQUIRE(fdn_conv64_wino_ok(bx.ed, bx.eh, bx.ew), "conv64 (winograd): W extent %d is not a multiple of 4", bx.ew);
-        const WinoPlan pl = wino_plan(N, bx);
+        WinoPlan pl = wino_plan(N, bx, false);
+        // a secondary region too small to fill the chip on its own (< 1024 tiles = two rounds of workgroup slots): plan it by total work instead (see wino_plan)
+        if (a.nreg > 0 && !(fdn_conv64_wino_dbg & 256) &&
+            (long long)N * ((bx.ed + pl.td - 1) / pl.td) * ((bx.eh + pl.th - 1) / pl.th) * ((bx.ew / 4 + pl.tg - 1) / pl.tg) < 1024)
+            pl = wino_plan(N, bx, true);
         WinoRegion& r = a.reg[a.nreg++];
         r.first_block = (int)blocks;
         r.obd = bx.od; r.obh = bx.oh; r.obw = bx.ow; r.ebd = bx.ed; r.ebh = bx.eh; r.ebw = bx.ew;

@@ -9,7 +9,7 @@ for P in (48, 24):
     res = torch.randn_like(x)
     wf, wd = ops.pack_conv64_weights(w); y = torch.empty_like(x)
     pad = torch.empty((N, P + 2, P + 2, P + 2, 64), device="cuda"); out = torch.empty_like(x)
-    for bits in (128, 0, 128, 0):
+    for bits in (256, 0, 256, 0):
         lib.fdn_debug_set_conv64_wino_dbg(bits)
         def fwd(): ops.conv3d_fwd(x, w, None, ops.ACT_RELU, wpack=wf, out=y)
         def dgr(): ops.conv3d_dgrad_fused(x, wd, pad, out, skip=res, y_prev=y, act=ops.ACT_LEAKY)
@@ -20,4 +20,4 @@ for P in (48, 24):
             e0.record()
             for _ in range(30): fn()
             e1.record(); torch.cuda.synchronize()
-            print("P=%d %-12s bits %3d (128 = no XCD remap) %7.4f ms" % (P, name, bits, e0.elapsed_time(e1) / 30))
+            print("P=%d %-12s bits %3d (256 = old face tiling) %7.4f ms" % (P, name, bits, e0.elapsed_time(e1) / 30))
