@@ -394,7 +394,7 @@ WinoPlan wino_plan(int N, const FdnWinoBox& bx, bool tail) {
                 const int ltg = (td + da) * (th + db) * tg;
                 if (ltg > kWinoMaxLtg || ltg * (64 / kWinoCS / 4) > kWinoUA * 256) continue;
                 const double tiles = (double)N * ((bx.ed + td - 1) / td) * ((bx.eh + th - 1) / th) * ((ebg + tg - 1) / tg);
-                const double per_tile = 64.0 * tapfrac + 0.12 * ltg + 4.0;
+                const double per_tile = 64.0 * tapfrac + (tail ? 0.04 : 0.12) * ltg + 4.0;    // tail tiles: 0.04 / 0.12 / 0.30 measured 0.859 / 0.863 / 0.865 ms at (8,48^3)
                 const double rounds = 0.9 * (double)((long long)((tiles + 255) / 256)) + 0.1 * tiles / 256.0;
                 const double c = tail ? tiles * per_tile : rounds * per_tile;
                 if (c < best.cost) best = {td, th, tg, c};
