@@ -69,6 +69,7 @@ struct WinoArgs {
 };
 
 FDN_HOOK_VAR(int, fdn_conv64_wino_dbg, 0);
+FDN_HOOK_VAR(int, fdn_conv64_wino_tile, 0);            // test build: force the main region's tile, td | th << 8 | tg << 16 (0 = planner)
 
 constexpr int kWinoCS = 4;                 // cin slices
 constexpr int kWinoMaxLtg = 160;           // LDS: 6 planes x (160 rows x 80 B + 64) + tables = 76.1 KB -> 2 workgroups per CU
@@ -426,6 +427,9 @@ int fdn_conv64_wino_launch_boxes(const float* x, const float* upack, const float
         if (bx.ed <= 0 || bx.eh <= 0 || bx.ew <= 0) continue;
         FDN_REQUIRE(fdn_conv64_wino_ok(bx.ed, bx.eh, bx.ew), "conv64 (winograd): W extent %d is not a multiple of 4", bx.ew);
         WinoPlan pl = wino_plan(N, bx, false);
+        if (fdn_conv64_wino_tile && a.nreg == 0) {
+            pl.td = fdn_conv64_wino_tile & 255; pl.th = (fdn_conv64_wino_tile >> 8) & 255; pl.tg = (fdn_conv64_wino_tile >> 16) & 255;
+        }
         // a secondary region too small to fill the chip on its own (< 1024 tiles = two rounds of workgroup slots): plan it by total work instead (see wino_plan)
         if (a.nreg > 0 && !(fdn_conv64_wino_dbg & 256) &&
             (long long)N * ((bx.ed + pl.td - 1) / pl.td) * ((bx.eh + pl.th - 1) / pl.th) * ((bx.ew / 4 + pl.tg - 1) / pl.tg) < 1024)
@@ -473,6 +477,7 @@ int fdn_conv64_wino_launch(const float* x, const float* upack, const float* bias
 
 #ifdef FDN_TEST_HOOKS
 extern "C" int fdn_debug_set_conv64_wino_dbg(int bits) { fdn_conv64_wino_dbg = bits; return FDN_OK; }
+extern "C" int fdn_debug_set_conv64_wino_tile(int packed) { fdn_conv64_wino_tile = packed; return FDN_OK; }
 #endif
 
 int fdn_pack_conv64_wino_launch(const float* w, float* uf, float* ud, hipStream_t s) {
