@@ -1,0 +1,19 @@
+"""cfg2 train step with / without the weight-gradient launches on a second stream: python tools/abl_overlap.py"""
+import importlib, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+trainer = importlib.import_module("4dflownet_amd.trainer")
+P, R, B, LB, HB = 24, 2, 8, 8, 4
+rng = np.random.default_rng(1234)
+f = lambda lo, hi, s: rng.uniform(lo, hi, s).astype(np.float32)
+batch = tuple([f(-1, 1, (B, P, P, P, 1)) for _ in range(3)] + [f(0, 0.016, (B, P, P, P, 1)) for _ in range(3)] +
+              [f(-0.45, 0.45, (B, P * R, P * R, P * R, 1)) for _ in range(3)] + [np.full((B,), 1.5, np.float32), (rng.random((B, P * R, P * R, P * R)) < 0.12).astype(np.float32)])
+tc = trainer.TrainerController(P, R, quicksave_enable=False, low_resblock=LB, hi_resblock=HB)
+dev = tuple(tc.model._to_dev(a) for a in batch)
+for ov in (False, True, False, True):
+    tc.model.overlap_wgrad = ov
+    for _ in range(5): tc.train_step(dev)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(20): tc.train_step(dev)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
+    print("overlap_wgrad=%s: %.3f ms/step" % (ov, dt * 1e3))
