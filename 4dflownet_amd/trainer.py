@@ -3,7 +3,8 @@
 columns; the arithmetic runs in lib4dflow_hip.so.
 
 Differences that are deliberate and documented in DESIGN.md:
-  * no TensorBoard event files (TensorFlow is not a dependency); loss.csv carries the same scalars;
+  * the TensorBoard epoch scalars (:181-182, :396-412) are written by tfevents.SummaryWriter -- same directories, tags,
+    steps and TF2 scalar encoding, no TensorFlow dependency;
   * metrics accumulate on the device and are only synchronised when .result() is read, so a training loop that
     does not print every step never stalls the GPU (the reference forces a sync per step, :290);
   * with torch.distributed initialised, train_step sum-all-reduces the flat gradient over RCCL before Adam."""
@@ -16,7 +17,7 @@ import time
 import numpy as np
 import torch
 
-from . import ops, parallel
+from . import ops, parallel, tfevents
 from .network import Input, SR4DFlowNet
 
 L2_LAMBDA = 5e-7                      # SR4DFlowNet.py:99
@@ -189,6 +190,9 @@ class TrainerController:
             f.write(msg)
 
     def _prepare_logfile_and_summary(self):
+        # TrainerController.py:181-182: one event file per writer under <model_dir>/tensorboard/{train,validate}
+        self.train_writer = tfevents.SummaryWriter(self.model_dir + '/tensorboard/train')
+        self.val_writer = tfevents.SummaryWriter(self.model_dir + '/tensorboard/validate')
         self.logfile = self.model_dir + '/loss.csv'
         self._log('Network: %s\n' % self.network_name)
         self._log('Initial learning rate: %s\n' % self.learning_rate)
@@ -204,6 +208,23 @@ class TrainerController:
         for fname in os.listdir(here):
             if fname.endswith(".py"):
                 shutil.copy2(os.path.join(here, fname), os.path.join(dest, fname))
+
+    def _update_summary_logging(self, epoch, results=None):
+        """TrainerController.py:396-412: epoch-level scalars.  Train writer: '<name>/learning_rate' and every 'train_*' metric
+        with the prefix stripped ('<name>/loss', '/accuracy', '/mse', '/div'); validate writer: the 'val_*' metrics likewise;
+        step = the 0-based epoch.  ('l2_reg_loss' has neither prefix, so the reference does not log it -- nor do we.)
+        results: metric name -> value (the rank-combined epoch means); defaults to this process's running means."""
+        if results is None:
+            results = dict((k, v.result()) for k, v in self.loss_metrics.items())
+        self.train_writer.scalar("%s/learning_rate" % self.network_name, self.optimizer.lr, epoch)
+        for k in self.loss_metrics:
+            if k.startswith('train_'):
+                self.train_writer.scalar("%s/%s" % (self.network_name, k.replace('train_', '')), results[k], epoch)
+        for k in self.loss_metrics:
+            if k.startswith('val_'):
+                self.val_writer.scalar("%s/%s" % (self.network_name, k.replace('val_', '')), results[k], epoch)
+        self.train_writer.flush()
+        self.val_writer.flush()
 
     # ------------------------------------------------------------------ training loop
     def train_network(self, trainset, valset, n_epoch, testset=None, verbose=True):
@@ -242,6 +263,8 @@ class TrainerController:
                 time.time() - start_loop)
             loss_str = ','.join('%.5f' % res[k] for k in self.loss_metrics)
             log_line = "%d,%s,%.6f,%.1f" % (epoch + 1, loss_str, self.optimizer.lr, time.time() - start_loop)
+            if is0:
+                self._update_summary_logging(epoch, res)
             if res[self.accuracy_metric] < previous_loss:
                 if is0:
                     self.save_best_model()

@@ -36,6 +36,23 @@ def test_cfg1_train_network_checkpoint_restore_and_quicksave(tmp_path):
     rows = [l for l in lines if l[:2] in ("1,", "2,")]
     assert len(rows) == 2 and rows[0].split(",")[-5 if "%" in rows[0] else -1] is not None
     assert os.path.exists(os.path.join(md, "t4d-best.h5")) and os.path.exists(os.path.join(md, "optimizer.pkl"))
+    # TensorBoard epoch scalars (TrainerController.py:181-182,396-412): two writers, tags '<name>/<metric minus prefix>', step = epoch
+    import glob
+    tfevents = importlib.import_module("4dflownet_amd.tfevents")
+    csv_vals = dict(zip(header.replace("epoch, ", "epoch,").split(",")[1:10], rows[1].split(",")[1:10]))
+    for sub, prefix, extra in (("train", "train_", ["t4d/learning_rate"]), ("validate", "val_", [])):
+        files = glob.glob(os.path.join(md, "tensorboard", sub, "events.out.tfevents.*"))
+        assert len(files) == 1
+        ev = tfevents.read_events(files[0])
+        assert ev[0]["file_version"] == "brain.Event:2"
+        by_step = {}
+        for e in ev[1:]:
+            by_step.setdefault(e["step"], {}).update(e["scalars"])
+        assert sorted(by_step) == [0, 1]
+        want = sorted(extra + ["t4d/" + k for k in ("loss", "accuracy", "mse", "div")])
+        assert sorted(by_step[1]) == want
+        for k in ("loss", "accuracy", "mse", "div"):
+            assert abs(by_step[1]["t4d/" + k] - float(csv_vals[prefix + k])) <= 1e-5 + 1e-5 * abs(float(csv_vals[prefix + k]))
     q = h5io.read_all(os.path.join(md, "quicksave_t4d.h5"))
     assert q["u"].shape[1:] == (2, 16, 16, 16) and q["lr_u"].shape == (2, 16, 16, 16, 1) and q["mask"].shape == (2, 16, 16, 16)
     # the first step of a fresh controller equals the oracle on the same loader batch
