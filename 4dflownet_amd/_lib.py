@@ -1,8 +1,11 @@
-"""ctypes binding of lib4dflow_hip.so (include/fdn.h).  There is NO fallback: if the library is missing or a
-call fails, an exception is raised."""
+"""ctypes binding of lib4dflow_hip.so (include/fdn.h).  There is NO fallback: if the library is missing (and cannot be
+built) or a call fails, an exception is raised.  A library older than the sources in the tree is never loaded: `load()` goes
+through build.ensure_built(), which compares the build stamp and rebuilds under a file lock (or raises with FDN_NO_REBUILD=1)."""
 import contextlib
 import ctypes
 import os
+
+from . import build as _build
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib4dflow_hip.so")
@@ -79,10 +82,13 @@ _test = None
 _lib = None          # the library load() hands out: the product build, except inside `with test_build():`
 
 
-def _open(path, sigs):
-    if not os.path.exists(path):
-        raise FdnError("%s is not built (%s).  Run `python __graft_entry__.py` or "
-                       "`python 4dflownet_amd/build.py`; there is no CPU fallback." % (os.path.basename(path), path))
+def _open(path, sigs, test_hooks=False):
+    try:
+        built = _build.ensure_built(test_hooks=test_hooks)
+    except Exception as e:                        # hipcc missing / compile error / FDN_NO_REBUILD with a stale binary
+        raise FdnError("%s is not usable (%s): %s.  Run `python __graft_entry__.py` or `python 4dflownet_amd/build.py`; "
+                       "there is no CPU fallback." % (os.path.basename(path), path, e)) from e
+    assert os.path.samefile(built, path)
     lib = ctypes.CDLL(path)
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)          # AttributeError if an export is missing
@@ -111,7 +117,7 @@ def test_build():
     if _test is None:
         sigs = dict(SIGNATURES)
         sigs.update(DEBUG_SIGNATURES)
-        _test = _open(TEST_LIB_PATH, sigs)
+        _test = _open(TEST_LIB_PATH, sigs, test_hooks=True)
     prev = _lib
     _lib = _test
     try:

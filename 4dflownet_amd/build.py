@@ -1,8 +1,17 @@
-"""Builds lib4dflow_hip.so (gfx950 only) in-tree with hipcc.  No GPU is needed to build."""
+"""Builds lib4dflow_hip.so (gfx950 only) in-tree with hipcc.  No GPU is needed to build.
+
+Every built library carries a stamp (<lib>.stamp = sha256 over csrc/*.hip, csrc/*.h, include/fdn.h and the compiler flags).
+`ensure_built` -- called by `_lib.load()` before every dlopen -- compares it with the sources in the tree and rebuilds (or, with
+FDN_NO_REBUILD=1, raises StaleLibraryError) when they differ, so a binary older than its sources is never executed.  Builds are
+serialised by an exclusive file lock (csrc/../build/.lock): with several ranks per node (torch.distributed.run) the first rank to
+take the lock compiles, the others block on it and then find the fresh stamp."""
+import contextlib
+import fcntl
 import hashlib
 import os
 import subprocess
 import sys
+import time
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -33,18 +42,81 @@ def _stamp():
     return h.hexdigest()
 
 
+class StaleLibraryError(RuntimeError):
+    pass
+
+
+def lib_path(test_hooks=False):
+    return LIB_TEST if test_hooks else LIB
+
+
+def source_stamp(test_hooks=False):
+    """The stamp a library built from the sources currently in the tree would carry."""
+    return _stamp() + ("-DFDN_TEST_HOOKS" if test_hooks else "")
+
+
+def built_stamp(test_hooks=False):
+    """The stamp of the library in the tree, or None if the library or its stamp file is missing."""
+    lib = lib_path(test_hooks)
+    try:
+        if os.path.exists(lib):
+            with open(lib + ".stamp") as f:
+                return f.read()
+    except OSError:
+        pass
+    return None
+
+
+def is_current(test_hooks=False):
+    return built_stamp(test_hooks) == source_stamp(test_hooks)
+
+
+@contextlib.contextmanager
+def _build_lock():
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    with open(os.path.join(HERE, "build", ".lock"), "a+") as f:
+        fcntl.flock(f, fcntl.LOCK_EX)
+        try:
+            yield
+        finally:
+            fcntl.flock(f, fcntl.LOCK_UN)
+
+
+def ensure_built(test_hooks=False):
+    """Return the path of a library whose stamp matches the sources: as is when current, else rebuilt under the build lock.
+    FDN_NO_REBUILD=1 turns a stale or missing library into StaleLibraryError instead."""
+    if is_current(test_hooks):
+        return lib_path(test_hooks)
+    if os.environ.get("FDN_NO_REBUILD", "0") not in ("", "0"):
+        have = built_stamp(test_hooks)
+        raise StaleLibraryError("%s is %s (FDN_NO_REBUILD is set): run `python 4dflownet_amd/build.py`"
+                                % (os.path.basename(lib_path(test_hooks)),
+                                   "not built" if have is None else "older than its sources (stamp %s..., sources %s...)"
+                                   % (have[:12], source_stamp(test_hooks)[:12])))
+    return build_library(test_hooks=test_hooks)
+
+
 def build_library(force=False, verbose=False, test_hooks=False):
     """Compile every HIP translation unit for gfx950 and link the shared library.  Returns its path.
-    test_hooks=True builds lib4dflow_hip_test.so (adds the fdn_debug_* entry points)."""
-    lib = LIB_TEST if test_hooks else LIB
+    test_hooks=True builds lib4dflow_hip_test.so (adds the fdn_debug_* entry points).  Safe to call from several processes."""
+    if not force and is_current(test_hooks):
+        return lib_path(test_hooks)
+    with _build_lock():
+        if not force and is_current(test_hooks):           # another process built it while we waited for the lock
+            return lib_path(test_hooks)
+        return _build_locked(verbose, test_hooks)
+
+
+def _build_locked(verbose, test_hooks):
+    lib = lib_path(test_hooks)
     extra = ["-DFDN_TEST_HOOKS"] if test_hooks else []
     stamp_file = lib + ".stamp"
-    stamp = _stamp() + "".join(extra)
-    if not force and os.path.exists(lib) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
-        return lib
+    stamp = source_stamp(test_hooks)
     hipcc = _hipcc()
     objdir = os.path.join(HERE, "build", "test" if test_hooks else "product")
     os.makedirs(objdir, exist_ok=True)
+    if os.path.exists(stamp_file):
+        os.remove(stamp_file)                              # an interrupted build must not leave a matching stamp behind
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
@@ -58,11 +130,21 @@ def build_library(force=False, verbose=False, test_hooks=False):
 
     with ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    r = subprocess.run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", lib] + objs, capture_output=True, text=True)
+    tmp = lib + ".tmp%d" % os.getpid()                     # link beside the target, then rename: a reader never maps a half-written file
+    r = subprocess.run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", tmp] + objs, capture_output=True, text=True)
     if r.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
-    with open(stamp_file, "w") as f:
+    if source_stamp(test_hooks) != stamp:
+        os.remove(tmp)
+        raise RuntimeError("sources changed while %s was being built; run the build again" % os.path.basename(lib))
+    os.replace(tmp, lib)
+    with open(stamp_file + ".tmp", "w") as f:
         f.write(stamp)
+    os.replace(stamp_file + ".tmp", stamp_file)
+    with open(os.path.join(HERE, "build", "build.log"), "a") as f:
+        f.write("%s pid %d built %s stamp %s\n" % (time.strftime("%Y-%m-%d %H:%M:%S"), os.getpid(), os.path.basename(lib), stamp[:16]))
     return lib
 
 

@@ -53,18 +53,40 @@ def rotate_object(img, rotation_idx, plane_nr):
 
 
 class _VolumeCache:
-    """Decoded HDF5 datasets, keyed by (path, dataset name)."""
+    """Decoded HDF5 datasets, keyed by (path, file mtime, file size, dataset name): a file rewritten in the same process
+    (prepare_lowres followed by predict) is re-read, never served stale.  Bounded: least-recently-used datasets are dropped
+    once the decoded bytes exceed `max_bytes` (FDN_VOLUME_CACHE_BYTES, default 8 GiB -- a clinical 4D file with tens of
+    frames is a few GB; the reference holds nothing and re-opens the file for every row, PatchHandler3D.py:133-147)."""
 
-    def __init__(self):
-        self._d = {}
+    def __init__(self, max_bytes=None):
+        import collections
+        self._d = collections.OrderedDict()
+        self._bytes = 0
+        self.max_bytes = int(os.environ.get("FDN_VOLUME_CACHE_BYTES", 8 << 30)) if max_bytes is None else int(max_bytes)
+
+    @staticmethod
+    def _file_id(path):
+        st = os.stat(path)
+        return (os.path.realpath(path), st.st_mtime_ns, st.st_size)
 
     def get(self, path, name):
-        key = (path, name)
-        if key not in self._d:
-            with h5io.open_read(path) as f:
-                obj = f.get(name)
-                self._d[key] = None if obj is None else np.asarray(obj[...] if hasattr(obj, "id") else obj.read())
-        return self._d[key]
+        fid = self._file_id(path)
+        key = fid + (name,)
+        if key in self._d:
+            self._d.move_to_end(key)
+            return self._d[key]
+        for k in [k for k in self._d if k[0] == fid[0] and k[:3] != fid]:      # same file, older contents
+            self._bytes -= 0 if self._d[k] is None else self._d[k].nbytes
+            del self._d[k]
+        with h5io.open_read(path) as f:
+            obj = f.get(name)
+            arr = None if obj is None else np.asarray(obj[...] if hasattr(obj, "id") else obj.read())
+        self._d[key] = arr
+        self._bytes += 0 if arr is None else arr.nbytes
+        while self._bytes > self.max_bytes and len(self._d) > 1:
+            _, old = self._d.popitem(last=False)
+            self._bytes -= 0 if old is None else old.nbytes
+        return arr
 
 
 class _BatchedDataset:

@@ -69,7 +69,12 @@ class _Optimizer:
 
 class TrainerController:
     def __init__(self, patch_size, res_increase, initial_learning_rate=1e-4, quicksave_enable=True,
-                 network_name='4DFlowNet', low_resblock=8, hi_resblock=4, device=None, seed=0, dtype='float32'):
+                 network_name='4DFlowNet', low_resblock=8, hi_resblock=4, device=None, seed=0, dtype='float32',
+                 bucketed_allreduce=None):
+        """Reference arguments: TrainerController.py:18.  Extra (keyword-only in spirit): device, seed (Glorot draw), dtype
+        (activation storage, 'float32' | 'bfloat16'), bucketed_allreduce (data parallel only: True = one asynchronous SUM
+        all-reduce per gradient bucket started inside backward -- the default --, False = ONE all-reduce of the whole buffer
+        after backward; env FDN_DP_BUCKETED=0 selects the latter when the argument is None)."""
         self.div_weight = 0            # divergence loss is dead code in the reference (TrainerController.py:23,121)
         self.non_fluid_weight = 1
         self.res_increase = res_increase
@@ -96,6 +101,13 @@ class TrainerController:
         self._l2_version = -1          # model.weights_version those partials belong to
         self.unique_model_name = network_name
         self.model_dir = None
+        if bucketed_allreduce is None:
+            bucketed_allreduce = os.environ.get("FDN_DP_BUCKETED", "1") not in ("0", "false", "no")
+        self.bucketed_allreduce = bool(bucketed_allreduce)
+        # bench / diagnosis: with profile_allreduce set, every train_step appends a pair of HIP events that bracket the point where
+        # the compute stream waits for the gradient all-reduce(s): their distance is the EXPOSED collective time of that step
+        self.profile_allreduce = False
+        self.allreduce_wait_events = []
 
     # ------------------------------------------------------------------ steps
     def _unpack(self, data_pairs):
@@ -138,7 +150,8 @@ class TrainerController:
         # rank issues the same buckets in the same order, also a rank whose shard of a ragged batch is empty.
         pending = []
         reduce_bucket = None
-        if parallel.world_size() > 1:
+        dp = parallel.world_size() > 1
+        if dp and self.bucketed_allreduce:
             def reduce_bucket(lo, hi):
                 pending.append(parallel.allreduce_sum_start(m.flat_g_ext[lo:hi]))
         if B > 0:
@@ -151,8 +164,16 @@ class TrainerController:
             if reduce_bucket is not None:
                 for lo, hi in m.grad_buckets:
                     reduce_bucket(lo, hi)
+        if dp and not self.bucketed_allreduce:             # the plain form: one collective over the whole buffer after backward
+            pending.append(parallel.allreduce_sum_start(m.flat_g_ext))
+        if dp and self.profile_allreduce:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for h in pending:
             parallel.allreduce_wait(h)
+        if dp and self.profile_allreduce:
+            e1.record()
+            self.allreduce_wait_events.append((e0, e1))
         opt = self.optimizer
         opt.iterations += 1
         # L2 regulariser gradient: the (B,) loss vector carries the scalar L2 term B times (:249) -> B_global * 2*lambda*w

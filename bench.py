@@ -11,10 +11,14 @@ several ranks on one device over gloo and marks the line as such).
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the 64->64 3x3x3 MFMA conv, shared by forward and
 dgrad), `roofline_wgrad` for the second one (the 64->64 weight-gradient kernel); both from launch durations measured
-live by HIP events on the launch stream inside the timed region.  `achieved`/`frac` count ALGORITHMIC FLOPs; the
-fp32 kernels are Winograd kernels that execute half of them, so `frac` may exceed 1 -- `executed_frac` is the MFMA utilisation.  At N=1, after the timed region: `cpu_baseline` (the same
-train step on the host cores: torch-CPU/oneDNN, plus the numpy oracle as a second figure) and `secondary` (a loader-fed
-cfg2 run with the on-device input pipeline inside the timed loop, and a short cfg4 bf16 run)."""
+live by HIP events on the launch stream inside the timed region.  `achieved`/`frac` count the FLOPs the kernel EXECUTES on the
+matrix pipe (frac <= 1 = pipe utilisation); the fp32 kernels are Winograd kernels that execute half of the direct algorithm's
+multiplies, so the ALGORITHMIC rate (221 184 FLOP per voxel) is reported beside it as `algorithmic_achieved` /
+`algorithmic_frac` (> 1) / `algorithmic_speedup`.  At N=1, after the timed region: `cpu_baseline` (the same
+train step on the host cores: torch-CPU/oneDNN, plus the numpy oracle as a second figure) and `secondary` (a sustained run of
+>= 300 steps with per-step min/median/max, a loader-fed cfg2 run with the on-device input pipeline inside the timed loop, and a
+short cfg4 bf16 run).  At N>1 the line carries `per_rank_ms_per_step` and `allreduce_exposed_ms` (HIP events around the point
+where the compute stream waits for the gradient all-reduce), so a scaling shortfall is attributable at first sight."""
 import argparse
 import importlib
 import json
@@ -33,6 +37,9 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2516.6       # dense bf16: 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz
 FLOP_PER_VOXEL_CONV64 = 2.0 * 27 * 64 * 64   # 3.0576 GFLOP per 24^3 patch = 221 184 FLOP/voxel
+# committed PMC traffic summaries (tools/pmc_traffic.py), newest round first
+CFG2_TRAFFIC = ["r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"]
+CFG4_TRAFFIC = ["r3_cfg4_pmc_traffic.json", "r2_cfg4_pmc_traffic.json", "r1_cfg4_pmc_traffic.json"]
 
 
 def synthetic_batch(B, P, R, seed, device):
@@ -110,7 +117,7 @@ def pmc_traffic_bytes(fname, kernel):
         path = os.path.join(ROOT, "profiles", f)
         if os.path.exists(path):
             d = json.load(open(path))
-            rows = [(v["launches"], v["hbm_bytes_per_launch"]) for k, v in d.items() if kernel in k]
+            rows = [(v["launches"], v["hbm_bytes_per_launch"]) for k, v in d.items() if isinstance(v, dict) and "launches" in v and kernel in k]
             n = sum(r[0] for r in rows)
             if n:
                 return sum(r[0] * r[1] for r in rows) / n, f
@@ -173,8 +180,9 @@ def roofline_obj(timer, kind, bf16, kernel, traffic_files):
     n_launch, avg_ms, avg_flop, avg_exec = s
     if bf16:
         avg_exec = avg_flop                                   # the bf16 kernels are direct convolutions
-    achieved = avg_flop / (avg_ms * 1e-3) / 1e12
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+    achieved = avg_exec / (avg_ms * 1e-3) / 1e12              # FLOPs issued on the matrix pipe per second
+    algorithmic = avg_flop / (avg_ms * 1e-3) / 1e12           # direct-convolution FLOPs per second
     traffic, tfile = pmc_traffic_bytes(traffic_files, kernel.split(" ")[0])
     vox = avg_flop / FLOP_PER_VOXEL_CONV64
     esz = 2.0 if bf16 else 4.0
@@ -185,13 +193,15 @@ def roofline_obj(timer, kind, bf16, kernel, traffic_files):
             "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/%s)" % tfile if tfile else None,
             "algorithmic_bytes_per_launch": alg, "launches_timed": n_launch, "avg_launch_ms": avg_ms,
             "timing": "HIP events on the launch stream around every launch of the sampled timed steps (--event-every)",
-            "avg_launch_gflop": avg_flop / 1e9,
-            # frac is ALGORITHMIC FLOPs (221 184 per voxel) over the MFMA peak and exceeds 1 when the kernel executes
-            # fewer multiplies than the direct algorithm (fp32: Winograd along W); executed_frac is the matrix-pipe utilisation
-            "executed_gflop_per_launch": avg_exec / 1e9, "executed_frac": avg_exec / (avg_ms * 1e-3) / 1e12 / peak,
-            "note": None if bf16 else "frac > 1 is not a measurement error: achieved counts the ALGORITHMIC FLOPs of a direct 3x3x3 convolution "
-                                      "(SURVEY 8d), the kernel is a Winograd F(4,3)/F(3,4)-along-W kernel that executes half of them on the same "
-                                      "fp32 MFMA pipe; executed_frac is the pipe utilisation (PMC SQ_VALU_MFMA_BUSY_CYCLES agrees, profiles/README.md)"}
+            "executed_gflop_per_launch": avg_exec / 1e9,
+            # the direct 3x3x3 algorithm's FLOPs (221 184 per voxel) over the same launch time: what the contract calls
+            # ALGORITHMIC work.  > peak when the kernel executes fewer multiplies than the direct algorithm (fp32: Winograd along W)
+            "algorithmic_gflop_per_launch": avg_flop / 1e9, "algorithmic_achieved": algorithmic,
+            "algorithmic_frac": algorithmic / peak, "algorithmic_speedup": avg_flop / avg_exec,
+            "note": None if bf16 else "achieved/frac = FLOPs the Winograd F(4,3)/F(3,4)-along-W kernel EXECUTES on the fp32 MFMA pipe (half of the "
+                                      "direct algorithm's multiplies + 9 direct taps per dgrad shell position) = matrix-pipe utilisation; PMC "
+                                      "SQ_VALU_MFMA_BUSY_CYCLES agrees (profiles/README.md).  algorithmic_* prices the same launches with the "
+                                      "direct 3x3x3 FLOP count of SURVEY 8d and therefore exceeds the peak"}
 
 
 def timed_steps(step_fn, steps, warmup, parallel):
@@ -207,9 +217,38 @@ def timed_steps(step_fn, steps, warmup, parallel):
     return time.perf_counter() - t0
 
 
-def secondary_runs(trainer, parallel, device, P, R, B, LB, HB):
+def secondary_runs(trainer, parallel, device, P, R, B, LB, HB, sustained_steps=300):
     """Short extra measurements at N=1 (VERDICT r1 #5/#6), outside the headline timed region."""
     sec = {}
+    # (0) sustained: the headline workload for >= 300 steps / >= 10 s, one HIP event per step boundary (no host sync inside):
+    # the spread of the per-step times shows what the 20-step headline window can hide (clock / thermal state)
+    try:
+        tc = trainer.TrainerController(P, R, initial_learning_rate=1e-4, quicksave_enable=False, low_resblock=LB, hi_resblock=HB,
+                                       device=device, seed=0)
+        batch = synthetic_batch(B, P, R, 1234, device)
+        for _ in range(5):
+            tc.train_step(batch)
+        torch.cuda.synchronize()
+        n_sus = sustained_steps
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_sus + 1)]
+        t0 = time.perf_counter()
+        evs[0].record()
+        for i in range(n_sus):
+            tc.train_step(batch)
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        per = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(n_sus)])
+        sec["sustained"] = {"value": n_sus * B / wall, "unit": "patches/s", "steps": n_sus, "seconds": wall,
+                            "ms_per_step": {"mean": wall / n_sus * 1e3, "min": float(per.min()), "median": float(np.median(per)),
+                                            "p95": float(np.percentile(per, 95)), "max": float(per.max())},
+                            "ms_per_step_by_quarter": [float(q.mean()) for q in np.array_split(per, 4)],
+                            "workload": "the headline cfg2 train_step, same synthetic batch, %d consecutive steps; per-step times from "
+                                        "HIP events recorded at the step boundaries on the launch stream" % n_sus}
+        del tc, batch, evs
+    except Exception as e:
+        sec["sustained"] = {"error": repr(e)}
+    torch.cuda.empty_cache()
     # (1) cfg2 with the on-device input pipeline inside the timed loop: CSV rows -> fdn_gather_patches -> train_step
     try:
         data_device = importlib.import_module("4dflownet_amd.data_device")
@@ -274,9 +313,9 @@ def secondary_runs(trainer, parallel, device, P, R, B, LB, HB):
                             "workload": "cfg4 train_step: patch_size=32 res_increase=4 batch=4 bf16 activations, fp32 accumulation/parameters",
                             "train_step_tflops": steps * B4 / dt * 3.0 * f4 / 1e12,
                             "roofline": roofline_obj(timer, "conv", True, "conv64_bf16_kernel (3x3x3 64->64 fwd + dgrad launches)",
-                                                     ["r2_cfg4_pmc_traffic.json", "r1_cfg4_pmc_traffic.json"]),
+                                                     CFG4_TRAFFIC),
                             "roofline_wgrad": roofline_obj(timer, "wgrad", True, "wgrad64_bf16_kernel (3x3x3 64->64 weight gradient)",
-                                                           ["r2_cfg4_pmc_traffic.json", "r1_cfg4_pmc_traffic.json"])}
+                                                           CFG4_TRAFFIC)}
         del tc, batch
     except Exception as e:
         sec["cfg4_bf16"] = {"error": repr(e)}
@@ -321,6 +360,9 @@ def self_spawn(args):
                          "(use --oversubscribe only to self-test the launcher)" % (args.gpus, ngpu))
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ)
+    # This pool's host driver only supports dmabuf IPC (image documentation: without HSA_ENABLE_IPC_MODE_LEGACY=0 RCCL's buffer
+    # registration across processes fails with `hipIpcGetMemHandle: invalid argument`).  The image exports it already; setdefault
+    # keeps a caller's explicit choice and only covers an environment that was built without it.
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
@@ -344,6 +386,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--event-every", type=int, default=4, help="bracket the conv launches with HIP events in every K-th timed step (1 = all)")
+    ap.add_argument("--sustained-steps", type=int, default=300, help="length of the secondary `sustained` run (N=1)")
+    ap.add_argument("--single-allreduce", action="store_true",
+                    help="N>1: ONE all-reduce of the whole gradient buffer after backward instead of the three buckets started inside it")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="launcher self-test: allow more ranks than GPUs (ranks share devices, gloo with host staging); not a scaling number")
     args = ap.parse_args()
@@ -368,19 +413,27 @@ def main():
     # the world size the collective actually sees: all-reduce a one per rank
     rccl_ranks = int(round(parallel.allreduce_sum_(torch.ones(1, device=device)).item()))
 
+    # never benchmark a binary older than its sources: (re)build under the build lock (one rank compiles, the others wait), then
+    # load -- load() itself re-checks the stamp and fails loudly if the HIP library is missing or stale
+    build = importlib.import_module("4dflownet_amd.build")
+    build.build_library()
+    parallel.barrier()
     fdn = importlib.import_module("4dflownet_amd")
     trainer = importlib.import_module("4dflownet_amd.trainer")
-    fdn._lib.load()                                   # fail loudly if the HIP library is missing
+    fdn._lib.load()
     P, R, B, LB, HB = args.patch, args.res, args.batch, args.low, args.hi
     bf16 = args.dtype == "bf16"
     tc = trainer.TrainerController(P, R, initial_learning_rate=1e-4, quicksave_enable=False, low_resblock=LB,
-                                   hi_resblock=HB, device=device, seed=0, dtype="bfloat16" if bf16 else "float32")
+                                   hi_resblock=HB, device=device, seed=0, dtype="bfloat16" if bf16 else "float32",
+                                   bucketed_allreduce=not args.single_allreduce)
+    tc.profile_allreduce = world > 1
     batch = synthetic_batch(B, P, R, 1234 + rank, device)
     timer = LaunchTimer(tc.model.ops)
     timer.install()
 
     for _ in range(args.warmup):
         tc.train_step(batch)
+    tc.allreduce_wait_events.clear()
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -390,19 +443,27 @@ def main():
         timer.enabled = i % max(1, args.event_every) == 0
         tc.train_step(batch)
     torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0               # this rank's own work is done (before the closing barrier)
     parallel.barrier()
     dt = time.perf_counter() - t0
     timer.enabled = False
     timer.uninstall()
 
     dt = parallel.allreduce_sum_host([dt], op="max")[0]
+    # N>1 diagnostics: every rank's own time to finish its K steps, and the EXPOSED gradient all-reduce time per step (HIP events
+    # around the stream wait in front of Adam; the rest of the collective ran under backward)
+    mine = [0.0] * world
+    mine[rank] = dt_local / args.steps * 1e3
+    per_rank_ms = parallel.allreduce_sum_host(mine)
+    waits = [e0.elapsed_time(e1) for e0, e1 in tc.allreduce_wait_events]
+    mine[rank] = float(np.mean(waits)) if waits else 0.0
+    per_rank_wait = parallel.allreduce_sum_host(mine)
     if rank != 0:
         if parallel.is_dist():
             parallel.barrier()
         return
     fwd_flop = fwd_flop_per_patch(tc.model.specs, P, R, LB)
-    tr = ["r2_cfg4_pmc_traffic.json", "r1_cfg4_pmc_traffic.json"] if args.config == "cfg4" else (
-        [] if bf16 else ["r2_pmc_traffic.json", "r1_pmc_traffic.json"])
+    tr = CFG4_TRAFFIC if args.config == "cfg4" else ([] if bf16 else CFG2_TRAFFIC)
     line = {
         "metric": "3D patches/sec (train step, patch=%d, res×%d)" % (P, R),
         "value": args.steps * B * world / dt,
@@ -422,20 +483,27 @@ def main():
                    "global_batch": B * world, "parallelism": "dp%d" % world,
                    "collective": ("none" if world == 1 else
                                   "gloo, host-staged (OVERSUBSCRIBED launcher self-test: %d ranks on %d GPU -- not a scaling number)" % (world, ngpu)
-                                  if oversub else "RCCL sum all-reduce of the flat fp32 gradient (%d B) per step" % (4 * (tc.model.n_params + 1)))},
+                                  if oversub else "RCCL sum all-reduce of the flat fp32 gradient (%d B) per step, %s"
+                                  % (4 * (tc.model.n_params + 1), "3 buckets started inside backward" if tc.bucketed_allreduce
+                                     else "one call after backward"))},
         "roofline": roofline_obj(timer, "conv", bf16, "%s (3x3x3 64->64 fwd + dgrad launches%s)"
                                  % (("conv64_bf16_kernel", "") if bf16 else ("conv64_wino_kernel", "; Winograd F(4,3) along W, dgrad shell slabs on conv64_mfma_kernel")), tr),
         "roofline_wgrad": roofline_obj(timer, "wgrad", bf16, "%s (3x3x3 64->64 weight gradient + partial reduction%s)"
                                        % (("wgrad64_bf16_kernel", "") if bf16 else ("wgrad64_wino_kernel", "; Winograd F(3,4) along W")), tr),
         "train_step_tflops": args.steps * B * world / dt * 3.0 * fwd_flop / 1e12,
+        "lib_source_stamp": build.source_stamp()[:16],          # sha256 prefix of csrc/ + include/fdn.h + flags the binary was built from
     }
+    if world > 1:
+        line["per_rank_ms_per_step"] = per_rank_ms
+        line["allreduce_exposed_ms"] = {"per_rank_mean": per_rank_wait, "max": max(per_rank_wait),
+                                        "how": "HIP events on the compute stream around allreduce_wait (trainer.train_step), mean over the timed steps"}
     if oversub:
         line["oversubscribed"] = True
     del tc, batch
     torch.cuda.empty_cache()
     if world == 1 and not bf16 and args.config == "cfg2":
         if not args.no_secondary:
-            line["secondary"] = secondary_runs(trainer, parallel, device, P, R, B, LB, HB)
+            line["secondary"] = secondary_runs(trainer, parallel, device, P, R, B, LB, HB, args.sustained_steps)
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(P, R, LB, HB)
     print(json.dumps(line), flush=True)

@@ -185,3 +185,23 @@ def test_py_function_bridge_alias():
     row = G["loader"][0]["csv_row"]
     a = ph.load_data_using_patch_index(row); b = ph.load_patches_from_index_file(row)
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_volume_cache_rereads_a_rewritten_file_and_is_bounded(tmp_path):
+    """the decoded-volume cache is keyed on (path, mtime, size) and bounded (LRU by decoded bytes)."""
+    import time
+    data = importlib.import_module("4dflownet_amd.data")
+    h5io = importlib.import_module("4dflownet_amd.h5io")
+    p = str(tmp_path / "v.h5")
+    a = np.arange(24, dtype=np.float32).reshape(1, 2, 3, 4)
+    h5io.append_datasets(p, [("u", a), ("v", a + 1)])
+    c = data._VolumeCache(max_bytes=a.nbytes + a.nbytes // 2)
+    assert np.array_equal(c.get(p, "u"), a) and c.get(p, "u") is c.get(p, "u")        # second access is the cached array
+    assert c.get(p, "missing") is None
+    c.get(p, "v")                                                                  # over budget: the least recently used entry goes
+    assert c._bytes <= c.max_bytes and not any(k[-1] == "u" for k in c._d)
+    os.remove(p)
+    time.sleep(0.01)
+    h5io.append_datasets(p, [("u", a * 2), ("v", a)])                               # same path, new contents
+    assert np.array_equal(c.get(p, "u"), a * 2)
+    assert all(k[:3] == c._file_id(p) for k in c._d)                                # nothing of the old file is left

@@ -235,3 +235,117 @@ def test_bucketed_rccl_allreduce_inside_backward_is_transparent(fdn):
         tc.train_step(O.synthetic_batch(2, P, R, seed=seed))
         assert np.array_equal(tc.model.flat_g_ext.cpu().numpy(), grads[k])
     assert np.array_equal(tc.model.flat_w.cpu().numpy(), w)
+
+
+def _rccl_delayed_worker(rank, world, port, q, bucketed):
+    """As _rccl_worker, but every collective is (a) issued behind a ~100 ms spin kernel on a side stream, so it completes long
+    after backward has finished and the host has reached the Adam launch, and (b) preceded on that stream by `bucket += 1`,
+    so its completion is visible in the data.  If train_step launched Adam without making the compute stream wait for the
+    handles, Adam would consume the un-incremented gradients."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group(backend="nccl", rank=0, world_size=1)
+    parallel = importlib.import_module("4dflownet_amd.parallel")
+    trainer = importlib.import_module("4dflownet_amd.trainer")
+    parallel.world_size = lambda: 2
+    side = torch.cuda.Stream()
+    started = []
+    # calibrate the spin kernel (its cycle counter's rate differs between devices): aim at ~60 ms per collective
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda._sleep(1_000_000); torch.cuda.synchronize()
+    e0.record(); torch.cuda._sleep(10_000_000); e1.record(); torch.cuda.synchronize()
+    spin = int(10_000_000 * 60.0 / max(e0.elapsed_time(e1), 1e-3))
+
+    def delayed_start(flat):
+        side.wait_stream(torch.cuda.current_stream())            # the bucket's producers
+        with torch.cuda.stream(side):
+            torch.cuda._sleep(spin)
+            flat.add_(1.0)
+            h = torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM, async_op=True)
+        started.append(flat.numel())
+        return h
+    parallel.allreduce_sum_start = delayed_start
+    tc = trainer.TrainerController(P, R, initial_learning_rate=LR, quicksave_enable=False, low_resblock=2, hi_resblock=HB, seed=0,
+                                   bucketed_allreduce=bucketed)
+    tc.profile_allreduce = True
+    import time
+    host_ms = []
+    for seed in (41, 42):
+        t0 = time.perf_counter()
+        tc.train_step(O.synthetic_batch(2, P, R, seed=seed))
+        host_ms.append((time.perf_counter() - t0) * 1e3)         # the host must NOT have blocked on the collectives
+    torch.cuda.synchronize()
+    waits = [e0.elapsed_time(e1) for e0, e1 in tc.allreduce_wait_events]
+    q.put((0, tc.model.flat_w.cpu().numpy().copy(), tc.model.flat_g_ext.cpu().numpy().copy(), started, waits, host_ms))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("bucketed", [True, False])
+def test_adam_cannot_overtake_a_slow_allreduce(fdn, bucketed):
+    """Stress form of the test above: collectives that finish ~0.1 s late must still be ordered before the
+    Adam launch on the compute stream -- for the bucketed path and for the single post-backward all-reduce."""
+    trainer = importlib.import_module("4dflownet_amd.trainer")
+    ops = importlib.import_module("4dflownet_amd.ops")
+    (_, w, g, started, waits, host_ms), = _run(_rccl_delayed_worker, world=1, extra=(bucketed,))
+    # reference: plain single-process steps whose gradient buffer (incl. the batch slot) is incremented right before Adam
+    tc = trainer.TrainerController(P, R, initial_learning_rate=LR, quicksave_enable=False, low_resblock=2, hi_resblock=HB, seed=0)
+    n = tc.model.n_params
+    adam = ops.adam_step
+
+    def adam_after_increment(*a, **k):
+        tc.model.flat_g_ext.add_(1.0)
+        return adam(*a, **k)
+    ops.adam_step = adam_after_increment
+    try:
+        for seed in (41, 42):
+            tc.train_step(O.synthetic_batch(2, P, R, seed=seed))
+    finally:
+        ops.adam_step = adam
+    assert started == ([hi - lo for lo, hi in tc.model.grad_buckets] * 2 if bucketed else [n + 1] * 2)
+    assert np.array_equal(g, tc.model.flat_g_ext.cpu().numpy())
+    assert np.array_equal(w, tc.model.flat_w.cpu().numpy())
+    # the delay really was exposed on the compute stream (>= one spin kernel per step), the host never blocked on it
+    assert len(waits) == 2 and min(waits) > 20.0, waits
+    assert host_ms[1] < min(waits), (host_ms, waits)
+
+
+def _rccl_two_gpu_worker(rank, world, port, q):
+    parallel = _init(rank, world, port)
+    assert torch.distributed.get_backend() == "nccl"
+    trainer = importlib.import_module("4dflownet_amd.trainer")
+    handles = []
+    start = parallel.allreduce_sum_start
+
+    def counting_start(flat):
+        h = start(flat)
+        handles.append((flat.numel(), h is not None))
+        return h
+    parallel.allreduce_sum_start = counting_start
+    tc = trainer.TrainerController(P, R, initial_learning_rate=LR, quicksave_enable=False, low_resblock=2, hi_resblock=HB, seed=0)
+    gb = O.synthetic_batch(4, P, R, seed=51)
+    rows = [2 * rank, 2 * rank + 1]
+    for _ in range(3):
+        tc.train_step(tuple(a[rows] for a in gb))
+    torch.cuda.synchronize()
+    parallel.barrier()
+    q.put((rank, tc.model.flat_g_ext.cpu().numpy().copy(), tc.model.flat_w.cpu().numpy().copy(), handles))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
+def test_bucketed_rccl_allreduce_two_gpus(fdn):
+    """The asynchronous bucketed path with a REAL peer over xGMI: only runs where two devices are visible (the driver's
+    multi-GPU node); self-skips on the 1-GPU box."""
+    trainer = importlib.import_module("4dflownet_amd.trainer")
+    res = _run(_rccl_two_gpu_worker)
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    assert all(is_async for _, is_async in res[0][3]) and len(res[0][3]) == 9
+    assert res[0][1][-1] == 4.0
+    tc = trainer.TrainerController(P, R, initial_learning_rate=LR, quicksave_enable=False, low_resblock=2, hi_resblock=HB, seed=0)
+    gb = O.synthetic_batch(4, P, R, seed=51)
+    for _ in range(3):
+        tc.train_step(gb)
+    ref = tc.model.flat_g_ext.cpu().numpy()[:-1].astype(np.float64)
+    d = res[0][1][:-1].astype(np.float64) - ref
+    assert np.linalg.norm(d) <= 1e-3 * np.linalg.norm(ref)
