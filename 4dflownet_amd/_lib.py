@@ -23,16 +23,16 @@ SIGNATURES = {
     "fdn_last_error": (ctypes.c_char_p, []),
     "fdn_input_features": (c_i, [c_fp] * 8 + [c_i64, c_fp]),
     "fdn_pack_conv64_weights": (c_i, [c_fp, c_fp, c_fp, c_fp]),
-    "fdn_conv3d_fwd": (c_i, [c_fp] * 7 + [c_i] * 10 + [c_f, c_fp]),
-    "fdn_conv3d_dgrad": (c_i, [c_fp] * 4 + [c_i] * 9 + [c_fp]),
+    "fdn_conv3d_fwd": (c_i, [c_fp] * 7 + [c_i] * 10 + [c_f, c_i, c_fp]),
+    "fdn_conv3d_dgrad": (c_i, [c_fp] * 4 + [c_i] * 10 + [c_fp]),
     "fdn_conv_cout1_dgrad_folded": (c_i, [c_fp, c_fp, c_fp, c_i, c_f, c_fp, c_fp, c_fp, c_sz, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "fdn_fold_halo": (c_i, [c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_f, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
-    "fdn_conv3d_dgrad_fused": (c_i, [c_fp] * 5 + [c_i, c_f, c_fp, c_i, c_i, c_i, c_i, c_fp]),
-    "fdn_conv3d_dgrad_fused_part": (c_i, [c_fp] * 5 + [c_i, c_f, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "fdn_conv3d_dgrad_fused": (c_i, [c_fp] * 5 + [c_i, c_f, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "fdn_conv3d_dgrad_fused_part": (c_i, [c_fp] * 5 + [c_i, c_f, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "fdn_fold_halo_border": (c_i, [c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_f, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "fdn_conv1x1_dgrad": (c_i, [c_fp] * 6 + [c_i64, c_fp]),
     "fdn_conv3d_wgrad_workspace_bytes": (c_sz, [c_i] * 7),
-    "fdn_conv3d_wgrad": (c_i, [c_fp] * 6 + [c_sz] + [c_i] * 9 + [c_fp]),
+    "fdn_conv3d_wgrad": (c_i, [c_fp] * 6 + [c_sz] + [c_i] * 10 + [c_fp]),
     "fdn_upsample_trilinear_fwd": (c_i, [c_fp, c_fp] + [c_i] * 6 + [c_fp]),
     "fdn_upsample_trilinear_bwd": (c_i, [c_fp, c_fp, c_i, c_f, c_fp] + [c_i] * 6 + [c_fp]),
     "fdn_loss_metrics": (c_i, [c_fp] * 8 + [c_i, c_i64, c_fp]),

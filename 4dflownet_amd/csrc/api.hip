@@ -34,7 +34,7 @@ FDN_HOOK_VAR(int, fdn_wgrad64_force_direct, 0);
 extern "C" int fdn_debug_set_wgrad64_direct(int on) { fdn_wgrad64_force_direct = on; return FDN_OK; }
 #endif
 
-extern "C" int fdn_version(void) { return 120; }
+extern "C" int fdn_version(void) { return 130; }
 extern "C" const char* fdn_last_error(void) { return g_err; }
 
 // small-channel kernels (small_convs.hip), templated on the activation storage type (float / uint16_t = bf16 bits)
@@ -64,8 +64,9 @@ size_t fdn_small_wgrad_workspace_bytes(int Cin, int Cout, int K);
 
 extern "C" int fdn_conv3d_fwd(const float* x, const float* x2, const float* w, const float* wpack, const float* bias,
                               const float* residual, float* y, int N, int D, int H, int W, int Cin, int Cout, int K,
-                              int ldy, int y_coff, int act, float alpha, void* stream) {
+                              int ldy, int y_coff, int act, float alpha, int algo, void* stream) {
     FDN_REQUIRE(x && y, "fdn_conv3d_fwd: x/y is NULL");
+    FDN_REQUIRE(algo == FDN_ALGO_AUTO || algo == FDN_ALGO_DIRECT, "fdn_conv3d_fwd: bad algo %d", algo);
     FDN_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "fdn_conv3d_fwd: bad dims N=%d D=%d H=%d W=%d", N, D, H, W);
     FDN_REQUIRE(act >= FDN_ACT_NONE && act <= FDN_ACT_LEAKY, "fdn_conv3d_fwd: bad act %d", act);
     hipStream_t s = (hipStream_t)stream;
@@ -73,7 +74,7 @@ extern "C" int fdn_conv3d_fwd(const float* x, const float* x2, const float* w, c
         FDN_REQUIRE(wpack, "fdn_conv3d_fwd: the 64->64 MFMA path needs wpack (fdn_pack_conv64_weights)");
         FDN_REQUIRE(ldy == 64 && y_coff == 0, "fdn_conv3d_fwd: 64->64 path writes dense rows (ldy=64,y_coff=0)");
         FDN_REQUIRE(D <= 1022 && H <= 1022 && W <= 1022, "fdn_conv3d_fwd: dims too large");
-        return fdn_conv64_launch(x, wpack, bias, residual, y, N, D, H, W, D, H, W, 0, 0, act, alpha, s);
+        return fdn_conv64_launch(x, wpack, bias, residual, y, N, D, H, W, D, H, W, 0, 0, act, alpha, s, algo);
     }
     FDN_REQUIRE(residual == nullptr, "fdn_conv3d_fwd: residual only on the 64->64 path");
     if (Cin == 3 && Cout == 64 && K == 3) {
@@ -93,8 +94,9 @@ extern "C" int fdn_conv3d_fwd(const float* x, const float* x2, const float* w, c
 }
 
 extern "C" int fdn_conv3d_dgrad(const float* dz, const float* w, const float* wpack, float* dxpad, int N, int D,
-                                int H, int W, int Cin, int Cout, int K, int lddz, int dz_coff, void* stream) {
+                                int H, int W, int Cin, int Cout, int K, int lddz, int dz_coff, int algo, void* stream) {
     FDN_REQUIRE(dz && dxpad, "fdn_conv3d_dgrad: dz/dxpad is NULL");
+    FDN_REQUIRE(algo == FDN_ALGO_AUTO || algo == FDN_ALGO_DIRECT, "fdn_conv3d_dgrad: bad algo %d", algo);
     FDN_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "fdn_conv3d_dgrad: bad dims");
     hipStream_t s = (hipStream_t)stream;
     if (Cin == 64 && Cout == 64 && K == 3) {
@@ -102,7 +104,7 @@ extern "C" int fdn_conv3d_dgrad(const float* dz, const float* w, const float* wp
         FDN_REQUIRE(lddz == 64 && dz_coff == 0, "fdn_conv3d_dgrad: 64->64 path reads dense rows");
         FDN_REQUIRE(D <= 1020 && H <= 1020 && W <= 1020, "fdn_conv3d_dgrad: dims too large");
         return fdn_conv64_launch(dz, wpack, nullptr, nullptr, dxpad, N, D, H, W, D + 2, H + 2, W + 2, -1, 1,
-                                 FDN_ACT_NONE, 0.f, s);
+                                 FDN_ACT_NONE, 0.f, s, algo);
     }
     if (Cin == 64 && Cout == 1 && K == 3) {
         FDN_REQUIRE(w, "fdn_conv3d_dgrad(64->1): needs w");
@@ -114,23 +116,25 @@ extern "C" int fdn_conv3d_dgrad(const float* dz, const float* w, const float* wp
 
 extern "C" int fdn_conv3d_dgrad_fused(const float* dz, const float* wpack, float* dxpad, const float* skip,
                                       const float* y_prev, int act, float alpha, float* dz_prev, int N, int D, int H,
-                                      int W, void* stream) {
+                                      int W, int algo, void* stream) {
     FDN_REQUIRE(dz && wpack && dxpad && dz_prev, "fdn_conv3d_dgrad_fused: NULL argument");
+    FDN_REQUIRE(algo == FDN_ALGO_AUTO || algo == FDN_ALGO_DIRECT, "fdn_conv3d_dgrad_fused: bad algo %d", algo);
     FDN_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && D <= 1020 && H <= 1020 && W <= 1020, "fdn_conv3d_dgrad_fused: bad dims");
     FDN_REQUIRE(act >= FDN_ACT_NONE && act <= FDN_ACT_LEAKY, "fdn_conv3d_dgrad_fused: bad act %d", act);
     return fdn_conv64_launch_ex(dz, wpack, nullptr, nullptr, dxpad, skip, y_prev, dz_prev, N, D, H, W, D + 2, H + 2, W + 2,
-                                -1, 1, act, alpha, (hipStream_t)stream);
+                                -1, 1, act, alpha, (hipStream_t)stream, 3, algo);
 }
 
 extern "C" int fdn_conv3d_dgrad_fused_part(const float* dz, const float* wpack, float* dxpad, const float* skip,
                                            const float* y_prev, int act, float alpha, float* dz_prev, int N, int D, int H,
-                                           int W, int parts, void* stream) {
+                                           int W, int parts, int algo, void* stream) {
     FDN_REQUIRE(dz && wpack && dxpad && dz_prev, "fdn_conv3d_dgrad_fused_part: NULL argument");
+    FDN_REQUIRE(algo == FDN_ALGO_AUTO || algo == FDN_ALGO_DIRECT, "fdn_conv3d_dgrad_fused_part: bad algo %d", algo);
     FDN_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && D <= 1020 && H <= 1020 && W <= 1020, "fdn_conv3d_dgrad_fused_part: bad dims");
     FDN_REQUIRE(act >= FDN_ACT_NONE && act <= FDN_ACT_LEAKY, "fdn_conv3d_dgrad_fused_part: bad act %d", act);
     FDN_REQUIRE(parts >= 1 && parts <= 3, "fdn_conv3d_dgrad_fused_part: parts must be FDN_DGRAD_INNER | FDN_DGRAD_SHELL");
     return fdn_conv64_launch_ex(dz, wpack, nullptr, nullptr, dxpad, skip, y_prev, dz_prev, N, D, H, W, D + 2, H + 2, W + 2,
-                                -1, 1, act, alpha, (hipStream_t)stream, parts);
+                                -1, 1, act, alpha, (hipStream_t)stream, parts, algo);
 }
 
 extern "C" int fdn_fold_halo_border(const float* dxpad0, const float* dxpad1, const float* dxpad2, int nsrc,
@@ -153,8 +157,9 @@ extern "C" size_t fdn_conv3d_wgrad_workspace_bytes(int N, int D, int H, int W, i
 
 extern "C" int fdn_conv3d_wgrad(const float* x, const float* x2, const float* dz, float* dw, float* dbias,
                                 void* workspace, size_t workspace_bytes, int N, int D, int H, int W, int Cin, int Cout,
-                                int K, int lddz, int dz_coff, void* stream) {
+                                int K, int lddz, int dz_coff, int algo, void* stream) {
     FDN_REQUIRE(x && dz && dw, "fdn_conv3d_wgrad: x/dz/dw is NULL");
+    FDN_REQUIRE(algo == FDN_ALGO_AUTO || algo == FDN_ALGO_DIRECT, "fdn_conv3d_wgrad: bad algo %d", algo);
     FDN_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "fdn_conv3d_wgrad: bad dims");
     const size_t need = fdn_conv3d_wgrad_workspace_bytes(N, D, H, W, Cin, Cout, K);
     if (workspace_bytes < need || (need && !workspace)) {
@@ -166,9 +171,10 @@ extern "C" int fdn_conv3d_wgrad(const float* x, const float* x2, const float* dz
     int rc;
     if (Cin == 64 && Cout == 64 && K == 3) {
         FDN_REQUIRE(lddz == 64 && dz_coff == 0, "fdn_conv3d_wgrad: 64->64 path reads dense dz rows");
-        // Winograd F(3,4) along W (wgrad64_wino.hip): half the multiplies of the direct kernel (kept for the test build's A/B runs)
-        rc = fdn_wgrad64_force_direct ? fdn_wgrad64_launch(x, dz, dw, workspace, workspace_bytes, N, D, H, W, s)
-                                      : fdn_wgrad64_wino_launch(x, dz, dw, workspace, workspace_bytes, N, D, H, W, s);
+        // Winograd F(3,4) along W (wgrad64_wino.hip): half the multiplies of the direct kernel, which FDN_ALGO_DIRECT selects
+        rc = (fdn_wgrad64_force_direct || algo == FDN_ALGO_DIRECT)
+                 ? fdn_wgrad64_launch(x, dz, dw, workspace, workspace_bytes, N, D, H, W, s)
+                 : fdn_wgrad64_wino_launch(x, dz, dw, workspace, workspace_bytes, N, D, H, W, s);
     } else if (Cin == 3 && Cout == 64 && K == 3) {
         FDN_REQUIRE(lddz == 64 && dz_coff == 0, "fdn_conv3d_wgrad(3->64): dense dz rows");
         rc = fdn_wgrad_cin3_launch(x, dz, dw, workspace, workspace_bytes, N, D, H, W, s);

@@ -598,7 +598,7 @@ FdnTile fdn_plan_tile(int N, int OD, int OH, int OW, int max_vox, int max_halo_r
 
 int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, const float* residual, float* y,
                          const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
-                         int OW, int off, int zero_mode, int act, float alpha, hipStream_t s, int parts) {
+                         int OW, int off, int zero_mode, int act, float alpha, hipStream_t s, int parts, int algo) {
     // staged rows are addressed with 32-bit byte offsets from the sample's first voxel (256 B per voxel)
     FDN_REQUIRE((long long)ID * IH * IW < (1ll << 24), "conv64: a sample of %dx%dx%d voxels exceeds the 32-bit row addressing", ID, IH, IW);
     Conv64Args a;
@@ -607,9 +607,9 @@ int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, 
     a.N = N; a.ID = ID; a.IH = IH; a.IW = IW; a.OD = OD; a.OH = OH; a.OW = OW;
     a.off = off; a.zero_mode = zero_mode; a.act = act; a.alpha = alpha; a.dbg = fdn_conv64_dbg;
     const Box full{0, 0, 0, OD, OH, OW, 0, 2, 0, 2, 0, 2};
-    // Winograd F(4,3) along W (conv64_wino.hip) whenever the W extent is a multiple of 4: half the MFMA work.  A forced
-    // direct layout (test build) selects the direct kernel below.
-    const bool wino = fdn_conv64_force_layout == 0 || fdn_conv64_force_layout == 7;
+    // Winograd F(4,3) along W (conv64_wino.hip) whenever the W extent is a multiple of 4: half the MFMA work.  FDN_ALGO_DIRECT
+    // (per call) or a forced direct layout (test build) selects the direct kernel below.
+    const bool wino = algo != FDN_ALGO_DIRECT && (fdn_conv64_force_layout == 0 || fdn_conv64_force_layout == 7);
     const float* upack = wpack + kDirectPackFloats;
     if (!(fout && zero_mode && off == -1 && fdn_conv64_shell_slabs)) {
         if (wino && fdn_conv64_wino_ok(OD, OH, OW))
@@ -651,9 +651,9 @@ int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, 
 
 int fdn_conv64_launch(const float* x, const float* wpack, const float* bias, const float* residual, float* y, int N,
                       int ID, int IH, int IW, int OD, int OH, int OW, int off, int zero_mode, int act, float alpha,
-                      hipStream_t s) {
+                      hipStream_t s, int algo) {
     return fdn_conv64_launch_ex(x, wpack, bias, residual, y, nullptr, nullptr, nullptr, N, ID, IH, IW, OD, OH, OW, off,
-                                zero_mode, act, alpha, s, 3);
+                                zero_mode, act, alpha, s, 3, algo);
 }
 
 int fdn_fold_halo_border_launch(const float* s0, const float* s1, const float* s2, int nsrc, const float* skip,

@@ -133,10 +133,11 @@ FdnTile fdn_plan_tile(int N, int OD, int OH, int OW, int max_vox, int max_halo_r
 // entry points implemented in the per-kernel translation units
 int fdn_conv64_launch(const float* x, const float* wpack, const float* bias, const float* residual, float* y,
                       int N, int ID, int IH, int IW, int OD, int OH, int OW, int off, int zero_mode, int act,
-                      float alpha, hipStream_t s);
+                      float alpha, hipStream_t s, int algo = FDN_ALGO_AUTO);
 int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, const float* residual, float* y,
                          const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
-                         int OW, int off, int zero_mode, int act, float alpha, hipStream_t s, int parts = 3);
+                         int OW, int off, int zero_mode, int act, float alpha, hipStream_t s, int parts = 3,
+                         int algo = FDN_ALGO_AUTO);
 // Winograd F(4,3)-along-W variant of the 64->64 conv (conv64_wino.hip): one output box with all 27 taps
 struct FdnWinoBox { int od, oh, ow, ed, eh, ew, ta0, ta1, tb0, tb1; };   // output box + its non-zero (kd, kh) tap ranges
 bool fdn_conv64_wino_ok(int ebd, int ebh, int ebw);

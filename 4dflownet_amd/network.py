@@ -58,9 +58,12 @@ class _T:
 
 
 class FlowNetModel:
-    def __init__(self, res_increase, low_resblock=8, hi_resblock=4, device=None, seed=0, dtype="float32"):
+    def __init__(self, res_increase, low_resblock=8, hi_resblock=4, device=None, seed=0, dtype="float32", conv_algo=None):
         """dtype: storage type of activations and activation gradients -- "float32" (the reference's arithmetic) or
-        "bfloat16" (BASELINE.json configs[3]; parameters, their gradients, the prediction and the optimizer stay fp32)."""
+        "bfloat16" (BASELINE.json configs[3]; parameters, their gradients, the prediction and the optimizer stay fp32).
+        conv_algo (fp32 mode): algorithm of the 64->64 3x3x3 layers -- "auto" (FDN_ALGO_AUTO: Winograd along W where the W
+        extent allows it), "direct" (FDN_ALGO_DIRECT everywhere), or a dict {layer name: "direct"} that pins single layers
+        (forward, dgrad and wgrad of that layer) to the direct kernels; None reads FDN_CONV_ALGO (default "auto")."""
         if not torch.cuda.is_available():
             raise FdnError("FlowNetModel needs a ROCm GPU: the hot path is HIP-only (no CPU fallback)")
         dtype = {"float32": "float32", "fp32": "float32", "f32": "float32", torch.float32: "float32",
@@ -115,6 +118,7 @@ class FlowNetModel:
         assert off == n
         self.is_kernel = torch.tensor(is_kernel, device=self.device)
         self._w64_offsets = torch.tensor([L.w_off for L in self.layers if L.wp_f is not None], device=self.device, dtype=torch.int64)
+        self.set_conv_algo(conv_algo)
         self.weights_version = 0       # bumped by weights_changed(): lets the trainer know whether Adam's sum-of-squares is current
         self._ws = None
         self._ws_bias = None
@@ -130,6 +134,23 @@ class FlowNetModel:
         cut_mid = self.layers[6 + 2 * (self.low_resblock // 2)].w_off
         self.grad_buckets = [b for b in ((cut_hi, n + 1), (cut_mid, cut_hi), (0, cut_mid)) if b[1] > b[0]]
         self.glorot_uniform_init(seed)
+
+    def set_conv_algo(self, conv_algo=None):
+        """See __init__.  Takes effect from the next forward()."""
+        import os
+        if conv_algo is None:
+            conv_algo = os.environ.get("FDN_CONV_ALGO", "auto")
+        names = {"auto": ops.ALGO_AUTO, "winograd": ops.ALGO_AUTO, "direct": ops.ALGO_DIRECT}
+        per_layer = {}
+        if isinstance(conv_algo, dict):
+            per_layer, conv_algo = conv_algo, conv_algo.get("*", "auto")
+        if conv_algo not in names or any(v not in names for v in per_layer.values()):
+            raise ValueError("conv_algo must be 'auto', 'direct' or {layer name: 'auto'|'direct'}")
+        known = set(L.name for L in self.layers)
+        unknown = [k for k in per_layer if k != "*" and k not in known]
+        if unknown:
+            raise ValueError("conv_algo: unknown layer(s) %s" % unknown)
+        self.conv_algo = dict((L.name, names[per_layer.get(L.name, conv_algo)]) for L in self.layers)
 
     # ------------------------------------------------------------------ parameters
     def glorot_uniform_init(self, seed=0):
@@ -195,7 +216,7 @@ class FlowNetModel:
         return t.contiguous()
 
     def _conv(self, x, L, act, residual=None, x2=None, out=None, ldy=None, y_coff=0):
-        return self.ops.conv3d_fwd(x, L.w, L.b, act, ops.LEAKY_ALPHA, residual, x2, L.wp_f, out, ldy, y_coff)
+        return self.ops.conv3d_fwd(x, L.w, L.b, act, ops.LEAKY_ALPHA, residual, x2, L.wp_f, out, ldy, y_coff, algo=self.conv_algo[L.name])
 
     def forward(self, inputs, training=False):
         """inputs: [u, v, w, u_mag, v_mag, w_mag], each (B,P,P,P,1) or (B,P,P,P).  Returns a device tensor
@@ -270,7 +291,7 @@ class FlowNetModel:
         ws = self._workspace(self.ops.wgrad_workspace_bytes(N, D, H, W, L.cin, L.cout, L.k))
         if not self.overlap_wgrad:
             self.ops.conv3d_wgrad(x, dz, L.k, L.cin, L.cout, x2=x2, dw=L.gw, dbias=L.gb if bias else None, workspace=ws, lddz=lddz,
-                             dz_coff=dz_coff)
+                             dz_coff=dz_coff, algo=self.conv_algo[L.name])
             return
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
@@ -278,7 +299,7 @@ class FlowNetModel:
         self._side.wait_stream(main)                      # dz (and the workspace allocation) are ready
         with torch.cuda.stream(self._side):
             self.ops.conv3d_wgrad(x, dz, L.k, L.cin, L.cout, x2=x2, dw=L.gw, dbias=L.gb if bias else None, workspace=ws, lddz=lddz,
-                             dz_coff=dz_coff)
+                             dz_coff=dz_coff, algo=self.conv_algo[L.name])
         for t in (x, dz, x2):                             # keep the caching allocator from recycling them too early
             if t is not None:
                 t.record_stream(self._side)
@@ -300,13 +321,14 @@ class FlowNetModel:
             main = torch.cuda.current_stream()
             self._side.wait_stream(main)
             with torch.cuda.stream(self._side):
-                self.ops.conv3d_dgrad_fused(dz, L.wp_d, pad, out, parts=ops.DGRAD_SHELL)
-            self.ops.conv3d_dgrad_fused(dz, L.wp_d, pad, out, skip=skip, y_prev=y_prev, act=act, parts=ops.DGRAD_INNER)
+                self.ops.conv3d_dgrad_fused(dz, L.wp_d, pad, out, parts=ops.DGRAD_SHELL, algo=self.conv_algo[L.name])
+            self.ops.conv3d_dgrad_fused(dz, L.wp_d, pad, out, skip=skip, y_prev=y_prev, act=act, parts=ops.DGRAD_INNER,
+                                        algo=self.conv_algo[L.name])
             main.wait_stream(self._side)
             for t in (dz, pad):
                 t.record_stream(self._side)
         else:
-            self.ops.conv3d_dgrad_fused(dz, L.wp_d, pad, out, skip=skip, y_prev=y_prev, act=act)
+            self.ops.conv3d_dgrad_fused(dz, L.wp_d, pad, out, skip=skip, y_prev=y_prev, act=act, algo=self.conv_algo[L.name])
         self.ops.fold_halo_border([pad], out, skip, y_prev, act)
         return out
 
@@ -350,7 +372,8 @@ class FlowNetModel:
             self._wgrad(rb.t, dz_g, L1, bias=False)
             pad = self._pad_like(rb.t)
             y_m, a_m = act_of(rb) if hidx == 2 else (None, ACT_NONE)
-            self.ops.conv3d_dgrad_fused(dz_g, L1.wp_d, pad, dz, skip=dz if hidx > 0 else None, y_prev=y_m, act=a_m)
+            self.ops.conv3d_dgrad_fused(dz_g, L1.wp_d, pad, dz, skip=dz if hidx > 0 else None, y_prev=y_m, act=a_m,
+                                        algo=self.conv_algo[L1.name])
             pads.append(pad)
             del dz_g
             li += 2
@@ -408,10 +431,10 @@ class SR4DFlowNet:
         self.res_increase = res_increase
 
     def build_network(self, u, v, w, u_mag, v_mag, w_mag, low_resblock=8, hi_resblock=4, channel_nr=64, device=None,
-                      seed=0, dtype="float32"):
+                      seed=0, dtype="float32", conv_algo=None):
         channel_nr = 64   # noqa: F841  (the reference overwrites the argument)
         for t in (u, v, w, u_mag, v_mag, w_mag):
             shp = getattr(t, "shape", None)
             if shp is not None and len(shp) == 5 and shp[-1] != 1:
                 raise ValueError("inputs must have a single channel, got shape %s" % (tuple(shp),))
-        return FlowNetModel(self.res_increase, low_resblock, hi_resblock, device=device, seed=seed, dtype=dtype)
+        return FlowNetModel(self.res_increase, low_resblock, hi_resblock, device=device, seed=seed, dtype=dtype, conv_algo=conv_algo)

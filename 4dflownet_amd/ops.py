@@ -8,6 +8,8 @@ from . import _lib
 from ._lib import FdnError, check
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+# FDN_ALGO_*: per-call algorithm of the 64->64 3x3x3 entry points (AUTO = Winograd along W when W % 4 == 0, DIRECT = never)
+ALGO_AUTO, ALGO_DIRECT = 0, 1
 LEAKY_ALPHA = 0.2
 CONV64_PACK_FLOATS = 81 * 64 * 64     # FDN_CONV64_PACK_FLOATS: direct stream (27 taps) + Winograd F(4,3) stream (54)
 
@@ -55,7 +57,7 @@ def pack_conv64_weights(w, wp_fwd=None, wp_dgrad=None, want_dgrad=True):
 
 
 def conv3d_fwd(x, w, bias=None, act=ACT_NONE, alpha=LEAKY_ALPHA, residual=None, x2=None, wpack=None, out=None,
-               ldy=None, y_coff=0):
+               ldy=None, y_coff=0, algo=ALGO_AUTO):
     """x (N,D,H,W,Cin[/2 if x2]); w Keras layout (K,K,K,Cin,Cout)."""
     N, D, H, W = x.shape[:4]
     K, Cin, Cout = w.shape[0], w.shape[3], w.shape[4]
@@ -68,12 +70,12 @@ def conv3d_fwd(x, w, bias=None, act=ACT_NONE, alpha=LEAKY_ALPHA, residual=None, 
         wpack, _ = pack_conv64_weights(w, want_dgrad=False)
     check(_lib.load().fdn_conv3d_fwd(_p(x, "x"), _p(x2, allow_none=True), _p(w, "w"), _p(wpack, allow_none=True),
                                      _p(bias, allow_none=True), _p(residual, allow_none=True), _p(out, "out"),
-                                     N, D, H, W, Cin, Cout, K, ldy, y_coff, act, float(alpha), _stream()),
+                                     N, D, H, W, Cin, Cout, K, ldy, y_coff, act, float(alpha), int(algo), _stream()),
           "fdn_conv3d_fwd")
     return out
 
 
-def conv3d_dgrad(dz, w, wpack_dgrad=None, out=None, lddz=None, dz_coff=0, spatial=None):
+def conv3d_dgrad(dz, w, wpack_dgrad=None, out=None, lddz=None, dz_coff=0, spatial=None, algo=ALGO_AUTO):
     """Returns the gradient on the PADDED input grid (N,D+2,H+2,W+2,Cin) for K=3."""
     K, Cin, Cout = w.shape[0], w.shape[3], w.shape[4]
     N, D, H, W = dz.shape[:4] if spatial is None else spatial
@@ -84,7 +86,7 @@ def conv3d_dgrad(dz, w, wpack_dgrad=None, out=None, lddz=None, dz_coff=0, spatia
     if Cin == 64 and Cout == 64 and K == 3 and wpack_dgrad is None:
         _, wpack_dgrad = pack_conv64_weights(w)
     check(_lib.load().fdn_conv3d_dgrad(_p(dz, "dz"), _p(w, "w"), _p(wpack_dgrad, allow_none=True), _p(out, "dxpad"),
-                                       N, D, H, W, Cin, Cout, K, lddz, dz_coff, _stream()), "fdn_conv3d_dgrad")
+                                       N, D, H, W, Cin, Cout, K, lddz, dz_coff, int(algo), _stream()), "fdn_conv3d_dgrad")
     return out
 
 
@@ -120,7 +122,8 @@ def fold_halo(dxpads, skip=None, y_prev=None, act=ACT_NONE, alpha=LEAKY_ALPHA, o
 DGRAD_INNER, DGRAD_SHELL = 1, 2
 
 
-def conv3d_dgrad_fused(dz, wpack_dgrad, dxpad, out, skip=None, y_prev=None, act=ACT_NONE, alpha=LEAKY_ALPHA, parts=3):
+def conv3d_dgrad_fused(dz, wpack_dgrad, dxpad, out, skip=None, y_prev=None, act=ACT_NONE, alpha=LEAKY_ALPHA, parts=3,
+                       algo=ALGO_AUTO):
     """64->64 dgrad; interior voxels of `out` are finished in the conv epilogue (skip may alias out), the rest lands
     in the padded scratch `dxpad` for fold_halo_border.  parts: DGRAD_INNER | DGRAD_SHELL -- the two pieces write disjoint
     positions and may run on different streams."""
@@ -128,11 +131,11 @@ def conv3d_dgrad_fused(dz, wpack_dgrad, dxpad, out, skip=None, y_prev=None, act=
     if parts == 3:
         check(_lib.load().fdn_conv3d_dgrad_fused(_p(dz, "dz"), _p(wpack_dgrad, "wpack"), _p(dxpad, "dxpad"),
                                                  _p(skip, allow_none=True), _p(y_prev, allow_none=True), act, float(alpha),
-                                                 _p(out, "out"), N, D, H, W, _stream()), "fdn_conv3d_dgrad_fused")
+                                                 _p(out, "out"), N, D, H, W, int(algo), _stream()), "fdn_conv3d_dgrad_fused")
     else:
         check(_lib.load().fdn_conv3d_dgrad_fused_part(_p(dz, "dz"), _p(wpack_dgrad, "wpack"), _p(dxpad, "dxpad"),
                                                       _p(skip, allow_none=True), _p(y_prev, allow_none=True), act, float(alpha),
-                                                      _p(out, "out"), N, D, H, W, int(parts), _stream()),
+                                                      _p(out, "out"), N, D, H, W, int(parts), int(algo), _stream()),
               "fdn_conv3d_dgrad_fused_part")
     return out
 
@@ -162,7 +165,7 @@ def wgrad_workspace_bytes(N, D, H, W, Cin, Cout, K):
 
 
 def conv3d_wgrad(x, dz, K, Cin, Cout, x2=None, want_bias=False, dw=None, dbias=None, workspace=None, lddz=None,
-                 dz_coff=0):
+                 dz_coff=0, algo=ALGO_AUTO):
     N, D, H, W = x.shape[:4]
     if lddz is None:
         lddz = dz.shape[-1]
@@ -176,7 +179,7 @@ def conv3d_wgrad(x, dz, K, Cin, Cout, x2=None, want_bias=False, dw=None, dbias=N
     check(_lib.load().fdn_conv3d_wgrad(_p(x, "x"), _p(x2, allow_none=True), _p(dz, "dz"), _p(dw, "dw"),
                                        _p(dbias, allow_none=True), _p(workspace, "workspace"),
                                        workspace.numel() * workspace.element_size(), N, D, H, W, Cin, Cout, K, lddz,
-                                       dz_coff, _stream()), "fdn_conv3d_wgrad")
+                                       dz_coff, int(algo), _stream()), "fdn_conv3d_wgrad")
     return dw, dbias
 
 

@@ -60,8 +60,9 @@ def pack_conv64_weights(w, wp_fwd=None, wp_dgrad=None, want_dgrad=True):
 
 
 def conv3d_fwd(x, w, bias=None, act=ACT_NONE, alpha=LEAKY_ALPHA, residual=None, x2=None, wpack=None, out=None,
-               ldy=None, y_coff=0):
-    """x bf16 (N,D,H,W,Cin[/2 if x2]); w fp32 Keras layout; output bf16, except Cout == 1 (prediction) -> fp32."""
+               ldy=None, y_coff=0, algo=0):
+    """x bf16 (N,D,H,W,Cin[/2 if x2]); w fp32 Keras layout; output bf16, except Cout == 1 (prediction) -> fp32.
+    algo is accepted for signature parity with ops.conv3d_fwd and ignored: the bf16 kernels are direct convolutions."""
     N, D, H, W = x.shape[:4]
     K, Cin, Cout = w.shape[0], w.shape[3], w.shape[4]
     odt = torch.float32 if Cout == 1 else BF16
@@ -91,7 +92,7 @@ def conv64_fwd(x, wpack, bias=None, act=ACT_NONE, alpha=LEAKY_ALPHA, residual=No
     return out
 
 
-def conv3d_dgrad_fused(dz, wpack_dgrad, dxpad, out, skip=None, y_prev=None, act=ACT_NONE, alpha=LEAKY_ALPHA):
+def conv3d_dgrad_fused(dz, wpack_dgrad, dxpad, out, skip=None, y_prev=None, act=ACT_NONE, alpha=LEAKY_ALPHA, algo=0):
     N, D, H, W = dz.shape[:4]
     check(_lib.load().fdn_conv64_dgrad_fused_bf16(_pb(dz, "dz"), _pb(wpack_dgrad, "wpack"), _pf(dxpad, "dxpad"),
                                                   _pb(skip, allow_none=True), _pb(y_prev, allow_none=True), act,
@@ -144,7 +145,7 @@ def wgrad_workspace_bytes(N, D, H, W, Cin, Cout, K):
 
 
 def conv3d_wgrad(x, dz, K, Cin, Cout, x2=None, want_bias=False, dw=None, dbias=None, workspace=None, lddz=None,
-                 dz_coff=0):
+                 dz_coff=0, algo=0):
     """x bf16; dz bf16, except Cout == 1 where dz is the fp32 prediction gradient; dw / dbias fp32."""
     N, D, H, W = x.shape[:4]
     if lddz is None:

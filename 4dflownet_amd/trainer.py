@@ -70,11 +70,12 @@ class _Optimizer:
 class TrainerController:
     def __init__(self, patch_size, res_increase, initial_learning_rate=1e-4, quicksave_enable=True,
                  network_name='4DFlowNet', low_resblock=8, hi_resblock=4, device=None, seed=0, dtype='float32',
-                 bucketed_allreduce=None):
+                 bucketed_allreduce=None, conv_algo=None):
         """Reference arguments: TrainerController.py:18.  Extra (keyword-only in spirit): device, seed (Glorot draw), dtype
         (activation storage, 'float32' | 'bfloat16'), bucketed_allreduce (data parallel only: True = one asynchronous SUM
         all-reduce per gradient bucket started inside backward -- the default --, False = ONE all-reduce of the whole buffer
-        after backward; env FDN_DP_BUCKETED=0 selects the latter when the argument is None)."""
+        after backward; env FDN_DP_BUCKETED=0 selects the latter when the argument is None), conv_algo ('auto' | 'direct' |
+        {layer name: ...}: algorithm of the 64->64 layers, see FlowNetModel)."""
         self.div_weight = 0            # divergence loss is dead code in the reference (TrainerController.py:23,121)
         self.non_fluid_weight = 1
         self.res_increase = res_increase
@@ -87,7 +88,7 @@ class TrainerController:
         u_mag, v_mag, w_mag = Input(input_shape, 'u_mag'), Input(input_shape, 'v_mag'), Input(input_shape, 'w_mag')
         net = SR4DFlowNet(res_increase)
         self.model = net.build_network(u, v, w, u_mag, v_mag, w_mag, low_resblock, hi_resblock, device=device, seed=seed,
-                                       dtype=dtype)
+                                       dtype=dtype, conv_algo=conv_algo)
         self.device = self.model.device
 
         names = ['train_loss', 'val_loss', 'train_accuracy', 'val_accuracy', 'train_mse', 'val_mse', 'train_div',

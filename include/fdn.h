@@ -42,6 +42,15 @@ extern "C" {
 #define FDN_ACT_RELU 1  /* Conv3D(activation='relu')            src/Network/SR4DFlowNet.py:17-25,39,42,45 */
 #define FDN_ACT_LEAKY 2 /* tf.keras.layers.LeakyReLU(alpha=0.2) src/Network/SR4DFlowNet.py:113,118 */
 
+/* Algorithm selector of the 64->64 3x3x3 entry points (fdn_conv3d_fwd / _dgrad / _dgrad_fused[_part] / _wgrad; ignored by
+ * every other (Cin,Cout,K)).  Per call, no global state.
+ *   FDN_ALGO_AUTO   : the planner's choice -- 1-D Winograd along W (F(4,3) forward / dgrad, F(3,4) wgrad: half the multiplies,
+ *                     fp32 error a few 1e-7 of sum|x||w| instead of ~1e-7) whenever the W extent is a multiple of 4, else direct;
+ *   FDN_ALGO_DIRECT : always the direct convolution (plain fp32 FMA chains over the 27 taps, no transform) -- for
+ *                     parity-critical runs and for layers whose operands are too ill-conditioned for the transform. */
+#define FDN_ALGO_AUTO 0
+#define FDN_ALGO_DIRECT 1
+
 int fdn_version(void);
 const char* fdn_last_error(void);
 
@@ -74,13 +83,13 @@ int fdn_pack_conv64_weights_batch(const float* w_base, const int64_t* w_offsets,
  * the three 64->1 heads write straight into the (N,V,3) prediction: SR4DFlowNet.py:49). */
 int fdn_conv3d_fwd(const float* x, const float* x2, const float* w, const float* wpack, const float* bias,
                    const float* residual, float* y, int N, int D, int H, int W, int Cin, int Cout, int K,
-                   int ldy, int y_coff, int act, float alpha, void* stream);
+                   int ldy, int y_coff, int act, float alpha, int algo, void* stream);
 
 /* Gradient w.r.t. the PADDED conv input (Conv3DBackpropInputV2): dxpad (N,D+2,H+2,W+2,Cin) for K=3.
  * dz rows are read at dz[voxel*lddz + dz_coff + c].  Fold the halo with fdn_fold_halo.
  * Supported (Cin,Cout,K): (64,64,3) [needs wpack = wp_dgrad], (64,1,3). */
 int fdn_conv3d_dgrad(const float* dz, const float* w, const float* wpack, float* dxpad, int N, int D, int H,
-                     int W, int Cin, int Cout, int K, int lddz, int dz_coff, void* stream);
+                     int W, int Cin, int Cout, int K, int lddz, int dz_coff, int algo, void* stream);
 
 /* The 64->1 head conv's input gradient with the halo fold and the producer's activation gradient fused
  * (no padded intermediate): dz_prev[i] = act'(y_prev[i]) * sum_{(o,t): clamp(o+t-1)=i} w[t] * dz[o].
@@ -104,14 +113,15 @@ int fdn_fold_halo(const float* dxpad0, const float* dxpad1, const float* dxpad2,
  * which applies the same formula on the surface voxels with up to 3 padded sources.  skip may alias dz_prev
  * (gradient fan-in over several consumers: call with y_prev=NULL for all but the last).  wpack = wp_dgrad. */
 int fdn_conv3d_dgrad_fused(const float* dz, const float* wpack, float* dxpad, const float* skip, const float* y_prev,
-                           int act, float alpha, float* dz_prev, int N, int D, int H, int W, void* stream);
+                           int act, float alpha, float* dz_prev, int N, int D, int H, int W, int algo, void* stream);
 /* The same in two independent pieces, for callers that overlap them on two streams (they write disjoint positions; both must
  * have completed before fdn_fold_halo_border): FDN_DGRAD_INNER = the D x H x W box (finishes the interior of dz_prev, writes its
  * surface voxels to dxpad), FDN_DGRAD_SHELL = the one-voxel shell of the padded grid (dxpad only; ignores skip / y_prev). */
 #define FDN_DGRAD_INNER 1
 #define FDN_DGRAD_SHELL 2
 int fdn_conv3d_dgrad_fused_part(const float* dz, const float* wpack, float* dxpad, const float* skip, const float* y_prev,
-                                int act, float alpha, float* dz_prev, int N, int D, int H, int W, int parts, void* stream);
+                                int act, float alpha, float* dz_prev, int N, int D, int H, int W, int parts, int algo,
+                                void* stream);
 int fdn_fold_halo_border(const float* dxpad0, const float* dxpad1, const float* dxpad2, int nsrc, const float* skip,
                          const float* y_prev, int act, float alpha, float* dz_prev, int N, int D, int H, int W,
                          void* stream);
@@ -127,7 +137,7 @@ int fdn_conv1x1_dgrad(const float* dz, const float* w, const float* ya, const fl
 size_t fdn_conv3d_wgrad_workspace_bytes(int N, int D, int H, int W, int Cin, int Cout, int K);
 int fdn_conv3d_wgrad(const float* x, const float* x2, const float* dz, float* dw, float* dbias,
                      void* workspace, size_t workspace_bytes, int N, int D, int H, int W, int Cin, int Cout,
-                     int K, int lddz, int dz_coff, void* stream);
+                     int K, int lddz, int dz_coff, int algo, void* stream);
 
 /* upsample3d: trilinear, align_corners=True, integer factor R.  src/Network/SR4DFlowNet.py:53-90.
  * fwd: x (N,D,H,W,C) -> y (N,DR,HR,WR,C).

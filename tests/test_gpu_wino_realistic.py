@@ -1,0 +1,246 @@
+"""Winograd parity on REALISTIC operand distributions.
+
+The fp32 product path runs every 64->64 3x3x3 layer through 1-D Winograd kernels (F(4,3) along W for forward / dgrad,
+F(3,4) for wgrad).  Their transforms cancel (B^T rows like 4x0 - 5x2 + x4), so their error depends on the operands'
+offset and dynamic range, which N(0,1) test data does not exercise.  Here:
+
+  (a) synthetic operands with DC offset and wide range: x = |N(0,1)|*s + m for m/s in {0, 10, 100}, gradients dz with
+      magnitudes log-uniform over 1e-6..1, kernels with a non-zero mean / exactly centred;
+  (b) the REAL operands of the cfg2 network (paper default: patch 24, res x2, 8 + 4 ResBlocks, batch 8) after >= 300 product
+      train steps on patches of the reference's example_data*.h5: every 64->64 layer's input activation, output gradient
+      and trained kernel.
+
+Every result is compared PER ELEMENT against a float64 evaluation of sampled outputs (corners, edges, faces, interior),
+normalised two ways:  e_cond = |err| / sum|x||w|  (the conditioning-aware bound any fp32 summation obeys) and
+e_max = max|err| / max|ref| per tensor.  The direct kernels (FDN_ALGO_DIRECT) run beside the Winograd ones and their errors
+are printed in the same table.  north_star tolerance: 1e-3 relative fp32 -> asserted with a >= 10x margin (1e-4).
+Semantics: src/Network/SR4DFlowNet.py:93-120 (conv3d with SYMMETRIC padding, resnet_block)."""
+import contextlib
+import importlib
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_fullsize import gather_rows, ref_dgrad, ref_forward, ref_wgrad_rows, sample_voxels
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+DATA = os.path.join(HERE, "golden", "data")
+
+TOL = 1e-4            # north_star 1e-3 with a 10x margin
+PICKS = [(0, 0, 0, 0), (1, 1, 1, 17), (2, 2, 2, 63), (0, 2, 1, 31), (2, 0, 1, 40), (1, 0, 2, 5), (1, 2, 0, 58), (0, 1, 2, 22)]
+
+
+def _rel_cond(e, cond):
+    """max |err| / sum|x||w| over the elements whose bound is non-zero; where it is zero (e.g. a dead post-ReLU input channel)
+    every product is zero and the result must be exactly zero."""
+    live = cond > 0
+    assert (e[~live] == 0).all()
+    return float((e[live] / cond[live]).max()) if live.any() else 0.0
+
+
+def conv_errors(ops, x, w, dz, rng, n_random=160, algos=("auto", "direct")):
+    """Forward, fused dgrad (+ border fold) and wgrad of one 64->64 layer with both algorithms; sampled float64 references.
+    Returns {kind: {algo: (e_cond, e_max)}}."""
+    N, D, H, W = x.shape[:4]
+    dims = (N, D, H, W)
+    pts = sample_voxels(N, D, H, W, n_random, rng)
+    w64 = w.double().cpu().numpy()
+    wf, wd = ops.pack_conv64_weights(w)
+    xa, dza, wa = x.abs(), dz.abs(), np.abs(w64)
+    ref_f, cond_f = ref_forward(x, w64, pts, dims), ref_forward(xa, wa, pts, dims)
+    ref_d, cond_d = ref_dgrad(dz, w64, pts, dims), ref_dgrad(dza, wa, pts, dims)
+    ref_w, cond_w = ref_wgrad_rows(x, dz, PICKS), ref_wgrad_rows(xa, dza, PICKS)
+    ws = torch.empty(ops.wgrad_workspace_bytes(N, D, H, W, 64, 64, 3) // 4 + 1, device=x.device)
+    out = {"fwd": {}, "dgrad": {}, "wgrad": {}}
+    for name in algos:
+        algo = ops.ALGO_AUTO if name == "auto" else ops.ALGO_DIRECT
+        y = ops.conv3d_fwd(x, w, None, ops.ACT_NONE, 0.2, None, wpack=wf, algo=algo)
+        e = np.abs(gather_rows(y, pts) - ref_f)
+        out["fwd"][name] = (_rel_cond(e, cond_f), float(e.max() / np.abs(ref_f).max()))
+        del y
+        pad = torch.empty((N, D + 2, H + 2, W + 2, 64), device=x.device)
+        dx = torch.empty_like(dz)
+        ops.conv3d_dgrad_fused(dz, wd, pad, dx, algo=algo)
+        ops.fold_halo_border([pad], dx)
+        e = np.abs(gather_rows(dx, pts) - ref_d)
+        out["dgrad"][name] = (_rel_cond(e, cond_d), float(e.max() / np.abs(ref_d).max()))
+        del pad, dx
+        dw, _ = ops.conv3d_wgrad(x, dz, 3, 64, 64, workspace=ws, algo=algo)
+        got = np.asarray([dw[a, b, c, ci].double().cpu().numpy() for (a, b, c, ci) in PICKS])
+        e = np.abs(got - ref_w)
+        out["wgrad"][name] = (_rel_cond(e, cond_w), float(e.max() / np.abs(ref_w).max()))
+    return out
+
+
+def fmt(tag, res):
+    cells = []
+    for kind in ("fwd", "dgrad", "wgrad"):
+        (wc, wm), (dc, dm) = res[kind]["auto"], res[kind]["direct"]
+        cells.append("%s wino %.1e/%.1e direct %.1e/%.1e" % (kind, wc, wm, dc, dm))
+    return "%-34s | %s" % (tag, " | ".join(cells))
+
+
+@pytest.mark.parametrize("m_over_s", [0, 10, 100])
+@pytest.mark.parametrize("wmode", ["shifted", "centred"])
+def test_wino_kernels_on_offset_and_wide_range_operands(fdn, m_over_s, wmode, capsys):
+    """(a): error normalised by sum|x||w| must stay <= 1e-4 whatever the offset; the output-scale error is printed beside the
+    direct kernel's (with a DC offset and zero-mean kernels the RESULT is a small difference of large terms for any fp32
+    summation order -- that loss is the problem's conditioning, visible in the direct column as well)."""
+    ops = fdn.ops
+    rng = np.random.default_rng(100 + m_over_s)
+    g = torch.Generator(device="cuda").manual_seed(7 + m_over_s)
+    N, P = 2, 24
+    s = 0.7
+    x = torch.randn((N, P, P, P, 64), device="cuda", generator=g).abs() * s + m_over_s * s
+    mag = 10.0 ** (-6.0 * torch.rand((N, P, P, P, 64), device="cuda", generator=g))
+    dz = mag * torch.sign(torch.randn((N, P, P, P, 64), device="cuda", generator=g))
+    w = torch.randn((3, 3, 3, 64, 64), device="cuda", generator=g) * 0.03
+    if wmode == "shifted":
+        w = w + 0.015                                   # trained kernels drift away from zero mean
+    else:
+        w = w - w.mean(dim=(0, 1, 2, 3), keepdim=True)  # exactly zero mean per output channel: the DC part of x cancels
+    res = conv_errors(ops, x, w, dz, rng)
+    with capsys.disabled():
+        print("\n[wino-parity a] " + fmt("m/s=%d kernels %s" % (m_over_s, wmode), res))
+    for kind in ("fwd", "dgrad", "wgrad"):
+        e_cond, e_max = res[kind]["auto"]
+        assert e_cond <= TOL, (kind, res[kind])
+        # forward sees the offset operand x; dgrad / wgrad results are sums over dz (no offset): those must also meet the
+        # output-scale tolerance.  wgrad contracts x with dz, so the DC offset of x scales signal and error alike.
+        if kind != "fwd" or m_over_s == 0 or wmode == "shifted":
+            assert e_max <= TOL, (kind, res[kind])
+
+
+@pytest.fixture(scope="module")
+def trained(fdn):
+    """The cfg2 network after 320 product train steps (batch 8, lr 1e-4) on 64 patches of example_data*.h5, plus one recorded
+    step: for every 64->64 layer its input activation x and output gradient dz as the backward pass saw them."""
+    data = importlib.import_module("4dflownet_amd.data")
+    data_device = importlib.import_module("4dflownet_amd.data_device")
+    patch_index = importlib.import_module("4dflownet_amd.patch_index")
+    trainer = importlib.import_module("4dflownet_amd.trainer")
+    import tempfile
+    with tempfile.TemporaryDirectory() as td, contextlib.redirect_stdout(io.StringIO()):
+        csv = os.path.join(td, "t.csv")
+        patch_index.generate_patch_index(DATA, "example_data.h5", "example_data_HR.h5", csv, patch_size=24, n_patch=64,
+                                         minimum_coverage=0.05, seed=0)
+        rows = data.load_indexes(csv)
+        ds = data_device.DevicePatchHandler3D(DATA, 24, 2, 8, 0.6).initialize_dataset(rows, shuffle=True, shard=(0, 1))
+    tc = trainer.TrainerController(24, 2, initial_learning_rate=1e-4, quicksave_enable=False, low_resblock=8, hi_resblock=4, seed=0)
+    steps = 0
+    first = None
+    while steps < 320:
+        tc.reset_metrics()
+        for batch in ds:
+            tc.train_step(batch)
+            steps += 1
+        if first is None:
+            first = tc.loss_metrics["train_loss"].result()
+    last = tc.loss_metrics["train_loss"].result()
+    assert np.isfinite(last) and last < 0.5 * first, (first, last)      # it did train
+    batch = next(iter(ds))
+    rec = {}
+    m = tc.model
+    orig = m._wgrad
+
+    def recording_wgrad(x, dz, L, **k):
+        if (L.k, L.cin, L.cout) == (3, 64, 64):
+            rec[L.name] = (x, dz)
+        return orig(x, dz, L, **k)
+    m._wgrad = recording_wgrad
+    inputs, hires, venc, mask = tc._unpack(batch)
+    pred = m.forward(inputs, training=True)
+    _, dpred = fdn.ops.loss_metrics(pred, hires[0], hires[1], hires[2], mask, want_grad=True)
+    m.backward(dpred)
+    m._wgrad = orig
+    torch.cuda.synchronize()
+    return {"tc": tc, "rec": rec, "batch": batch, "steps": steps, "loss": (first, last)}
+
+
+def test_wino_kernels_on_trained_cfg2_operands(fdn, trained, capsys):
+    """(b): every 64->64 layer of the trained cfg2 network with its real activation, gradient and kernel, Winograd vs float64,
+    direct beside it.  Both normalisations <= 1e-4 on every layer and kernel."""
+    ops = fdn.ops
+    tc, rec = trained["tc"], trained["rec"]
+    layers = [L for L in tc.model.layers if (L.k, L.cin, L.cout) == (3, 64, 64)]
+    assert len(rec) == len(layers) == 30
+    rng = np.random.default_rng(9)
+    worst = {}
+    lines = []
+    for L in layers:
+        x, dz = rec[L.name]
+        xs = x.float()
+        stats = "x mean/std %.2g/%.2g |dz| max %.1e w mean/std %.1e/%.1e" % (
+            float(xs.mean()), float(xs.std()), float(dz.abs().max()), float(L.w.mean()), float(L.w.std()))
+        res = conv_errors(ops, x, L.w.contiguous(), dz, rng, n_random=96)
+        lines.append(fmt("%s %s" % (L.name, "x".join(str(d) for d in x.shape[1:4])), res) + " | " + stats)
+        for kind in res:
+            for algo in res[kind]:
+                k = (kind, algo)
+                worst[k] = tuple(max(a, b) for a, b in zip(worst.get(k, (0, 0)), res[kind][algo]))
+    with capsys.disabled():
+        print("\n[wino-parity b] cfg2 after %d train steps (loss %.4f -> %.4f); columns: e_cond/e_max" % (
+            trained["steps"], trained["loss"][0], trained["loss"][1]))
+        for l in lines:
+            print("[wino-parity b] " + l)
+        print("[wino-parity b] WORST " + " | ".join("%s %s %.1e/%.1e" % (k[0], k[1], v[0], v[1]) for k, v in sorted(worst.items())))
+    for (kind, algo), (e_cond, e_max) in worst.items():
+        assert e_cond <= TOL and e_max <= TOL, (kind, algo, e_cond, e_max)
+
+
+def test_trained_cfg2_step_winograd_vs_direct_vs_oracle(fdn, trained, oracle, capsys):
+    """End to end at the trained state: one cfg2 train step's prediction, loss and all 48 parameter gradients with the Winograd
+    product path vs the same step with FDN_ALGO_DIRECT on every layer (conv_algo='direct'), and -- for one patch -- vs the
+    float64 oracle.  Tolerance 1e-4 (norm) between the algorithms, north_star 1e-3 against the oracle."""
+    trainer = importlib.import_module("4dflownet_amd.trainer")
+    tc = trained["tc"]
+    batch = trained["batch"]
+    w_trained = tc.model.get_weights()
+
+    def grads_of(conv_algo, rows):
+        t = trainer.TrainerController(24, 2, initial_learning_rate=1e-4, quicksave_enable=False, low_resblock=8, hi_resblock=4,
+                                      seed=0, conv_algo=conv_algo)
+        t.model.set_weights(w_trained)
+        sub = tuple(a[rows] for a in batch)
+        inputs, hires, venc, mask = t._unpack(sub)
+        pred = t.model.forward(inputs, training=True)
+        out, dpred = fdn.ops.loss_metrics(pred, hires[0], hires[1], hires[2], mask, want_grad=True)
+        t.model.backward(dpred)
+        torch.cuda.synchronize()
+        return pred.double().cpu().numpy(), out[:, 0].double().cpu().numpy(), t.model.flat_g.double().cpu().numpy(), t
+
+    rows = slice(0, 8)
+    pw, lw, gw, tw = grads_of("auto", rows)
+    pd, ld, gd, td = grads_of("direct", rows)
+    assert set(tw.model.conv_algo.values()) == {fdn.ops.ALGO_AUTO} and set(td.model.conv_algo.values()) == {fdn.ops.ALGO_DIRECT}
+    rel = lambda a, b: float(np.linalg.norm((a - b).ravel()) / np.linalg.norm(b.ravel()))
+    e_pred, e_loss, e_grad = rel(pw, pd), float(np.abs(lw - ld).max() / np.abs(ld).max()), rel(gw, gd)
+    per_layer = []
+    for L in tw.model.layers:
+        n = L.w.numel()
+        per_layer.append(rel(gw[L.w_off:L.w_off + n], gd[L.w_off:L.w_off + n]))
+    with capsys.disabled():
+        print("\n[wino-parity c] trained cfg2 step, Winograd vs direct product path (B=8): pred %.2e loss %.2e grad %.2e, worst layer grad %.2e"
+              % (e_pred, e_loss, e_grad, max(per_layer)))
+    assert e_pred <= TOL and e_loss <= TOL and e_grad <= TOL and max(per_layer) <= 10 * TOL
+    # one patch against the float64 oracle (CPU restatement of SR4DFlowNet.py:7-120, TrainerController.py:84-156)
+    O = oracle
+    p1, l1, g1, _ = grads_of("auto", slice(0, 1))
+    params = O.init_params(0, 8, 4, np.float64)          # list of {"w", "b"} in creation order: fill in the trained values
+    it = iter(w_trained)
+    for layer in params:
+        layer["w"] = np.asarray(next(it), np.float64)
+        if layer["b"] is not None:
+            layer["b"] = np.asarray(next(it), np.float64)
+    assert next(it, None) is None
+    sub = tuple(np.asarray(a[0:1].cpu() if isinstance(a, torch.Tensor) else a[0:1], np.float64) for a in batch)
+    ref = O.loss_and_grads(params, sub, 2, 8, 4, f32_coeffs=True)
+    gref = O.flatten(ref["grads"])
+    e_l, e_g = float(np.abs(l1 - ref["mse"]).max() / np.abs(ref["mse"]).max()), rel(g1, gref)
+    with capsys.disabled():
+        print("[wino-parity c] one patch vs float64 oracle at the trained weights: loss %.2e grad(norm) %.2e" % (e_l, e_g))
+    assert e_l <= 1e-3 and e_g <= 1e-3
