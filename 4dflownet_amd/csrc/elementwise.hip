@@ -148,6 +148,11 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__
                                                             int H, int W, int CV, int R, float sd, float sh, float sw) {
     constexpr int E = FdnVec<T>::E;
     extern __shared__ __attribute__((aligned(16))) float rowbuf[];      // [OW][CV * E]
+    constexpr int kUpPairs = 32 * 32;                                   // <= 32 candidate rows per axis (host checks R)
+    __shared__ int s_row[kUpPairs];
+    __shared__ float s_wgt[kUpPairs];
+    __shared__ int s_od[32], s_oh[32], s_nd, s_nh;
+    __shared__ float s_wd[32], s_wh[32];
     const int OD = D * R, OH = H * R, OW = W * R;
     const int C = CV * E;
     const float isd = sd > 0.f ? 1.f / sd : 0.f, ish = sh > 0.f ? 1.f / sh : 0.f, isw = sw > 0.f ? 1.f / sw : 0.f;
@@ -166,27 +171,50 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__
         axis_range(h, ish, OH, oh0, oh1);
         if (sd == 0.f) { od0 = 0; od1 = OD - 1; }
         if (sh == 0.f) { oh0 = 0; oh1 = OH - 1; }
-        __syncthreads();                                   // rowbuf of the previous row fully consumed
+        __syncthreads();                                   // rowbuf and the pair list of the previous row fully consumed
+        // The high-res rows (od, oh) with a non-zero weight on this low-res row, as a compact block-uniform list: the fold below
+        // then has no data-dependent branch around its loads, which are requested four rows at a time before the first use
+        // (a `continue` per candidate row made every load its own round trip: 103 us for 280 MB at cfg2).
+        if (threadIdx.x < 64) {
+            // lanes 0..31: the depth candidates od0.., lanes 32..63: the height candidates oh0..; ballot + prefix count compacts the
+            // ones with a non-zero weight in index order (deterministic), wave 0 only
+            const int lane = threadIdx.x;
+            const bool dl = lane < 32;
+            const int c = dl ? od0 + lane : oh0 + (lane - 32);
+            float wgt = 0.f;
+            if (c <= (dl ? od1 : oh1)) wgt = dl ? axis_weight(c, d, sd, D) : axis_weight(c, h, sh, H);
+            const unsigned long long m = __ballot(wgt != 0.f);
+            const unsigned long long mine = dl ? (m & 0xffffffffull) : (m >> 32);
+            if (wgt != 0.f) {
+                const int pos = __popcll(mine & ((1ull << (lane & 31)) - 1ull));
+                if (dl) { s_od[pos] = c; s_wd[pos] = wgt; } else { s_oh[pos] = c; s_wh[pos] = wgt; }
+            }
+            if (lane == 0) { s_nd = __popcll(m & 0xffffffffull); s_nh = __popcll(m >> 32); }
+        }
+        __syncthreads();
+        const int nd_ = s_nd, nh_ = s_nh, npairs = nd_ * nh_;
+        for (int k = threadIdx.x; k < npairs; k += blockDim.x) {
+            const int a = k / nh_, b = k - a * nh_;
+            s_row[k] = (n * OD + s_od[a]) * OH + s_oh[b];
+            s_wgt[k] = s_wd[a] * s_wh[b];
+        }
+        __syncthreads();
         for (int i = threadIdx.x; i < OW * CV; i += blockDim.x) {
             float acc[E];
 #pragma unroll
             for (int e = 0; e < E; ++e) acc[e] = 0.f;
-            for (int od = od0; od <= od1; ++od) {
-                const float wd = axis_weight(od, d, sd, D);
-                if (wd == 0.f) continue;
-                float accd[E];
+            for (int k0 = 0; k0 < npairs; k0 += 4) {
+                float g[4][E], wv[4];
 #pragma unroll
-                for (int e = 0; e < E; ++e) accd[e] = 0.f;
-                for (int oh = oh0; oh <= oh1; ++oh) {
-                    const float wh = axis_weight(oh, h, sh, H);
-                    if (wh == 0.f) continue;
-                    float g[E];
-                    FdnVec<T>::ld(dy + ((((int64_t)n * OD + od) * OH + oh) * OW * CV + i) * E, g);
-#pragma unroll
-                    for (int e = 0; e < E; ++e) accd[e] += g[e] * wh;
+                for (int u = 0; u < 4; ++u) {
+                    const int k = min(k0 + u, npairs - 1);         // tail: re-read the last row with weight 0 (cache hit)
+                    wv[u] = k0 + u < npairs ? s_wgt[k] : 0.f;
+                    FdnVec<T>::ld(dy + ((int64_t)s_row[k] * OW * CV + i) * E, g[u]);
                 }
 #pragma unroll
-                for (int e = 0; e < E; ++e) acc[e] += accd[e] * wd;
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int e = 0; e < E; ++e) acc[e] += g[u][e] * wv[u];
             }
 #pragma unroll
             for (int e = 0; e < E; ++e) rowbuf[i * E + e] = acc[e];
@@ -428,7 +456,8 @@ static int upsample_bwd_t(const T* dy, const T* y_prev, int act, float alpha, T*
     FDN_REQUIRE(dy && dx && C % E == 0 && R >= 1 && N > 0 && D > 0 && H > 0 && W > 0, "fdn_upsample_trilinear_bwd: bad argument");
     const int64_t rows = (int64_t)N * D * H;
     const size_t lds = (size_t)W * R * C * sizeof(float);
-    FDN_REQUIRE(rows < (1ll << 31) && lds <= 160 * 1024, "fdn_upsample_trilinear_bwd: row of %d x %d channels does not fit the LDS stage", W * R, C);
+    FDN_REQUIRE(rows * R * R < (1ll << 31) && lds <= 160 * 1024, "fdn_upsample_trilinear_bwd: row of %d x %d channels does not fit the LDS stage", W * R, C);
+    FDN_REQUIRE(R <= 13, "fdn_upsample_trilinear_bwd: R = %d > 13 (the adjoint keeps <= 32 candidate rows per axis)", R);
     if (lds > 48 * 1024) {
         if (int rc = fdn_func_max_lds((const void*)upsample_bwd_kernel<T>, 160 * 1024, "upsample_bwd")) return rc;
     }
