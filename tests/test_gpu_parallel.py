@@ -309,8 +309,9 @@ def test_adam_cannot_overtake_a_slow_allreduce(fdn, bucketed):
     assert started == ([hi - lo for lo, hi in tc.model.grad_buckets] * 2 if bucketed else [n + 1] * 2)
     assert np.array_equal(g, tc.model.flat_g_ext.cpu().numpy())
     assert np.array_equal(w, tc.model.flat_w.cpu().numpy())
-    # the delay really was exposed on the compute stream (>= one spin kernel per step), the host never blocked on it
-    assert len(waits) == 2 and min(waits) > 20.0, waits
+    # the delay really was exposed on the compute stream and the host never blocked on it.  (Judged on the second step: in the
+    # first one the host is slow -- communicator set-up inside the first collective -- and may reach the wait after the GPU is done.)
+    assert len(waits) == 2 and waits[1] > 20.0, waits
     assert host_ms[1] < 0.5 * waits[1], (host_ms, waits)
 
 
