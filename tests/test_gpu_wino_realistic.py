@@ -35,10 +35,13 @@ PICKS = [(0, 0, 0, 0), (1, 1, 1, 17), (2, 2, 2, 63), (0, 2, 1, 31), (2, 0, 1, 40
 
 
 def _rel_cond(e, cond):
-    """max |err| / sum|x||w| over the elements whose bound is non-zero; where it is zero (e.g. a dead post-ReLU input channel)
-    every product is zero and the result must be exactly zero."""
+    """max |err| / sum|x||w| over the elements whose bound is non-zero.  Where the bound of ONE tap is zero (a dead post-ReLU
+    channel; or a channel that is non-zero only in the last plane, which tap 0 never reads) the direct kernel returns an exact
+    zero; the Winograd kernel forms the three W taps jointly from transformed data, so its zero is a cancellation of the other
+    taps' products, exact to rounding only (measured 2e-16 next to bounds of 1e-3): such elements must stay below 1e-6 of the
+    tensor's largest bound."""
     live = cond > 0
-    assert (e[~live] == 0).all()
+    assert (e[~live] <= 1e-6 * cond.max()).all(), (e[~live].max(), cond.max())
     return float((e[live] / cond[live]).max()) if live.any() else 0.0
 
 
