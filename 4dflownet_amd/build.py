@@ -38,7 +38,9 @@ def _stamp():
     for name in sorted(n for n in os.listdir(CSRC) if n.endswith((".hip", ".h"))) + ["../../include/fdn.h"]:
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(name.encode()); h.update(f.read())
-    h.update(" ".join(FLAGS).encode())
+    # the flags enter with the checkout's own path replaced: the same sources must stamp alike wherever the tree is copied
+    # (the GPU box runs a snapshot under another root; a path-dependent stamp would rebuild there on every call)
+    h.update(" ".join(f.replace(ROOT, "<root>") for f in FLAGS).encode())
     return h.hexdigest()
 
 

@@ -109,3 +109,19 @@ def test_two_ranks_racing_for_a_stale_library_build_it_once(tmp_path):
     outs = [_out(p) for p in procs]
     assert all("LOADED 7 True" in o for o in outs), outs
     assert len(_builds(pkg)) == 1, (pkg / "build" / "build.log").read_text()
+
+
+def test_stamp_does_not_depend_on_where_the_tree_lives(tmp_path):
+    """The GPU box runs a snapshot of the tree under another root: identical sources must give the identical stamp there,
+    or every call would rebuild (and no committed profile could be matched to the sources it was measured on)."""
+    stamps = []
+    for sub in ("a", "some/deeper/b"):
+        d = tmp_path / sub
+        d.mkdir(parents=True)
+        root, pkg = _scratch_tree(d)
+        out = subprocess.run([sys.executable, "-c", "import importlib,sys; sys.path.insert(0, %r); "
+                              "print(importlib.import_module('pkgcopy.build').source_stamp())" % str(root)],
+                             capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        stamps.append(out.stdout.strip())
+    assert stamps[0] == stamps[1] and len(stamps[0]) == 64
