@@ -13,7 +13,8 @@
 //   * dz: 2 transposing reads (w 0-3, 4-7) -> B operand, shared by the 9 taps.
 //   * x : per b, 3 transposing reads of the halo row (w 0-3, 4-7, 8-11); the operands of the three c taps are 16-bit
 //     funnel shifts of that 12-voxel window (c = 1: 4 x v_alignbit; c = 0, 2: register selection).
-//     11 LDS reads + 12 VALU per 9 MFMAs instead of 20 reads.
+//     11 LDS reads + 12 VALU per 9 MFMAs instead of 20 reads; the b = 2 group of an h-pair is kept as the b = 0 group of the
+//     next one (same rows, same lanes): 8.75 reads per 9 MFMAs on average.
 //   * LDS image: 128 B per voxel, the two 64-B halves swapped on rows with bit 1 set -> any 4 consecutive rows x 64 B
 //     cover all 64 banks (conflict-free transposing reads); every k-step offset is a multiple of 4 rows, so the per-lane
 //     addresses are computed once and the steps are immediates.
@@ -183,11 +184,21 @@ __global__ __launch_bounds__(256, 2) void wgrad64_bf16_kernel(Wgrad64BfArgs p) {
 
         // ---- 8 k-steps of 16 voxels: (d, h-pair), each 3 groups (b) of 3 MFMAs.  The transposing reads of group q + 1 are
         // issued before the MFMAs of group q (LDS latency is ~3 MFMA slots; hipcc on its own issues them right before use)
+        // Halo-row ring (round 3): the operands of tap b = 2 at h-pair hp (rows 2hp+2 on lanes 0-31, 2hp+3 on lanes 32-63) ARE the
+        // operands of tap b = 0 at h-pair hp+1, in the same lanes -- that group is read once and kept: 8 instead of 11 transposing
+        // reads per k-step for three of the four h-pairs of a plane (8.75 on average; (4,128^3): 1.87 -> 1.77 ms).  The loop is fully
+        // unrolled, so the slot a group lives in is a compile-time function of q (two slots suffice: a kept group is consumed twice
+        // in a row).  Also priced: forming the b = 1 group from the halves of b = 0 and b = 2 (v_permlane32_swap + select: 5 reads per
+        // k-step) -- the swap destroys both sources, the copies push the kernel from 256 VGPRs into 34 spills; not kept.
         u32x2 gq[2][3], zq[2][2];
+        auto reuse = [](int q) { return q % 3 == 0 && (q / 3) % (TH / 2) != 0; };      // b == 0 and not the first h-pair of a plane
+        auto slot = [&](int q) { int s_ = 0; for (int i = 1; i <= q; ++i) if (!reuse(i)) s_ ^= 1; return s_; };
         auto issue = [&](int q, u32x2 (&g)[3], u32x2 (&z)[2]) {       // q = (kd * 4 + hp) * 3 + b
             const int ks = q / 3, b = q % 3, kd = ks / (TH / 2), hp = ks % (TH / 2);
             const int dX = (kd * XH * XW + hp * 2 * XW) * 128;
-            g[0] = tr_read(xs + xoff[b][0] + dX); g[1] = tr_read(xs + xoff[b][1] + dX); g[2] = tr_read(xs + xoff[b][2] + dX);
+            if (!reuse(q)) {
+                g[0] = tr_read(xs + xoff[b][0] + dX); g[1] = tr_read(xs + xoff[b][1] + dX); g[2] = tr_read(xs + xoff[b][2] + dX);
+            }
             if (b == 0) {
                 const int dZ = (kd * TH * TW + hp * 2 * TW) * 128;
                 z[0] = tr_read(zs + zoff[0] + dZ); z[1] = tr_read(zs + zoff[1] + dZ);
@@ -198,9 +209,9 @@ __global__ __launch_bounds__(256, 2) void wgrad64_bf16_kernel(Wgrad64BfArgs p) {
 #pragma unroll
         for (int q = 0; q < TD * (TH / 2) * 3; ++q) {
             const int b = q % 3;
-            if (q + 1 < TD * (TH / 2) * 3) issue(q + 1, gq[(q + 1) & 1], zq[((q + 1) / 3) & 1]);
+            if (q + 1 < TD * (TH / 2) * 3) issue(q + 1, gq[slot(q + 1)], zq[((q + 1) / 3) & 1]);
             __builtin_amdgcn_sched_barrier(0);
-            const u32x2 g0 = gq[q & 1][0], g1 = gq[q & 1][1], g2 = gq[q & 1][2];
+            const u32x2 g0 = gq[slot(q)][0], g1 = gq[slot(q)][1], g2 = gq[slot(q)][2];
             if (b == 0) {
                 const u32x2 z0 = zq[(q / 3) & 1][0], z1 = zq[(q / 3) & 1][1];
                 bv = __builtin_bit_cast(bf16x8, (u32x4){z0.x, z0.y, z1.x, z1.y});
