@@ -62,6 +62,7 @@ DEBUG_SIGNATURES = {
     "fdn_debug_set_conv64_mt": (c_i, [c_i]),
     "fdn_debug_set_conv64_dbg": (c_i, [c_i]),
     "fdn_debug_set_conv64_shell_slabs": (c_i, [c_i]),
+    "fdn_debug_set_conv64_wface_direct": (c_i, [c_i]),
     "fdn_debug_set_conv64_bf16_mt": (c_i, [c_i]),
     "fdn_debug_set_conv64_bf16_dbg": (c_i, [c_i]),
     "fdn_debug_set_heads_mfma": (c_i, [c_i]),

@@ -35,6 +35,7 @@
 // test/bench hooks: compile-time constants in the product library, settable through fdn_debug_* in the test build only
 FDN_HOOK_VAR(int, fdn_conv64_force_layout, 0);   // 0 = auto, 1..6 = index into the variant table below
 FDN_HOOK_VAR(int, fdn_conv64_dbg, 0);            // ablation bits, see Conv64Args::dbg
+FDN_HOOK_VAR(int, fdn_conv64_wface_direct, 0);   // fused dgrad, Winograd path: 1 = the w faces as a separate direct-kernel launch (round 2), 0 = a region of the Winograd launch
 FDN_HOOK_VAR(int, fdn_conv64_shell_slabs, 1);    // fused dgrad: 1 = inner box + 6 shell slabs, 0 = one launch over the padded grid
 
 template <int MT, int NW, int CS>
@@ -631,18 +632,22 @@ int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, 
     // write disjoint positions, so a caller may issue them on different streams and join before the border fold.
     if (wino && fdn_conv64_wino_ok(ID, IH, IW)) {
         // ONE Winograd launch: the inner box (fused-fold epilogue) + the d and h faces of the shell restricted to the inner W
-        // range (one depth resp. height tap each: a third of the work per tile, dispatched last, they fill the tail); the two w
-        // faces -- a single W tap, nothing to transform -- over the full (d,h) range as one short launch of the direct kernel.
-        const FdnWinoBox wb[5] = {
-            {1, 1, 1, ID, IH, IW, 0, 2, 0, 2},
-            {0, 0, 1, 1, OH, IW, 2, 2, 0, 2}, {ID + 1, 0, 1, 1, OH, IW, 0, 0, 0, 2},        // d faces, full h
-            {1, 0, 1, ID, 1, IW, 0, 2, 2, 2}, {1, IH + 1, 1, ID, 1, IW, 0, 2, 0, 0}};       // h faces, d inner
+        // range (one depth resp. height tap each: a third of the work per tile, dispatched last, they fill the tail) + the pair of
+        // w faces over the full (d,h) range as a region of its own (a single W tap = one Winograd coordinate per face: K loop over
+        // xi in {0, 5}, no output transform; conv64_wino.hip).  Until round 3 the w faces were a separate launch of the direct kernel.
+        const FdnWinoBox wb[6] = {
+            {1, 1, 1, ID, IH, IW, 0, 2, 0, 2, 0},
+            {0, 0, 1, 1, OH, IW, 2, 2, 0, 2, 0}, {ID + 1, 0, 1, 1, OH, IW, 0, 0, 0, 2, 0},        // d faces, full h
+            {1, 0, 1, ID, 1, IW, 0, 2, 2, 2, 0}, {1, IH + 1, 1, ID, 1, IW, 0, 2, 0, 0, 0},       // h faces, d inner
+            {0, 0, 0, OD, OH, 4, 0, 2, 0, 2, 1}};                                                // w faces, full (d,h)
         const Box wfaces[2] = {{0, 0, 0, OD, OH, 1, 0, 2, 0, 2, 2, 2}, {0, 0, IW + 1, OD, OH, 1, 0, 2, 0, 2, 0, 0}};
-        const int first = (parts & 1) ? 0 : 1, count = (parts & 1) ? ((parts & 2) ? 5 : 1) : 4;
+        const bool wface_direct = fdn_conv64_wface_direct != 0;       // test build: the round-2 path (direct-kernel slab launch)
+        const int first = (parts & 1) ? 0 : 1;
+        const int count = ((parts & 1) ? 1 : 0) + ((parts & 2) ? (wface_direct ? 4 : 5) : 0);
         if (int rc = fdn_conv64_wino_launch_boxes(x, upack, bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, wb + first,
                                                   count, off, zero_mode, act, alpha, s))
             return rc;
-        return (parts & 2) ? launch_boxes(a, wfaces, 2, s) : FDN_OK;
+        return ((parts & 2) && wface_direct) ? launch_boxes(a, wfaces, 2, s) : FDN_OK;
     }
     if (parts == 3) return launch_boxes(a, boxes, 7, s);
     if (parts & 1) return launch_boxes(a, boxes, 1, s);
@@ -675,4 +680,5 @@ int fdn_fold_halo_border_launch(const float* s0, const float* s1, const float* s
 extern "C" int fdn_debug_set_conv64_mt(int layout) { fdn_conv64_force_layout = layout; return FDN_OK; }
 extern "C" int fdn_debug_set_conv64_dbg(int bits) { fdn_conv64_dbg = bits; return FDN_OK; }
 extern "C" int fdn_debug_set_conv64_shell_slabs(int on) { fdn_conv64_shell_slabs = on; return FDN_OK; }
+extern "C" int fdn_debug_set_conv64_wface_direct(int on) { fdn_conv64_wface_direct = on; return FDN_OK; }
 #endif

@@ -39,9 +39,16 @@ namespace {
 //   forward     : 1 region, all taps.
 //   fused dgrad : the inner D x H x W box of the padded grid with all taps + the two d faces (1 depth tap) and the two h faces
 //                 (1 height tap) of the shell, each W-inner: they cost a third of an inner tile, are dispatched last and fill
-//                 the launch's tail.  (The two w faces have a single W tap -- nothing to transform -- and stay on the direct kernel.)
+//                 the launch's tail.
+//   w faces     : (round 3) the two w faces of the shell have a single W tap each, and in the Winograd domain that tap is ONE
+//                 coordinate: the left face (padded w = 0) needs g[2] = U_5, the right face (w = OW-1) needs g[0] = 4 U_0.  A
+//                 w-face region therefore reuses the staging code unchanged -- a "group" is a (d,h) position, its six loads are
+//                 x[IW-1], four out-of-range rows, x[0], so that B^T x gives V_0 = 4 x[IW-1], V_5 = x[0], V_1..4 = 0 -- runs
+//                 the K loop over xi in {0, 5} only (a third of a tile's MFMAs), and stores M_5 / M_0 without an output
+//                 transform.  It replaces the separate direct-kernel launch per dgrad (24 us avg, 0.72 ms per cfg2 step).
 struct WinoRegion {
     int first_block;
+    int wface;                            // 1 = the w-face pair (see above)
     int obd, obh, obw, ebd, ebh, ebw;
     int ta0, ta1, tb0, tb1;
     int td, th, tg, ntd, nth, ntg;        // tile in (d, h, groups) and tile counts
@@ -65,7 +72,7 @@ struct WinoArgs {
     int dbg;                // ablation bits (test build only): 1 = weight stream stride 0, 4 = no staging, 8 = no epilogue,
                             // 16 = no transform arithmetic, 32 = epilogue arithmetic without the stores, 128 = no XCD remap, 256 = plan the shell faces like stand-alone launches
     int nreg;
-    WinoRegion reg[5];
+    WinoRegion reg[6];
 };
 
 FDN_HOOK_VAR(int, fdn_conv64_wino_dbg, 0);
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void conv64_wino_kernel(WinoArgs p) {
             const int pd = p0d + md, ph = p0h + mh, pw = p0w + 4 * (r2 - mh * R.tg);
             if (pd < R.obd + R.ebd && ph < R.obh + R.ebh && pw < R.obw + R.ebw) {
                 g = ((n * p.OD + pd) * p.OH + ph) * p.OW + pw;
-                if (p.fout) {
+                if (p.fout && !(GEN && R.wface)) {
                     const int id = pd - 1, ih = ph - 1;
                     iw0 = pw - 1;
                     if (id >= 1 && id <= p.ID - 2 && ih >= 1 && ih <= p.IH - 2) gf = ((n * p.ID + id) * p.IH + ih) * p.IW + iw0;
@@ -194,7 +201,8 @@ __global__ __launch_bounds__(256, 2) void conv64_wino_kernel(WinoArgs p) {
         for (int nn = 0; nn < 6; ++nn) {
             int qw = qw0 + nn;
             bool ok = okl;
-            if (p.zero_mode) ok = ok && (unsigned)qw < (unsigned)p.IW;
+            if (GEN && R.wface) { qw = nn == 0 ? p.IW - 1 : 0; ok = ok && (nn == 0 || nn == 5); }     // V_0 = 4 x[IW-1], V_5 = x[0]
+            else if (p.zero_mode) ok = ok && (unsigned)qw < (unsigned)p.IW;
             else qw = min(max(qw, 0), p.IW - 1);
             soff[u][nn] = ok ? (unsigned)(lbase + qw) * 256u + (unsigned)(chunk * 16) : 0xffffffffu;
         }
@@ -217,6 +225,77 @@ __global__ __launch_bounds__(256, 2) void conv64_wino_kernel(WinoArgs p) {
     auto lda = [&](int slot, int tapb, int jj) {             // tapb: byte offset of the (a,b) tap's line
         A[slot] = *(const f32x4*)(smem + abase + tapb + (jj / KG) * planeb + (jj % KG) * 32);
     };
+
+    if (GEN && R.wface) {
+        // ---- w-face tile (see WinoRegion): its own slice loop, so that nothing of the main path's fragment rings is live here.
+        // Staging: two loads per item (x[IW-1] -> plane 0 scaled by 4, x[0] -> plane 5), planes 1..4 are never read.
+        // K loop: 9 (kd,kh) taps x xi in {0, 5} x KG k-groups = a third of a tile's MFMAs; weight fragments are refilled in place
+        // for the next tap three steps (12 MFMAs) ahead, voxel fragments one step ahead.
+        constexpr int NE = 2 * KG;
+        auto jj_of = [](int e) { return (e < KG ? 0 : 5) * KG + (e % KG); };
+#pragma unroll 1
+        for (int sl = 0; sl < CS; ++sl) {
+            if (sl) __syncthreads();
+            {
+                const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*)(p.x + in_n * 64 + sl * (64 / CS)), 0, sample_bytes - sl * (256 / CS), 0x00020000);
+                f32x4 xr[UA], xl[UA];
+#pragma unroll
+                for (int u = 0; u < UA; ++u) {
+                    if (u * 256 >= R.items) break;
+                    xr[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, soff[u][0], 0, 0));
+                    xl[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, soff[u][5], 0, 0));
+                }
+#pragma unroll
+                for (int u = 0; u < UA; ++u) {
+                    if (u * 256 >= R.items) break;
+                    if (vrow[u] < 0) continue;
+                    *(f32x4*)(smem + vrow[u]) = 4.f * xr[u];                     // V_0 = 4 x0 - 5 x2 + x4 with x2 = x4 = 0
+                    *(f32x4*)(smem + vrow[u] + 5 * planeb) = xl[u];              // V_5 = 4 x1 - 5 x3 + x5 with x1 = x3 = 0
+                }
+            }
+            __syncthreads();
+            f32x4 Bw[NE], Aw[2];
+            auto ldbw = [&](int e, int tap) {
+                Bw[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, wsoff(sl, tap, jj_of(e)), 0));
+            };
+            auto ldaw = [&](int slot, int tapb, int e) {
+                Aw[slot] = *(const f32x4*)(smem + abase + tapb + (jj_of(e) / KG) * planeb + (jj_of(e) % KG) * 32);
+            };
+#pragma unroll
+            for (int e = 0; e < NE; ++e) ldbw(e, 0);
+            ldaw(0, 0, 0);
+#pragma unroll 1
+            for (int tap9 = 0; tap9 < 9; ++tap9) {
+                const int tn = tap9 < 8 ? tap9 + 1 : 8;          // the last tap reloads itself (harmless)
+                const int ta_ = tap9 / 3, tn_a = tn / 3;
+                const int tapb = (ta_ * R.hh + (tap9 - 3 * ta_)) * R.tg * LROW;
+                const int tapb_n = (tn_a * R.hh + (tn - 3 * tn_a)) * R.tg * LROW;
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    if (e + 1 < NE) ldaw((e + 1) & 1, tapb, e + 1);
+                    else ldaw((e + 1) & 1, tapb_n, 0);
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        if (e < KG) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Bw[e][s4], Aw[e & 1][s4], acc[0], 0, 0, 0);
+                        else acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(Bw[e][s4], Aw[e & 1][s4], acc[5], 0, 0, 0);
+                    }
+                    ldbw(e, tn);
+                }
+            }
+        }
+        // padded scratch only (shell positions are finished by the border fold): left face at w = 0, right face at w = OW-1
+        const int g0w = mtab[wave_m * 32 + li];
+        if (g0w < 0) return;
+        float* yl = p.y + (size_t)g0w * 64 + cofs;
+        float* yr = yl + (size_t)(p.OW - 1) * 64;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            *(f32x4*)(yl + q * 4) = (f32x4){acc[5][q * 4], acc[5][q * 4 + 1], acc[5][q * 4 + 2], acc[5][q * 4 + 3]};
+            *(f32x4*)(yr + q * 4) = (f32x4){acc[0][q * 4], acc[0][q * 4 + 1], acc[0][q * 4 + 2], acc[0][q * 4 + 3]};
+        }
+        return;
+    }
 
 #pragma unroll 1
     for (int sl = 0; sl < CS; ++sl) {
@@ -395,7 +474,7 @@ WinoPlan wino_plan(int N, const FdnWinoBox& bx, bool tail) {
                 const int ltg = (td + da) * (th + db) * tg;
                 if (ltg > kWinoMaxLtg || ltg * (64 / kWinoCS / 4) > kWinoUA * 256) continue;
                 const double tiles = (double)N * ((bx.ed + td - 1) / td) * ((bx.eh + th - 1) / th) * ((ebg + tg - 1) / tg);
-                const double per_tile = 64.0 * tapfrac + (tail ? 0.04 : 0.12) * ltg + 4.0;    // tail tiles: 0.04 / 0.12 / 0.30 measured 0.859 / 0.863 / 0.865 ms at (8,48^3)
+                const double per_tile = 64.0 * tapfrac * (bx.wface ? 1.0 / 3 : 1.0) + (tail ? 0.04 : 0.12) * ltg + 4.0;    // tail tiles: 0.04 / 0.12 / 0.30 measured 0.859 / 0.863 / 0.865 ms at (8,48^3)
                 const double rounds = 0.9 * (double)((long long)((tiles + 255) / 256)) + 0.1 * tiles / 256.0;
                 const double c = tail ? tiles * per_tile : rounds * per_tile;
                 if (c < best.cost) best = {td, th, tg, c};
@@ -413,7 +492,7 @@ int fdn_conv64_wino_launch_boxes(const float* x, const float* upack, const float
                                  int OW, const FdnWinoBox* boxes, int nbox, int off, int zero_mode, int act, float alpha,
                                  hipStream_t s) {
     FDN_REQUIRE((long long)ID * IH * IW < (1ll << 24), "conv64 (winograd): a sample of %dx%dx%d voxels exceeds the 32-bit row addressing", ID, IH, IW);
-    FDN_REQUIRE(nbox >= 1 && nbox <= 5, "conv64 (winograd): %d regions", nbox);
+    FDN_REQUIRE(nbox >= 1 && nbox <= 6, "conv64 (winograd): %d regions", nbox);
     constexpr int CS = kWinoCS, LROW = 256 / CS + 16, CH = 256 / CS / 16;
     WinoArgs a;
     a.x = x; a.up = upack; a.bias = bias; a.res = residual; a.y = y; a.fskip = fskip; a.fy = fy; a.fout = fout;
@@ -426,7 +505,9 @@ int fdn_conv64_wino_launch_boxes(const float* x, const float* upack, const float
         const FdnWinoBox& bx = boxes[i];
         if (bx.ed <= 0 || bx.eh <= 0 || bx.ew <= 0) continue;
         FDN_REQUIRE(fdn_conv64_wino_ok(bx.ed, bx.eh, bx.ew), "conv64 (winograd): W extent %d is not a multiple of 4", bx.ew);
-        WinoPlan pl = wino_plan(N, bx, false);
+        FDN_REQUIRE(!bx.wface || (zero_mode && fout && bx.ew == 4 && bx.ow == 0 && bx.ta0 == 0 && bx.ta1 == 2 && bx.tb0 == 0 && bx.tb1 == 2),
+                    "conv64 (winograd): a w-face region belongs to a fused dgrad launch");
+        WinoPlan pl = wino_plan(N, bx, bx.wface != 0);
         if (fdn_conv64_wino_tile && a.nreg == 0) {
             pl.td = fdn_conv64_wino_tile & 255; pl.th = (fdn_conv64_wino_tile >> 8) & 255; pl.tg = (fdn_conv64_wino_tile >> 16) & 255;
         }
@@ -436,6 +517,7 @@ int fdn_conv64_wino_launch_boxes(const float* x, const float* upack, const float
             pl = wino_plan(N, bx, true);
         WinoRegion& r = a.reg[a.nreg++];
         r.first_block = (int)blocks;
+        r.wface = bx.wface;
         r.obd = bx.od; r.obh = bx.oh; r.obw = bx.ow; r.ebd = bx.ed; r.ebh = bx.eh; r.ebw = bx.ew;
         r.ta0 = bx.ta0; r.ta1 = bx.ta1; r.tb0 = bx.tb0; r.tb1 = bx.tb1;
         r.td = pl.td; r.th = pl.th; r.tg = pl.tg;

@@ -139,7 +139,9 @@ int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, 
                          int OW, int off, int zero_mode, int act, float alpha, hipStream_t s, int parts = 3,
                          int algo = FDN_ALGO_AUTO);
 // Winograd F(4,3)-along-W variant of the 64->64 conv (conv64_wino.hip): one output box with all 27 taps
-struct FdnWinoBox { int od, oh, ow, ed, eh, ew, ta0, ta1, tb0, tb1; };   // output box + its non-zero (kd, kh) tap ranges
+// output box + its non-zero (kd, kh) tap ranges.  wface = 1: the pair of w faces of a fused dgrad's shell (box = the (d,h) range of the
+// padded grid, ow = 0, ew = 4: one "group" per (d,h) position; see conv64_wino.hip)
+struct FdnWinoBox { int od, oh, ow, ed, eh, ew, ta0, ta1, tb0, tb1, wface; };
 bool fdn_conv64_wino_ok(int ebd, int ebh, int ebw);
 int fdn_conv64_wino_launch_boxes(const float* x, const float* upack, const float* bias, const float* residual, float* y,
                                  const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,

@@ -93,9 +93,14 @@ def test_conv64_dgrad_and_fold(ops, shape):
 
 
 @pytest.mark.parametrize("shape,layout", [(sh, lo) for sh in SHAPES + [(1, 1, 1, 1), (1, 2, 3, 1)] for lo in (0, 1, 2, 3, 4, 5, 6)] +
-                         [(sh, lo) for sh in WINO_SHAPES for lo in (0, 7, 5)])
+                         [(sh, lo) for sh in WINO_SHAPES for lo in (0, 7, 5, 8)])
 def test_conv64_dgrad_fused_fold(ops, fdn, shape, layout):
-    """dgrad with the interior fold in the conv epilogue + border kernel == oracle dgrad (+ skip, * act')."""
+    """dgrad with the interior fold in the conv epilogue + border kernel == oracle dgrad (+ skip, * act').
+    layout 0 = product library (Winograd launch incl. the w-face region), 7 = forced Winograd (test build), 8 = Winograd with the
+    w faces on the separate direct-kernel launch (the round-2 path, kept as a test-build switch), 1..6 = direct layouts."""
+    wface_direct = layout == 8
+    if wface_direct:
+        layout = 7
     rng = np.random.default_rng(6)
     N, D, H, W = shape
     dz = rng.normal(size=(N, D, H, W, 64)).astype(np.float32)
@@ -107,6 +112,7 @@ def test_conv64_dgrad_fused_fold(ops, fdn, shape, layout):
     with variant_lib(fdn, layout) as lib:          # layout == 0: the product library (planner, shell slabs)
         if lib is not None:
             lib.fdn_debug_set_conv64_mt(layout)
+            lib.fdn_debug_set_conv64_wface_direct(1 if wface_direct else 0)
             # odd layouts also exercise the single padded-grid launch; the default is inner box + six 9-tap shell slabs
             lib.fdn_debug_set_conv64_shell_slabs(0 if layout in (1, 3, 5) else 1)
         try:
@@ -127,6 +133,7 @@ def test_conv64_dgrad_fused_fold(ops, fdn, shape, layout):
             if lib is not None:
                 lib.fdn_debug_set_conv64_mt(0)
                 lib.fdn_debug_set_conv64_shell_slabs(1)
+                lib.fdn_debug_set_conv64_wface_direct(0)
 
 
 @pytest.mark.parametrize("shape", SHAPES + [(2, 16, 16, 16), (1, 1, 1, 1), (1, 2, 3, 1), (1, 3, 20, 33), (5, 9, 8, 24), (2, 24, 24, 24),
