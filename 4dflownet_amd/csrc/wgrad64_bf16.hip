@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void wgrad64_bf16_kernel(Wgrad64BfArgs p) {
         // issued before the MFMAs of group q (LDS latency is ~3 MFMA slots; hipcc on its own issues them right before use)
         // Halo-row ring (round 3): the operands of tap b = 2 at h-pair hp (rows 2hp+2 on lanes 0-31, 2hp+3 on lanes 32-63) ARE the
         // operands of tap b = 0 at h-pair hp+1, in the same lanes -- that group is read once and kept: 8 instead of 11 transposing
-        // reads per k-step for three of the four h-pairs of a plane (8.75 on average; (4,128^3): 1.87 -> 1.77 ms).  The loop is fully
+        // reads per k-step for three of the four h-pairs of a plane (8.75 on average; A/B on one box at (4,128^3): 1.755 -> 1.72 ms).  The loop is fully
         // unrolled, so the slot a group lives in is a compile-time function of q (two slots suffice: a kept group is consumed twice
         // in a row).  Also priced: forming the b = 1 group from the halves of b = 0 and b = 2 (v_permlane32_swap + select: 5 reads per
         // k-step) -- the swap destroys both sources, the copies push the kernel from 256 VGPRs into 34 spills; not kept.
