@@ -562,8 +562,18 @@ template <typename T> int fdn_conv_cin3_fwd_mfma_launch(const T* x, const float*
 template <typename T> int fdn_wgrad_cin3_mfma_launch(const T* x, const T* dz, float* partial, int nblocks, int N, int D, int H,
                                                      int W, hipStream_t s);
 FDN_HOOK_VAR(int, fdn_cin3_use_mfma, 1);
+// conv1x1_mfma.hip: the 1x1x1 (64+64) -> 64 layer and its gradients as MFMA GEMMs (default; the VALU kernels stay selectable in the
+// test build: fdn_debug_set_conv1x1_mfma(0))
+template <typename T> int fdn_conv1x1_fwd_mfma_launch(const T* xa, const T* xb, const float* w, const float* bias, T* y, int64_t nvox,
+                                                      int act, float alpha, hipStream_t s);
+template <typename T> int fdn_conv1x1_dgrad_mfma_launch(const T* dz, const float* w, const T* ya, const T* yb, T* dxa, T* dxb,
+                                                        int64_t nvox, hipStream_t s);
+template <typename T> int fdn_wgrad_1x1_mfma_launch(const T* xa, const T* xb, const T* dz, float* partial, int nblocks, int64_t nvox,
+                                                    hipStream_t s);
+FDN_HOOK_VAR(int, fdn_conv1x1_use_mfma, 1);
 #ifdef FDN_TEST_HOOKS
 extern "C" int fdn_debug_set_cin3_mfma(int on) { fdn_cin3_use_mfma = on; return FDN_OK; }
+extern "C" int fdn_debug_set_conv1x1_mfma(int on) { fdn_conv1x1_use_mfma = on; return FDN_OK; }
 #endif
 
 template <typename T>
@@ -606,6 +616,7 @@ int fdn_conv_cout1_fwd_launch(const T* x, const float* w, const float* bias, flo
 template <typename T>
 int fdn_conv1x1_fwd_launch(const T* xa, const T* xb, const float* w, const float* bias, T* y, int64_t nvox, int act,
                            float alpha, hipStream_t s) {
+    if (fdn_conv1x1_use_mfma) return fdn_conv1x1_fwd_mfma_launch<T>(xa, xb, w, bias, y, nvox, act, alpha, s);
     hipLaunchKernelGGL(conv1x1_fwd_kernel<T>, dim3(nblocks_for(nvox, 64, 2048)), dim3(256), 0, s, xa, xb, w, bias, y, nvox,
                        act, alpha);
     FDN_CHECK_LAUNCH("conv1x1_fwd_kernel");
@@ -615,6 +626,7 @@ int fdn_conv1x1_fwd_launch(const T* xa, const T* xb, const float* w, const float
 template <typename T>
 int fdn_conv1x1_dgrad_launch(const T* dz, const float* w, const T* ya, const T* yb, T* dxa, T* dxb, int64_t nvox,
                              hipStream_t s) {
+    if (fdn_conv1x1_use_mfma) return fdn_conv1x1_dgrad_mfma_launch<T>(dz, w, ya, yb, dxa, dxb, nvox, s);
     hipLaunchKernelGGL(conv1x1_dgrad_kernel<T>, dim3(nblocks_for(nvox, 32, 2048)), dim3(256), 0, s, dz, w, ya, yb, dxa, dxb,
                        nvox);
     FDN_CHECK_LAUNCH("conv1x1_dgrad_kernel");
@@ -694,6 +706,13 @@ int fdn_conv_cout1_dgrad_folded_launch(const float* dz, const float* w, const T*
 
 template <typename T>
 int fdn_wgrad_1x1_launch(const T* xa, const T* xb, const T* dz, float* dw, void* ws, size_t, int64_t nvox, hipStream_t s) {
+    if (fdn_conv1x1_use_mfma) {
+        // one workgroup per CU (128 KB of LDS for the cross-wave sum); >= 64 voxel pairs per wave
+        int nbm = (int)((nvox / 2 + 255) / 256);
+        nbm = nbm < 1 ? 1 : (nbm > 256 ? 256 : nbm);
+        if (int rc = fdn_wgrad_1x1_mfma_launch<T>(xa, xb, dz, (float*)ws, nbm, nvox, s)) return rc;
+        return reduce_partials((const float*)ws, dw, nbm, 128 * 64, s);
+    }
     const int nb = nblocks_for(nvox, 32 * 4, kSmallBlocks);
     hipLaunchKernelGGL(wgrad_1x1_kernel<T>, dim3(nb), dim3(256), 0, s, xa, xb, dz, (float*)ws, nvox);
     FDN_CHECK_LAUNCH("wgrad_1x1_kernel");
