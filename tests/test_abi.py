@@ -101,3 +101,32 @@ def test_oracle_is_test_infrastructure_only():
                        for n in ast.walk(fn))
             if uses:
                 assert fn.name in funcs or fn.name.startswith("_cpu"), (fname, fn.name)
+
+
+def test_round3_profiles_carry_the_sources_they_were_measured_on():
+    """profiles/r3_*: every file names the commit and the library source stamp it was measured on.  A stamp
+    that differs from the tree's is reported as a warning, not a failure: it means kernels changed after the last profile run."""
+    import glob
+    import json
+    import warnings
+    from importlib import import_module
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r3_*")))
+    if not files:
+        pytest.skip("no round-3 profiles collected yet")
+    stamp = import_module("4dflownet_amd.build").source_stamp()
+    stale = []
+    for f in files:
+        if f.endswith(".json"):
+            meta = json.load(open(f)).get("_meta")
+            assert meta and re.fullmatch(r"[0-9a-f]{40}(\+dirty)?", meta["commit"]) and re.fullmatch(r"[0-9a-f]{64}", meta["lib_source_stamp"]), f
+            got = meta["lib_source_stamp"]
+        else:
+            first = open(f).readline()
+            m = re.match(r"# commit ([0-9a-f]{40}(?:\+dirty)?) lib_source_stamp ([0-9a-f]{64})", first)
+            assert m, (f, first)
+            got = m.group(2)
+        if got != stamp:
+            stale.append(os.path.basename(f))
+    if stale:
+        warnings.warn("profiles measured on other kernel sources than the tree's (re-run tools/profile_round.sh): %s" % ", ".join(stale))
