@@ -26,6 +26,10 @@ struct Conv64Region {
     // rows), its two 16-B chunks swapped when ((zh >> swz_hs) + ((zw >> 2) & swz_wm)) & 1.
     int hs, lrows;
     int swz_hs, swz_wm;
+    // bf16 kernel, general variant only: 1 = the region's first two axes are (h, d) instead of (d, h) -- every d / h field above is
+    // then in KERNEL order (ob"d" = first h, t"a" = height taps, ...).  Used for the two d faces of a fused dgrad's shell: their
+    // single tap is the depth tap, and the kernel slides its 8 accumulator planes along the first axis, which must have 3 taps.
+    int swap_dh;
 };
 
 struct Conv64Args {

@@ -126,6 +126,7 @@ __global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
                 const int f = ((zh >> R.swz_hs) + ((zw >> 2) & R.swz_wm)) & 1;
                 lo[u] = ((zd * R.hh + zh) * R.hs + zw) * ROWB + ((chunk ^ f) << 4);
                 int qd = q0d + zd, qh = q0h + zh, qw = q0w + zw;
+                if (GEN && R.swap_dh) { const int t_ = qd; qd = qh; qh = t_; }           // kernel axes (h, d) -> real (d, h)
                 const bool inside = (unsigned)qd < (unsigned)p.ID && (unsigned)qh < (unsigned)p.IH && (unsigned)qw < (unsigned)p.IW;
                 qd = min(max(qd, 0), p.ID - 1);
                 qh = min(max(qh, 0), p.IH - 1);
@@ -160,8 +161,12 @@ __global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
     auto load_w = [&](u32x4 (&dst)[3], int sl, int tb, int tc) {
         const int bc = tb * 3 + tc;
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
-            if (!GEN || a < na) dst[a] = wbase[((((sl & 3) * 9 + bc) * 3 + ta0 + a) * 128) * wstride];
+        for (int a = 0; a < 3; ++a) {
+            if (GEN && a >= na) continue;
+            // stream index = ((slice * 9 + kh * 3 + kw) * 3 + kd); a swapped region slides along h: its "depth" tap is kh, its tb is kd
+            const int idx = (GEN && R.swap_dh) ? (((sl & 3) * 9 + (ta0 + a) * 3 + tc) * 3 + tb) : (((sl & 3) * 9 + bc) * 3 + ta0 + a);
+            dst[a] = wbase[(idx * 128) * wstride];
+        }
     };
     // step `it` of a slice -> tap (tb0 + it / nc, tc0 + it % nc); nb * nc is 9 or 3
     load_w(wq[0], 0, tb0, tc0);
@@ -174,8 +179,10 @@ __global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
         const int md = m >> 6, pr = m & 63;
         if (md < R.td && pr < prn) {
             const int mh = fdn_div20(pr, R.mg_tw);
-            const int pd = p0d + md, ph = p0h + mh, pw = p0w + (pr - mh * R.tw);
+            int pd = p0d + md, ph = p0h + mh;
+            const int pw = p0w + (pr - mh * R.tw);
             if (pd < R.obd + R.ebd && ph < R.obh + R.ebh && pw < R.obw + R.ebw) {
+                if (GEN && R.swap_dh) { const int t_ = pd; pd = ph; ph = t_; }            // kernel axes (h, d) -> real (d, h)
                 g = ((n * p.OD + pd) * p.OH + ph) * p.OW + pw;
                 if (p.fout) {
                     const int id = pd - 1, ih = ph - 1, iw = pw - 1;
@@ -462,11 +469,15 @@ extern "C" int fdn_pack_conv64_weights_bf16(const float* w, uint16_t* wp_fwd, ui
 // --------------------------------------------------------------------------------------------
 namespace {
 
-struct Box { int od, oh, ow, ed, eh, ew, ta0, ta1, tb0, tb1, tc0, tc1; };
+// swap = 1: the box is given in KERNEL order (first axis = h, second = d, taps likewise), see Conv64Region::swap_dh
+struct Box { int od, oh, ow, ed, eh, ew, ta0, ta1, tb0, tb1, tc0, tc1, swap; };
 struct Plan { FdnTile t; double cost; };
 
 // tile = td planes (<= MT) of th x tw (<= 64) positions; a tile's MFMA time does not depend on how full the plane block is
-int lds_hs(int hw) { int hs = hw; while ((hs & 7) != 4) ++hs; return hs; }
+// rows of tw + halo positions are padded to hs = 4 mod 8 (conflict-free b128 reads of 2-D position blocks); a column of positions (hw = 1:
+// the w faces of a dgrad shell) is dense as it is -- consecutive positions are consecutive 32-B rows -- and padded 4x it would cap the tile
+// at 2 planes
+int lds_hs(int hw) { if (hw == 1) return 1; int hs = hw; while ((hs & 7) != 4) ++hs; return hs; }
 
 // tail: one of several regions sharing a launch (the six shell slabs of a fused dgrad): total work counts, not rounds over a chip of its own
 Plan best_plan(int N, const Box& bx, int mt, int max_rows, int max_lrows, bool tail = false) {
@@ -543,6 +554,7 @@ int launch_bf16(Conv64BfArgs& a, const Box* boxes, int nbox, hipStream_t s) {
         // a column (tw <= 2) -> by h quad
         r.swz_hs = t.tw <= 2 ? 2 : 0;
         r.swz_wm = t.tw >= 16 ? 1 : 0;
+        r.swap_dh = bx.swap;
 #ifdef FDN_TEST_HOOKS                                    // the planner's choices, test build only (the product library reads no environment)
         if (getenv("FDN_DEBUG_PLAN"))
             fprintf(stderr, "conv64_bf16<MT=%d> box %d: out (%d,%d,%d)+(%d,%d,%d) taps a[%d,%d] b[%d,%d] c[%d,%d] tile %dx%dx%d x(%d,%d,%d) rows %d lrows %d hs %d %s\n",
@@ -578,14 +590,17 @@ int fdn_conv64_bf16_launch(const uint16_t* x, const uint16_t* wpack, const float
     a.fskip = fskip; a.fy = fy; a.fout = fout;
     a.N = N; a.ID = ID; a.IH = IH; a.IW = IW; a.OD = OD; a.OH = OH; a.OW = OW;
     a.off = off; a.zero_mode = zero_mode; a.act = act; a.alpha = alpha; a.dbg = fdn_conv64bf_dbg;
-    const Box full{0, 0, 0, OD, OH, OW, 0, 2, 0, 2, 0, 2};
+    const Box full{0, 0, 0, OD, OH, OW, 0, 2, 0, 2, 0, 2, 0};
     if (!(fout && zero_mode && off == -1)) return launch_boxes(a, &full, 1, s);
     // fused dgrad on the padded grid: inner box (27 taps) + six 1-voxel shell slabs (9 taps), as in conv64_mfma.hip
+    // The d faces (one depth tap) are handed over in kernel order (h, d): the kernel slides its accumulator planes along the first
+    // axis, which needs the 3-tap axis there -- planes = 8 h rows x (1 x <=64 w) positions instead of 1 plane x 60 positions per tile
+    // (2288 -> 408 tiles at (4,128^3)).  The w faces stage a dense column of positions (lds_hs): 8 planes per tile instead of 2.
     const Box boxes[7] = {
-        {1, 1, 1, ID, IH, IW, 0, 2, 0, 2, 0, 2},
-        {0, 0, 0, 1, OH, OW, 2, 2, 0, 2, 0, 2},       {ID + 1, 0, 0, 1, OH, OW, 0, 0, 0, 2, 0, 2},
-        {1, 0, 0, ID, 1, OW, 0, 2, 2, 2, 0, 2},       {1, IH + 1, 0, ID, 1, OW, 0, 2, 0, 0, 0, 2},
-        {1, 1, 0, ID, IH, 1, 0, 2, 0, 2, 2, 2},       {1, 1, IW + 1, ID, IH, 1, 0, 2, 0, 2, 0, 0}};
+        {1, 1, 1, ID, IH, IW, 0, 2, 0, 2, 0, 2, 0},
+        {0, 0, 0, OH, 1, OW, 0, 2, 2, 2, 0, 2, 1},    {0, ID + 1, 0, OH, 1, OW, 0, 2, 0, 0, 0, 2, 1},     // d faces: (h, d = 0 | ID+1, w)
+        {1, 0, 0, ID, 1, OW, 0, 2, 2, 2, 0, 2, 0},    {1, IH + 1, 0, ID, 1, OW, 0, 2, 0, 0, 0, 2, 0},
+        {1, 1, 0, ID, IH, 1, 0, 2, 0, 2, 2, 2, 0},    {1, 1, IW + 1, ID, IH, 1, 0, 2, 0, 2, 0, 0, 0}};
     return launch_boxes(a, boxes, 7, s);
 }
 
