@@ -80,7 +80,8 @@ int fdn_pack_conv64_weights_batch(const float* w_base, const int64_t* w_offsets,
  * (3,64,3), (64,1,3), (128,64,1) [x = first 64 input channels, x2 = last 64: the concat at
  * SR4DFlowNet.py:23 is never materialised].  x2, wpack, bias, residual may be NULL where unused.
  * Output rows are written at y[voxel*ldy + y_coff + c] (ldy=Cout,y_coff=0 for a dense tensor;
- * the three 64->1 heads write straight into the (N,V,3) prediction: SR4DFlowNet.py:49). */
+ * the three 64->1 heads write straight into the (N,V,3) prediction: SR4DFlowNet.py:49).
+ * algo: FDN_ALGO_AUTO | FDN_ALGO_DIRECT, consulted by the (64,64,3) path only (see above); here and in the entry points below. */
 int fdn_conv3d_fwd(const float* x, const float* x2, const float* w, const float* wpack, const float* bias,
                    const float* residual, float* y, int N, int D, int H, int W, int Cin, int Cout, int K,
                    int ldy, int y_coff, int act, float alpha, int algo, void* stream);
