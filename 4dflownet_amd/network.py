@@ -8,6 +8,7 @@ Parameters live in ONE flat fp32 device buffer in Keras trainable_variables orde
 creation order conv3d, conv3d_1, ... conv3d_35), gradients in a second flat buffer of the same layout, so the
 data-parallel all-reduce and the Adam step are one call each."""
 import math
+import os
 
 import numpy as np
 import torch
@@ -137,7 +138,6 @@ class FlowNetModel:
 
     def set_conv_algo(self, conv_algo=None):
         """See __init__.  Takes effect from the next forward()."""
-        import os
         if conv_algo is None:
             conv_algo = os.environ.get("FDN_CONV_ALGO", "auto")
         names = {"auto": ops.ALGO_AUTO, "winograd": ops.ALGO_AUTO, "direct": ops.ALGO_DIRECT}
