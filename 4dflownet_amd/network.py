@@ -45,6 +45,25 @@ def layer_specs(low_resblock=8, hi_resblock=4):
     return specs
 
 
+def keras_layer_order(low_resblock=8, hi_resblock=4):
+    """Indices (into layer_specs) of the conv layers in the order tf.keras lists them in `model.layers` -- and hence their
+    variables in `model.trainable_variables` / `optimizer.get_weights()` (TrainerController.py:223,347-394).
+
+    A functional Keras model sorts its layers by depth from the output, deepest first, and within one depth by the order
+    in which a depth-first walk from the output reaches them [TF 2.x `Network._map_graph_network` / `_build_map`; restated from
+    the published algorithm, TensorFlow is absent here].  Only layers at EQUAL depth can change places relative to creation
+    order, and the graph of SR4DFlowNet.py:7-51 has two such groups:
+      * the pc and phase branches -- the walk enters `concatenate([phase, pc])` (:23) through `phase` first, so at each depth
+        the phase conv precedes the pc conv: conv3d_2, conv3d, conv3d_3, conv3d_1;
+      * the three heads -- `concatenate([u_path, v_path, w_path])` (:49) is entered through u first: the three 64->64 convs
+        (conv3d_30, _32, _34 at cfg2), then the three 64->1 convs (conv3d_31, _33, _35).
+    tests/golden/make_golden_tf.py stores the variable names a real TensorFlow produces; tests/test_tf_golden.py checks this
+    function against them when that file exists."""
+    n_trunk = 6 + 2 * (low_resblock + hi_resblock)
+    h = n_trunk
+    return [2, 0, 3, 1] + list(range(4, n_trunk)) + [h, h + 2, h + 4, h + 1, h + 3, h + 5]
+
+
 class _Layer:
     __slots__ = ("name", "k", "cin", "cout", "w", "b", "gw", "gb", "wp_f", "wp_d", "w_off", "b_off")
 
@@ -183,6 +202,18 @@ class FlowNetModel:
             out.append(L.w)
             if L.b is not None:
                 out.append(L.b)
+        return out
+
+    def keras_variable_order(self):
+        """Positions (into self.trainable_variables) in Keras `trainable_variables` order: see keras_layer_order."""
+        first = {}
+        k = 0
+        for i, L in enumerate(self.layers):
+            first[i] = (k, 2 if L.b is not None else 1)
+            k += first[i][1]
+        out = []
+        for i in keras_layer_order(self.low_resblock, self.hi_resblock):
+            out.extend(range(first[i][0], first[i][0] + first[i][1]))
         return out
 
     def get_weights(self):

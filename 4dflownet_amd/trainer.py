@@ -319,38 +319,44 @@ class TrainerController:
     def save_best_model(self):
         """TrainerController.py:347-363: '<dir>/<name>-best.h5' + optimizer.pkl = [iterations, m..., v...].
 
-        ORDER of the m / v arrays: layer CREATION order (conv3d, conv3d_1, ... kernel then bias), the order of this
-        model's trainable_variables.  Keras writes optimizer.weights in `model.trainable_variables` order, which for a
-        functional model is its depth-sorted layer list: the parallel pc / phase branches and the three heads interleave
-        there ([TF], unverifiable here: TensorFlow is absent).  Several of those layers share a shape, so a pickle written
-        by the reference cannot be told apart from ours by shapes alone: optimizer.pkl is a restart file for THIS
-        implementation, not an interchange format (the .h5 weights, keyed by layer name, are)."""
+        ORDER of the m / v arrays: Keras writes `optimizer.get_weights()`, whose slots follow `model.trainable_variables`, i.e. the
+        functional model's depth-sorted layer list -- NOT creation order: the phase convs precede the pc convs of equal depth and the
+        three heads interleave (network.keras_layer_order).  The pickle is written (and read back by restore_model) in that order, so
+        a restart file can travel between the reference and this implementation.  [TF]: the order is restated from Keras' published
+        graph-sorting algorithm, TensorFlow is absent here; tests/test_tf_golden.py checks it against real variable names the day
+        tests/golden/tf_golden.npz exists.  Several layers share a shape, so a wrong order cannot be detected from shapes alone."""
         self.model.save('%s-best.h5' % self.model_path)
         tv = self.model.trainable_variables
         sizes = [t.numel() for t in tv]
         shapes = [tuple(t.shape) for t in tv]
         m = [a.reshape(s) for a, s in zip(np.split(self.optimizer.m.cpu().numpy(), np.cumsum(sizes)[:-1]), shapes)]
         v = [a.reshape(s) for a, s in zip(np.split(self.optimizer.v.cpu().numpy(), np.cumsum(sizes)[:-1]), shapes)]
-        weight_values = [np.int64(self.optimizer.iterations)] + m + v
+        order = self.model.keras_variable_order()
+        weight_values = [np.int64(self.optimizer.iterations)] + [m[i] for i in order] + [v[i] for i in order]
         with open('%s/optimizer.pkl' % self.model_dir, 'wb') as f:
             pickle.dump(weight_values, f)
 
     def restore_model(self, old_model_dir, old_model_file):
-        """TrainerController.py:365-394."""
+        """TrainerController.py:365-394.  optimizer.pkl slots are in Keras trainable_variables order (see save_best_model)."""
         with open("%s/optimizer.pkl" % old_model_dir, 'rb') as f:
             opt_weights = pickle.load(f)
-        n = len(self.model.trainable_variables)
+        tv = self.model.trainable_variables
+        n = len(tv)
         if len(opt_weights) != 1 + 2 * n:
             raise ValueError("optimizer.pkl holds %d arrays, expected %d" % (len(opt_weights), 1 + 2 * n))
-        shapes = [tuple(t.shape) for t in self.model.trainable_variables]
-        for k, (a, shp) in enumerate(zip(list(opt_weights[1:1 + n]) + list(opt_weights[1 + n:]), shapes + shapes)):
-            if tuple(np.shape(a)) != shp:
-                raise ValueError("optimizer.pkl: array %d has shape %s, expected %s (slot order = layer creation order, "
-                                 "see save_best_model)" % (k + 1, tuple(np.shape(a)), shp))
+        order = self.model.keras_variable_order()
+        m_k, v_k = list(opt_weights[1:1 + n]), list(opt_weights[1 + n:])
+        m, v = [None] * n, [None] * n
+        for slot, i in enumerate(order):
+            for name, src, dst in (("m", m_k, m), ("v", v_k, v)):
+                if tuple(np.shape(src[slot])) != tuple(tv[i].shape):
+                    raise ValueError("optimizer.pkl: %s slot %d has shape %s, expected %s (slots follow Keras trainable_variables order, "
+                                     "see save_best_model)" % (name, slot, tuple(np.shape(src[slot])), tuple(tv[i].shape)))
+                dst[i] = src[slot]
         self.optimizer.iterations = int(opt_weights[0])
         flat = lambda arrs: torch.from_numpy(np.concatenate([np.asarray(a, np.float32).reshape(-1) for a in arrs]))
-        self.optimizer.m.copy_(flat(opt_weights[1:1 + n]))
-        self.optimizer.v.copy_(flat(opt_weights[1 + n:]))
+        self.optimizer.m.copy_(flat(m))
+        self.optimizer.v.copy_(flat(v))
         self.model.load_weights("%s/%s" % (old_model_dir, old_model_file))
 
     def quicksave(self, testset, epoch_nr):

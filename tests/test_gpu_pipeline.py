@@ -64,10 +64,22 @@ def test_cfg1_train_network_checkpoint_restore_and_quicksave(tmp_path):
     assert np.abs(loss.cpu().numpy() - ref["loss"]).max() / np.abs(ref["loss"]).max() < 1e-4
     # restore: weights + Adam slots come back exactly
     tc3 = trainer.TrainerController(P, R, initial_learning_rate=2e-4, quicksave_enable=False, low_resblock=LB, hi_resblock=HB, seed=9)
+    tc.save_best_model()                      # the checkpoint now holds the controller's CURRENT state (epoch 2 need not have been the best)
     tc3.restore_model(md, "t4d-best.h5")
     best = h5io.read_keras_weights(os.path.join(md, "t4d-best.h5"))
     assert np.array_equal(tc3.model.layers[7].w.cpu().numpy(), best["conv3d_7"][0])
     assert tc3.optimizer.iterations > 0 and float(tc3.optimizer.v.abs().sum()) > 0
+    # optimizer.pkl is written in Keras trainable_variables order (network.keras_layer_order) and read back through the inverse
+    # permutation: the restored slots equal the saved controller's, and the file's first kernel slot is conv3d_2's (phase branch)
+    assert torch.equal(tc3.optimizer.m, tc.optimizer.m) and torch.equal(tc3.optimizer.v, tc.optimizer.v)
+    import pickle
+    slots = pickle.load(open(os.path.join(md, "optimizer.pkl"), "rb"))
+    ntv = len(tc.model.trainable_variables)
+    assert len(slots) == 1 + 2 * ntv
+    L2_, L0_ = tc.model.layers[2], tc.model.layers[0]
+    m_flat = tc.optimizer.m.cpu().numpy()
+    assert np.array_equal(slots[1].reshape(-1), m_flat[L2_.w_off:L2_.w_off + L2_.w.numel()])          # conv3d_2/kernel first
+    assert np.array_equal(slots[3].reshape(-1), m_flat[L0_.w_off:L0_.w_off + L0_.w.numel()])          # then conv3d/kernel
 
 
 def test_predictor_end_to_end_on_example_volume(tmp_path):

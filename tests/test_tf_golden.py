@@ -60,6 +60,33 @@ def test_generator_script_is_importable_and_names_match_the_oracle():
         assert ns["layer_names"](LB, HB) == [p["name"] for p in O.init_params(0, LB, HB)]
 
 
+def test_keras_layer_order_is_a_permutation_that_only_swaps_equal_depth_layers():
+    """network.keras_layer_order: the order Keras lists the conv layers in (model.layers / trainable_variables / optimizer slots)."""
+    network = importlib.import_module("4dflownet_amd.network")
+    assert network.keras_layer_order(8, 4) == [2, 0, 3, 1] + list(range(4, 30)) + [30, 32, 34, 31, 33, 35]
+    for LB, HB in ((1, 1), (2, 0), (0, 1), (8, 4)):
+        order = network.keras_layer_order(LB, HB)
+        specs = network.layer_specs(LB, HB)
+        assert sorted(order) == list(range(len(specs)))
+        # layers that change places have identical (K, Cin, Cout, bias): the reason shapes cannot reveal a wrong order
+        for pos, i in enumerate(order):
+            assert specs[pos][1:] == specs[i][1:] or {pos, i} <= set(range(4)) | set(range(len(specs) - 6, len(specs)))
+
+
+@needs_npz
+def test_keras_variable_order_matches_real_tensorflow_names():
+    """The day tf_golden.npz exists: the derived order must be the one a real TensorFlow reports (settles optimizer.pkl)."""
+    network = importlib.import_module("4dflownet_amd.network")
+    for c in load_cases():
+        specs = network.layer_specs(c["LB"], c["HB"])
+        expect = []
+        for i in network.keras_layer_order(c["LB"], c["HB"]):
+            expect.append("%s/kernel:0" % specs[i][0])
+            if specs[i][4]:
+                expect.append("%s/bias:0" % specs[i][0])
+        assert c["names"] == expect, (c["names"][:8], expect[:8])
+
+
 @needs_npz
 def test_oracle_reproduces_the_tensorflow_reference():
     for c in load_cases():
