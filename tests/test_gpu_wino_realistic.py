@@ -136,7 +136,8 @@ def trained(fdn):
     tc = trainer.TrainerController(24, 2, initial_learning_rate=1e-4, quicksave_enable=False, low_resblock=8, hi_resblock=4, seed=0)
     steps = 0
     first = None
-    while steps < 320:
+    target = int(os.environ.get("FDN_WINO_TRAIN_STEPS", "320"))        # longer runs by hand: FDN_WINO_TRAIN_STEPS=1600 pytest ... -s
+    while steps < target:
         tc.reset_metrics()
         for batch in ds:
             tc.train_step(batch)
