@@ -57,6 +57,23 @@ def source_stamp(test_hooks=False):
     return _stamp() + ("-DFDN_TEST_HOOKS" if test_hooks else "")
 
 
+def suite_stamp():
+    """sha256 over everything a `pytest -m gpu` + smoke() run executes besides the kernels: the library stamp, the package's
+    python, the GPU tests (+ conftest, the golden fixtures' loaders), the oracle and the entry points.  A tracked GPU test log
+    (profiles/r*_gputest.txt, tools/gputest_round.sh) carries it, so a log older than the code it vouches for is detectable."""
+    import glob
+    h = hashlib.sha256(_stamp().encode())
+    files = (glob.glob(os.path.join(HERE, "*.py")) + glob.glob(os.path.join(ROOT, "tests", "test_gpu_*.py")) +
+             glob.glob(os.path.join(ROOT, "oracle", "*.py")) +
+             [os.path.join(ROOT, "tests", n) for n in ("conftest.py", "test_tf_golden.py", "test_fft_downsampling.py")] +
+             [os.path.join(ROOT, "__graft_entry__.py")])
+    for path in sorted(files):
+        if os.path.exists(path):
+            with open(path, "rb") as f:
+                h.update(os.path.relpath(path, ROOT).encode()); h.update(f.read())
+    return h.hexdigest()
+
+
 def built_stamp(test_hooks=False):
     """The stamp of the library in the tree, or None if the library or its stamp file is missing."""
     lib = lib_path(test_hooks)

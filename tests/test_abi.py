@@ -130,3 +130,32 @@ def test_round3_profiles_carry_the_sources_they_were_measured_on():
             stale.append(os.path.basename(f))
     if stale:
         warnings.warn("profiles measured on other kernel sources than the tree's (re-run tools/profile_round.sh): %s" % ", ".join(stale))
+
+
+def test_tracked_gpu_test_log_matches_the_tree():
+    """profiles/r*_gputest.txt (tools/gputest_round.sh -> tools/collect_profiles.py) is the round's parity record: the whole
+    `-m gpu` suite + smoke() on an MI355X, naming the kernel sources (lib_source_stamp) and the python / tests / oracle
+    (suite_stamp) it ran on.  The log must be a green run; a missing log or one whose stamps differ from the
+    tree's is reported as a WARNING, not a failure -- it means product code changed after the last recorded GPU run, and the
+    round is not finished until `bash tools/gputest_round.sh` has been re-run and collected."""
+    import glob
+    import warnings
+    from importlib import import_module
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    logs = sorted(glob.glob(os.path.join(root, "profiles", "r*_gputest.txt")), key=lambda p: int(re.search(r"r(\d+)_", p).group(1)))
+    if not logs:
+        warnings.warn("no tracked GPU test log under profiles/ (run tools/gputest_round.sh through gpurun, then tools/collect_profiles.py)")
+        return
+    body = open(logs[-1]).read()
+    head = body.splitlines()[0]
+    m = re.match(r"# commit ([0-9a-f]{40}(?:\+dirty)?) lib_source_stamp ([0-9a-f]{64}) suite_stamp ([0-9a-f]{64})", head)
+    assert m, head
+    assert "== pytest exit code 0" in body and "== smoke exit code 0" in body, "the tracked GPU test log is not a green run"
+    assert re.search(r"^\d+ passed", body, re.M) and not re.search(r"^\d+ failed|\d+ error", body, re.M)
+    assert "[wino-parity" in body                    # the per-layer Winograd parity tables travel with the log
+    build = import_module("4dflownet_amd.build")
+    stale = [k for k, got, want in (("kernels", m.group(2), build.source_stamp()), ("python/tests", m.group(3), build.suite_stamp()))
+             if got != want]
+    if stale:
+        warnings.warn("%s: %s changed since the recorded GPU run -- re-run tools/gputest_round.sh and collect it" %
+                      (os.path.basename(logs[-1]), " and ".join(stale)))
