@@ -21,7 +21,7 @@ LIB = os.path.join(HERE, "lib4dflow_hip.so")
 # Test build: the same sources with -DFDN_TEST_HOOKS, which adds the fdn_debug_* variant-forcing / ablation entry points
 # (process-global switches).  Loaded only by tests/ and tools/ through _lib.test_build(); the product library has none.
 LIB_TEST = os.path.join(HERE, "lib4dflow_hip_test.so")
-SOURCES = ["api.hip", "conv64_mfma.hip", "conv64_wino.hip", "conv64_bf16.hip", "wgrad64_mfma.hip", "wgrad64_wino.hip", "wgrad64_bf16.hip", "small_convs.hip", "cin3_mfma.hip", "conv1x1_mfma.hip", "heads_mfma.hip", "elementwise.hip", "patch_gather.hip"]
+SOURCES = ["api.hip", "conv64_mfma.hip", "conv64_wino.hip", "conv64_wino2d.hip", "conv64_bf16.hip", "wgrad64_mfma.hip", "wgrad64_wino.hip", "wgrad64_bf16.hip", "small_convs.hip", "cin3_mfma.hip", "conv1x1_mfma.hip", "heads_mfma.hip", "elementwise.hip", "patch_gather.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-I", os.path.join(ROOT, "include"), "-I", CSRC]
 

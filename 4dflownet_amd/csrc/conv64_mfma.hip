@@ -455,29 +455,34 @@ __global__ void pack_conv64_kernel(const float* __restrict__ w, float* __restric
 
 // every 64->64 layer of the network in ONE launch: blockIdx.y = layer, packs[layer][fwd|dgrad][direct | winograd]
 __global__ void pack_conv64_batch_kernel(const float* __restrict__ w_base, const int64_t* __restrict__ w_offsets, float* __restrict__ packs) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over 81*64*64 packed elements per direction
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over 153*64*64 packed elements per direction
     const float* w = w_base + w_offsets[blockIdx.y];
-    float* pf = packs + (size_t)blockIdx.y * 2 * (81 * 64 * 64);
-    float* pd = pf + 81 * 64 * 64;
+    float* pf = packs + (size_t)blockIdx.y * 2 * FDN_CONV64_PACK_FLOATS;
+    float* pd = pf + FDN_CONV64_PACK_FLOATS;
     if (idx < 27 * 64 * 64) fdn_pack_direct_one(w, pf, pd, idx);
     else if (idx < 81 * 64 * 64) fdn_pack_wino_one(w, pf + 27 * 64 * 64, pd + 27 * 64 * 64, idx - 27 * 64 * 64);
+    else if (idx < 153 * 64 * 64) fdn_pack_wino2d_one(w, pf + 81 * 64 * 64, pd + 81 * 64 * 64, idx - 81 * 64 * 64);
 }
 
-// pack = [direct stream, 27*64*64 floats | Winograd F(4,3) stream, 54*64*64 floats]  (FDN_CONV64_PACK_FLOATS in fdn.h)
+// pack = [direct stream, 27*64*64 floats | Winograd F(4,3) stream, 54*64*64 | 2-D F(2,3)xF(4,3) stream, 72*64*64]  (FDN_CONV64_PACK_FLOATS in fdn.h)
 constexpr int kDirectPackFloats = 27 * 64 * 64;
+constexpr int kWino1PackFloats = 54 * 64 * 64;
 
 extern "C" int fdn_pack_conv64_weights(const float* w, float* wp_fwd, float* wp_dgrad, void* stream) {
     FDN_REQUIRE(w != nullptr, "fdn_pack_conv64_weights: w is NULL");
     hipLaunchKernelGGL(pack_conv64_kernel, dim3((27 * 64 * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w,
                        wp_fwd, wp_dgrad);
     FDN_CHECK_LAUNCH("fdn_pack_conv64_weights");
-    return fdn_pack_conv64_wino_launch(w, wp_fwd ? wp_fwd + kDirectPackFloats : nullptr,
-                                       wp_dgrad ? wp_dgrad + kDirectPackFloats : nullptr, (hipStream_t)stream);
+    if (int rc = fdn_pack_conv64_wino_launch(w, wp_fwd ? wp_fwd + kDirectPackFloats : nullptr,
+                                             wp_dgrad ? wp_dgrad + kDirectPackFloats : nullptr, (hipStream_t)stream))
+        return rc;
+    return fdn_pack_conv64_wino2d_launch(w, wp_fwd ? wp_fwd + kDirectPackFloats + kWino1PackFloats : nullptr,
+                                         wp_dgrad ? wp_dgrad + kDirectPackFloats + kWino1PackFloats : nullptr, (hipStream_t)stream);
 }
 
 extern "C" int fdn_pack_conv64_weights_batch(const float* w_base, const int64_t* w_offsets, int n_layers, float* packs, void* stream) {
     FDN_REQUIRE(w_base && w_offsets && packs && n_layers > 0, "fdn_pack_conv64_weights_batch: NULL argument or n_layers<=0");
-    hipLaunchKernelGGL(pack_conv64_batch_kernel, dim3((81 * 64 * 64 + 255) / 256, (unsigned)n_layers), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(pack_conv64_batch_kernel, dim3((FDN_CONV64_PACK_FLOATS + 255) / 256, (unsigned)n_layers), dim3(256), 0, (hipStream_t)stream,
                        w_base, w_offsets, packs);
     FDN_CHECK_LAUNCH("fdn_pack_conv64_weights_batch");
     return FDN_OK;
@@ -612,7 +617,13 @@ int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, 
     // (per call) or a forced direct layout (test build) selects the direct kernel below.
     const bool wino = algo != FDN_ALGO_DIRECT && (fdn_conv64_force_layout == 0 || fdn_conv64_force_layout == 7);
     const float* upack = wpack + kDirectPackFloats;
+    const float* upack2 = upack + kWino1PackFloats;
+    // 2-D Winograd (conv64_wino2d.hip: F(2,3) along H on top of F(4,3) along W, a third fewer multiplies again) when H is even too
+    const bool wino2 = wino && algo != FDN_ALGO_WINO_W && fdn_conv64_force_layout == 0;
     if (!(fout && zero_mode && off == -1 && fdn_conv64_shell_slabs)) {
+        if (wino2 && fdn_conv64_wino2d_ok(OD, OH, OW, ID, IH, IW))
+            return fdn_conv64_wino2d_launch(x, upack2, bias, residual, y, nullptr, nullptr, nullptr, N, ID, IH, IW, OD, OH, OW, 0, 0, 0,
+                                            OD, OH, OW, off, zero_mode, act, alpha, s);
         if (wino && fdn_conv64_wino_ok(OD, OH, OW))
             return fdn_conv64_wino_launch(x, upack, bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, 0, 0, 0, OD, OH,
                                           OW, off, zero_mode, act, alpha, s);

@@ -54,3 +54,49 @@ __device__ __forceinline__ void fdn_pack_wino_one(const float* __restrict__ w, f
         ud[idx] = v;
     }
 }
+
+// 2-D Winograd stream (conv64_wino2d.hip): U = Gh g Gw^T over the (kh, kw) taps, F(2,3) along H (Gh = (1,0,0) (1/2,1/2,1/2)
+// (1/2,-1/2,1/2) (0,0,1)) x F(4,3) along W (G above), per depth tap kd.  The kernel forms the F(2,3) input coordinate 2 as
+// x1 - x2 = -(B^T x)_2, so U[xh = 2] is stored NEGATED.
+// layout [nb = cout/16][xh][kd][xw][g = cin/16][q][i][s]: a 1-KB unit = the row operand of v_mfma_f32_16x16x4_f32 for 4 k-steps:
+// lane (i = lane & 15, q = lane >> 4), k-step s  <->  cout 16 nb + i, cin 16 g + 4 q + s.
+//   fwd  : U = sum Gh[xh][kh] Gw[xw][kw] w[kd][kh][kw][cin][cout]
+//   dgrad: contraction over the layer's cout, taps flipped: U = sum Gh Gw w[2-kd][2-kh][2-kw][ci = 16 nb + i][co = 16 g + 4 q + s]
+__device__ __forceinline__ void fdn_pack_wino2d_one(const float* __restrict__ w, float* __restrict__ uf, float* __restrict__ ud, int idx) {
+    const int s = idx & 3;
+    const int i = (idx >> 2) & 15;
+    const int q = (idx >> 6) & 3;
+    const int g = (idx >> 8) & 3;
+    int rest = idx >> 10;                // ((nb*4 + xh)*3 + kd)*6 + xw
+    const int xw = rest % 6; rest /= 6;
+    const int kd = rest % 3; rest /= 3;
+    const int xh = rest & 3;
+    const int nb = rest >> 2;
+    const int k = 16 * g + 4 * q + s;
+    const int cj = 16 * nb + i;
+    const float G[6][3] = {{0.25f, 0.f, 0.f}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
+                           {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
+    const float H[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {-0.5f, 0.5f, -0.5f}, {0.f, 0.f, 1.f}};     // row 2 = -(1/2,-1/2,1/2)
+    if (uf) {
+        float v = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            float r = 0.f;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) r = __builtin_fmaf(G[xw][t], w[(((kd * 3 + kh) * 3 + t) * 64 + k) * 64 + cj], r);
+            v = __builtin_fmaf(H[xh][kh], r, v);
+        }
+        uf[idx] = v;
+    }
+    if (ud) {
+        float v = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            float r = 0.f;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) r = __builtin_fmaf(G[xw][t], w[((26 - ((kd * 3 + kh) * 3 + t)) * 64 + cj) * 64 + k], r);
+            v = __builtin_fmaf(H[xh][kh], r, v);
+        }
+        ud[idx] = v;
+    }
+}

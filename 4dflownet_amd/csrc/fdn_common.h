@@ -152,6 +152,13 @@ int fdn_conv64_wino_launch(const float* x, const float* upack, const float* bias
                            int OW, int obd, int obh, int obw, int ebd, int ebh, int ebw, int off, int zero_mode, int act,
                            float alpha, hipStream_t s);
 int fdn_pack_conv64_wino_launch(const float* w, float* uf, float* ud, hipStream_t s);
+// 2-D Winograd variant (conv64_wino2d.hip): F(2,3) along H x F(4,3) along W; one output box with all 27 taps
+bool fdn_conv64_wino2d_ok(int ebd, int ebh, int ebw, int ID, int IH, int IW);
+int fdn_conv64_wino2d_launch(const float* x, const float* upack2, const float* bias, const float* residual, float* y,
+                             const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
+                             int OW, int obd, int obh, int obw, int ebd, int ebh, int ebw, int off, int zero_mode, int act,
+                             float alpha, hipStream_t s);
+int fdn_pack_conv64_wino2d_launch(const float* w, float* uf, float* ud, hipStream_t s);
 int fdn_fold_halo_border_launch(const float* s0, const float* s1, const float* s2, int nsrc, const float* skip,
                                 const float* yprev, int act, float alpha, float* out, int N, int D, int H, int W,
                                 hipStream_t s);

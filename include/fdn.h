@@ -44,12 +44,16 @@ extern "C" {
 
 /* Algorithm selector of the 64->64 3x3x3 entry points (fdn_conv3d_fwd / _dgrad / _dgrad_fused[_part] / _wgrad; ignored by
  * every other (Cin,Cout,K)).  Per call, no global state.
- *   FDN_ALGO_AUTO   : the planner's choice -- 1-D Winograd along W (F(4,3) forward / dgrad, F(3,4) wgrad: half the multiplies,
- *                     fp32 error a few 1e-7 of sum|x||w| instead of ~1e-7) whenever the W extent is a multiple of 4, else direct;
+ *   FDN_ALGO_AUTO   : the planner's choice.  Forward / dgrad: 2-D Winograd, F(2,3) along H x F(4,3) along W (a third of the
+ *                     direct multiplies) when H is even and W a multiple of 4, else 1-D Winograd along W (F(4,3): half the
+ *                     multiplies) when W is a multiple of 4, else direct.  wgrad: F(3,4) along W when W is a multiple of 4.
+ *                     fp32 error a few 1e-7 of sum|x||w| instead of ~1e-7;
  *   FDN_ALGO_DIRECT : always the direct convolution (plain fp32 FMA chains over the 27 taps, no transform) -- for
- *                     parity-critical runs and for layers whose operands are too ill-conditioned for the transform. */
+ *                     parity-critical runs and for layers whose operands are too ill-conditioned for the transform;
+ *   FDN_ALGO_WINO_W : Winograd along W only (the 1-D kernels), never the H transform. */
 #define FDN_ALGO_AUTO 0
 #define FDN_ALGO_DIRECT 1
+#define FDN_ALGO_WINO_W 2
 
 int fdn_version(void);
 const char* fdn_last_error(void);
@@ -62,10 +66,10 @@ int fdn_input_features(const float* u, const float* v, const float* w, const flo
 /* Re-layout one 3x3x3 64->64 Keras kernel (27,64,64) into the MFMA operand streams used by
  * fdn_conv3d_fwd (wp_fwd) and fdn_conv3d_dgrad / fdn_conv3d_dgrad_fused (wp_dgrad: taps flipped,
  * Cin/Cout swapped).  Each output is FDN_CONV64_PACK_FLOATS floats: the direct-convolution stream
- * (27 taps) followed by the Winograd F(4,3)-along-W stream U = G g (9 (kd,kh) taps x 6 transform
- * coordinates), which the conv entry points select when the W extent is a multiple of 4.
- * Either output may be NULL. */
-#define FDN_CONV64_PACK_FLOATS (81 * 64 * 64)
+ * (27 taps), the Winograd F(4,3)-along-W stream U = G g (9 (kd,kh) taps x 6 transform coordinates)
+ * and the 2-D stream U = Gh g Gw^T (3 kd taps x 4 x 6 coordinates); the conv entry points select
+ * among them by the extents (see FDN_ALGO_*).  Either output may be NULL. */
+#define FDN_CONV64_PACK_FLOATS (153 * 64 * 64)
 int fdn_pack_conv64_weights(const float* w, float* wp_fwd, float* wp_dgrad, void* stream);
 /* The same for n_layers kernels in ONE launch (after every optimizer step): layer i lives at
  * w_base + w_offsets[i] (w_offsets: DEVICE array of n_layers float offsets), its two streams at
@@ -81,7 +85,7 @@ int fdn_pack_conv64_weights_batch(const float* w_base, const int64_t* w_offsets,
  * SR4DFlowNet.py:23 is never materialised].  x2, wpack, bias, residual may be NULL where unused.
  * Output rows are written at y[voxel*ldy + y_coff + c] (ldy=Cout,y_coff=0 for a dense tensor;
  * the three 64->1 heads write straight into the (N,V,3) prediction: SR4DFlowNet.py:49).
- * algo: FDN_ALGO_AUTO | FDN_ALGO_DIRECT, consulted by the (64,64,3) path only (see above); here and in the entry points below. */
+ * algo: FDN_ALGO_AUTO | FDN_ALGO_DIRECT | FDN_ALGO_WINO_W, consulted by the (64,64,3) path only (see above); here and in the entry points below. */
 int fdn_conv3d_fwd(const float* x, const float* x2, const float* w, const float* wpack, const float* bias,
                    const float* residual, float* y, int N, int D, int H, int W, int Cin, int Cout, int K,
                    int ldy, int y_coff, int act, float alpha, int algo, void* stream);

@@ -55,7 +55,7 @@ def test_header_is_plain_c_and_links_from_c(fdn, tmp_path):
                    '    /* every prototype is visible to C: take the address of a few */\n'
                    '    int (*f)(const float*, float*, float*, void*) = fdn_pack_conv64_weights;\n'
                    '    size_t (*g)(int, int, int, int, int, int, int) = fdn_conv3d_wgrad_workspace_bytes;\n'
-                   '    printf("%d %d %d %s\\n", fdn_version(), f != 0, (int)(g(8, 24, 24, 24, 64, 64, 3) > 0), FDN_CONV64_PACK_FLOATS == 81 * 4096 ? "ok" : "bad");\n'
+                   '    printf("%d %d %d %s\\n", fdn_version(), f != 0, (int)(g(8, 24, 24, 24, 64, 64, 3) > 0), FDN_CONV64_PACK_FLOATS == 153 * 4096 ? "ok" : "bad");\n'
                    '    /* an argument error comes back as a code + message, not as an exception */\n'
                    '    int rc = fdn_l2_sumsq(0, 0, 0, 0, 0);\n'
                    '    printf("%d %s\\n", rc, fdn_last_error());\n'

@@ -75,6 +75,56 @@ def test_conv64_fwd(ops, fdn, shape, mt):
                 lib.fdn_debug_set_conv64_mt(0)
 
 
+# H even and W a multiple of 4 -> FDN_ALGO_AUTO takes the 2-D Winograd kernel (F(2,3) along H x F(4,3) along W, conv64_wino2d.hip).
+# Shapes: one partial tile, ragged tile grids in d / h / w, the smallest grid (1,2,4), H = 2, a multi-tile launch at the cfg2 low-res grid.
+WINO2D_SHAPES = [(1, 5, 8, 12), (3, 4, 4, 4), (2, 9, 2, 24), (1, 1, 2, 4), (1, 17, 10, 8), (2, 24, 24, 24), (1, 3, 6, 20), (1, 11, 14, 28)]
+
+
+@pytest.mark.parametrize("shape,tile", [(sh, 0) for sh in WINO2D_SHAPES] +
+                         [((2, 24, 24, 24), t) for t in (8 | 1 << 8 | 4 << 16, 8 | 4 << 8 | 1 << 16, 16 | 2 << 8 | 1 << 16, 5 | 2 << 8 | 2 << 16, 32 | 1 << 8 | 1 << 16)] +
+                         [((1, 17, 10, 8), 3 | 1 << 8 | 2 << 16)])
+def test_conv64_fwd_wino2d(ops, fdn, shape, tile):
+    """2-D Winograd forward == oracle, with every epilogue variant; == the 1-D Winograd and direct kernels to fp32 rounding.
+    tile != 0: a forced (td, ch, cw) tile through the test build (tiles the planner would not pick at this size)."""
+    rng = np.random.default_rng(11)
+    N, D, H, W = shape
+    x = rng.normal(size=(N, D, H, W, 64)).astype(np.float32)
+    w = (rng.normal(size=(3, 3, 3, 64, 64)) * 0.05).astype(np.float32)
+    b = rng.normal(size=64).astype(np.float32)
+    res = rng.normal(size=(N, D, H, W, 64)).astype(np.float32)
+    with variant_lib(fdn, tile) as lib:
+        if lib is not None:
+            lib.fdn_debug_set_conv64_wino2d_tile(tile)
+        try:
+            for act, bias, r in [(O.ACT_RELU, b, None), (O.ACT_LEAKY, None, res), (O.ACT_NONE, None, None)]:
+                ref = O.conv3d_fwd(x.astype(np.float64), w.astype(np.float64), None if bias is None else bias.astype(np.float64),
+                                   act, 0.2, None if r is None else r.astype(np.float64))
+                got = ops.conv3d_fwd(dev(x), dev(w), None if bias is None else dev(bias), act, 0.2,
+                                     None if r is None else dev(r), algo=ops.ALGO_AUTO)
+                close(got, ref, name="conv64 fwd 2-D winograd act=%d" % act)
+                for algo in (ops.ALGO_WINO_W, ops.ALGO_DIRECT):
+                    other = ops.conv3d_fwd(dev(x), dev(w), None if bias is None else dev(bias), act, 0.2,
+                                           None if r is None else dev(r), algo=algo)
+                    close(got, other.cpu().numpy(), name="2-D winograd vs algo %d" % algo)
+        finally:
+            if lib is not None:
+                lib.fdn_debug_set_conv64_wino2d_tile(0)
+
+
+@pytest.mark.parametrize("shape", [(1, 5, 6, 6), (2, 7, 10, 14), (1, 1, 2, 2)])
+def test_conv64_dgrad_padded_wino2d(ops, shape):
+    """Zero-boundary mode of the 2-D kernel: the plain padded-grid dgrad (D+2, H+2, W+2 with H+2 even, W+2 a multiple of 4) + fold."""
+    rng = np.random.default_rng(12)
+    N, D, H, W = shape
+    dz = rng.normal(size=(N, D, H, W, 64)).astype(np.float32)
+    w = (rng.normal(size=(3, 3, 3, 64, 64)) * 0.05).astype(np.float32)
+    dx = O.conv3d_dgrad(dz.astype(np.float64), w.astype(np.float64), (N, D, H, W, 64))
+    pad = ops.conv3d_dgrad(dev(dz), dev(w))
+    close(ops.fold_halo([pad]), dx, name="padded dgrad (2-D winograd) + fold")
+    pad1 = ops.conv3d_dgrad(dev(dz), dev(w), algo=ops.ALGO_DIRECT)
+    close(pad, pad1.cpu().numpy(), name="padded dgrad 2-D winograd vs direct")
+
+
 @pytest.mark.parametrize("shape", SHAPES)
 def test_conv64_dgrad_and_fold(ops, shape):
     rng = np.random.default_rng(2)
