@@ -653,8 +653,18 @@ int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, 
             {0, 0, 0, OD, OH, 4, 0, 2, 0, 2, 1}};                                                // w faces, full (d,h)
         const Box wfaces[2] = {{0, 0, 0, OD, OH, 1, 0, 2, 0, 2, 2, 2}, {0, 0, IW + 1, OD, OH, 1, 0, 2, 0, 2, 0, 0}};
         const bool wface_direct = fdn_conv64_wface_direct != 0;       // test build: the round-2 path (direct-kernel slab launch)
-        const int first = (parts & 1) ? 0 : 1;
-        const int count = ((parts & 1) ? 1 : 0) + ((parts & 2) ? (wface_direct ? 4 : 5) : 0);
+        int first = (parts & 1) ? 0 : 1;
+        int count = ((parts & 1) ? 1 : 0) + ((parts & 2) ? (wface_direct ? 4 : 5) : 0);
+        if ((parts & 1) && wino2 && fdn_conv64_wino2d_ok(ID, IH, IW, ID, IH, IW)) {
+            // round 4: the inner box (all 27 taps, fused-fold epilogue; 95 % / 91 % of the positions at 48^3 / 24^3) on the 2-D Winograd
+            // kernel, the shell faces as a launch of their own on the 1-D kernel (their single depth / height / width tap has nothing to
+            // transform along that axis)
+            if (int rc = fdn_conv64_wino2d_launch(x, upack2, bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, 1, 1, 1, ID, IH,
+                                                  IW, off, zero_mode, act, alpha, s))
+                return rc;
+            first = 1; count -= 1;
+            if (count == 0) return FDN_OK;
+        }
         if (int rc = fdn_conv64_wino_launch_boxes(x, upack, bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, wb + first,
                                                   count, off, zero_mode, act, alpha, s))
             return rc;

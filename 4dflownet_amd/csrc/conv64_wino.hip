@@ -501,6 +501,9 @@ int fdn_conv64_wino_launch_boxes(const float* x, const float* upack, const float
     a.nreg = 0;
     long long blocks = 0;
     int max_ltg = 0;
+    // a launch that starts with a shell face carries no main region (round 4: the inner box of a fused dgrad runs on the 2-D kernel):
+    // all of its regions share the chip, so all are planned by total work
+    const bool shell_only = boxes[0].wface || boxes[0].ta0 != 0 || boxes[0].ta1 != 2 || boxes[0].tb0 != 0 || boxes[0].tb1 != 2;
     for (int i = 0; i < nbox; ++i) {
         const FdnWinoBox& bx = boxes[i];
         if (bx.ed <= 0 || bx.eh <= 0 || bx.ew <= 0) continue;
@@ -512,7 +515,7 @@ int fdn_conv64_wino_launch_boxes(const float* x, const float* upack, const float
             pl.td = fdn_conv64_wino_tile & 255; pl.th = (fdn_conv64_wino_tile >> 8) & 255; pl.tg = (fdn_conv64_wino_tile >> 16) & 255;
         }
         // a secondary region too small to fill the chip on its own (< 1024 tiles = two rounds of workgroup slots): plan it by total work instead (see wino_plan)
-        if (a.nreg > 0 && !(fdn_conv64_wino_dbg & 256) &&
+        if ((a.nreg > 0 || shell_only) && !(fdn_conv64_wino_dbg & 256) &&
             (long long)N * ((bx.ed + pl.td - 1) / pl.td) * ((bx.eh + pl.th - 1) / pl.th) * ((bx.ew / 4 + pl.tg - 1) / pl.tg) < 1024)
             pl = wino_plan(N, bx, true);
         WinoRegion& r = a.reg[a.nreg++];

@@ -313,26 +313,41 @@ __global__ __launch_bounds__(256, 2) void conv64_wino2d_kernel(Wino2Args p) {
         if (g0 < 0) continue;
         if (FUSED) {
             // dgrad on the inner box of the padded grid: voxels strictly inside the volume get exactly one contribution and are
-            // finished here (dz_prev = (dgrad + skip) * act'(y)); surface voxels go to the padded scratch for the border fold
+            // finished here (dz_prev = (dgrad + skip) * act'(y)); surface voxels go to the padded scratch for the border fold.
+            // Branch-free per voxel: every lane requests skip / y for its 8 voxels at once (a surface voxel reads row 0 of the tensor,
+            // which nobody writes in this launch, and discards it), then picks value and destination -- a branch per voxel would put
+            // a memory round trip between every pair of stores.
             const int gf0 = mtab[32 + mb * 16 + c];
             const int hw = mtab[64 + mb * 16 + c];
             const int ph = hw & 0xffff, pw = hw >> 16;                    // padded coordinates of the cell's first voxel
+            size_t of[2][4];
+            bool in[2][4];
 #pragma unroll
             for (int hr = 0; hr < 2; ++hr)
 #pragma unroll
                 for (int wi = 0; wi < 4; ++wi) {
                     const int ih = ph + hr - 1, iw = pw + wi - 1;
-                    f32x4 z = Y[hr][wi][mb];
-                    if (gf0 >= 0 && ih >= 1 && ih <= p.IH - 2 && iw >= 1 && iw <= p.IW - 2) {
-                        const size_t o = (size_t)(gf0 + hr * p.IW + wi) * 64 + cofs;
-                        const f32x4 sk = p.fskip ? *(const f32x4*)(p.fskip + o) : (f32x4){0.f, 0.f, 0.f, 0.f};
-                        const f32x4 ym = p.fy ? *(const f32x4*)(p.fy + o) : (f32x4){1.f, 1.f, 1.f, 1.f};
+                    in[hr][wi] = gf0 >= 0 && ih >= 1 && ih <= p.IH - 2 && iw >= 1 && iw <= p.IW - 2;
+                    of[hr][wi] = in[hr][wi] ? (size_t)(gf0 + hr * p.IW + wi) * 64 + cofs : (size_t)cofs;
+                }
+            f32x4 sk[2][4], ym[2][4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) z[e] = (z[e] + sk[e]) * (ym[e] > 0.f ? 1.f : slope);
-                        *(f32x4*)(p.fout + o) = z;
-                    } else {
-                        *(f32x4*)(p.y + (size_t)(g0 + hr * p.OW + wi) * 64 + cofs) = z;
-                    }
+            for (int hr = 0; hr < 2; ++hr)
+#pragma unroll
+                for (int wi = 0; wi < 4; ++wi) {
+                    sk[hr][wi] = p.fskip ? *(const f32x4*)(p.fskip + of[hr][wi]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    ym[hr][wi] = p.fy ? *(const f32x4*)(p.fy + of[hr][wi]) : (f32x4){1.f, 1.f, 1.f, 1.f};
+                }
+#pragma unroll
+            for (int hr = 0; hr < 2; ++hr)
+#pragma unroll
+                for (int wi = 0; wi < 4; ++wi) {
+                    const f32x4 z = Y[hr][wi][mb];
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = in[hr][wi] ? (z[e] + sk[hr][wi][e]) * (ym[hr][wi][e] > 0.f ? 1.f : slope) : z[e];
+                    float* dst = in[hr][wi] ? p.fout + of[hr][wi] : p.y + (size_t)(g0 + hr * p.OW + wi) * 64 + cofs;
+                    *(f32x4*)dst = v;
                 }
         } else {
             f32x4 z[2][4];

@@ -38,8 +38,8 @@ PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64
 PEAK_BF16_MFMA_TFLOPS = 2516.6       # dense bf16: 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz
 FLOP_PER_VOXEL_CONV64 = 2.0 * 27 * 64 * 64   # 3.0576 GFLOP per 24^3 patch = 221 184 FLOP/voxel
 # committed PMC traffic summaries (tools/pmc_traffic.py), newest round first
-CFG2_TRAFFIC = ["r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"]
-CFG4_TRAFFIC = ["r3_cfg4_pmc_traffic.json", "r2_cfg4_pmc_traffic.json", "r1_cfg4_pmc_traffic.json"]
+CFG2_TRAFFIC = ["r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"]
+CFG4_TRAFFIC = ["r4_cfg4_pmc_traffic.json", "r3_cfg4_pmc_traffic.json", "r2_cfg4_pmc_traffic.json", "r1_cfg4_pmc_traffic.json"]
 
 
 def synthetic_batch(B, P, R, seed, device):
@@ -62,51 +62,89 @@ class LaunchTimer:
 
     def __init__(self, ops):
         self.ops = ops
-        self.records = {"conv": [], "wgrad": []}
+        self.records = {"conv": [], "shell": [], "wgrad": []}
         self.enabled = False
         self._orig = {}
 
-    def _wrap(self, name, kind, shape_of, is64, shell):
-        orig = getattr(self.ops, name, None)
-        if orig is None:
-            return
-        self._orig[name] = orig
-        rec = self.records[kind]
-
-        def f(*a, **k):
-            if not self.enabled or not is64(*a, **k):
-                return orig(*a, **k)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); out = orig(*a, **k); e1.record()
-            N, D, H, W = shape_of(*a, **k)
-            # positions of the padded grid outside the volume: the fused dgrad computes them with 9 of the 27 taps (shell slabs)
-            extra = N * ((D + 2) * (H + 2) * (W + 2) - D * H * W) if shell else 0
-            rec.append((N * D * H * W, e0, e1, extra))
-            return out
-        setattr(self.ops, name, f)
-
     def install(self):
+        ops = self.ops
         shp = lambda t: tuple(t.shape[:4])
-        self._wrap("conv3d_fwd", "conv", lambda x, w, *a, **k: shp(x), lambda x, w, *a, **k: tuple(w.shape) == (3, 3, 3, 64, 64), False)
-        self._wrap("conv3d_dgrad_fused", "conv", lambda dz, *a, **k: shp(dz), lambda *a, **k: True, True)
-        self._wrap("conv3d_wgrad", "wgrad", lambda x, dz, K, Cin, Cout, *a, **k: shp(x),
-                   lambda x, dz, K, Cin, Cout, *a, **k: (K, Cin, Cout) == (3, 64, 64), False)
+
+        def bracket(kind, vox, exec_flop, fn):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); out = fn(); e1.record()
+            self.records[kind].append((vox, e0, e1, exec_flop))
+            return out
+
+        fwd, dgf, wg = ops.conv3d_fwd, ops.conv3d_dgrad_fused, ops.conv3d_wgrad
+        self._orig = {"conv3d_fwd": fwd, "conv3d_dgrad_fused": dgf, "conv3d_wgrad": wg}
+
+        def conv3d_fwd(x, w, *a, **k):
+            if not self.enabled or tuple(w.shape) != (3, 3, 3, 64, 64):
+                return fwd(x, w, *a, **k)
+            N, D, H, W = shp(x)
+            return bracket("conv", N * D * H * W, executed_conv64_flop(N, D, H, W, x.dtype, k.get("algo", 0)), lambda: fwd(x, w, *a, **k))
+
+        def conv3d_dgrad_fused(dz, *a, **k):
+            if not self.enabled:
+                return dgf(dz, *a, **k)
+            N, D, H, W = shp(dz)
+            if dz.dtype != torch.float32 or "parts" in k:
+                # bf16 mode: ONE launch covers the inner box and the shell (conv64_bf16.hip); priced as algorithmic work
+                return bracket("conv", N * D * H * W, N * D * H * W * FLOP_PER_VOXEL_CONV64, lambda: dgf(dz, *a, **k))
+            # fp32: the entry point issues the inner box and the shell faces as two launches of two kernels (conv64_wino2d_kernel /
+            # conv64_wino_kernel); issue them through the same entry point as the two `parts` they are, so that each kernel gets its own
+            # HIP-event bracket -- same launches, same order, same stream
+            out = bracket("conv", N * D * H * W, executed_conv64_flop(N, D, H, W, dz.dtype, k.get("algo", 0)),
+                          lambda: dgf(dz, *a, parts=1, **k))
+            bracket("shell", 0, executed_shell_flop(N, D, H, W), lambda: dgf(dz, *a, parts=2, **k))
+            return out
+
+        def conv3d_wgrad(x, dz, K, Cin, Cout, *a, **k):
+            if not self.enabled or (K, Cin, Cout) != (3, 64, 64):
+                return wg(x, dz, K, Cin, Cout, *a, **k)
+            N, D, H, W = shp(x)
+            f = 1.0 if x.dtype != torch.float32 or W % 4 else 0.5           # Winograd F(3,4) along W: 13.5 of 27 tap-equivalents
+            return bracket("wgrad", N * D * H * W, f * N * D * H * W * FLOP_PER_VOXEL_CONV64, lambda: wg(x, dz, K, Cin, Cout, *a, **k))
+
+        ops.conv3d_fwd, ops.conv3d_dgrad_fused, ops.conv3d_wgrad = conv3d_fwd, conv3d_dgrad_fused, conv3d_wgrad
 
     def uninstall(self):
         for name, orig in self._orig.items():
             setattr(self.ops, name, orig)
 
     def summary(self, kind):
+        """(launches, mean ms, mean ALGORITHMIC FLOP per launch = 221 184 x voxels, mean EXECUTED FLOP per launch)"""
         recs = self.records[kind]
         n = len(recs)
         if n == 0:
             return None
         total_ms = sum(e0.elapsed_time(e1) for _, e0, e1, _ in recs)
         total_flop = sum(vox * FLOP_PER_VOXEL_CONV64 for vox, _, _, _ in recs)
-        # FLOPs the MFMA pipe actually executes: Winograd F(4,3)/F(3,4) along W needs 13.5 tap-equivalents per voxel instead of
-        # 27 (W extents here are multiples of 4); the dgrad shell positions run 9 direct taps each
-        exec_flop = sum(0.5 * vox * FLOP_PER_VOXEL_CONV64 + extra * 9 * 2.0 * 64 * 64 for vox, _, _, extra in recs)
-        return n, total_ms / n, total_flop / n, exec_flop / n
+        return n, total_ms / n, total_flop / n, sum(ex for _, _, _, ex in recs) / n
+
+
+def executed_conv64_flop(N, D, H, W, dtype=None, algo=0):
+    """FLOPs the matrix pipe executes for one 64->64 3x3x3 forward (or fused-dgrad inner box) over N x D x H x W voxels, by the kernel
+    FDN_ALGO_AUTO picks (conv64_mfma.hip: fdn_conv64_launch_ex): 2-D Winograd F(2,3)xF(4,3) = 9 of the 27 tap-equivalents per
+    voxel when H is even and W a multiple of 4, 1-D Winograd F(4,3) along W = 13.5 when only W qualifies, else all 27."""
+    taps = 27.0
+    if (dtype is None or dtype == torch.float32) and algo != 1:
+        if W % 4 == 0:
+            taps = 13.5
+            if H % 2 == 0 and algo == 0:
+                taps = 9.0
+    return N * D * H * W * taps * 2.0 * 64 * 64
+
+
+def executed_shell_flop(N, D, H, W):
+    """The shell launch of a fused dgrad (padded grid (D+2)(H+2)(W+2) minus the inner box), conv64_wino_kernel regions: the two d
+    faces and the two h faces over the inner W range have ONE depth resp. height tap x 3 x 3 others, transformed along W
+    (9 taps x 6/4 / ... = 4.5 tap-equivalents per position); the two w faces run 9 (kd,kh) taps x one Winograd coordinate each
+    (9 tap-equivalents per position)."""
+    dh_faces = 2 * (H + 2) * W + 2 * D * W
+    w_faces = 2 * (D + 2) * (H + 2)
+    return N * (dh_faces * 4.5 + w_faces * 9.0) * 2.0 * 64 * 64
 
 
 def pmc_traffic_bytes(fname, kernel):
@@ -184,6 +222,9 @@ def roofline_obj(timer, kind, bf16, kernel, traffic_files):
     achieved = avg_exec / (avg_ms * 1e-3) / 1e12              # FLOPs issued on the matrix pipe per second
     algorithmic = avg_flop / (avg_ms * 1e-3) / 1e12           # direct-convolution FLOPs per second
     traffic, tfile = pmc_traffic_bytes(traffic_files, kernel.split(" ")[0])
+    if kind == "shell":                                       # no algorithmic work of its own: part of the fused dgrad
+        return {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                "traffic": traffic, "launches_timed": n_launch, "avg_launch_ms": avg_ms, "executed_gflop_per_launch": avg_exec / 1e9}
     vox = avg_flop / FLOP_PER_VOXEL_CONV64
     esz = 2.0 if bf16 else 4.0
     # conv: in + out rows + the weight stream; wgrad: x + dz rows + the dW it writes (fp32)
@@ -198,10 +239,10 @@ def roofline_obj(timer, kind, bf16, kernel, traffic_files):
             # ALGORITHMIC work.  > peak when the kernel executes fewer multiplies than the direct algorithm (fp32: Winograd along W)
             "algorithmic_gflop_per_launch": avg_flop / 1e9, "algorithmic_achieved": algorithmic,
             "algorithmic_frac": algorithmic / peak, "algorithmic_speedup": avg_flop / avg_exec,
-            "note": None if bf16 else "achieved/frac = FLOPs the Winograd F(4,3)/F(3,4)-along-W kernel EXECUTES on the fp32 MFMA pipe (half of the "
-                                      "direct algorithm's multiplies + 9 direct taps per dgrad shell position) = matrix-pipe utilisation; PMC "
-                                      "SQ_VALU_MFMA_BUSY_CYCLES agrees (profiles/README.md).  algorithmic_* prices the same launches with the "
-                                      "direct 3x3x3 FLOP count of SURVEY 8d and therefore exceeds the peak"}
+            "note": None if bf16 else "achieved/frac = FLOPs the Winograd kernel EXECUTES on the fp32 MFMA pipe (forward / dgrad inner box: "
+                                      "2-D F(2,3)xF(4,3), a third of the direct algorithm's multiplies; wgrad: F(3,4) along W, half) = matrix-pipe "
+                                      "utilisation; PMC SQ_VALU_MFMA_BUSY_CYCLES agrees (profiles/README.md).  algorithmic_* prices the same "
+                                      "launches with the direct 3x3x3 FLOP count of SURVEY 8d and therefore exceeds the peak"}
 
 
 def timed_steps(step_fn, steps, warmup, parallel):
@@ -486,10 +527,13 @@ def main():
                                   if oversub else "RCCL sum all-reduce of the flat fp32 gradient (%d B) per step, %s"
                                   % (4 * (tc.model.n_params + 1), "3 buckets started inside backward" if tc.bucketed_allreduce
                                      else "one call after backward"))},
-        "roofline": roofline_obj(timer, "conv", bf16, "%s (3x3x3 64->64 fwd + dgrad launches%s)"
-                                 % (("conv64_bf16_kernel", "") if bf16 else ("conv64_wino_kernel", "; Winograd F(4,3) along W, dgrad shell slabs on conv64_mfma_kernel")), tr),
+        "roofline": roofline_obj(timer, "conv", bf16, "%s (3x3x3 64->64 forward + fused-dgrad%s launches%s)"
+                                 % (("conv64_bf16_kernel", "", "") if bf16 else
+                                    ("conv64_wino2d_kernel", " inner-box", "; 2-D Winograd F(2,3) along H x F(4,3) along W")), tr),
         "roofline_wgrad": roofline_obj(timer, "wgrad", bf16, "%s (3x3x3 64->64 weight gradient + partial reduction%s)"
                                        % (("wgrad64_bf16_kernel", "") if bf16 else ("wgrad64_wino_kernel", "; Winograd F(3,4) along W")), tr),
+        "roofline_dgrad_shell": None if bf16 else roofline_obj(timer, "shell", False, "conv64_wino_kernel (shell faces of the fused dgrad: "
+                                                               "d / h faces F(4,3) along W, w faces one Winograd coordinate)", tr),
         "train_step_tflops": args.steps * B * world / dt * 3.0 * fwd_flop / 1e12,
         "lib_source_stamp": build.source_stamp()[:16],          # sha256 prefix of csrc/ + include/fdn.h + flags the binary was built from
     }

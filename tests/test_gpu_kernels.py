@@ -143,10 +143,12 @@ def test_conv64_dgrad_and_fold(ops, shape):
 
 
 @pytest.mark.parametrize("shape,layout", [(sh, lo) for sh in SHAPES + [(1, 1, 1, 1), (1, 2, 3, 1)] for lo in (0, 1, 2, 3, 4, 5, 6)] +
-                         [(sh, lo) for sh in WINO_SHAPES for lo in (0, 7, 5, 8)])
+                         [(sh, lo) for sh in WINO_SHAPES for lo in (0, 7, 5, 8)] +
+                         [(sh, 0) for sh in [(1, 5, 8, 12), (2, 9, 2, 24), (1, 1, 2, 4), (1, 3, 6, 20), (1, 11, 14, 28), (1, 2, 4, 4)]])   # 2-D Winograd inner box
 def test_conv64_dgrad_fused_fold(ops, fdn, shape, layout):
     """dgrad with the interior fold in the conv epilogue + border kernel == oracle dgrad (+ skip, * act').
-    layout 0 = product library (Winograd launch incl. the w-face region), 7 = forced Winograd (test build), 8 = Winograd with the
+    layout 0 = product library (H even, W % 4 == 0: inner box on the 2-D Winograd kernel + the shell faces as a 1-D Winograd launch;
+    W % 4 == 0 only: one 1-D Winograd launch incl. the w-face region), 7 = forced 1-D Winograd (test build), 8 = Winograd with the
     w faces on the separate direct-kernel launch (the round-2 path, kept as a test-build switch), 1..6 = direct layouts."""
     wface_direct = layout == 8
     if wface_direct:

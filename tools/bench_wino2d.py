@@ -40,6 +40,14 @@ def main():
             t = timeit(lambda: ops.conv3d_fwd(x, w, None, ops.ACT_RELU, wpack=wp, out=out, algo=algo))
             t2 = timeit(lambda: ops.conv3d_fwd(x, w, None, ops.ACT_LEAKY, residual=res, wpack=wp, out=out, algo=algo))
             print("fwd %-20s N=%d P=%d : %.3f ms (%.1f TF algorithmic)   +res+leaky %.3f ms" % (name, N, P, t, flop / t / 1e9, t2), flush=True)
+        pad = torch.empty(N, P + 2, P + 2, P + 2, 64, device="cuda")
+        dxo = torch.empty_like(x)
+        for name, algo in (("2-D inner + 1-D shell", ops.ALGO_AUTO), ("1-D F(4,3), one launch", ops.ALGO_WINO_W)):
+            t = timeit(lambda: (ops.conv3d_dgrad_fused(x, wd, pad, dxo, skip=res, y_prev=out, act=ops.ACT_LEAKY, algo=algo),
+                                ops.fold_halo_border([pad], dxo, res, out, ops.ACT_LEAKY)))
+            ti = timeit(lambda: ops.conv3d_dgrad_fused(x, wd, pad, dxo, skip=res, y_prev=out, act=ops.ACT_LEAKY, parts=1, algo=algo))
+            ts = timeit(lambda: ops.conv3d_dgrad_fused(x, wd, pad, dxo, skip=res, y_prev=out, act=ops.ACT_LEAKY, parts=2, algo=algo))
+            print("dgrad fused+border %-24s N=%d P=%d : %.3f ms   (inner box alone %.3f, shell alone %.3f)" % (name, N, P, t, ti, ts), flush=True)
         if "--ablate" in sys.argv:
             with fdn._lib.test_build() as lib:
                 for bits, what in ((0, "full"), (4, "no staging"), (8, "no epilogue"), (1, "weights from one unit"), (13, "K loop only"), (128, "no XCD remap")):
