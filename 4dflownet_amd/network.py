@@ -81,8 +81,9 @@ class FlowNetModel:
     def __init__(self, res_increase, low_resblock=8, hi_resblock=4, device=None, seed=0, dtype="float32", conv_algo=None):
         """dtype: storage type of activations and activation gradients -- "float32" (the reference's arithmetic) or
         "bfloat16" (BASELINE.json configs[3]; parameters, their gradients, the prediction and the optimizer stay fp32).
-        conv_algo (fp32 mode): algorithm of the 64->64 3x3x3 layers -- "auto" (FDN_ALGO_AUTO: Winograd along W where the W
-        extent allows it), "direct" (FDN_ALGO_DIRECT everywhere), or a dict {layer name: "direct"} that pins single layers
+        conv_algo (fp32 mode): algorithm of the 64->64 3x3x3 layers -- "auto" (FDN_ALGO_AUTO: 2-D Winograd F(2,3)xF(4,3) forward / dgrad
+        where H is even and W a multiple of 4, Winograd along W where only W allows it), "winograd_w" (FDN_ALGO_WINO_W: the 1-D kernels
+        only), "direct" (FDN_ALGO_DIRECT everywhere), or a dict {layer name: "direct"} that pins single layers
         (forward, dgrad and wgrad of that layer) to the direct kernels; None reads FDN_CONV_ALGO (default "auto")."""
         if not torch.cuda.is_available():
             raise FdnError("FlowNetModel needs a ROCm GPU: the hot path is HIP-only (no CPU fallback)")
@@ -159,12 +160,12 @@ class FlowNetModel:
         """See __init__.  Takes effect from the next forward()."""
         if conv_algo is None:
             conv_algo = os.environ.get("FDN_CONV_ALGO", "auto")
-        names = {"auto": ops.ALGO_AUTO, "winograd": ops.ALGO_AUTO, "direct": ops.ALGO_DIRECT}
+        names = {"auto": ops.ALGO_AUTO, "winograd": ops.ALGO_AUTO, "direct": ops.ALGO_DIRECT, "winograd_w": ops.ALGO_WINO_W}
         per_layer = {}
         if isinstance(conv_algo, dict):
             per_layer, conv_algo = conv_algo, conv_algo.get("*", "auto")
         if conv_algo not in names or any(v not in names for v in per_layer.values()):
-            raise ValueError("conv_algo must be 'auto', 'direct' or {layer name: 'auto'|'direct'}")
+            raise ValueError("conv_algo must be 'auto', 'direct', 'winograd_w' or {layer name: one of these}")
         known = set(L.name for L in self.layers)
         unknown = [k for k in per_layer if k != "*" and k not in known]
         if unknown:
