@@ -60,7 +60,9 @@ class _VolumeCache:
 
     def __init__(self, max_bytes=None):
         import collections
+        import threading
         self._d = collections.OrderedDict()
+        self._lock = threading.RLock()             # the loader's worker threads share one cache
         self._bytes = 0
         self.max_bytes = int(os.environ.get("FDN_VOLUME_CACHE_BYTES", 8 << 30)) if max_bytes is None else int(max_bytes)
 
@@ -70,6 +72,10 @@ class _VolumeCache:
         return (os.path.realpath(path), st.st_mtime_ns, st.st_size)
 
     def get(self, path, name):
+        with self._lock:
+            return self._get(path, name)
+
+    def _get(self, path, name):
         fid = self._file_id(path)
         key = fid + (name,)
         if key in self._d:
@@ -91,26 +97,117 @@ class _VolumeCache:
 
 class _BatchedDataset:
     """What initialize_dataset returns: iterable of batched 11-tuples; reshuffled on every pass
-    (ds.shuffle(len).map(load).batch(bs).prefetch(bs), PatchHandler3D.py:25-36)."""
+    (ds.shuffle(len).map(load, num_parallel_calls).batch(bs).prefetch(bs), PatchHandler3D.py:25-36).
 
-    def __init__(self, handler, indexes, shuffle, seed, shard):
+    Like the reference's tf.data pipeline it runs AHEAD of the consumer: a producer thread assembles up to `prefetch` batches
+    (FDN_LOADER_PREFETCH, default 2; 0 = synchronous) while the train step of the previous one runs, loading the samples of a batch
+    on `n_parallel` worker threads (the `map` parallelism: None = min(4, cores), as AUTOTUNE would pick; <= 1 = in the producer
+    thread).  pinned=True (scripts/trainer.py with FDN_HOST_LOADER=1; FDN_LOADER_PINNED=1) stacks the samples straight into PINNED
+    host buffers, so the consumer's host-to-device copy is one DMA per tensor instead of a pageable copy; those buffers form a
+    ring of prefetch + 2 batches, i.e. a batch is valid only until the consumer has asked for two more (the training loop's
+    pattern) -- the default hands out fresh arrays the caller may keep, like tf.data does."""
+
+    def __init__(self, handler, indexes, shuffle, seed, shard, n_parallel=None, prefetch=None, pinned=None):
         self.h = handler
         self.indexes = np.atleast_2d(indexes)
         self.sampler = parallel.ShardedIndexSampler(len(self.indexes), handler.batch_size, shuffle, seed,
                                                     rank_=shard[0], world=shard[1])
+        self.n_parallel = min(4, os.cpu_count() or 1) if n_parallel is None else int(n_parallel)
+        self.prefetch = int(os.environ.get("FDN_LOADER_PREFETCH", "2")) if prefetch is None else int(prefetch)
+        self.pinned = (os.environ.get("FDN_LOADER_PINNED", "0") not in ("", "0")) if pinned is None else bool(pinned)
+        self._ring = None
 
     def __len__(self):
         return len(self.sampler)
 
-    def __iter__(self):
-        for rows in self.sampler:
-            samples = [self.h.load_patches_from_index_file(self.indexes[r]) for r in rows]
-            if not samples:
-                P, H = self.h.patch_size, self.h.patch_size * self.h.res_increase
-                z = lambda *s: np.zeros(s, np.float32)
-                yield tuple([z(0, P, P, P, 1)] * 6 + [z(0, H, H, H, 1)] * 3 + [z(0), z(0, H, H, H)])
+    def _slots(self):
+        """Ring of pinned batch buffers (plain numpy without a GPU): slot -> 11 arrays of the full batch shape."""
+        if self._ring is None:
+            P, H, B = self.h.patch_size, self.h.patch_size * self.h.res_increase, self.h.batch_size
+            shapes = [(B, P, P, P, 1)] * 6 + [(B, H, H, H, 1)] * 3 + [(B,), (B, H, H, H)]
+            pin = False
+            try:
+                import torch
+                pin = torch.cuda.is_available()
+            except Exception:
+                pass
+
+            def alloc(shape):
+                if pin:
+                    import torch
+                    return torch.empty(shape, dtype=torch.float32).pin_memory().numpy()
+                return np.empty(shape, np.float32)
+            self._ring = [[alloc(sh) for sh in shapes] for _ in range(max(self.prefetch, 0) + 2)]
+        return self._ring
+
+    def _assemble(self, rows, pool, slot):
+        if len(rows) == 0:
+            P, H = self.h.patch_size, self.h.patch_size * self.h.res_increase
+            z = lambda *s: np.zeros(s, np.float32)
+            return tuple([z(0, P, P, P, 1)] * 6 + [z(0, H, H, H, 1)] * 3 + [z(0), z(0, H, H, H)])
+        load = lambda r: self.h.load_patches_from_index_file(self.indexes[r])
+        samples = list(pool.map(load, rows)) if pool is not None else [load(r) for r in rows]
+        if not self.pinned:
+            return tuple(np.stack([s_[i] for s_ in samples], axis=0) for i in range(11))
+        bufs = self._slots()[slot]
+        out = []
+        for i in range(11):
+            dst = bufs[i][:len(samples)]
+            if tuple(dst.shape[1:]) != tuple(np.shape(samples[0][i])):      # a patch cut short by the volume's edge: no fixed buffer
+                out.append(np.stack([s_[i] for s_ in samples], axis=0))
                 continue
-            yield tuple(np.stack([s[i] for s in samples], axis=0) for i in range(11))
+            for b, s_ in enumerate(samples):
+                dst[b] = s_[i]
+            out.append(dst)
+        return tuple(out)
+
+    def __iter__(self):
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(self.n_parallel) if self.n_parallel > 1 else None
+        nslot = max(self.prefetch, 0) + 2
+        if self.prefetch <= 0:
+            try:
+                for k, rows in enumerate(self.sampler):
+                    yield self._assemble(rows, pool, k % nslot)
+            finally:
+                if pool is not None:
+                    pool.shutdown(wait=False)
+            return
+        import queue
+        import threading
+        q = queue.Queue(maxsize=self.prefetch)
+        stop = threading.Event()
+
+        def produce():
+            try:
+                for k, rows in enumerate(self.sampler):
+                    item = self._assemble(rows, pool, k % nslot)
+                    while not stop.is_set():
+                        try:
+                            q.put(("batch", item), timeout=0.1)
+                            break
+                        except queue.Full:
+                            pass
+                    if stop.is_set():
+                        return
+                q.put(("end", None))
+            except BaseException as e:                      # surfaces in the consumer, not in a dead thread
+                q.put(("error", e))
+
+        t = threading.Thread(target=produce, name="fdn-loader", daemon=True)
+        t.start()
+        try:
+            while True:
+                kind, item = q.get()
+                if kind == "end":
+                    break
+                if kind == "error":
+                    raise item
+                yield item
+        finally:
+            stop.set()
+            if pool is not None:
+                pool.shutdown(wait=False)
 
 
 class PatchHandler3D:
@@ -127,14 +224,16 @@ class PatchHandler3D:
         self.mask_colname = 'mask'
         self._cache = _VolumeCache()
 
-    def initialize_dataset(self, indexes, shuffle, n_parallel=None, seed=0, shard=None):
-        """indexes: (N,10) array from load_indexes.  n_parallel is accepted for compatibility (slicing from the
-        in-memory cache needs no worker pool).  shard=(rank, world) splits every global batch across ranks;
-        default: the current torch.distributed rank/world (single process -> no sharding)."""
+    def initialize_dataset(self, indexes, shuffle, n_parallel=None, seed=0, shard=None, prefetch=None, pinned=None):
+        """indexes: (N,10) array from load_indexes.  n_parallel = worker threads that load the samples of a batch (the reference's
+        `map(..., num_parallel_calls=n_parallel)`; None = auto), prefetch = batches assembled ahead of the consumer (the
+        reference's `.prefetch`; None = FDN_LOADER_PREFETCH or 2, 0 = synchronous), pinned = stack into a ring of pinned host
+        buffers (see _BatchedDataset).  shard=(rank, world) splits every global batch across ranks; default: the current
+        torch.distributed rank/world (single process -> no sharding)."""
         print("Total dataset:", len(np.atleast_2d(indexes)), 'shuffle', shuffle)
         if shard is None:
             shard = (parallel.rank(), parallel.world_size())
-        return _BatchedDataset(self, indexes, shuffle, seed, shard)
+        return _BatchedDataset(self, indexes, shuffle, seed, shard, n_parallel, prefetch, pinned)
 
     def load_data_using_patch_index(self, indexes):
         """The tf.py_function bridge of the reference (PatchHandler3D.py:40-47) is unnecessary here; same result."""

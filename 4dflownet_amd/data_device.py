@@ -46,7 +46,7 @@ class DevicePatchHandler3D(PatchHandler3D):
             self._dev[key] = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
         return self._dev[key]
 
-    def initialize_dataset(self, indexes, shuffle, n_parallel=None, seed=0, shard=None):
+    def initialize_dataset(self, indexes, shuffle, n_parallel=None, seed=0, shard=None, prefetch=None, pinned=None):
         print("Total dataset:", len(np.atleast_2d(indexes)), 'shuffle', shuffle)
         if shard is None:
             shard = (parallel.rank(), parallel.world_size())

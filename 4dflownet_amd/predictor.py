@@ -2,7 +2,7 @@
 de-normalise -> zero sub-pixel velocities -> append u,v,w (+dx/res_increase) to the output HDF5.
 
 With torch.distributed initialised (BASELINE cfg5) the patch list is split contiguously across ranks; every rank
-runs its share through the HIP forward and the HR patches are all-gathered so rank 0 stitches and writes."""
+runs its share through the same pipelined HIP forward loop and sends exactly its rows to rank 0, which stitches and writes."""
 import os
 import time
 
@@ -27,19 +27,23 @@ def save_to_h5(output_filepath, col_name, dataset, compression=None):
     h5io.append_dataset(output_filepath, col_name, dataset, compression=compression)
 
 
-def _predict_pipelined(network, velocities, magnitudes, batch_size, lo, hi):
-    """Single-process path: the float64 conversion runs on the device, every batch's result travels to a pinned staging buffer on
-    a copy stream while the next batch computes, and the host moves it into the result array in that shadow -- the loop costs the
-    forward time only."""
-    S = velocities[0].shape[1] * network.res_increase
-    res = np.empty((hi - lo, S, S, S, 3), dtype=np.float64)
+def _stage(network, batch_size, S):
+    """Two pinned float64 staging buffers + a copy stream, kept on the network between calls."""
     key = (batch_size, S)
     st = getattr(network, "_predict_stage", None)
     if st is None or st[0] != key:
         st = (key, [torch.empty((batch_size, S, S, S, 3), dtype=torch.float64).pin_memory() for _ in range(2)],
               torch.cuda.Stream(device=network.device))
         network._predict_stage = st
-    _, stage, copy_stream = st
+    return st[1], st[2]
+
+
+def _drain_to_host(network, chunks, res, batch_size):
+    """chunks: iterable of (first row, device tensor (cnt,S,S,S,3) fp32 or fp64) in production order.  Converts to float64 on the
+    device, moves every chunk to a pinned staging buffer on a copy stream while the producer of the NEXT chunk runs, and copies it
+    into `res` in that shadow: the loop costs the producer's time only."""
+    S = res.shape[1]
+    stage, copy_stream = _stage(network, batch_size, S)
     main = torch.cuda.current_stream(network.device)
     inflight = [None, None]                      # per staging slot: (event, first row, row count, device tensor kept alive)
 
@@ -50,50 +54,108 @@ def _predict_pipelined(network, velocities, magnitudes, batch_size, lo, hi):
             res[r0:r0 + cnt] = stage[slot][:cnt].numpy()
             inflight[slot] = None
 
-    for k, s in enumerate(range(lo, hi, batch_size)):
-        e = min(s + batch_size, hi)
-        ins = [velocities[i][s:e] for i in range(3)] + [magnitudes[i][s:e] for i in range(3)]
-        out64 = network.forward(ins).double()
+    for k, (r0, out) in enumerate(chunks):
+        out64 = out.double()
+        cnt = out64.shape[0]
         slot = k & 1
-        drain(slot)                              # the copy issued two batches ago has long finished; frees the staging slot
+        drain(slot)                              # the copy issued two chunks ago has long finished; frees the staging slot
         copy_stream.wait_stream(main)
         with torch.cuda.stream(copy_stream):
-            stage[slot][:e - s].copy_(out64, non_blocking=True)
+            stage[slot][:cnt].copy_(out64, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(copy_stream)
         out64.record_stream(copy_stream)
-        inflight[slot] = (ev, s - lo, e - s, out64)
-        drain(slot ^ 1)                          # the previous batch's rows, while this batch computes
+        inflight[slot] = (ev, r0, cnt, out64)
+        drain(slot ^ 1)                          # the previous chunk's rows, while this one is produced
     drain(0); drain(1)
     return res
 
 
+def _forward_chunks(network, velocities, magnitudes, batch_size, lo, hi, base=0, keep=None):
+    """The batched forward loop of predictor.py:79-94 over patches [lo, hi): yields (row - base, prediction) per batch; with `keep`
+    (a device buffer) every prediction is also stored at rows [row - lo, ...) of it."""
+    for s in range(lo, hi, batch_size):
+        e = min(s + batch_size, hi)
+        ins = [velocities[i][s:e] for i in range(3)] + [magnitudes[i][s:e] for i in range(3)]
+        out = network.forward(ins)
+        if keep is not None:
+            keep[s - lo:e - lo].copy_(out)
+        yield s - base, out
+
+
+def _predict_pipelined(network, velocities, magnitudes, batch_size, lo, hi):
+    """Single-process path: forward + float64 conversion on the device, results to the host behind the next batch's compute."""
+    S = velocities[0].shape[1] * network.res_increase
+    res = np.empty((hi - lo, S, S, S, 3), dtype=np.float64)
+    return _drain_to_host(network, _forward_chunks(network, velocities, magnitudes, batch_size, lo, hi, base=lo), res, batch_size)
+
+
+def shard_bounds(n, world):
+    """Contiguous shards of the patch list: rank r owns rows [bounds[r], bounds[r+1]) (the last ranks may own none)."""
+    per = (n + world - 1) // world
+    return [min(r * per, n) for r in range(world + 1)]
+
+
 def predict_patches(network, velocities, magnitudes, batch_size):
-    """The batched predict loop of predictor.py:79-94 (results accumulate in float64 like np.zeros + np.append
-    there), with the patch list sharded over ranks when running data-parallel."""
+    """The batched predict loop of predictor.py:79-94 (results accumulate in float64 like np.zeros + np.append there).
+
+    Data-parallel (BASELINE cfg5): the patch list is sharded contiguously over the ranks, every rank runs the same pipelined loop
+    on its shard, and rank 0 -- the only rank that stitches and writes -- receives exactly the rows each rank owns (no padding, no
+    copy to ranks that do not need it).  Returns the (n,S,S,S,3) float64 array on rank 0 and None on the other ranks.
+      nccl (= RCCL): fp32 predictions travel device-to-device; rank 0 then converts to float64 on the device and drains through the
+      pinned staging buffers.
+      gloo (CPU tests, two ranks on one device): every rank drains its own shard to the host and sends the float64 rows."""
     n = len(velocities[0])
     world, rank = parallel.world_size(), parallel.rank()
     if world == 1:
         return _predict_pipelined(network, velocities, magnitudes, batch_size, 0, n)
-    per = (n + world - 1) // world
-    lo, hi = min(rank * per, n), min((rank + 1) * per, n)
-    outs = []
-    for s in range(lo, hi, batch_size):
-        e = min(s + batch_size, hi)
-        ins = [velocities[i][s:e] for i in range(3)] + [magnitudes[i][s:e] for i in range(3)]
-        outs.append(network.forward(ins))
+    import torch.distributed as dist
     S = velocities[0].shape[1] * network.res_increase
-    mine = torch.cat(outs, 0) if outs else torch.zeros((0, S, S, S, 3), device=network.device)
-    pad = torch.zeros((per, S, S, S, 3), device=network.device)
-    pad[:mine.shape[0]] = mine
-    gathered = parallel.all_gather_equal(pad)
-    mine = torch.cat([g[:max(0, min((r + 1) * per, n) - min(r * per, n))] for r, g in enumerate(gathered)], 0)
-    return mine.cpu().numpy().astype(np.float64)
+    bounds = shard_bounds(n, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    dev = torch.device(network.device)
+    if dev.type == "cuda" and not parallel._host_staged():
+        if rank == 0:
+            full = torch.empty((n, S, S, S, 3), device=dev, dtype=torch.float32)
+            res = np.empty((n, S, S, S, 3), dtype=np.float64)
+            _drain_to_host(network, _forward_chunks(network, velocities, magnitudes, batch_size, lo, hi), res, batch_size)
+            # receives are posted AFTER the own shard (a pending RCCL receive is a kernel spinning on a few CUs); the peers finish
+            # their equal shards at about the same time, so only the transfer itself (1.3 MB per patch over xGMI) is exposed
+            reqs = [dist.irecv(full[bounds[r]:bounds[r + 1]], src=r) for r in range(1, world) if bounds[r + 1] > bounds[r]]
+            for q in reqs:
+                q.wait()                              # makes the current stream wait for the transfer; no host sync
+            step = max(batch_size, 1)
+            _drain_to_host(network, ((s, full[s:min(s + step, n)]) for s in range(hi, n, step)), res, batch_size)
+            return res
+        if hi > lo:
+            mine = torch.empty((hi - lo, S, S, S, 3), device=dev, dtype=torch.float32)
+            for _ in _forward_chunks(network, velocities, magnitudes, batch_size, lo, hi, keep=mine):
+                pass
+            dist.send(mine, dst=0)
+        return None
+    # host transport
+    if dev.type == "cuda":
+        mine = _predict_pipelined(network, velocities, magnitudes, batch_size, lo, hi)
+    else:                                             # CPU stand-in network (tests): same loop without the staging machinery
+        mine = np.empty((hi - lo, S, S, S, 3), dtype=np.float64)
+        for r0, out in _forward_chunks(network, velocities, magnitudes, batch_size, lo, hi, base=lo):
+            mine[r0:r0 + out.shape[0]] = out.detach().cpu().numpy().astype(np.float64)
+    if rank == 0:
+        res = np.empty((n, S, S, S, 3), dtype=np.float64)
+        res[lo:hi] = mine
+        for r in range(1, world):
+            if bounds[r + 1] > bounds[r]:
+                dist.recv(torch.from_numpy(res[bounds[r]:bounds[r + 1]]), src=r)     # straight into the result rows
+        return res
+    if hi > lo:
+        dist.send(torch.from_numpy(mine), dst=0)
+    return None
 
 
 def predict_file(network, input_filepath, output_filepath, patch_size, res_increase, batch_size=8,
                  round_small_values=True, verbose=True):
-    """predictor.py:67-115 for every row of the input file.  Returns the list of (u,v,w) volumes written."""
+    """predictor.py:67-115 for every row of the input file.  Returns the list of (u,v,w) volumes written (rank 0; the other ranks
+    of a data-parallel run compute their shard of every row's patches and return an empty list)."""
     pgen = PatchGenerator(patch_size, res_increase)
     dataset = ImageDataset()
     nr_rows = dataset.get_dataset_len(input_filepath)
@@ -104,7 +166,9 @@ def predict_file(network, input_filepath, output_filepath, patch_size, res_incre
         velocities, magnitudes = pgen.patchify(dataset)
         t0 = time.time()
         results = predict_patches(network, velocities, magnitudes, batch_size)
-        if verbose and is0:
+        if not is0:
+            continue                              # rank 0 holds the gathered patches: it alone stitches and writes
+        if verbose:
             print("Processed row %d/%d: %d patches in %.2f secs." % (nrow + 1, nr_rows, len(results), time.time() - t0))
         vols, cols = [], []
         for i in range(3):
@@ -117,8 +181,7 @@ def predict_file(network, input_filepath, output_filepath, patch_size, res_incre
             cols.append((dataset.velocity_colnames[i], v))
         if dataset.dx is not None:
             cols.append((dataset.dx_colname, np.expand_dims(dataset.dx / res_increase, axis=0)))
-        if is0:
-            h5io.append_datasets(output_filepath, cols, compression='gzip')     # u, v, w (+ dx/R): one pass over the file
+        h5io.append_datasets(output_filepath, cols, compression='gzip')     # u, v, w (+ dx/R): one pass over the file
         written.append(tuple(vols))
     return written
 

@@ -329,6 +329,51 @@ def secondary_runs(trainer, parallel, device, P, R, B, LB, HB, sustained_steps=3
     except Exception as e:                                 # secondary figures must never take the headline line down
         sec["cfg2_loader_fed"] = {"error": repr(e)}
     torch.cuda.empty_cache()
+    # (1b) the same with the HOST loader (scripts/trainer.py under FDN_HOST_LOADER=1): PatchHandler3D, producer thread + worker pool
+    # + pinned staging ring, one blocking H2D copy per tensor; and the loader alone (what one rank's host side can supply)
+    try:
+        data = importlib.import_module("4dflownet_amd.data")
+        patch_index = importlib.import_module("4dflownet_amd.patch_index")
+        ddir = os.path.join(ROOT, "tests", "golden", "data")
+        import contextlib, io, tempfile
+        with tempfile.TemporaryDirectory() as td:
+            csv_path = os.path.join(td, "benchh%d.csv" % P)
+            with contextlib.redirect_stdout(io.StringIO()):
+                patch_index.generate_patch_index(ddir, "example_data.h5", "example_data_HR.h5", csv_path, patch_size=P, n_patch=8 * B,
+                                                 minimum_coverage=0.05, seed=0)
+                rows = data.load_indexes(csv_path)
+                ph = data.PatchHandler3D(ddir, P, R, B, 0.6)
+                ds = ph.initialize_dataset(rows, shuffle=True, shard=(0, 1), pinned=True)
+        for _ in ds:                                       # warm the volume cache / allocate the pinned ring
+            pass
+        t0 = time.perf_counter()
+        n_rows = sum(b[0].shape[0] for b in ds)
+        dt_alone = time.perf_counter() - t0
+        tc = trainer.TrainerController(P, R, initial_learning_rate=1e-4, quicksave_enable=False, low_resblock=LB, hi_resblock=HB,
+                                       device=device, seed=0)
+        n_full = [0]
+
+        def epoch_h():
+            for batch in ds:
+                if batch[0].shape[0] == B:
+                    tc.train_step(batch)
+                    n_full[0] += 1
+        epoch_h()
+        torch.cuda.synchronize()
+        n_full[0] = 0
+        t0 = time.perf_counter()
+        epoch_h()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        sec["cfg2_host_loader_fed"] = {"value": n_full[0] * B / dt, "unit": "patches/s", "ms_per_step": dt / n_full[0] * 1e3, "steps": n_full[0],
+                                       "loader_alone_patches_per_s": n_rows / dt_alone, "loader_threads": ds.n_parallel, "prefetch": ds.prefetch,
+                                       "workload": "cfg2 train_step fed by the host loader data.PatchHandler3D (volumes cached in host memory, "
+                                                   "producer thread + %d worker threads, pinned staging ring, blocking H2D copy per tensor); "
+                                                   "loader_alone = the same epoch without the train step" % ds.n_parallel}
+        del tc, ds, ph
+    except Exception as e:
+        sec["cfg2_host_loader_fed"] = {"error": repr(e)}
+    torch.cuda.empty_cache()
     # (2) cfg4: patch 32, res x4, batch 4, bf16 activations (BASELINE.json configs[3])
     try:
         P4, R4, B4 = 32, 4, 4
@@ -389,6 +434,88 @@ def secondary_runs(trainer, parallel, device, P, R, B, LB, HB, sustained_steps=3
         del net, res
     except Exception as e:
         sec["cfg5_predictor"] = {"error": repr(e)}
+    torch.cuda.empty_cache()
+    return sec
+
+
+def secondary_runs_dp(trainer, parallel, device, P, R, B, LB, HB, rank, world):
+    """N > 1: the two secondary legs that have a data-parallel form, run by ALL ranks (collectives inside), barrier + synchronize on
+    both sides, max over ranks -- same timing rule as the headline.
+      cfg5_predictor  : predictor.predict_patches on the synthetic 100^3 volume, the patch list sharded over the ranks, rows gathered
+                        to rank 0 (gather included, stitching excluded); value = patches of the whole job per second
+      cfg2_loader_fed : the cfg2 train step fed by the on-device loader, every rank drawing its shard of each global batch."""
+    sec = {}
+    try:
+        predictor = importlib.import_module("4dflownet_amd.predictor")
+        tiler = importlib.import_module("4dflownet_amd.tiler")
+
+        class _Vol:
+            pass
+        rng = np.random.default_rng(0)
+        vol = _Vol()
+        for n_ in ("u", "v", "w"):
+            setattr(vol, n_, rng.uniform(-1, 1, (100, 100, 100)).astype(np.float32))
+        for n_ in ("mag_u", "mag_v", "mag_w"):
+            setattr(vol, n_, rng.uniform(0, 0.016, (100, 100, 100)).astype(np.float32))
+        net = predictor.prepare_network(P, R, LB, HB, device=device)
+        vel, mag = tiler.PatchGenerator(P, R).patchify(vol)
+        n_patch = len(vel[0])
+        predictor.predict_patches(net, vel, mag, B)                     # warm-up (allocations, staging buffers, RCCL channels)
+        parallel.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        predictor.predict_patches(net, vel, mag, B)
+        torch.cuda.synchronize(); parallel.barrier()
+        dt = parallel.allreduce_sum_host([time.perf_counter() - t0], op="max")[0]
+        sec["cfg5_predictor"] = {"value": n_patch / dt, "unit": "patches/s", "patches": int(n_patch), "ranks": world,
+                                 "patches_per_rank": [b - a for a, b in zip(predictor.shard_bounds(n_patch, world)[:-1],
+                                                                             predictor.shard_bounds(n_patch, world)[1:])],
+                                 "workload": "predictor.predict_patches on a synthetic 100^3 volume (patch_size=%d res_increase=%d batch=%d, "
+                                             "fp32): contiguous shards of the patch list, pipelined forward per rank, rows gathered to rank 0; "
+                                             "host<->device copies and the gather included, stitching excluded" % (P, R, B)}
+        del net
+    except Exception as e:
+        sec["cfg5_predictor"] = {"error": repr(e)}
+    torch.cuda.empty_cache()
+    try:
+        data_device = importlib.import_module("4dflownet_amd.data_device")
+        patch_index = importlib.import_module("4dflownet_amd.patch_index")
+        data = importlib.import_module("4dflownet_amd.data")
+        ddir = os.path.join(ROOT, "tests", "golden", "data")
+        import contextlib, io, tempfile
+        with tempfile.TemporaryDirectory() as td:
+            csv_path = os.path.join(td, "bench%d_%d.csv" % (P, rank))
+            with contextlib.redirect_stdout(io.StringIO()):
+                patch_index.generate_patch_index(ddir, "example_data.h5", "example_data_HR.h5", csv_path, patch_size=P, n_patch=8 * B * world,
+                                                 minimum_coverage=0.05, seed=0)          # same seed on every rank: the same rows
+                rows = data.load_indexes(csv_path)
+                ph = data_device.DevicePatchHandler3D(ddir, P, R, B, 0.6, device=device)
+                ds = ph.initialize_dataset(rows, shuffle=True, shard=(rank, world))
+        tc = trainer.TrainerController(P, R, initial_learning_rate=1e-4, quicksave_enable=False, low_resblock=LB, hi_resblock=HB,
+                                       device=device, seed=0)
+        n_steps = [0]
+
+        def epoch():
+            for batch in ds:
+                tc.train_step(batch)                               # ragged tails included: an empty shard still joins the all-reduce
+                n_steps[0] += 1
+        epoch()
+        parallel.barrier(); torch.cuda.synchronize()
+        n_steps[0] = 0
+        t0 = time.perf_counter()
+        epoch()
+        torch.cuda.synchronize()
+        mine = [0.0] * world
+        mine[rank] = (time.perf_counter() - t0) / max(n_steps[0], 1) * 1e3
+        parallel.barrier()
+        dt = parallel.allreduce_sum_host([time.perf_counter() - t0], op="max")[0]
+        sec["cfg2_loader_fed"] = {"value": len(rows) / dt, "unit": "patches/s", "ms_per_step": dt / n_steps[0] * 1e3, "steps": n_steps[0],
+                                  "per_rank_ms_per_step": parallel.allreduce_sum_host(mine), "ranks": world,
+                                  "workload": "cfg2 train_step fed by DevicePatchHandler3D on every rank (example_data*.h5 resident in HBM, %d rows "
+                                              "with random rotations, shuffle, each global batch of %d split over the ranks, gradient all-reduce)"
+                                              % (len(rows), B * world)}
+        del tc, ds, ph
+    except Exception as e:
+        sec["cfg2_loader_fed"] = {"error": repr(e)}
     torch.cuda.empty_cache()
     return sec
 
@@ -499,10 +626,22 @@ def main():
     waits = [e0.elapsed_time(e1) for e0, e1 in tc.allreduce_wait_events]
     mine[rank] = float(np.mean(waits)) if waits else 0.0
     per_rank_wait = parallel.allreduce_sum_host(mine)
+    sec_dp = None
+    if world > 1 and not bf16 and args.config == "cfg2" and not args.no_secondary:
+        specs_keep = tc.model.specs
+        n_params_keep, bucketed_keep = tc.model.n_params, tc.bucketed_allreduce
+        del tc, batch
+        torch.cuda.empty_cache()
+        sec_dp = secondary_runs_dp(trainer, parallel, device, P, R, B, LB, HB, rank, world)
     if rank != 0:
         if parallel.is_dist():
             parallel.barrier()
         return
+    if sec_dp is not None:
+        class _Keep:                                          # the headline controller was released before the secondary legs
+            pass
+        tc = _Keep(); tc.model = _Keep(); tc.model.specs = specs_keep; tc.model.n_params = n_params_keep; tc.bucketed_allreduce = bucketed_keep
+        batch = None
     fwd_flop = fwd_flop_per_patch(tc.model.specs, P, R, LB)
     tr = CFG4_TRAFFIC if args.config == "cfg4" else ([] if bf16 else CFG2_TRAFFIC)
     line = {
@@ -543,6 +682,8 @@ def main():
                                         "how": "HIP events on the compute stream around allreduce_wait (trainer.train_step), mean over the timed steps"}
     if oversub:
         line["oversubscribed"] = True
+    if sec_dp is not None:
+        line["secondary"] = sec_dp
     del tc, batch
     torch.cuda.empty_cache()
     if world == 1 and not bf16 and args.config == "cfg2":

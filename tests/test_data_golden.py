@@ -205,3 +205,32 @@ def test_volume_cache_rereads_a_rewritten_file_and_is_bounded(tmp_path):
     h5io.append_datasets(p, [("u", a * 2), ("v", a)])                               # same path, new contents
     assert np.array_equal(c.get(p, "u"), a * 2)
     assert all(k[:3] == c._file_id(p) for k in c._d)                                # nothing of the old file is left
+
+
+@pytest.mark.parametrize("n_parallel,prefetch,pinned", [(None, None, None), (1, 0, False), (3, 2, True), (2, 1, True), (0, 3, False)])
+def test_prefetching_loader_yields_the_same_batches(n_parallel, prefetch, pinned):
+    """The producer thread, the per-batch worker pool (`n_parallel`, PatchHandler3D.py:32) and the pinned staging ring change WHEN
+    a batch is assembled, never its contents or order: every configuration yields the synchronous loader's batches bit for bit
+    (each batch is copied when received -- with pinned=True a batch is only valid until two more have been requested)."""
+    idx = data.load_indexes(os.path.join(DATA, "validate.csv"))
+    ref = [tuple(np.array(a) for a in b) for b in
+           data.PatchHandler3D(DATA, 16, 2, 4, 0.6).initialize_dataset(idx, shuffle=True, seed=5, shard=(0, 1), n_parallel=1, prefetch=0)]
+    ds = data.PatchHandler3D(DATA, 16, 2, 4, 0.6).initialize_dataset(idx, shuffle=True, seed=5, shard=(0, 1), n_parallel=n_parallel,
+                                                                     prefetch=prefetch, pinned=pinned)
+    for epoch in range(2):
+        got = [tuple(np.array(a) for a in b) for b in ds]
+        if epoch == 0:
+            assert len(got) == len(ref) == 3
+            for g, r in zip(got, ref):
+                assert all(np.array_equal(x, y) and x.dtype == y.dtype for x, y in zip(g, r))
+    it = iter(ds)                                   # an abandoned iterator must not leave the producer stuck
+    next(it)
+    del it
+
+
+def test_loader_errors_surface_in_the_consumer():
+    idx = data.load_indexes(os.path.join(DATA, "validate.csv")).copy()
+    idx[1, 0] = "no_such_file.h5"
+    ds = data.PatchHandler3D(DATA, 16, 2, 4, 0.6).initialize_dataset(idx, shuffle=False, shard=(0, 1), prefetch=2)
+    with pytest.raises(Exception):
+        list(ds)

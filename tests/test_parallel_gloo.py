@@ -103,7 +103,7 @@ def _predict_worker(rank, world, port, q):
     predictor = importlib.import_module("4dflownet_amd.predictor")
     parallel.init_from_env(backend="gloo")
     out = []
-    for n in (5, 1, 4):                         # ragged: 3 + 2, 1 + 0, 2 + 2 patches per rank
+    for n in CFG5_CASES[world]:
         vel, mag = _patches(n)
         out.append(predictor.predict_patches(_FakeNet(), vel, mag, batch_size=2))
     parallel.barrier()
@@ -111,10 +111,18 @@ def _predict_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_cfg5_patch_list_sharded_over_ranks_and_all_gathered():
-    """Inference: the patch list is split contiguously over ranks, every rank ends up with the complete,
-    correctly ordered result (all_gather, no other collective)."""
-    world = 2
+# patches per case; world 2: shards 3+2, 1+0 (an empty shard), 2+2; world 3: 3+3+1, 1+1+0, 1+0+0, 2+2+2
+CFG5_CASES = {2: (5, 1, 4), 3: (7, 2, 1, 6)}
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_cfg5_patch_list_sharded_over_ranks_and_gathered_to_root(world):
+    """Inference: the patch list is split contiguously over ranks (predictor.shard_bounds), every rank sends
+    exactly the rows it owns to rank 0 -- no padding, no copy to ranks that do not stitch -- and rank 0 ends up with the complete,
+    correctly ordered float64 result; ragged and empty shards included.  The other ranks return None."""
+    predictor = importlib.import_module("4dflownet_amd.predictor")
+    assert predictor.shard_bounds(5, 2) == [0, 3, 5] and predictor.shard_bounds(1, 2) == [0, 1, 1]
+    assert predictor.shard_bounds(7, 3) == [0, 3, 6, 7] and predictor.shard_bounds(1, 3) == [0, 1, 1, 1]
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -125,13 +133,14 @@ def test_cfg5_patch_list_sharded_over_ranks_and_all_gathered():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for k, n in enumerate((5, 1, 4)):
+    for k, n in enumerate(CFG5_CASES[world]):
         vel, mag = _patches(n)
         ref = _FakeNet().forward([v for v in vel] + [m for m in mag]).numpy().astype(np.float64)
-        for r in range(world):
-            got = res[r][1][k]
-            assert got.shape == (n, 8, 8, 8, 3) and got.dtype == np.float64
-            np.testing.assert_array_equal(got, ref)
+        got = res[0][1][k]
+        assert got.shape == (n, 8, 8, 8, 3) and got.dtype == np.float64
+        np.testing.assert_array_equal(got, ref)
+        for r in range(1, world):
+            assert res[r][1][k] is None
 
 
 def _helpers_worker(rank, world, port, q):
