@@ -1,22 +1,13 @@
-"""First-step gradient of a small network on the three conv paths (2-D Winograd, 1-D Winograd, direct) against the float64 oracle:
-pairwise relative L2 / max, overall and per layer.  Separates kernel error from ReLU-kink flips (debugging aid)."""
+"""First-step gradient of a small network on the three conv paths (2-D Winograd, 1-D Winograd, direct): pairwise relative L2 / max,
+overall and per layer.  Separates kernel error from ReLU-kink flips (debugging aid; the oracle comparison lives in tests/)."""
 import importlib, os, sys
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 fdn = importlib.import_module("4dflownet_amd")
 trainer = importlib.import_module("4dflownet_amd.trainer")
-O = importlib.import_module("oracle.flownet_oracle") if "--oracle" in sys.argv else None
 P, R, LB, HB, B = 8, 2, 2, 1, 2
-rng = np.random.default_rng(77)
-def batch_of():
-    r = np.random.default_rng(77)
-    f = lambda *s: r.normal(size=s).astype(np.float32)
-    return None
-sb = importlib.import_module("bench").synthetic_batch if False else None
-import types
-# the test's own batch generator lives in the oracle; rebuild it without importing the oracle when not asked to
+
 def synthetic_batch(B, P, R, seed):
     r = np.random.default_rng(seed)
     lr = [r.uniform(-1, 1, (B, P, P, P)).astype(np.float32) for _ in range(3)]
@@ -25,7 +16,7 @@ def synthetic_batch(B, P, R, seed):
     mask = (r.uniform(0, 1, (B, P * R, P * R, P * R)) > 0.3).astype(np.float32)
     venc = np.ones((B,), np.float32)
     return tuple(lr + mg + hr + [venc, mask])
-batch = synthetic_batch(B, P, R, 77) if O is None else O.synthetic_batch(B, P, R, seed=77)
+batch = synthetic_batch(B, P, R, 77)
 g = {}
 for name in ("auto", "winograd_w", "direct"):
     tc = trainer.TrainerController(P, R, initial_learning_rate=1e-4, quicksave_enable=False, low_resblock=LB, hi_resblock=HB, seed=3, conv_algo=name)
