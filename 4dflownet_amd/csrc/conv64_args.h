@@ -24,8 +24,9 @@ struct Conv64Region {
     // bf16 kernel only: LDS image geometry.  Staged voxel (zd,zh,zw) lives in LDS row (zd*hh + zh)*hs + zw (hs >= hw,
     // hs = 4 mod 8 so that the two 4-row runs a ds_read_b128 lane group takes from rows zh, zh+1 fall on the same bank
     // rows), its two 16-B chunks swapped when ((zh >> swz_hs) + ((zw >> 2) & swz_wm)) & 1.
-    int hs, lrows;
+    int hs, lrows, lrows_p;     // lrows_p = lrows rounded up to 32 (one LDS buffer = whole 1-KB pieces)
     int swz_hs, swz_wm;
+    unsigned mg_hhhs, mg_hs;    // magic divisors for LDS-row -> (zd, zh, zw') (direct-to-LDS staging of the FAST kernel)
     // bf16 kernel, general variant only: 1 = the region's first two axes are (h, d) instead of (d, h) -- every d / h field above is
     // then in KERNEL order (ob"d" = first h, t"a" = height taps, ...).  Used for the two d faces of a fused dgrad's shell: their
     // single tap is the depth tap, and the kernel slides its 8 accumulator planes along the first axis, which must have 3 taps.

@@ -40,7 +40,7 @@ struct Conv64BfCfg {
     static constexpr int NP = 8;                          // staging passes of 128 rows -> at most 1024 staged voxels
     static constexpr int MAXROWS = NP * 128;
     static constexpr int LDS_BUDGET = 160 * 1024 / 2 - 256;                   // two workgroups per CU
-    static constexpr int MAXLROWS = (LDS_BUDGET - MCAP * 4) / (2 * ROWB);     // LDS rows per buffer
+    static constexpr int MAXLROWS = (LDS_BUDGET - MCAP * 4) / (2 * ROWB) / 32 * 32;   // LDS rows per buffer, whole 1-KB pieces (32 rows)
 };
 
 __device__ __forceinline__ bf16x8 ld_bf16x8(const void* p) { return __builtin_bit_cast(bf16x8, *(const u32x4*)p); }
@@ -100,18 +100,65 @@ __global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
     const int tdi = fdn_udiv40(b, R.mg_thw_hi, R.mg_thw_lo);
     b -= tdi * (R.nth * R.ntw);
     const int thi = fdn_udiv40(b, R.mg_ntw_hi, R.mg_ntw_lo);
-    const int bufB = R.lrows * ROWB;
+    const int bufB = R.lrows_p * ROWB;
     int* mtab = (int*)(smem + 2 * bufB);
     const int p0d = R.obd + tdi * R.td, p0h = R.obh + thi * R.th, p0w = R.obw + (b - thi * R.ntw) * R.tw;
     const int prn = R.th * R.tw;                          // positions per plane block (<= 64)
 
-    // ---- staging descriptors of this thread: NP staged voxels x one 16-B chunk (the same for every slice) ----
+    // ---- staging descriptors of this thread (the same for every slice) ----
     const int chunk = tid & 1;
     const int q0d = p0d - 1 + p.off + ta0, q0h = p0h - 1 + p.off + tb0, q0w = p0w - 1 + p.off + tc0;
     const int cstride = R.hh * R.hw;                      // staged voxels per plane
-    int gv[NP];                                           // input voxel index (clamped), sign bit set = store zeros
-    int lo[NP];                                           // LDS byte offset inside a buffer, -1 = nothing to stage
-    {
+    // FAST: direct-to-LDS staging (buffer_load_dwordx4 ... lds).  The destination of such a load is M0 + lane * 16, i.e. the LDS image
+    // has to be LANE-LINEAR: item i = pass * 256 + tid is LDS row i >> 1 (rows in padded order (zd, zh, zw' < hs)), 16-B slot i & 1;
+    // the conflict-avoiding chunk swizzle moves to the SOURCE side (slot c receives channel chunk c ^ f).  Pad rows, rows past the
+    // image and (dgrad) voxels outside the volume read past the buffer's range, which returns -- and stores -- zeros.  One
+    // instruction per 1 KB, no data registers, no ds_write, no zero-select: the staging of a slice is NPL VMEM instructions per wave.
+    constexpr int NPL = FAST ? (C::MAXLROWS * 2 + 255) / 256 : 1;
+    unsigned goff[NPL];                                   // byte offset from the sample's first voxel, or kOob
+    constexpr unsigned kOob = 0x80000000u;
+    const int nitems = R.lrows_p * 2;                       // buffers are padded to whole 1-KB pieces (32 rows): no partial wave
+    if (FAST) {
+        const int hhhs = R.hh * R.hs;
+#pragma unroll
+        for (int u = 0; u < NPL; ++u) {
+            const int i = u * 256 + tid;
+            const int r = i >> 1;
+            goff[u] = kOob;
+            if (r < R.lrows) {
+                const int zd = fdn_div20(r, R.mg_hhhs);
+                const int r2 = r - zd * hhhs;
+                const int zh = fdn_div20(r2, R.mg_hs);
+                const int zw = r2 - zh * R.hs;
+                const int f = ((zh >> R.swz_hs) + ((zw >> 2) & R.swz_wm)) & 1;
+                int qd = q0d + zd, qh = q0h + zh, qw = q0w + zw;
+                const bool inside = (unsigned)qd < (unsigned)p.ID && (unsigned)qh < (unsigned)p.IH && (unsigned)qw < (unsigned)p.IW;
+                qd = min(max(qd, 0), p.ID - 1);
+                qh = min(max(qh, 0), p.IH - 1);
+                qw = min(max(qw, 0), p.IW - 1);
+                if (zw < R.hw && (inside || !p.zero_mode)) {
+                    unsigned v = (unsigned)((qd * p.IH + qh) * p.IW + qw);
+                    if (p.dbg & 4) v = (unsigned)(r & 255);  // ablation: real data, but always the same 32 KB (cache hits)
+                    goff[u] = v * 128u + (unsigned)((chunk ^ f) << 4);
+                }
+            }
+        }
+    }
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.x + (size_t)n * p.ID * p.IH * p.IW * 64), 0, (unsigned)(p.ID * p.IH * p.IW) * 128u, 0x00020000);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto stage_dma = [&](char* buf, int sl, int u0, int u1) {
+#pragma unroll
+        for (int u = 0; u < NPL; ++u) {
+            if (u < u0 || u >= u1) continue;
+            if (u * 256 + wave_u * 64 >= nitems) continue;            // wave-uniform: the whole 1-KB piece lies past the (padded) image
+            fdn_lds_dma16(xrsrc, buf + (u * 256 + wave_u * 64) * 16, goff[u], sl * 32);
+        }
+    };
+    // GEN: register staging -- NP staged voxels x one 16-B chunk per thread, written to a padded / swizzled image by ds_write
+    int gv[GEN ? NP : 1];                                 // input voxel index (clamped), sign bit set = store zeros
+    int lo[GEN ? NP : 1];                                 // LDS byte offset inside a buffer, -1 = nothing to stage
+    if (GEN) {
         const int rows_eff = R.rows;
         const int in_n = n * p.ID * p.IH * p.IW;
 #pragma unroll
@@ -140,19 +187,22 @@ __global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
     const uint16_t* xchunk = p.x + chunk * 8;
     // staged in two halves of NP/2 voxels that share four registers (half 0: loaded at step 0, written at step 3; half 1: steps 4, 7)
     constexpr int NH = NP / 2;
-    u32x4 sv[NH];
+    u32x4 sv[GEN ? NH : 1];
     auto stage_load = [&](int sl, int half) {       // unconditional loads (clamped address), zero selection afterwards
+        if (!GEN) return;
 #pragma unroll
         for (int u = 0; u < NH; ++u) sv[u] = *(const u32x4*)(xchunk + (size_t)(gv[half * NH + u] & 0x7fffffff) * 64 + sl * 16);
     };
     auto stage_write = [&](char* buf, int half) {
+        if (!GEN) return;
 #pragma unroll
         for (int u = 0; u < NH; ++u) {
             if (gv[half * NH + u] < 0) sv[u] = (u32x4){0u, 0u, 0u, 0u};
             if (lo[half * NH + u] >= 0) *(u32x4*)(buf + lo[half * NH + u]) = sv[u];
         }
     };
-    stage_load(0, 0);
+    if (GEN) stage_load(0, 0);
+    else stage_dma(smem, 0, 0, NPL);
 
     // ---- weight fragments: stream [slice 4][b*3+c][a][kh][cout row 64] x 16 B, two register sets, two steps ahead ----
     const int wstride = (p.dbg & 1) ? 0 : 1;
@@ -245,8 +295,10 @@ __global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
         }
     };
 
-    stage_write(smem, 0);
-    stage_load(0, 1); stage_write(smem, 1);
+    if (GEN) {
+        stage_write(smem, 0);
+        stage_load(0, 1); stage_write(smem, 1);
+    }
     __syncthreads();
     if (FAST) {
         // 9 unrolled steps per slice; weights two steps ahead (running into the next slice) in two register sets; the next
@@ -266,10 +318,10 @@ __global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
                 kstep(std::true_type{}, cur, it / 3, it % 3, wq[it % 3]);
                 if (PREFETCH || it < 6)
                     load_w(wq[it % 3], sl + (it + 3) / 9, tb0 + ((it + 3) % 9) / 3, tc0 + ((it + 3) % 9) % 3);
-                if (PREFETCH && it == 0) stage_load((sl + 1) & 3, 0);
-                if (PREFETCH && it == 3) stage_write(nxt, 0);
-                if (PREFETCH && it == 4) stage_load((sl + 1) & 3, 1);
-                if (PREFETCH && it == 7) stage_write(nxt, 1);
+                // the next slice goes straight from memory into the other buffer, in two bursts (VMEM operations return in order: a burst
+                // sits in front of the weight fragments requested after it)
+                if (PREFETCH && it == 0) stage_dma(nxt, (sl + 1) & 3, 0, NPL / 2);
+                if (PREFETCH && it == 4) stage_dma(nxt, (sl + 1) & 3, NPL / 2, NPL);
                 // keep every step's loads inside the step: under register pressure the scheduler otherwise sinks the
                 // weight refills down to their first use, i.e. prefetch distance 0
                 __builtin_amdgcn_sched_barrier(0);
@@ -511,7 +563,7 @@ int launch_regions(Conv64BfArgs& a, hipStream_t s) {
         Conv64Region& r = a.reg[i];
         r.first_block = blocks;
         blocks += a.N * r.ntd * r.nth * r.ntw;
-        if (r.lrows > max_lrows) max_lrows = r.lrows;
+        if (r.lrows_p > max_lrows) max_lrows = r.lrows_p;
     }
     // every region's mtab sits behind ITS two buffers; size the allocation for the largest region
     const size_t lds = (size_t)max_lrows * C::ROWB * 2 + C::MCAP * 4;
@@ -543,6 +595,9 @@ int launch_bf16(Conv64BfArgs& a, const Box* boxes, int nbox, hipStream_t s) {
         r.rows = (t.td + (bx.ta1 - bx.ta0)) * r.hh * r.hw;
         r.hs = lds_hs(r.hw);
         r.lrows = (t.td + (bx.ta1 - bx.ta0)) * r.hh * r.hs;
+        r.lrows_p = (r.lrows + 31) & ~31;
+        r.mg_hhhs = fdn_magic20(r.hh * r.hs);
+        r.mg_hs = fdn_magic20(r.hs);
         r.mg_hhhw = fdn_magic20(r.hh * r.hw);
         r.mg_hw = fdn_magic20(r.hw);
         r.mg_thtw = fdn_magic20(t.th * t.tw);

@@ -67,6 +67,14 @@ template <> struct FdnVec<uint16_t> {
     }
 };
 
+// Direct-to-LDS load (gfx950 `buffer_load_dwordx4 ... lds`): every lane reads 16 B at rsrc + voff + soff and the wave writes the
+// 64 x 16 B to LDS at lds + lane * 16 (lds is wave-uniform: it travels in M0).  Out-of-range lanes store zeros.  The compiler counts
+// it in vmcnt like any other vector-memory load.  (A __device__ function, not a lambda inside the kernel: the builtin does not exist
+// in the host pass, and a lambda that uses it silently takes the kernel's host stub with it.)
+__device__ __forceinline__ void fdn_lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds, unsigned voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
+
 void fdn_set_error(const char* fmt, ...);
 
 // hipFuncAttributeMaxDynamicSharedMemorySize, set once per (device, kernel) under a lock: the C-ABI is re-entrant per
