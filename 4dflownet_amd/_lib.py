@@ -74,6 +74,7 @@ DEBUG_SIGNATURES = {
     "fdn_debug_set_cin3_mfma": (c_i, [c_i]),
     "fdn_debug_set_conv1x1_mfma": (c_i, [c_i]),
     "fdn_debug_set_wgrad64_wino_dbg": (c_i, [c_i]),
+    "fdn_debug_set_wgrad64_wino_nodep": (c_i, [c_i]),
 }
 
 

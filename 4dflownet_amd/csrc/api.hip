@@ -174,7 +174,7 @@ extern "C" int fdn_conv3d_wgrad(const float* x, const float* x2, const float* dz
         // Winograd F(3,4) along W (wgrad64_wino.hip): half the multiplies of the direct kernel, which FDN_ALGO_DIRECT selects
         rc = (fdn_wgrad64_force_direct || algo == FDN_ALGO_DIRECT)
                  ? fdn_wgrad64_launch(x, dz, dw, workspace, workspace_bytes, N, D, H, W, s)
-                 : fdn_wgrad64_wino_launch(x, dz, dw, workspace, workspace_bytes, N, D, H, W, s);
+                 : fdn_wgrad64_wino_launch(x, dz, dw, workspace, workspace_bytes, N, D, H, W, s, algo);
     } else if (Cin == 3 && Cout == 64 && K == 3) {
         FDN_REQUIRE(lddz == 64 && dz_coff == 0, "fdn_conv3d_wgrad(3->64): dense dz rows");
         rc = fdn_wgrad_cin3_launch(x, dz, dw, workspace, workspace_bytes, N, D, H, W, s);

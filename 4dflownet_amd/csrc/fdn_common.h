@@ -174,7 +174,7 @@ int fdn_wgrad64_launch(const float* x, const float* dz, float* dw, void* ws, siz
                        int W, hipStream_t s);
 size_t fdn_wgrad64_workspace_bytes(int N, int D, int H, int W);
 int fdn_wgrad64_wino_launch(const float* x, const float* dz, float* dw, void* ws, size_t ws_bytes, int N, int D, int H,
-                            int W, hipStream_t s);
+                            int W, hipStream_t s, int algo = FDN_ALGO_AUTO);
 size_t fdn_wgrad64_wino_workspace_bytes(int N, int D, int H, int W);
 int fdn_wgrad64_reduce_launch(const float* partial, float* dw, int S, hipStream_t s);
 

@@ -24,6 +24,15 @@
 //   tile k+1 are transformed and written to buffer (k+1)%3, the raw rows of tile k+2 are loaded, one barrier per tile.
 //   The output transform runs inside the workgroup; partials dW[S][27] go to the workspace and are summed by the direct
 //   kernel's reduction (wgrad64_reduce_kernel: same partial layout).
+//
+// Round 4 -- F(3,2) along D on top of it (DEP = true, D even): two dz planes d0, d0+1 and the three depth taps need 6 plane
+// products; with the four x planes x[d0-1 .. d0+2] combined by the B^T of F(2,3) (x0-x2, x1+x2, x2-x1, x1-x3), the dz planes by
+// A (z0, z0+z1, z0-z1, -z1) four suffice:  M[xd] += V[xd] (x) Z[xd],  dW[a] = sum_xd G^T[a][xd] M[xd]  (G^T = (1,1/2,1/2,0)
+// (0,1/2,-1/2,0) (0,1/2,1/2,1)) -- a third fewer multiplies again.  The grid becomes S splits x 4 depth COORDINATES xd; a workgroup
+// walks tiles of plane PAIRS and is otherwise the kernel above: every transform item loads its chunk from TWO planes and combines
+// them before the W transform.  x's second plane travels by direct-to-LDS loads into a private 24-KB scratch (no registers; the
+// kernel has none to spare), dz's second plane in two extra registers.  The depth output transform runs in the reduction kernel
+// (wgrad64_reduce_dep_kernel), which sums the S x 4 partials with the G^T weights.
 #include "fdn_common.h"
 
 namespace {
@@ -33,6 +42,7 @@ struct WgWinoArgs {
     const float* dz;
     float* partial;
     int N, D, H, W;
+    int DT;                      // depth units of the tile walk: D planes, or D / 2 plane pairs (DEP)
     int nth, ntw, ntiles, S;
     unsigned bytes;              // size of x (= of dz) in bytes; < 4 GB (checked by the launcher)
     int dbg;                     // ablation bits (test build): 1 = no raw loads, 2 = no transform / LDS writes, 4 = no LDS operand reads, 8 = no XCD placement, 16 = depth-fastest tile order
@@ -45,8 +55,12 @@ constexpr int GROWB = 1536;                             // bytes per (line, grou
 constexpr int VBYTES = (WTH + 2) * WTG * GROWB;         // transformed x: 8 halo lines
 constexpr int ZBYTES = WTH * WTG * GROWB;               // transformed dz
 constexpr int WBUFB = VBYTES + ZBYTES;                  // 43 008 B; three buffers = 126 KB
+constexpr int XSCRATCH = 6 * 4096;                      // DEP: x chunks of the second plane, [chunk 6][x-thread 256] x 16 B, filled by LDS-DMA
+constexpr int ZSCRATCH = 2 * 3072;                      // DEP: dz chunks 2, 3 of the second plane, [2][dz-thread 192] x 16 B
 
+template <bool DEP>
 __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
+    constexpr int NP = DEP ? 4 : 3;                     // workgroups per split: depth coordinates xd (DEP) or depth taps a
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -63,11 +77,11 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
     // the plane stride, 9 x 64 KB at 48^3, and pile onto the same memory channels.  Test-build bit 16.)
     int a, split;
     {
-        const int G = 3 * p.S, qx = G >> 3, rx = G & 7;
+        const int G = NP * p.S, qx = G >> 3, rx = G & 7;
         const int xcd = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
         const int q = (FDN_DBG_BITS(p) & 8) ? (int)blockIdx.x : xcd * qx + min(xcd, rx) + j;
-        split = q / 3;
-        a = q - 3 * split;               // kernel-depth tap
+        split = q / NP;
+        a = q - NP * split;              // kernel-depth tap, or depth coordinate xd (DEP)
     }
     const int c16 = tid & 15;        // 16-B chunk (4 channels) of a 256-B row
     const int ig = (tid >> 4) & 1;   // group of this thread's transform item
@@ -85,7 +99,7 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
 
     // tile walk: tile = split + k*S in the order (n, d, th, tw), decoded incrementally with S pre-split the same way: scalar work only
     const bool dfast = (FDN_DBG_BITS(p) & 16) != 0;
-    const int per_c = p.D, per_r = p.ntw * per_c, per_n = p.nth * per_r;
+    const int per_c = p.DT, per_r = p.ntw * per_c, per_n = p.nth * per_r;
     const int per_d = p.nth * p.ntw;
     int tn, td, th, tw;
     int sn, sd, sh, sw;
@@ -114,13 +128,13 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
         if (kload + 1 < nk) {
             ++kload;
             if (dfast) {
-                td += sd; if (td >= p.D) { td -= p.D; ++tw; }
+                td += sd; if (td >= p.DT) { td -= p.DT; ++tw; }
                 tw += sw; if (tw >= p.ntw) { tw -= p.ntw; ++th; }
                 th += sh; if (th >= p.nth) { th -= p.nth; ++tn; }
             } else {
                 tw += sw; if (tw >= p.ntw) { tw -= p.ntw; ++th; }
                 th += sh; if (th >= p.nth) { th -= p.nth; ++td; }
-                td += sd; if (td >= p.D) { td -= p.D; ++tn; }
+                td += sd; if (td >= p.DT) { td -= p.DT; ++tn; }
             }
             tn += sn;
         }
@@ -128,7 +142,17 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
 
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.dz, 0, p.bytes, 0x00020000);
-    f32x4 raw[6];                         // this thread's raw rows: 6 x chunks (waves 0-3) or 4 dz chunks (waves 4-6)
+    f32x4 raw[6];                         // this thread's raw rows: 6 x chunks (waves 0-3) or 4 dz chunks (waves 4-6; DEP: + chunks 0, 1 of the second plane)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    char* const xscr = smem + 3 * WBUFB + wave_u * 1024;     // DEP: this wave's 1-KB pieces of the x scratch (chunk nn at + nn * 4096)
+    char* const zscr = smem + 3 * WBUFB + XSCRATCH + (wave_u & 3) * 1024;   // ... and of the dz scratch (chunks 2, 3 of the second plane at + 0 / + 3072)
+    // DEP: the two planes of this workgroup's depth coordinate and their weights: V = xA + sx xB, Z = cA zA + cB zB
+    // (the second plane must not lie BELOW the first: a buffer load's scalar offset cannot be negative -- coordinate 2 is therefore
+    // formed as -(x2 - x1) = x1 - x2 with the sign moved to the dz side, -(z0 - z1))
+    const float sx = a == 1 ? 1.f : -1.f;
+    const float cA = a >= 2 ? -1.f : 1.f, cB = 1.f;
+    const bool has_zb = DEP && (a == 1 || a == 2);
+    unsigned dxb = 0, dzb = 0;            // byte distance of the second plane from the first (>= 0)
     auto bload = [&](__amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so) {
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)vo, (int)so, 0));
     };
@@ -136,17 +160,29 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
     // (zero outside the volume).  The (sample, plane, tile origin) part of an address is a scalar offset and the (line, voxel,
     // chunk) part a per-thread constant, so a tile whose halo box lies inside its plane costs NO vector ALU work (every VALU
     // instruction takes its cycles from the fp32 MFMA stream of its SIMD); border tiles clamp per thread.
-    unsigned tc[6];                       // per-thread constant part, relative to the tile's halo origin (x) / origin (dz)
-#pragma unroll
-    for (int nn = 0; nn < 6; ++nn) tc[nn] = (unsigned)((il * p.W + 4 * ig + nn) * 256 + c16 * 16);
+    // per-thread constant part, relative to the tile's halo origin (x) / origin (dz); the voxel part nn * 256 is an instruction immediate
+    const unsigned tc0 = (unsigned)((il * p.W + 4 * ig) * 256 + c16 * 16);
     unsigned rowoff = 0;                  // border tiles: byte offset of this thread's (clamped) line, chunk included
     bool x_in = false, z_in = false;
     unsigned x_so = 0, z_so = 0;
     auto locate = [&]() {                 // once per tile, after advance(): scalar unless the tile touches the plane border
-        const int qd = min(max(td + a - 1, 0), p.D - 1);
+        int qd, zd;
+        if (DEP) {
+            // plane pair (d0, d0 + 1); x planes of coordinate xd: (d0-1, d0+1) (d0, d0+1) (d0, d0+1) (d0, d0+2), edge-clamped;
+            // dz planes: d0 | d0, d0+1 | d0, d0+1 | d0+1
+            const int d0 = 2 * td;
+            const int pa = a == 0 ? d0 - 1 : d0, pb = a == 3 ? d0 + 2 : d0 + 1;
+            qd = min(max(pa, 0), p.D - 1);
+            dxb = (unsigned)((min(max(pb, 0), p.D - 1) - qd) * p.H * p.W) * 256u;
+            zd = a == 3 ? d0 + 1 : d0;
+            dzb = (unsigned)(p.H * p.W) * 256u;
+        } else {
+            qd = min(max(td + a - 1, 0), p.D - 1);
+            zd = td;
+        }
         const int h0 = th * WTH - 1, w0 = tw * WTW - 1;
         const unsigned xplane = (unsigned)((tn * p.D + qd) * p.H * p.W) * 256u;
-        const unsigned zplane = (unsigned)((tn * p.D + td) * p.H * p.W) * 256u;
+        const unsigned zplane = (unsigned)((tn * p.D + zd) * p.H * p.W) * 256u;
         x_in = h0 >= 0 && h0 + WTH + 2 <= p.H && w0 >= 0 && w0 + WTW + 2 <= p.W;
         z_in = h0 + 1 + WTH <= p.H && w0 + 1 + WTW <= p.W;
         x_so = xplane + (unsigned)((h0 * p.W + w0) * 256);
@@ -156,15 +192,39 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
     };
     auto load_x = [&](int nn) {
         if (!xitem || (FDN_DBG_BITS(p) & 1)) return;
-        if (x_in) raw[nn] = bload(xrs, tc[nn], x_so);
-        else raw[nn] = bload(xrs, rowoff + (unsigned)(min(max(tw * WTW + 4 * ig - 1 + nn, 0), p.W - 1) * 256), 0);
+        const unsigned vo = x_in ? tc0 + (unsigned)(nn * 256) : rowoff + (unsigned)(min(max(tw * WTW + 4 * ig - 1 + nn, 0), p.W - 1) * 256);
+        const unsigned so = x_in ? x_so : 0u;
+        raw[nn] = bload(xrs, vo, so);
+        if (DEP) fdn_lds_dma16(xrs, xscr + nn * 4096, vo, (int)(so + dxb));       // the same chunk of the second plane -> scratch
     };
     auto load_z = [&](int j) {
         if (!zitem || (FDN_DBG_BITS(p) & 1)) return;
-        if (z_in) raw[j] = bload(zrs, tc[j], z_so);
-        else {
-            const int qw = tw * WTW + 4 * ig + j;
-            raw[j] = bload(zrs, (rowoff != 0xffffffffu && qw < p.W) ? rowoff + (unsigned)(qw * 256) : 0xffffffffu, 0);
+        const int qw = tw * WTW + 4 * ig + j;
+        const unsigned vo = z_in ? tc0 + (unsigned)(j * 256) : ((rowoff != 0xffffffffu && qw < p.W) ? rowoff + (unsigned)(qw * 256) : 0xffffffffu);
+        const unsigned so = z_in ? z_so : 0u;
+        raw[j] = bload(zrs, vo, so);
+        if (DEP && has_zb) {               // second plane: chunks 0, 1 in the two spare registers, chunks 2, 3 through the scratch
+            const unsigned vb = vo == 0xffffffffu ? vo : vo + dzb;               // (so + dzb could wrap past a "reads zero" offset)
+            if (j < 2) raw[4 + j] = bload(zrs, vb, so);
+            else fdn_lds_dma16(zrs, zscr + (j - 2) * 3072, vb, (int)so);
+        }
+    };
+    // DEP: combine the two planes of an item before its W transform (x: second plane from the scratch this thread's own LDS-DMA filled)
+    auto combine_x = [&]() {
+        if (!DEP || !xitem || (FDN_DBG_BITS(p) & 2)) return;
+        // hipcc orders a ds_read behind a pending LDS-DMA only across a barrier; this read-back of the wave's own pieces needs the
+        // wait spelled out.  The pieces were requested a tile ago (slots 6-11 of the previous iteration): nothing is lost here.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int nn = 0; nn < 6; ++nn) raw[nn] += sx * *(const f32x4*)(xscr + nn * 4096 + lane * 16);
+    };
+    auto combine_z = [&]() {
+        if (!DEP || !zitem || (FDN_DBG_BITS(p) & 2)) return;
+        if (has_zb) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // as in combine_x (chunks 2, 3 come back from the scratch)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (has_zb) raw[j] = cA * raw[j] + cB * (j < 2 ? raw[4 + j] : *(const f32x4*)(zscr + (j - 2) * 3072 + lane * 16));
+            else raw[j] = cA * raw[j];
         }
     };
     // LDS image of a (line, group): [parity e][ (xp0,xp1) pairs: 64 ch x 2 | xp2: 64 ch ]  (xi = 2 xp + e): a wave reads its three
@@ -200,6 +260,7 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
     for (int nn = 0; nn < 6; ++nn) load_x(nn);
 #pragma unroll
     for (int j = 0; j < 4; ++j) load_z(j);
+    combine_x(); combine_z();
 #pragma unroll
     for (int e = 0; e < 2; ++e) { write_v(e, smem); write_z(e, smem); }
     advance();
@@ -253,6 +314,8 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
             }
             __builtin_amdgcn_sched_barrier(0);
             // pipeline stages, pinned to slots: transform + write tile k+1, then load the raw rows of tile k+2
+            if (s == 0) combine_x();
+            if (s == 2) combine_z();
             if (s < 2) write_v(s, nxt);
             else if (s < 4) write_z(s - 2, nxt);
             else if (s == 5) { advance(); locate(); }
@@ -304,7 +367,7 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
         }
     }
     if (eh == 0) {
-        float* out = p.partial + ((size_t)split * 27 + a * 9) * 4096;
+        float* out = p.partial + ((size_t)split * (NP * 9) + a * 9) * 4096;     // DEP: [split][xd][b*3+t], mixed into the depth taps by the reduction
 #pragma unroll
         for (int k = 0; k < 9; ++k)
 #pragma unroll
@@ -315,11 +378,36 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
     }
 }
 
-int wgrad64_wino_splits(int N, int D, int H, int W) {
-    const long long ntiles = (long long)N * D * ((H + WTH - 1) / WTH) * ((W + WTW - 1) / WTW);
-    long long S = 85;                  // 3 * 85 = 255 workgroups: one (8 waves, 126 KB of LDS) per CU
+// DEP: (D / 2) depth units and 4 workgroups per split
+bool wgrad64_wino_dep_ok(int D) { return D >= 2 && (D & 1) == 0; }
+int wgrad64_wino_splits(int N, int D, int H, int W, bool dep) {
+    const long long ntiles = (long long)N * (dep ? D / 2 : D) * ((H + WTH - 1) / WTH) * ((W + WTW - 1) / WTW);
+    long long S = dep ? 63 : 85;       // 4 * 63 = 252 / 3 * 85 = 255 workgroups: one (8 waves, 126-150 KB of LDS) per CU
     if (ntiles < S) S = ntiles > 0 ? ntiles : 1;
     return (int)S;
+}
+
+// dw[a][k] = sum_s sum_xd G^T[a][xd] partial[s][xd][k]  (k over the 9 (b,t) taps x 64 x 64), G^T = (1,1/2,1/2,0) (0,1/2,-1/2,0) (0,1/2,1/2,1).
+// Same block shape as wgrad64_reduce_kernel: 64 float4 columns x 4 quarters of S, combined through LDS in a fixed order.
+__global__ __launch_bounds__(256) void wgrad64_reduce_dep_kernel(const float* __restrict__ partial, float* __restrict__ dw, int S) {
+    __shared__ f32x4 red[3][3][64];
+    const int col = threadIdx.x & 63, qtr = threadIdx.x >> 6;
+    const int e4 = blockIdx.x * 64 + col;                       // 9*1024 float4 columns of one (b,t) block set
+    const f32x4* p = (const f32x4*)partial + e4;
+    const int s0q = (S * qtr) >> 2, s1q = (S * (qtr + 1)) >> 2;
+    f32x4 m0 = {0.f, 0.f, 0.f, 0.f}, m1 = m0, m2 = m0, m3 = m0;
+    for (int s = s0q; s < s1q; ++s) {
+        const f32x4* ps = p + (size_t)s * (36 * 1024);
+        m0 += ps[0]; m1 += ps[9 * 1024]; m2 += ps[18 * 1024]; m3 += ps[27 * 1024];
+    }
+    const f32x4 t0 = m0 + 0.5f * (m1 + m2), t1 = 0.5f * (m1 - m2), t2 = 0.5f * (m1 + m2) + m3;
+    if (qtr) { red[qtr - 1][0][col] = t0; red[qtr - 1][1][col] = t1; red[qtr - 1][2][col] = t2; }
+    __syncthreads();
+    if (qtr == 0) {
+        ((f32x4*)dw)[e4] = (t0 + red[0][0][col]) + (red[1][0][col] + red[2][0][col]);
+        ((f32x4*)dw)[9 * 1024 + e4] = (t1 + red[0][1][col]) + (red[1][1][col] + red[2][1][col]);
+        ((f32x4*)dw)[18 * 1024 + e4] = (t2 + red[0][2][col]) + (red[1][2][col] + red[2][2][col]);
+    }
 }
 
 }  // namespace
@@ -328,25 +416,44 @@ int wgrad64_wino_splits(int N, int D, int H, int W) {
 extern "C" int fdn_debug_set_wgrad64_wino_dbg(int bits) { fdn_wgrad64_wino_dbg = bits; return FDN_OK; }
 #endif
 
+FDN_HOOK_VAR(int, fdn_wgrad64_wino_nodep, 0);          // test build: 1 = never the depth transform (the round-2 kernel)
+
 size_t fdn_wgrad64_wino_workspace_bytes(int N, int D, int H, int W) {
-    return (size_t)wgrad64_wino_splits(N, D, H, W) * 27 * 4096 * sizeof(float);
+    const size_t a = (size_t)wgrad64_wino_splits(N, D, H, W, false) * 27, b = wgrad64_wino_dep_ok(D) ? (size_t)wgrad64_wino_splits(N, D, H, W, true) * 36 : 0;
+    return (a > b ? a : b) * 4096 * sizeof(float);
 }
 
 int fdn_wgrad64_wino_launch(const float* x, const float* dz, float* dw, void* ws, size_t ws_bytes, int N, int D, int H,
-                            int W, hipStream_t s) {
+                            int W, hipStream_t s, int algo) {
+    // F(3,2) along D on top of F(3,4) along W whenever D is even (FDN_ALGO_WINO_W keeps the W-only kernel selectable)
+    const bool dep = wgrad64_wino_dep_ok(D) && algo != FDN_ALGO_WINO_W && !fdn_wgrad64_wino_nodep;
     WgWinoArgs a;
     a.x = x; a.dz = dz; a.partial = (float*)ws;
     a.N = N; a.D = D; a.H = H; a.W = W;
+    a.DT = dep ? D / 2 : D;
     a.nth = (H + WTH - 1) / WTH; a.ntw = (W + WTW - 1) / WTW;
-    a.ntiles = N * D * a.nth * a.ntw;
-    a.S = wgrad64_wino_splits(N, D, H, W);
+    a.ntiles = N * a.DT * a.nth * a.ntw;
+    a.S = wgrad64_wino_splits(N, D, H, W, dep);
     FDN_REQUIRE((long long)N * D * H * W * 256 < (1ll << 32), "wgrad64: x of %dx%dx%dx%dx64 floats exceeds the 32-bit buffer addressing", N, D, H, W);
-    FDN_REQUIRE(ws_bytes >= (size_t)a.S * 27 * 4096 * sizeof(float), "wgrad64 (winograd): workspace too small");
+    FDN_REQUIRE(ws_bytes >= (size_t)a.S * (dep ? 36 : 27) * 4096 * sizeof(float), "wgrad64 (winograd): workspace too small");
     a.bytes = (unsigned)((long long)N * D * H * W * 256);
     a.dbg = fdn_wgrad64_wino_dbg;
+    if (dep) {
+        const size_t lds = (size_t)3 * WBUFB + XSCRATCH + ZSCRATCH;
+        if (int rc = fdn_func_max_lds((const void*)wgrad64_wino_kernel<true>, (int)lds, "wgrad64_wino")) return rc;
+        hipLaunchKernelGGL(wgrad64_wino_kernel<true>, dim3(4 * a.S), dim3(512), lds, s, a);
+        FDN_CHECK_LAUNCH("wgrad64_wino_kernel");
+        hipLaunchKernelGGL(wgrad64_reduce_dep_kernel, dim3(9 * 1024 / 64), dim3(256), 0, s, (const float*)ws, dw, a.S);
+        FDN_CHECK_LAUNCH("wgrad64_reduce_dep_kernel");
+        return FDN_OK;
+    }
     const size_t lds = (size_t)3 * WBUFB;
-    if (int rc = fdn_func_max_lds((const void*)wgrad64_wino_kernel, (int)lds, "wgrad64_wino")) return rc;
-    hipLaunchKernelGGL(wgrad64_wino_kernel, dim3(3 * a.S), dim3(512), lds, s, a);
+    if (int rc = fdn_func_max_lds((const void*)wgrad64_wino_kernel<false>, (int)lds, "wgrad64_wino")) return rc;
+    hipLaunchKernelGGL(wgrad64_wino_kernel<false>, dim3(3 * a.S), dim3(512), lds, s, a);
     FDN_CHECK_LAUNCH("wgrad64_wino_kernel");
     return fdn_wgrad64_reduce_launch((const float*)ws, dw, a.S, s);
 }
+
+#ifdef FDN_TEST_HOOKS
+extern "C" int fdn_debug_set_wgrad64_wino_nodep(int on) { fdn_wgrad64_wino_nodep = on; return FDN_OK; }
+#endif

@@ -104,7 +104,8 @@ class LaunchTimer:
             if not self.enabled or (K, Cin, Cout) != (3, 64, 64):
                 return wg(x, dz, K, Cin, Cout, *a, **k)
             N, D, H, W = shp(x)
-            f = 1.0 if x.dtype != torch.float32 or W % 4 else 0.5           # Winograd F(3,4) along W: 13.5 of 27 tap-equivalents
+            # Winograd F(3,4) along W: 13.5 of 27 tap-equivalents; with F(3,2) along D on top (D even): 9
+            f = 1.0 if x.dtype != torch.float32 or W % 4 or k.get("algo", 0) == 1 else (1.0 / 3 if D % 2 == 0 and k.get("algo", 0) == 0 else 0.5)
             return bracket("wgrad", N * D * H * W, f * N * D * H * W * FLOP_PER_VOXEL_CONV64, lambda: wg(x, dz, K, Cin, Cout, *a, **k))
 
         ops.conv3d_fwd, ops.conv3d_dgrad_fused, ops.conv3d_wgrad = conv3d_fwd, conv3d_dgrad_fused, conv3d_wgrad
@@ -240,7 +241,7 @@ def roofline_obj(timer, kind, bf16, kernel, traffic_files):
             "algorithmic_gflop_per_launch": avg_flop / 1e9, "algorithmic_achieved": algorithmic,
             "algorithmic_frac": algorithmic / peak, "algorithmic_speedup": avg_flop / avg_exec,
             "note": None if bf16 else "achieved/frac = FLOPs the Winograd kernel EXECUTES on the fp32 MFMA pipe (forward / dgrad inner box: "
-                                      "2-D F(2,3)xF(4,3), a third of the direct algorithm's multiplies; wgrad: F(3,4) along W, half) = matrix-pipe "
+                                      "2-D F(2,3)xF(4,3), a third of the direct algorithm's multiplies; wgrad: F(3,2) along D x F(3,4) along W, a third) = matrix-pipe "
                                       "utilisation; PMC SQ_VALU_MFMA_BUSY_CYCLES agrees (profiles/README.md).  algorithmic_* prices the same "
                                       "launches with the direct 3x3x3 FLOP count of SURVEY 8d and therefore exceeds the peak"}
 
@@ -670,7 +671,7 @@ def main():
                                  % (("conv64_bf16_kernel", "", "") if bf16 else
                                     ("conv64_wino2d_kernel", " inner-box", "; 2-D Winograd F(2,3) along H x F(4,3) along W")), tr),
         "roofline_wgrad": roofline_obj(timer, "wgrad", bf16, "%s (3x3x3 64->64 weight gradient + partial reduction%s)"
-                                       % (("wgrad64_bf16_kernel", "") if bf16 else ("wgrad64_wino_kernel", "; Winograd F(3,4) along W")), tr),
+                                       % (("wgrad64_bf16_kernel", "") if bf16 else ("wgrad64_wino_kernel", "; Winograd F(3,2) along D x F(3,4) along W")), tr),
         "roofline_dgrad_shell": None if bf16 else roofline_obj(timer, "shell", False, "conv64_wino_kernel (shell faces of the fused dgrad: "
                                                                "d / h faces F(4,3) along W, w faces one Winograd coordinate)", tr),
         "train_step_tflops": args.steps * B * world / dt * 3.0 * fwd_flop / 1e12,

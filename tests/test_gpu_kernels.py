@@ -190,18 +190,18 @@ def test_conv64_dgrad_fused_fold(ops, fdn, shape, layout):
 
 @pytest.mark.parametrize("shape", SHAPES + [(2, 16, 16, 16), (1, 1, 1, 1), (1, 2, 3, 1), (1, 3, 20, 33), (5, 9, 8, 24), (2, 24, 24, 24),
                                             (1, 7, 6, 8), (1, 2, 13, 7)])
-@pytest.mark.parametrize("direct", [0, 1])       # 0 = product library: Winograd F(3,4) kernel; 1 = the direct kernel (test build)
-def test_conv64_wgrad(ops, fdn, shape, direct):
+@pytest.mark.parametrize("direct", [0, 1, 2])    # 0 = product library, FDN_ALGO_AUTO: Winograd F(3,4) along W, + F(3,2) along D when D is even;
+def test_conv64_wgrad(ops, fdn, shape, direct):  # 1 = the direct kernel (test build); 2 = FDN_ALGO_WINO_W: the W-only Winograd kernel
     rng = np.random.default_rng(3)
     N, D, H, W = shape
     x = rng.normal(size=(N, D, H, W, 64)).astype(np.float32)
     dz = rng.normal(size=(N, D, H, W, 64)).astype(np.float32)
     ref = O.conv3d_wgrad(x.astype(np.float64), dz.astype(np.float64), 3)
-    with variant_lib(fdn, direct) as lib:
+    with variant_lib(fdn, direct == 1) as lib:
         if lib is not None:
             lib.fdn_debug_set_wgrad64_direct(1)
         try:
-            dw, db = ops.conv3d_wgrad(dev(x), dev(dz), 3, 64, 64, want_bias=True)
+            dw, db = ops.conv3d_wgrad(dev(x), dev(dz), 3, 64, 64, want_bias=True, algo=ops.ALGO_WINO_W if direct == 2 else ops.ALGO_AUTO)
         finally:
             if lib is not None:
                 lib.fdn_debug_set_wgrad64_direct(0)

@@ -48,6 +48,11 @@ def main():
             ti = timeit(lambda: ops.conv3d_dgrad_fused(x, wd, pad, dxo, skip=res, y_prev=out, act=ops.ACT_LEAKY, parts=1, algo=algo))
             ts = timeit(lambda: ops.conv3d_dgrad_fused(x, wd, pad, dxo, skip=res, y_prev=out, act=ops.ACT_LEAKY, parts=2, algo=algo))
             print("dgrad fused+border %-24s N=%d P=%d : %.3f ms   (inner box alone %.3f, shell alone %.3f)" % (name, N, P, t, ti, ts), flush=True)
+        for name, algo in (("F(3,2)_D x F(3,4)_W", ops.ALGO_AUTO), ("F(3,4)_W", ops.ALGO_WINO_W), ("direct", ops.ALGO_DIRECT)):
+            ws = torch.empty(ops.wgrad_workspace_bytes(N, P, P, P, 64, 64, 3) // 4 + 1, device="cuda")
+            dw = torch.empty(3, 3, 3, 64, 64, device="cuda")
+            t = timeit(lambda: ops.conv3d_wgrad(x, res, 3, 64, 64, dw=dw, workspace=ws, algo=algo))
+            print("wgrad %-22s N=%d P=%d : %.3f ms (%.1f TF algorithmic)" % (name, N, P, t, flop / t / 1e9), flush=True)
         if "--ablate" in sys.argv:
             with fdn._lib.test_build() as lib:
                 for bits, what in ((0, "full"), (4, "no staging"), (8, "no epilogue"), (1, "weights from one unit"), (13, "K loop only"), (128, "no XCD remap")):
