@@ -48,7 +48,7 @@ struct Conv64Cfg {
     static constexpr int CH = ROWB / 16;              // 16-B chunks per row
     static constexpr int KG = 8 / CS;                 // k-groups (8 cin) per staged slice
     // workgroups per CU the variant is sized for (VGPR cap via launch bounds, LDS via MAXROWS)
-    static constexpr int WG_PER_CU = MCAP == 256 ? (CS == 4 ? 3 : 2) : (MCAP == 128 ? (CS == 4 ? 5 : 3) : (CS == 4 ? 6 : 4));
+    static constexpr int WG_PER_CU = MCAP == 256 ? (CS == 4 ? 3 : 2) : (MCAP == 128 ? (CS == 4 ? 4 : 3) : (CS == 4 ? 6 : 4));   // <1,1,4>: 4, not the 5 its LDS would allow -- a 96-VGPR cap made it spill 32 registers
     static constexpr int MAXROWS = ((160 * 1024 / WG_PER_CU) - MCAP * 4 - 256) / LROW > 1000
                                        ? 1000 : ((160 * 1024 / WG_PER_CU) - MCAP * 4 - 256) / LROW;
     static constexpr int LDS_BYTES = MAXROWS * LROW + MCAP * 4;

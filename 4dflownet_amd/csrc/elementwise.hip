@@ -457,7 +457,13 @@ static int upsample_bwd_t(const T* dy, const T* y_prev, int act, float alpha, T*
     const int64_t rows = (int64_t)N * D * H;
     const size_t lds = (size_t)W * R * C * sizeof(float);
     FDN_REQUIRE(rows * R * R < (1ll << 31) && lds <= 160 * 1024, "fdn_upsample_trilinear_bwd: row of %d x %d channels does not fit the LDS stage", W * R, C);
-    FDN_REQUIRE(R <= 13, "fdn_upsample_trilinear_bwd: R = %d > 13 (the adjoint keeps <= 32 candidate rows per axis)", R);
+    // the adjoint compacts the high-res rows that can touch a low-res row with 32 lanes per axis: a low-res row reaches
+    // 2 (OD-1)/(D-1) high-res rows (align_corners scale) + the rounding margin, which exceeds 2R+1 on short axes
+    auto span = [](int n, int r) { return n > 1 ? (2 * (n * r - 1) + (n - 2)) / (n - 1) + 3 : n * r; };
+    FDN_REQUIRE(span(D, R) <= 32 && span(H, R) <= 32, "fdn_upsample_trilinear_bwd: R = %d on a %d x %d grid needs %d / %d candidate rows per axis "
+                "(the adjoint keeps <= 32)", R, D, H, span(D, R), span(H, R));
+    const size_t lds_static = 9 * 1024;             // the kernel's static __shared__ tables (s_row, s_wgt, ...) share the 160 KB
+    FDN_REQUIRE(lds + lds_static <= 160 * 1024, "fdn_upsample_trilinear_bwd: row of %d x %d channels + the kernel's tables do not fit the LDS", W * R, C);
     if (lds > 48 * 1024) {
         if (int rc = fdn_func_max_lds((const void*)upsample_bwd_kernel<T>, 160 * 1024, "upsample_bwd")) return rc;
     }

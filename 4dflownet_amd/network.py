@@ -4,9 +4,10 @@ into lib4dflow_hip.so.  Same names and argument meaning as the reference (SR4DFl
 callable on 6 arrays (B,P,P,P,1), has .predict(list), .trainable_variables, .save / .load_weights, and adds
 .backward(dpred) (what tape.gradient does in TrainerController.py:223).
 
-Parameters live in ONE flat fp32 device buffer in Keras trainable_variables order (kernel, bias per layer in
-creation order conv3d, conv3d_1, ... conv3d_35), gradients in a second flat buffer of the same layout, so the
-data-parallel all-reduce and the Adam step are one call each."""
+Parameters live in ONE flat fp32 device buffer in layer CREATION order (kernel, bias per layer: conv3d, conv3d_1, ...
+conv3d_35), gradients in a second flat buffer of the same layout, so the data-parallel all-reduce and the Adam step are one
+call each.  Keras' own `trainable_variables` order (depth-sorted layers, keras_layer_order) differs from creation order and
+is what optimizer.pkl uses: keras_variable_order() / trainable_variable_names() translate between the two."""
 import math
 import os
 
@@ -215,6 +216,15 @@ class FlowNetModel:
         out = []
         for i in keras_layer_order(self.low_resblock, self.hi_resblock):
             out.extend(range(first[i][0], first[i][0] + first[i][1]))
+        return out
+
+    def trainable_variable_names(self):
+        """Keras variable names ('conv3d_7/kernel:0', 'conv3d_7/bias:0'), one per entry of self.trainable_variables (creation order)."""
+        out = []
+        for L in self.layers:
+            out.append("%s/kernel:0" % L.name)
+            if L.b is not None:
+                out.append("%s/bias:0" % L.name)
         return out
 
     def get_weights(self):

@@ -175,6 +175,7 @@ class TrainerController:
         if dp and self.profile_allreduce:
             e1.record()
             self.allreduce_wait_events.append((e0, e1))
+            del self.allreduce_wait_events[:-4096]          # a diagnostic left on outside the bench must not grow without bound
         opt = self.optimizer
         opt.iterations += 1
         # L2 regulariser gradient: the (B,) loss vector carries the scalar L2 term B times (:249) -> B_global * 2*lambda*w
@@ -335,6 +336,13 @@ class TrainerController:
         weight_values = [np.int64(self.optimizer.iterations)] + [m[i] for i in order] + [v[i] for i in order]
         with open('%s/optimizer.pkl' % self.model_dir, 'wb') as f:
             pickle.dump(weight_values, f)
+        # The pickle itself stays what Keras writes (a bare list).  A sidecar names the slots, so restore_model can map by NAME and
+        # a file in another order (creation order: this repository before round 3) is re-ordered or refused instead of silently
+        # mis-assigned -- conv3d / conv3d_2 etc. share shapes, so shapes cannot tell.
+        names = self.model.trainable_variable_names()
+        with open('%s/optimizer_order.txt' % self.model_dir, 'w') as f:
+            f.write("# optimizer.pkl slot order: [iterations] + m slots + v slots, each in this variable order (Keras trainable_variables)\n")
+            f.write("\n".join(names[i] for i in order) + "\n")
 
     def restore_model(self, old_model_dir, old_model_file):
         """TrainerController.py:365-394.  optimizer.pkl slots are in Keras trainable_variables order (see save_best_model)."""
@@ -345,6 +353,22 @@ class TrainerController:
         if len(opt_weights) != 1 + 2 * n:
             raise ValueError("optimizer.pkl holds %d arrays, expected %d" % (len(opt_weights), 1 + 2 * n))
         order = self.model.keras_variable_order()
+        names = self.model.trainable_variable_names()
+        side = "%s/optimizer_order.txt" % old_model_dir
+        legacy = os.environ.get("FDN_OPTIMIZER_PKL_ORDER", "")
+        if os.path.exists(side):                              # written by save_best_model: map the slots by variable name
+            listed = [l.strip() for l in open(side) if l.strip() and not l.startswith("#")]
+            if sorted(listed) != sorted(names):
+                raise ValueError("optimizer_order.txt names %d variables that are not this model's" % len(set(listed) ^ set(names)))
+            order = [names.index(nm) for nm in listed]
+        elif legacy == "creation":                            # a pickle of this repository before round 3 (no sidecar, creation order)
+            order = list(range(n))
+        elif legacy not in ("", "keras"):
+            raise ValueError("FDN_OPTIMIZER_PKL_ORDER must be 'keras' or 'creation'")
+        else:
+            import warnings
+            warnings.warn("optimizer.pkl without optimizer_order.txt: assuming Keras trainable_variables order (what the reference writes); "
+                          "set FDN_OPTIMIZER_PKL_ORDER=creation for a file written by this repository before round 3")
         m_k, v_k = list(opt_weights[1:1 + n]), list(opt_weights[1 + n:])
         m, v = [None] * n, [None] * n
         for slot, i in enumerate(order):

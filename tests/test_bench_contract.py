@@ -59,3 +59,30 @@ def test_pmc_traffic_summaries_are_readable_and_skip_metadata(tmp_path):
             kern = "conv64_bf16_kernel" if "cfg4" in name else ("conv64_wino_kernel" if not name.startswith("r1_") else "conv64_mfma_kernel")
             v, f = b.pmc_traffic_bytes([name], kern)
             assert f == name and v > 1e6, (name, v)
+
+
+def test_bench_frac_agrees_with_the_pmc_busy_counter():
+    """roofline.frac of the committed bench line (executed FLOPs from the launch shapes / HIP-event time / peak) against the hardware's
+    own count, SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), from the PMC pass of the same round
+    (profiles/r*_pmc_sq.txt, tools/profile_round.sh): within 0.02 for the conv kernel.  The wgrad bracket of bench.py also contains the
+    12-us partial-sum reduction (no MFMA), so its frac sits below the kernel's own busy ratio: within 0.04."""
+    import glob
+    import re
+    import pytest
+    rounds = sorted(int(m.group(1)) for m in (re.fullmatch(r"r(\d+)_pmc_sq\.txt", os.path.basename(f))
+                                              for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq.txt"))) if m)
+    rounds = [r for r in rounds if r >= 4 and os.path.exists(os.path.join(ROOT, "profiles", "r%d_bench_line_nosecondary.json" % r))]
+    if not rounds:
+        pytest.skip("no round >= 4 profile collected yet")
+    r = rounds[-1]
+    line = json.load(open(os.path.join(ROOT, "profiles", "r%d_bench_line_nosecondary.json" % r)))
+    busy = {}
+    for l in open(os.path.join(ROOT, "profiles", "r%d_pmc_sq.txt" % r)):
+        m = re.search(r"::(\w+).*GRBM_GUI_ACTIVE=([0-9.e+]+).*SQ_VALU_MFMA_BUSY_CYCLES=([0-9.e+]+)", l)
+        if m:
+            busy[m.group(1)] = float(m.group(3)) / (1024.0 * float(m.group(2)) / 8.0)
+    conv_k = line["roofline"]["kernel"].split(" ")[0]
+    wg_k = line["roofline_wgrad"]["kernel"].split(" ")[0]
+    assert conv_k in busy and wg_k in busy, (conv_k, wg_k, sorted(busy))
+    assert abs(line["roofline"]["frac"] - busy[conv_k]) <= 0.02, (line["roofline"]["frac"], busy[conv_k])
+    assert -0.005 <= busy[wg_k] - line["roofline_wgrad"]["frac"] <= 0.04, (line["roofline_wgrad"]["frac"], busy[wg_k])

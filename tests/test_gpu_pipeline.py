@@ -80,6 +80,37 @@ def test_cfg1_train_network_checkpoint_restore_and_quicksave(tmp_path):
     m_flat = tc.optimizer.m.cpu().numpy()
     assert np.array_equal(slots[1].reshape(-1), m_flat[L2_.w_off:L2_.w_off + L2_.w.numel()])          # conv3d_2/kernel first
     assert np.array_equal(slots[3].reshape(-1), m_flat[L0_.w_off:L0_.w_off + L0_.w.numel()])          # then conv3d/kernel
+    # the sidecar names the slots: restore maps by NAME, so a creation-order file + its sidecar restores correctly,
+    # a file without a sidecar is taken as Keras order (warning), FDN_OPTIMIZER_PKL_ORDER=creation reads a pre-round-3 file
+    side = os.path.join(md, "optimizer_order.txt")
+    listed = [l.strip() for l in open(side) if l.strip() and not l.startswith("#")]
+    assert listed[0] == "conv3d_2/kernel:0" and listed[2] == "conv3d/kernel:0" and len(listed) == ntv
+    names = tc.model.trainable_variable_names()
+    inv = [None] * ntv
+    for slot, nm in enumerate(listed):
+        inv[names.index(nm)] = slot
+    legacy = [slots[0]] + [slots[1 + inv[i]] for i in range(ntv)] + [slots[1 + ntv + inv[i]] for i in range(ntv)]     # creation order
+    ld = str(tmp_path / "legacy")
+    os.makedirs(ld)
+    import shutil
+    shutil.copy(os.path.join(md, "t4d-best.h5"), ld)
+    pickle.dump(legacy, open(os.path.join(ld, "optimizer.pkl"), "wb"))
+    open(os.path.join(ld, "optimizer_order.txt"), "w").write("\n".join(names) + "\n")
+    tc4 = trainer.TrainerController(P, R, initial_learning_rate=2e-4, quicksave_enable=False, low_resblock=LB, hi_resblock=HB, seed=11)
+    tc4.restore_model(ld, "t4d-best.h5")
+    assert torch.equal(tc4.optimizer.m, tc.optimizer.m) and torch.equal(tc4.optimizer.v, tc.optimizer.v)
+    os.remove(os.path.join(ld, "optimizer_order.txt"))
+    os.environ["FDN_OPTIMIZER_PKL_ORDER"] = "creation"
+    try:
+        tc4.optimizer.m.zero_()
+        tc4.restore_model(ld, "t4d-best.h5")
+        assert torch.equal(tc4.optimizer.m, tc.optimizer.m)
+    finally:
+        del os.environ["FDN_OPTIMIZER_PKL_ORDER"]
+    # no sidecar, no override: Keras order is assumed (with a warning).  For THIS creation-order file that is the wrong guess; here
+    # the shape check catches it (conv3d's 3->64 kernel where a 64->64 one is expected) -- layers of equal shape could not be told apart
+    with pytest.warns(UserWarning, match="optimizer_order.txt"), pytest.raises(ValueError, match="slot"):
+        tc4.restore_model(ld, "t4d-best.h5")
 
 
 def test_predictor_end_to_end_on_example_volume(tmp_path):
