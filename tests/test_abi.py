@@ -111,9 +111,10 @@ def test_round3_profiles_carry_the_sources_they_were_measured_on():
     import warnings
     from importlib import import_module
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    files = sorted(glob.glob(os.path.join(root, "profiles", "r3_*")))
+    files = sorted(f for f in glob.glob(os.path.join(root, "profiles", "r[34]_*"))
+                   if not f.endswith(("_gputest.txt", "_wino2d_fwd_ablation.txt", "_wino2d_fwd_dgrad.txt", "_bf16_ab1.txt", "_fetch_calib.txt")))
     if not files:
-        pytest.skip("no round-3 profiles collected yet")
+        pytest.skip("no round-3/4 profiles collected yet")
     stamp = import_module("4dflownet_amd.build").source_stamp()
     stale = []
     for f in files:
