@@ -65,6 +65,7 @@ DEBUG_SIGNATURES = {
     "fdn_debug_set_conv64_wface_direct": (c_i, [c_i]),
     "fdn_debug_set_conv64_bf16_mt": (c_i, [c_i]),
     "fdn_debug_set_conv64_bf16_dbg": (c_i, [c_i]),
+    "fdn_debug_set_conv64_bf16_mode2": (c_i, [c_i]),
     "fdn_debug_set_heads_mfma": (c_i, [c_i]),
     "fdn_debug_set_wgrad64_direct": (c_i, [c_i]),
     "fdn_debug_set_conv64_wino_dbg": (c_i, [c_i]),

@@ -31,6 +31,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 FDN_HOOK_VAR(int, fdn_conv64bf_force_mt, 0);    // test/bench hook: 0 = auto, 4 / 8 = force the variant, +16 = full-depth tiles only
+FDN_HOOK_VAR(int, fdn_conv64bf_mode2, 1);       // test/bench hook: 0 = never the two-slice kernel (MODE 2)
 FDN_HOOK_VAR(int, fdn_conv64bf_dbg, 0);         // ablation bits: 1 = weight stride 0, 2 = no XCD remap, 4 = staging loads from a cache-resident 32 KB, 8 = no epilogue, 16 = plan the shell slabs like stand-alone launches
 
 template <int MT>
@@ -41,6 +42,7 @@ struct Conv64BfCfg {
     static constexpr int MAXROWS = NP * 128;
     static constexpr int LDS_BUDGET = 160 * 1024 / 2 - 256;                   // two workgroups per CU
     static constexpr int MAXLROWS = (LDS_BUDGET - MCAP * 4) / (2 * ROWB) / 32 * 32;   // LDS rows per buffer, whole 1-KB pieces (32 rows)
+    static constexpr int MAXLROWS2 = (LDS_BUDGET - MCAP * 4) / (2 * ROWB) / 16 * 16;  // MODE 2: ONE buffer of 64-B rows, whole 1-KB pieces (16 rows)
 };
 
 __device__ __forceinline__ bf16x8 ld_bf16x8(const void* p) { return __builtin_bit_cast(bf16x8, *(const u32x4*)p); }
@@ -59,14 +61,20 @@ __device__ __forceinline__ void ld_bf16x16(const uint16_t* src, float (&z)[16]) 
     for (int r = 0; r < 8; ++r) { z[r] = (float)lo[r]; z[8 + r] = (float)hi[r]; }
 }
 
-// FAST = true : every region of the launch has all 27 taps and td == MT (forward; the inner box of a fused dgrad): 9 unrolled
-//               (b,c) steps per slice with register-prefetched weights and in-loop staging of the next slice.
-// FAST = false: shell slabs / ragged tiles: rolled loop, predicated planes and taps.
-template <int MT, bool FAST>
+// MODE 1 (FAST): every region of the launch has all 27 taps and td == MT (forward; the inner box of a fused dgrad): 9 unrolled
+//               (b,c) steps per slice of 16 cin with register-prefetched weights and in-loop staging of the next slice (two LDS buffers).
+// MODE 2 (round 4): the same regions with 8 x 8 plane blocks, staged in TWO slices of 32 cin into ONE buffer of 64-B rows.  The memory
+//               system serves a 32-B piece of a bf16 row by fetching its whole 128-B line (tools/fetch_calib.hip), so four slices pull
+//               every line four times; two slices pull it twice.  One buffer means a tile's staging is not hidden behind its own K loop
+//               any more -- the co-resident workgroup's K loop runs meanwhile.
+// MODE 0      : shell slabs / ragged tiles: rolled loop, predicated planes and taps.
+template <int MT, int MODE>
 __global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
+    constexpr bool FAST = MODE != 0, S2 = MODE == 2;
     constexpr bool GEN = !FAST;
     using C = Conv64BfCfg<MT>;
-    constexpr int ROWB = C::ROWB, NP = C::NP;
+    constexpr int ROWB = S2 ? 64 : C::ROWB, NP = C::NP;
+    constexpr int SPR = ROWB / 16;                         // 16-B slots per LDS row
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -101,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
     b -= tdi * (R.nth * R.ntw);
     const int thi = fdn_udiv40(b, R.mg_ntw_hi, R.mg_ntw_lo);
     const int bufB = R.lrows_p * ROWB;
-    int* mtab = (int*)(smem + 2 * bufB);
+    int* mtab = (int*)(smem + (S2 ? 1 : 2) * bufB);
     const int p0d = R.obd + tdi * R.td, p0h = R.obh + thi * R.th, p0w = R.obw + (b - thi * R.ntw) * R.tw;
     const int prn = R.th * R.tw;                          // positions per plane block (<= 64)
 
@@ -114,16 +122,19 @@ __global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
     // the conflict-avoiding chunk swizzle moves to the SOURCE side (slot c receives channel chunk c ^ f).  Pad rows, rows past the
     // image and (dgrad) voxels outside the volume read past the buffer's range, which returns -- and stores -- zeros.  One
     // instruction per 1 KB, no data registers, no ds_write, no zero-select: the staging of a slice is NPL VMEM instructions per wave.
-    constexpr int NPL = FAST ? (C::MAXLROWS * 2 + 255) / 256 : 1;
+    // MODE 2: rows are dense (hs = hw) and hold four 16-B slots; slot s of a row with staged height index zh sits at physical slot
+    // s ^ (zh & 3): the four 4-lane runs of a ds_read_b128 lane group lie on four consecutive zh (8 x 8 plane block), i.e. on four
+    // different slots, and the four rows of a run on four different bank quads -- conflict-free for every tap shift.
+    constexpr int NPL = S2 ? (C::MAXLROWS2 * 4 + 255) / 256 : (FAST ? (C::MAXLROWS * 2 + 255) / 256 : 1);
     unsigned goff[NPL];                                   // byte offset from the sample's first voxel, or kOob
     constexpr unsigned kOob = 0x80000000u;
-    const int nitems = R.lrows_p * 2;                       // buffers are padded to whole 1-KB pieces (32 rows): no partial wave
+    const int nitems = R.lrows_p * SPR;                     // buffers are padded to whole 1-KB pieces: no partial wave
     if (FAST) {
         const int hhhs = R.hh * R.hs;
 #pragma unroll
         for (int u = 0; u < NPL; ++u) {
             const int i = u * 256 + tid;
-            const int r = i >> 1;
+            const int r = i / SPR, pslot = i % SPR;
             goff[u] = kOob;
             if (r < R.lrows) {
                 const int zd = fdn_div20(r, R.mg_hhhs);
@@ -139,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
                 if (zw < R.hw && (inside || !p.zero_mode)) {
                     unsigned v = (unsigned)((qd * p.IH + qh) * p.IW + qw);
                     if (p.dbg & 4) v = (unsigned)(r & 255);  // ablation: real data, but always the same 32 KB (cache hits)
-                    goff[u] = v * 128u + (unsigned)((chunk ^ f) << 4);
+                    goff[u] = v * 128u + (unsigned)((S2 ? (pslot ^ (zh & 3)) : (chunk ^ f)) << 4);
                 }
             }
         }
@@ -152,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
         for (int u = 0; u < NPL; ++u) {
             if (u < u0 || u >= u1) continue;
             if (u * 256 + wave_u * 64 >= nitems) continue;            // wave-uniform: the whole 1-KB piece lies past the (padded) image
-            fdn_lds_dma16(xrsrc, buf + (u * 256 + wave_u * 64) * 16, goff[u], sl * 32);
+            fdn_lds_dma16(xrsrc, buf + (u * 256 + wave_u * 64) * 16, goff[u], sl * ROWB);
         }
     };
     // GEN: register staging -- NP staged voxels x one 16-B chunk per thread, written to a padded / swizzled image by ds_write
@@ -274,13 +285,13 @@ __global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
     }
 
     // one (b,c) step on buffer `buf`: FULL = every plane and depth tap present (no predicates)
-    auto kstep = [&](auto fullc, const char* buf, int db, int dc, const u32x4 (&wsrc)[3]) {
+    auto kstep = [&](auto fullc, const char* buf, int db, int dc, const u32x4 (&wsrc)[3], int k2 = 0) {
         constexpr bool FULL = decltype(fullc)::value;
         bf16x8 wv[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) wv[a] = __builtin_bit_cast(bf16x8, wsrc[a]);
         const int f = (((mh0 + db) >> R.swz_hs) + (((mw0 + dc) >> 2) & R.swz_wm)) & 1;
-        const char* lp = buf + (lrow0 + db * R.hs + dc) * ROWB + ((kh ^ f) << 4);
+        const char* lp = buf + (lrow0 + db * R.hs + dc) * ROWB + (S2 ? (((k2 * 2 + kh) ^ ((mh0 + db) & 3)) << 4) : ((kh ^ f) << 4));
 #pragma unroll
         for (int pl = 0; pl < MT + 2; ++pl) {
             if (!FULL && pl >= npl) continue;
@@ -300,7 +311,28 @@ __global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
         stage_load(0, 1); stage_write(smem, 1);
     }
     __syncthreads();
-    if (FAST) {
+    if (S2) {
+        // two slices of 32 cin = 18 steps each: the two 16-cin halves of a row one after the other, 9 (b,c) taps each -- the SAME
+        // summation order as the four-slice kernel (cin group outermost), so the variants stay bit-identical; weights three steps
+        // ahead across the slice boundary; the second slice replaces the first in the same buffer between two barriers
+#pragma unroll 1
+        for (int sl = 0; sl < 2; ++sl) {
+#pragma unroll
+            for (int it = 0; it < 18; ++it) {
+                const int k2 = it / 9, bc = it % 9;
+                kstep(std::true_type{}, smem, bc / 3, bc % 3, wq[it % 3], k2);
+                // step it + 3 of the stream of 36 steps: 16-cin group n / 9, tap n % 9
+                const int nx = it + 3, slx = sl + nx / 18, itx = nx % 18;
+                if (slx < 2) load_w(wq[it % 3], slx * 2 + itx / 9, tb0 + (itx % 9) / 3, tc0 + (itx % 9) % 3);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (sl == 0) {
+                __syncthreads();                          // every wave is done reading slice 0
+                stage_dma(smem, 1, 0, NPL);
+                __syncthreads();                          // (the compiler drains the LDS-DMA queue in front of the barrier)
+            }
+        }
+    } else if (FAST) {
         // 9 unrolled steps per slice; weights two steps ahead (running into the next slice) in two register sets; the next
         // slice's voxels are loaded behind step 0's weight refill and written to the other buffer at step 7.  No branch
         // sits between a load and its use, so every wait is a counted vmcnt.  A slice has an odd number of steps, so the
@@ -532,7 +564,8 @@ struct Plan { FdnTile t; double cost; };
 int lds_hs(int hw) { if (hw == 1) return 1; int hs = hw; while ((hs & 7) != 4) ++hs; return hs; }
 
 // tail: one of several regions sharing a launch (the six shell slabs of a fused dgrad): total work counts, not rounds over a chip of its own
-Plan best_plan(int N, const Box& bx, int mt, int max_rows, int max_lrows, bool tail = false) {
+// mode2: 8 x 8 plane blocks only, dense LDS rows (hs = hw)
+Plan best_plan(int N, const Box& bx, int mt, int max_rows, int max_lrows, bool tail = false, bool mode2 = false) {
     const bool full_only = (fdn_conv64bf_force_mt & 16) && bx.ed >= mt;
     Plan best{{1, 1, 1, bx.ed, bx.eh, bx.ew}, 1e30};
     const int da = bx.ta1 - bx.ta0, db = bx.tb1 - bx.tb0, dc = bx.tc1 - bx.tc0;
@@ -541,7 +574,8 @@ Plan best_plan(int N, const Box& bx, int mt, int max_rows, int max_lrows, bool t
         for (int th = 1; th <= bx.eh && th <= 64; ++th)
             for (int tw = 1; tw <= bx.ew && th * tw <= 64; ++tw) {
                 const int rows = (td + da) * (th + db) * (tw + dc);
-                if (rows > max_rows || (td + da) * (th + db) * lds_hs(tw + dc) > max_lrows) continue;
+                if (mode2 && (th != 8 || tw != 8)) continue;
+                if (rows > max_rows || (td + da) * (th + db) * (mode2 ? tw + dc : lds_hs(tw + dc)) > max_lrows) continue;
                 FdnTile t{td, th, tw, (bx.ed + td - 1) / td, (bx.eh + th - 1) / th, (bx.ew + tw - 1) / tw};
                 const double tiles = (double)N * t.ntd * t.nth * t.ntw;
                 // tiles with td < mt (or a single depth tap) run the predicated K loop: ~1.5x per MFMA
@@ -553,11 +587,11 @@ Plan best_plan(int N, const Box& bx, int mt, int max_rows, int max_lrows, bool t
     return best;
 }
 
-template <int MT, bool FAST>
+template <int MT, int MODE>
 int launch_regions(Conv64BfArgs& a, hipStream_t s) {
     using C = Conv64BfCfg<MT>;
     if (a.nreg == 0) return FDN_OK;
-    if (int rc = fdn_func_max_lds((const void*)conv64_bf16_kernel<MT, FAST>, C::LDS_BUDGET, "conv64_bf16")) return rc;
+    if (int rc = fdn_func_max_lds((const void*)conv64_bf16_kernel<MT, MODE>, C::LDS_BUDGET, "conv64_bf16")) return rc;
     int blocks = 0, max_lrows = 0;
     for (int i = 0; i < a.nreg; ++i) {
         Conv64Region& r = a.reg[i];
@@ -566,8 +600,8 @@ int launch_regions(Conv64BfArgs& a, hipStream_t s) {
         if (r.lrows_p > max_lrows) max_lrows = r.lrows_p;
     }
     // every region's mtab sits behind ITS two buffers; size the allocation for the largest region
-    const size_t lds = (size_t)max_lrows * C::ROWB * 2 + C::MCAP * 4;
-    hipLaunchKernelGGL((conv64_bf16_kernel<MT, FAST>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+    const size_t lds = (size_t)max_lrows * 64 + C::MCAP * 4;          // two buffers of 32-B rows, or (MODE 2) one of 64-B rows
+    hipLaunchKernelGGL((conv64_bf16_kernel<MT, MODE>), dim3((unsigned)blocks), dim3(256), lds, s, a);
     FDN_CHECK_LAUNCH("conv64_bf16_kernel");
     return FDN_OK;
 }
@@ -576,8 +610,8 @@ int launch_regions(Conv64BfArgs& a, hipStream_t s) {
 template <int MT>
 int launch_bf16(Conv64BfArgs& a, const Box* boxes, int nbox, hipStream_t s) {
     using C = Conv64BfCfg<MT>;
-    Conv64BfArgs fast = a, slow = a;
-    fast.nreg = slow.nreg = 0;
+    Conv64BfArgs fast = a, fast2 = a, slow = a;
+    fast.nreg = fast2.nreg = slow.nreg = 0;
     for (int i = 0; i < nbox; ++i) {
         const Box& bx = boxes[i];
         if (bx.ed <= 0 || bx.eh <= 0 || bx.ew <= 0) continue;
@@ -586,16 +620,23 @@ int launch_bf16(Conv64BfArgs& a, const Box* boxes, int nbox, hipStream_t s) {
         if (i > 0 && !(fdn_conv64bf_dbg & 16) && (long long)a.N * t.ntd * t.nth * t.ntw < 1024)
             t = best_plan(a.N, bx, MT, C::MAXROWS, C::MAXLROWS, true).t;
         const bool is_fast = t.td == MT && bx.ta0 == 0 && bx.ta1 == 2 && bx.tb0 == 0 && bx.tb1 == 2 && bx.tc0 == 0 && bx.tc1 == 2;
-        Conv64BfArgs& dst = is_fast ? fast : slow;
+        // MODE 2 (two 32-cin slices, one LDS buffer): full 8 x 8 x MT tiles whose sample fits the 31-bit buffer offsets; a grid that
+        // divides into them exactly keeps the planner's tile, otherwise the 8 x 8 plan must not cost more tiles
+        bool is_fast2 = false;
+        if (is_fast && fdn_conv64bf_mode2 && (long long)a.ID * a.IH * a.IW * 128 < (1ll << 31)) {
+            const Plan p2 = best_plan(a.N, bx, MT, C::MAXROWS, C::MAXLROWS2, false, true);
+            if (p2.cost < 1e29 && p2.t.td == MT && (long long)p2.t.ntd * p2.t.nth * p2.t.ntw <= (long long)t.ntd * t.nth * t.ntw) { t = p2.t; is_fast2 = true; }
+        }
+        Conv64BfArgs& dst = is_fast2 ? fast2 : (is_fast ? fast : slow);
         Conv64Region& r = dst.reg[dst.nreg++];
         r.obd = bx.od; r.obh = bx.oh; r.obw = bx.ow; r.ebd = bx.ed; r.ebh = bx.eh; r.ebw = bx.ew;
         r.ta0 = bx.ta0; r.ta1 = bx.ta1; r.tb0 = bx.tb0; r.tb1 = bx.tb1; r.tc0 = bx.tc0; r.tc1 = bx.tc1;
         r.td = t.td; r.th = t.th; r.tw = t.tw; r.ntd = t.ntd; r.nth = t.nth; r.ntw = t.ntw;
         r.hh = t.th + (bx.tb1 - bx.tb0); r.hw = t.tw + (bx.tc1 - bx.tc0);
         r.rows = (t.td + (bx.ta1 - bx.ta0)) * r.hh * r.hw;
-        r.hs = lds_hs(r.hw);
+        r.hs = is_fast2 ? r.hw : lds_hs(r.hw);
         r.lrows = (t.td + (bx.ta1 - bx.ta0)) * r.hh * r.hs;
-        r.lrows_p = (r.lrows + 31) & ~31;
+        r.lrows_p = is_fast2 ? (r.lrows + 15) & ~15 : (r.lrows + 31) & ~31;
         r.mg_hhhs = fdn_magic20(r.hh * r.hs);
         r.mg_hs = fdn_magic20(r.hs);
         r.mg_hhhw = fdn_magic20(r.hh * r.hw);
@@ -617,9 +658,9 @@ int launch_bf16(Conv64BfArgs& a, const Box* boxes, int nbox, hipStream_t s) {
                     t.tw, t.ntd, t.nth, t.ntw, r.rows, r.lrows, r.hs, is_fast ? "FAST" : "general");
 #endif
     }
-    const int rc = launch_regions<MT, true>(fast, s);
-    if (rc != FDN_OK) return rc;
-    return launch_regions<MT, false>(slow, s);
+    if (int rc = launch_regions<MT, 2>(fast2, s)) return rc;
+    if (int rc = launch_regions<MT, 1>(fast, s)) return rc;
+    return launch_regions<MT, 0>(slow, s);
 }
 
 int launch_boxes(Conv64BfArgs& a, const Box* boxes, int nbox, hipStream_t s) {
@@ -677,4 +718,5 @@ int fdn_fold_halo_border_bf16_launch(const float* s0, const float* s1, const flo
 #ifdef FDN_TEST_HOOKS
 extern "C" int fdn_debug_set_conv64_bf16_mt(int mt) { fdn_conv64bf_force_mt = mt; return FDN_OK; }
 extern "C" int fdn_debug_set_conv64_bf16_dbg(int bits) { fdn_conv64bf_dbg = bits; return FDN_OK; }
+extern "C" int fdn_debug_set_conv64_bf16_mode2(int on) { fdn_conv64bf_mode2 = on; return FDN_OK; }
 #endif

@@ -52,8 +52,9 @@ def bops(fdn):
 SHAPES = [(2, 8, 8, 8), (1, 5, 7, 9), (1, 10, 12, 16), (3, 4, 4, 2), (1, 1, 1, 1), (1, 16, 16, 16), (1, 3, 20, 11),
           (3, 24, 24, 24), (1, 17, 9, 12)]
 # conv64 variants: 0 = planner, 4 / 8 = forced MT, +16 = full-depth tiles only (exercises the unrolled FAST kernel even
-# where the planner would cut a small grid into thin tiles)
-VARIANTS = [0, 4, 8, 20, 24]
+# where the planner would cut a small grid into thin tiles), +32 = never the two-slice kernel (MODE 2: 8 x 8 plane blocks, one LDS buffer
+# of 64-B rows) -- i.e. the four-slice double-buffered FAST kernel on the grids where MODE 2 would otherwise take over
+VARIANTS = [0, 4, 8, 20, 24, 52, 56]
 
 
 def rb(a):
@@ -72,7 +73,8 @@ def test_conv64_fwd_bf16(bops, fdn, shape, mt):
     wf, _ = bops.pack_conv64_weights(dev(w))
     with variant_lib(fdn, mt) as lib:
         if lib is not None:
-            lib.fdn_debug_set_conv64_bf16_mt(mt)
+            lib.fdn_debug_set_conv64_bf16_mt(mt & 31)
+            lib.fdn_debug_set_conv64_bf16_mode2(0 if mt & 32 else 1)
         try:
             for act, bias, r in [(O.ACT_RELU, b, None), (O.ACT_LEAKY, None, res), (O.ACT_NONE, None, None)]:
                 ref = O.conv3d_fwd(x, rb(w), None if bias is None else bias.astype(np.float64), act, 0.2, r)
@@ -82,6 +84,7 @@ def test_conv64_fwd_bf16(bops, fdn, shape, mt):
         finally:
             if lib is not None:
                 lib.fdn_debug_set_conv64_bf16_mt(0)
+                lib.fdn_debug_set_conv64_bf16_mode2(1)
 
 
 @pytest.mark.parametrize("shape", SHAPES + [(1, 2, 3, 1)])
@@ -97,7 +100,8 @@ def test_conv64_dgrad_fused_bf16(bops, fdn, shape, mt):
     _, wd = bops.pack_conv64_weights(dev(w))
     with variant_lib(fdn, mt) as lib:
         if lib is not None:
-            lib.fdn_debug_set_conv64_bf16_mt(mt)
+            lib.fdn_debug_set_conv64_bf16_mt(mt & 31)
+            lib.fdn_debug_set_conv64_bf16_mode2(0 if mt & 32 else 1)
         try:
             pad = torch.full((N, D + 2, H + 2, W + 2, 64), float("nan"), device="cuda")
             out = torch.full((N, D, H, W, 64), float("nan"), device="cuda", dtype=torch.bfloat16)
@@ -107,6 +111,7 @@ def test_conv64_dgrad_fused_bf16(bops, fdn, shape, mt):
         finally:
             if lib is not None:
                 lib.fdn_debug_set_conv64_bf16_mt(0)
+                lib.fdn_debug_set_conv64_bf16_mode2(1)
 
 
 @pytest.mark.parametrize("shape", [(2, 8, 8, 8), (1, 5, 7, 9), (1, 10, 12, 16), (3, 4, 4, 2), (2, 16, 16, 16), (1, 1, 1, 1)])

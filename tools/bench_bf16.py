@@ -37,9 +37,10 @@ def main():
         out = torch.empty_like(x)
         pad = torch.empty(N, P + 2, P + 2, P + 2, 64, device="cuda")
         gflop = 2 * 27 * 64 * 64 * N * P ** 3 / 1e9
-        for mt in (8, 4, 0):
-            lib.fdn_debug_set_conv64_bf16_mt(mt)
-            name = {8: "<MT8>", 4: "<MT4>", 0: "auto"}[mt]
+        for mt in (8, 4, 0, 32):
+            lib.fdn_debug_set_conv64_bf16_mt(mt & 31)
+            lib.fdn_debug_set_conv64_bf16_mode2(0 if mt & 32 else 1)
+            name = {8: "<MT8>", 4: "<MT4>", 0: "auto", 32: "auto-4slice"}[mt]
             for label, fn in [
                 ("fwd", lambda: bops.conv64_fwd(x, wf, None, 1, 0.2, None, out)),
                 ("fwd+res+leaky", lambda: bops.conv64_fwd(x, wf, None, 2, 0.2, res, out)),
@@ -56,7 +57,7 @@ def main():
                     ms = timeit(lambda: bops.conv64_fwd(x, wf, None, 1, 0.2, None, out))
                     print("    ablation %-26s: %8.3f ms %9.1f TF" % (what, ms, gflop / ms), flush=True)
                 lib.fdn_debug_set_conv64_bf16_dbg(0)
-        lib.fdn_debug_set_conv64_bf16_mt(0)
+        lib.fdn_debug_set_conv64_bf16_mt(0); lib.fdn_debug_set_conv64_bf16_mode2(1)
 
 
 if __name__ == "__main__":
