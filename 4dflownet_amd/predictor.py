@@ -121,9 +121,9 @@ def predict_patches(network, velocities, magnitudes, batch_size):
             _drain_to_host(network, _forward_chunks(network, velocities, magnitudes, batch_size, lo, hi), res, batch_size)
             # receives are posted AFTER the own shard (a pending RCCL receive is a kernel spinning on a few CUs); the peers finish
             # their equal shards at about the same time, so only the transfer itself (1.3 MB per patch over xGMI) is exposed
-            reqs = [dist.irecv(full[bounds[r]:bounds[r + 1]], src=r) for r in range(1, world) if bounds[r + 1] > bounds[r]]
-            for q in reqs:
-                q.wait()                              # makes the current stream wait for the transfer; no host sync
+            ops_ = [dist.P2POp(dist.irecv, full[bounds[r]:bounds[r + 1]], r) for r in range(1, world) if bounds[r + 1] > bounds[r]]
+            for q in (dist.batch_isend_irecv(ops_) if ops_ else []):     # one grouped RCCL launch for all peers
+                q.wait()                              # makes the current stream wait for the transfers; no host sync
             step = max(batch_size, 1)
             _drain_to_host(network, ((s, full[s:min(s + step, n)]) for s in range(hi, n, step)), res, batch_size)
             return res
@@ -131,7 +131,8 @@ def predict_patches(network, velocities, magnitudes, batch_size):
             mine = torch.empty((hi - lo, S, S, S, 3), device=dev, dtype=torch.float32)
             for _ in _forward_chunks(network, velocities, magnitudes, batch_size, lo, hi, keep=mine):
                 pass
-            dist.send(mine, dst=0)
+            for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, mine, 0)]):
+                q.wait()
         return None
     # host transport
     if dev.type == "cuda":
