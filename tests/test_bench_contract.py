@@ -86,3 +86,24 @@ def test_bench_frac_agrees_with_the_pmc_busy_counter():
     assert conv_k in busy and wg_k in busy, (conv_k, wg_k, sorted(busy))
     assert abs(line["roofline"]["frac"] - busy[conv_k]) <= 0.02, (line["roofline"]["frac"], busy[conv_k])
     assert -0.005 <= busy[wg_k] - line["roofline_wgrad"]["frac"] <= 0.04, (line["roofline_wgrad"]["frac"], busy[wg_k])
+
+
+def test_executed_flop_pricing_follows_the_kernel_the_planner_picks():
+    """bench.py prices `achieved` / `frac` with the multiplies the selected kernel EXECUTES (include/fdn.h, FDN_ALGO_*): 9 of 27
+    tap-equivalents per voxel for the 2-D Winograd conv kernel (H even, W % 4 == 0), 13.5 for W-only Winograd, 27 direct; the
+    shell launch of a fused dgrad: 4.5 per d/h-face position, 9 per w-face position."""
+    b = _bench()
+    per_tap = 2.0 * 64 * 64
+    vox = 8 * 48 ** 3
+    assert b.executed_conv64_flop(8, 48, 48, 48) == vox * 9 * per_tap
+    assert b.executed_conv64_flop(8, 48, 48, 48, algo=2) == vox * 13.5 * per_tap          # FDN_ALGO_WINO_W
+    assert b.executed_conv64_flop(8, 48, 48, 48, algo=1) == vox * 27 * per_tap            # FDN_ALGO_DIRECT
+    assert b.executed_conv64_flop(1, 5, 7, 12) == 5 * 7 * 12 * 13.5 * per_tap               # odd H: 1-D kernel
+    assert b.executed_conv64_flop(1, 5, 7, 9) == 5 * 7 * 9 * 27 * per_tap                   # W % 4 != 0: direct
+    assert abs(b.executed_conv64_flop(8, 48, 48, 48) / (vox * b.FLOP_PER_VOXEL_CONV64) - 1.0 / 3) < 1e-12
+    D = H = W = 24
+    shell = b.executed_shell_flop(8, D, H, W)
+    assert shell == 8 * ((2 * (H + 2) * W + 2 * D * W) * 4.5 + 2 * (D + 2) * (H + 2) * 9.0) * per_tap
+    # the shell against the inner box's executed work: 18 % at 24^3, 9 % at 48^3
+    assert 0.17 < shell / b.executed_conv64_flop(8, D, H, W) < 0.20
+    assert 0.08 < b.executed_shell_flop(8, 48, 48, 48) / b.executed_conv64_flop(8, 48, 48, 48) < 0.10

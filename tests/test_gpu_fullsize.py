@@ -122,6 +122,34 @@ def test_conv64_fp32_at_bench_shapes_sampled_float64(fdn, N, P):
     assert np.abs(gotw - refw).max() <= RTOL * full_scale, "wgrad"
 
 
+def test_conv64_fp32_at_the_2d_kernels_size_limit_sampled_float64(fdn):
+    """The 2-D Winograd kernel addresses a sample with 30-bit byte offsets (<= 2^22 voxels); a larger sample must take the 1-D
+    kernels instead (fdn_conv64_wino2d_ok).  Forward and fused dgrad just below the limit (160 x 160 x 160 = 4 096 000 voxels:
+    2-D kernels, the "reads zero" marker one step above the largest real offset) and just above it (164^3: fallback), sampled
+    against float64 -- every corner, edge, face sample and random interior voxels, i.e. the largest offsets of the tensor."""
+    ops = fdn.ops
+    rng = np.random.default_rng(9)
+    g = torch.Generator(device="cuda").manual_seed(13)
+    w = torch.randn((3, 3, 3, 64, 64), device="cuda", generator=g) * 0.03
+    w64 = w.double().cpu().numpy()
+    wf, wd = ops.pack_conv64_weights(w)
+    for P in (160, 164):
+        x = torch.randn((1, P, P, P, 64), device="cuda", generator=g)
+        pts = sample_voxels(1, P, P, P, 200, rng)
+        dims = (1, P, P, P)
+        y = ops.conv3d_fwd(x, w, None, ops.ACT_NONE, wpack=wf)
+        ref = ref_forward(x, w64, pts, dims)
+        assert np.abs(gather_rows(y, pts) - ref).max() <= RTOL * np.abs(ref).max(), ("fwd", P)
+        pad = torch.empty((1, P + 2, P + 2, P + 2, 64), device="cuda")
+        out = torch.empty_like(x)
+        ops.conv3d_dgrad_fused(x, wd, pad, out)
+        ops.fold_halo_border([pad], out)
+        refd = ref_dgrad(x, w64, pts, dims)
+        assert np.abs(gather_rows(out, pts) - refd).max() <= RTOL * np.abs(refd).max(), ("dgrad", P)
+        del x, y, pad, out
+        torch.cuda.empty_cache()
+
+
 def test_conv64_bf16_at_cfg4_shape_sampled_float64(fdn):
     """cfg4 launch shape (4,128^3,64) in bf16 storage: forward and fused dgrad, sampled voxels vs float64 of the same bf16
     operands (products exact, fp32 accumulation, one bf16 rounding of the result: within one bf16 ulp)."""

@@ -19,5 +19,5 @@ for P in ([int(sys.argv[2])] if len(sys.argv) > 2 else [48, 24]):
         for _ in range(20): ops.conv3d_wgrad(x, dz, 3, 64, 64, dw=dw, workspace=ws)
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 20
-        print("P=%d %-36s %7.3f ms (incl. reduce)  matrix pipe %.3f" % (P, name, ms, flop / 2 / ms * 1e-9 / 157.3))
+        print("P=%d %-36s %7.3f ms (incl. reduce)  matrix pipe %.3f" % (P, name, ms, flop / 3 / ms * 1e-9 / 157.3))
     lib.fdn_debug_set_wgrad64_wino_dbg(0)
