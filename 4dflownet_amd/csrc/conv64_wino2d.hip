@@ -200,7 +200,8 @@ __global__ __launch_bounds__(256, 2) void conv64_wino2d_kernel(Wino2Args p) {
         // ---- stage xh: V = x[ra] + sgn * x[rb], rows (0,2,-) (1,2,+) (1,2,-) (1,3,-); then B_w^T; all 64 cin ----
         {
             const float sgn = xh == 1 ? 1.f : -1.f;
-            const int items_eff = (FDN_DBG_BITS(p) & 4) ? 0 : p.items;
+            // a wave whose 64 items of a pass all lie past the tile's last item requests nothing in that pass (640 items: waves 2, 3 of pass 2)
+            const int items_eff = ((FDN_DBG_BITS(p) & 4) ? 0 : p.items) - __builtin_amdgcn_readfirstlane(wave) * 64;
             constexpr int DEP = kW2Dep;                       // items in flight per thread
             f32x4 xa[DEP][6], xb[DEP][6];
             auto issue = [&](int u, int buf) {
