@@ -116,6 +116,7 @@ def test_round3_profiles_carry_the_sources_they_were_measured_on():
     if not files:
         pytest.skip("no round-3/4 profiles collected yet")
     stamp = import_module("4dflownet_amd.build").source_stamp()
+    latest = max(int(re.match(r"r(\d+)_", os.path.basename(f)).group(1)) for f in files)
     stale = []
     for f in files:
         if f.endswith(".json"):
@@ -127,7 +128,7 @@ def test_round3_profiles_carry_the_sources_they_were_measured_on():
             m = re.match(r"# commit ([0-9a-f]{40}(?:\+dirty)?) lib_source_stamp ([0-9a-f]{64})", first)
             assert m, (f, first)
             got = m.group(2)
-        if got != stamp:
+        if got != stamp and os.path.basename(f).startswith("r%d_" % latest):     # older rounds' files are history: header check only
             stale.append(os.path.basename(f))
     if stale:
         warnings.warn("profiles measured on other kernel sources than the tree's (re-run tools/profile_round.sh): %s" % ", ".join(stale))
