@@ -41,3 +41,35 @@ def test_padded_lds_rows_are_conflict_free_for_ds_read_b128():
                     assert len(slots) == 16, (stride, base, off)
     # the unpadded 128-B stride is NOT conflict-free (that is why the first version needed an XOR swizzle)
     assert len({(i * 128) % 256 // 16 for i in groups[0]}) < 16
+
+
+def test_trainer_script_picks_the_host_loader_only_on_request(monkeypatch):
+    """scripts/trainer.py feeds train_network from the on-device loader (the measured path) unless FDN_HOST_LOADER is set, in which
+    case it builds data.PatchHandler3D and asks for the pinned staging ring.  No GPU needed: the device class is
+    stubbed, only the selection logic runs."""
+    import importlib
+    import importlib.util
+    import os
+    import sys
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fdn_trainer_script", os.path.join(root, "scripts", "trainer.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)                       # __main__ guard: nothing runs
+    made = []
+
+    class _Dev:
+        def __init__(self, *a):
+            made.append(a)
+    stub = types.ModuleType("4dflownet_amd.data_device")
+    stub.DevicePatchHandler3D = _Dev
+    monkeypatch.setitem(sys.modules, "4dflownet_amd.data_device", stub)
+    monkeypatch.delenv("FDN_HOST_LOADER", raising=False)
+    h, kw = mod.make_handler("/d", 16, 2, 20, 0.6)
+    assert isinstance(h, _Dev) and kw == {} and made == [("/d", 16, 2, 20, 0.6)]
+    monkeypatch.setenv("FDN_HOST_LOADER", "1")
+    h, kw = mod.make_handler("/d", 16, 2, 20, 0.6)
+    data = importlib.import_module("4dflownet_amd.data")
+    assert type(h) is data.PatchHandler3D and kw == {"pinned": True}
+    monkeypatch.setenv("FDN_HOST_LOADER", "0")
+    assert isinstance(mod.make_handler("/d", 16, 2, 20, 0.6)[0], _Dev)
