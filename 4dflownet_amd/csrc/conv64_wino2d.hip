@@ -308,75 +308,77 @@ __global__ __launch_bounds__(256, 2) void conv64_wino2d_kernel(Wino2Args p) {
     // ---- epilogue: lane = cell c of each M-block x cout 16w + 4q .. + 3; 8 voxels per cell ----
     const int cofs = wave * 16 + q * 4;
     const float slope = p.act == FDN_ACT_RELU ? 0.f : (p.act == FDN_ACT_LEAKY ? p.alpha : 1.f);
+    // Both M-blocks' operand loads (skip / y, or the residual) are requested before the first store: the stores of block 0 may alias
+    // the loads of block 1 as far as the compiler can tell (skip may BE the output), so left to itself it serialises two memory round
+    // trips at the end of every tile.  A lane reads exactly the addresses it writes, so hoisting the reads is safe.
+    int g0[2];
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-        const int g0 = mtab[mb * 16 + c];
-        if (g0 < 0) continue;
-        if (FUSED) {
-            // dgrad on the inner box of the padded grid: voxels strictly inside the volume get exactly one contribution and are
-            // finished here (dz_prev = (dgrad + skip) * act'(y)); surface voxels go to the padded scratch for the border fold.
-            // Branch-free per voxel: every lane requests skip / y for its 8 voxels at once (a surface voxel reads row 0 of the tensor,
-            // which nobody writes in this launch, and discards it), then picks value and destination -- a branch per voxel would put
-            // a memory round trip between every pair of stores.
+    for (int mb = 0; mb < 2; ++mb) g0[mb] = mtab[mb * 16 + c];
+    if (FUSED) {
+        // dgrad on the inner box of the padded grid: voxels strictly inside the volume get exactly one contribution and are finished
+        // here (dz_prev = (dgrad + skip) * act'(y)); surface voxels go to the padded scratch for the border fold.  Branch-free per
+        // voxel: a surface voxel (or a cell outside the box) reads row 0 of the tensor, which nobody writes in this launch, and
+        // discards it; value and destination are selected afterwards.
+        int fi[2][2][4];                      // voxel index into skip / y / dz_prev, or -1 (surface voxel, cell outside the box)
+        f32x4 sk[2][2][4], ym[2][2][4];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
             const int gf0 = mtab[32 + mb * 16 + c];
             const int hw = mtab[64 + mb * 16 + c];
             const int ph = hw & 0xffff, pw = hw >> 16;                    // padded coordinates of the cell's first voxel
-            size_t of[2][4];
-            bool in[2][4];
 #pragma unroll
             for (int hr = 0; hr < 2; ++hr)
 #pragma unroll
                 for (int wi = 0; wi < 4; ++wi) {
                     const int ih = ph + hr - 1, iw = pw + wi - 1;
-                    in[hr][wi] = gf0 >= 0 && ih >= 1 && ih <= p.IH - 2 && iw >= 1 && iw <= p.IW - 2;
-                    of[hr][wi] = in[hr][wi] ? (size_t)(gf0 + hr * p.IW + wi) * 64 + cofs : (size_t)cofs;
+                    const bool in = g0[mb] >= 0 && gf0 >= 0 && ih >= 1 && ih <= p.IH - 2 && iw >= 1 && iw <= p.IW - 2;
+                    fi[mb][hr][wi] = in ? gf0 + hr * p.IW + wi : -1;
+                    const size_t o = (size_t)(in ? fi[mb][hr][wi] : 0) * 64 + cofs;
+                    sk[mb][hr][wi] = p.fskip ? *(const f32x4*)(p.fskip + o) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    ym[mb][hr][wi] = p.fy ? *(const f32x4*)(p.fy + o) : (f32x4){1.f, 1.f, 1.f, 1.f};
                 }
-            f32x4 sk[2][4], ym[2][4];
+        }
 #pragma unroll
-            for (int hr = 0; hr < 2; ++hr)
-#pragma unroll
-                for (int wi = 0; wi < 4; ++wi) {
-                    sk[hr][wi] = p.fskip ? *(const f32x4*)(p.fskip + of[hr][wi]) : (f32x4){0.f, 0.f, 0.f, 0.f};
-                    ym[hr][wi] = p.fy ? *(const f32x4*)(p.fy + of[hr][wi]) : (f32x4){1.f, 1.f, 1.f, 1.f};
-                }
+        for (int mb = 0; mb < 2; ++mb) {
+            if (g0[mb] < 0) continue;
 #pragma unroll
             for (int hr = 0; hr < 2; ++hr)
 #pragma unroll
                 for (int wi = 0; wi < 4; ++wi) {
                     const f32x4 z = Y[hr][wi][mb];
+                    const bool in = fi[mb][hr][wi] >= 0;
                     f32x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = in[hr][wi] ? (z[e] + sk[hr][wi][e]) * (ym[hr][wi][e] > 0.f ? 1.f : slope) : z[e];
-                    float* dst = in[hr][wi] ? p.fout + of[hr][wi] : p.y + (size_t)(g0 + hr * p.OW + wi) * 64 + cofs;
+                    for (int e = 0; e < 4; ++e) v[e] = in ? (z[e] + sk[mb][hr][wi][e]) * (ym[mb][hr][wi][e] > 0.f ? 1.f : slope) : z[e];
+                    float* dst = in ? p.fout + (size_t)fi[mb][hr][wi] * 64 + cofs : p.y + (size_t)(g0[mb] + hr * p.OW + wi) * 64 + cofs;
                     *(f32x4*)dst = v;
                 }
-        } else {
-            f32x4 z[2][4];
+        }
+    } else {
+        f32x4 rv[2][2][4];
+        if (p.res) {
 #pragma unroll
-            for (int hr = 0; hr < 2; ++hr)
-#pragma unroll
-                for (int wi = 0; wi < 4; ++wi) z[hr][wi] = Y[hr][wi][mb];
-            if (p.res) {
-#pragma unroll
-                for (int hr = 0; hr < 2; ++hr)
-#pragma unroll
-                    for (int wi = 0; wi < 4; ++wi) z[hr][wi] += *(const f32x4*)(p.res + (size_t)(g0 + hr * p.OW + wi) * 64 + cofs);
-            }
-            if (p.bias) {
-                const f32x4 bv = *(const f32x4*)(p.bias + cofs);
+            for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                 for (int hr = 0; hr < 2; ++hr)
 #pragma unroll
-                    for (int wi = 0; wi < 4; ++wi) z[hr][wi] += bv;
-            }
+                    for (int wi = 0; wi < 4; ++wi)
+                        rv[mb][hr][wi] = *(const f32x4*)(p.res + (size_t)((g0[mb] >= 0 ? g0[mb] : 0) + hr * p.OW + wi) * 64 + cofs);
+        }
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bv = *(const f32x4*)(p.bias + cofs);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            if (g0[mb] < 0) continue;
 #pragma unroll
             for (int hr = 0; hr < 2; ++hr)
 #pragma unroll
                 for (int wi = 0; wi < 4; ++wi) {
-                    f32x4 v = z[hr][wi];
+                    f32x4 v = Y[hr][wi][mb] + bv;
+                    if (p.res) v += rv[mb][hr][wi];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], slope * v[e]);          // relu / leaky / none: slope in [0,1]
-                    *(f32x4*)(p.y + (size_t)(g0 + hr * p.OW + wi) * 64 + cofs) = v;
+                    *(f32x4*)(p.y + (size_t)(g0[mb] + hr * p.OW + wi) * 64 + cofs) = v;
                 }
         }
     }
