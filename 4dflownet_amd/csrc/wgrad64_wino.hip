@@ -55,6 +55,7 @@ constexpr int GROWB = 1536;                             // bytes per (line, grou
 constexpr int VBYTES = (WTH + 2) * WTG * GROWB;         // transformed x: 8 halo lines
 constexpr int ZBYTES = WTH * WTG * GROWB;               // transformed dz
 constexpr int WBUFB = VBYTES + ZBYTES;                  // 43 008 B; three buffers = 126 KB
+constexpr int kLocSlot = 5, kXSlot = 6, kZSlot = 13;      // pipeline slots: tile walk / raw x rows / raw dz rows of tile k+2
 constexpr int XSCRATCH = 6 * 4096;                      // DEP: x chunks of the second plane, [chunk 6][x-thread 256] x 16 B, filled by LDS-DMA
 constexpr int ZSCRATCH = 2 * 3072;                      // DEP: dz chunks 2, 3 of the second plane, [2][dz-thread 192] x 16 B
 
@@ -183,8 +184,10 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
         const int h0 = th * WTH - 1, w0 = tw * WTW - 1;
         const unsigned xplane = (unsigned)((tn * p.D + qd) * p.H * p.W) * 256u;
         const unsigned zplane = (unsigned)((tn * p.D + zd) * p.H * p.W) * 256u;
-        x_in = h0 >= 0 && h0 + WTH + 2 <= p.H && w0 >= 0 && w0 + WTW + 2 <= p.W;
-        z_in = h0 + 1 + WTH <= p.H && w0 + 1 + WTW <= p.W;
+        // (spelled as wave-uniform values: the compiler otherwise folds these into the per-thread item masks and wraps every
+        // load in a waterfall loop over its scalar offset)
+        x_in = __builtin_amdgcn_readfirstlane((int)(h0 >= 0 && h0 + WTH + 2 <= p.H && w0 >= 0 && w0 + WTW + 2 <= p.W)) != 0;
+        z_in = __builtin_amdgcn_readfirstlane((int)(h0 + 1 + WTH <= p.H && w0 + 1 + WTW <= p.W)) != 0;
         x_so = xplane + (unsigned)((h0 * p.W + w0) * 256);
         z_so = zplane + (unsigned)(((h0 + 1) * p.W + w0 + 1) * 256);
         if (!x_in && xitem) rowoff = xplane + (unsigned)(min(max(h0 + il, 0), p.H - 1) * p.W * 256 + c16 * 16);
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
     auto load_x = [&](int nn) {
         if (!xitem || (FDN_DBG_BITS(p) & 1)) return;
         const unsigned vo = x_in ? tc0 + (unsigned)(nn * 256) : rowoff + (unsigned)(min(max(tw * WTW + 4 * ig - 1 + nn, 0), p.W - 1) * 256);
-        const unsigned so = x_in ? x_so : 0u;
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)(x_in ? x_so : 0u));   // scalar operand: no waterfall loop
         raw[nn] = bload(xrs, vo, so);
         if (DEP) fdn_lds_dma16(xrs, xscr + nn * 4096, vo, (int)(so + dxb));       // the same chunk of the second plane -> scratch
     };
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
         if (!zitem || (FDN_DBG_BITS(p) & 1)) return;
         const int qw = tw * WTW + 4 * ig + j;
         const unsigned vo = z_in ? tc0 + (unsigned)(j * 256) : ((rowoff != 0xffffffffu && qw < p.W) ? rowoff + (unsigned)(qw * 256) : 0xffffffffu);
-        const unsigned so = z_in ? z_so : 0u;
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)(z_in ? z_so : 0u));
         raw[j] = bload(zrs, vo, so);
         if (DEP && has_zb) {               // second plane: chunks 0, 1 in the two spare registers, chunks 2, 3 through the scratch
             const unsigned vb = vo == 0xffffffffu ? vo : vo + dzb;               // (so + dzb could wrap past a "reads zero" offset)
@@ -314,13 +317,15 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
             }
             __builtin_amdgcn_sched_barrier(0);
             // pipeline stages, pinned to slots: transform + write tile k+1, then load the raw rows of tile k+2
+            // (the raw rows of tile k+2 are requested as soon as tile k+1's have been consumed: they are read again a whole tile
+            // later, in slots 0-3 of the next iteration -- requested after the barrier, the dz rows came back too late)
             if (s == 0) combine_x();
             if (s == 2) combine_z();
             if (s < 2) write_v(s, nxt);
             else if (s < 4) write_z(s - 2, nxt);
-            else if (s == 5) { advance(); locate(); }
-            else if (s >= 6 && s < 12) load_x(s - 6);
-            else if (s >= 13 && s < 17) load_z(s - 13);
+            if (s == kLocSlot) { advance(); locate(); }
+            if (s >= kXSlot && s < kXSlot + 6) load_x(s - kXSlot);
+            if (s >= kZSlot && s < kZSlot + 4) load_z(s - kZSlot);
             acc[b][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vp[(q + b) & 3].x, Zp[q & 1].x, acc[b][0], 0, 0, 0);
             acc[b][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vp[(q + b) & 3].y, Zp[q & 1].y, acc[b][1], 0, 0, 0);
             acc[b][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[(q + b) & 3], Zs[q & 1], acc[b][2], 0, 0, 0);
