@@ -76,6 +76,8 @@ DEBUG_SIGNATURES = {
     "fdn_debug_set_conv1x1_mfma": (c_i, [c_i]),
     "fdn_debug_set_wgrad64_wino_dbg": (c_i, [c_i]),
     "fdn_debug_set_wgrad64_wino_nodep": (c_i, [c_i]),
+    "fdn_debug_set_wgrad64_bf16_dbg": (c_i, [c_i]),
+    "fdn_debug_set_wgrad64_bf16_variant": (c_i, [c_i]),
 }
 
 

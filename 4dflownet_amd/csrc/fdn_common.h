@@ -75,6 +75,34 @@ __device__ __forceinline__ void fdn_lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char*
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
 }
 
+// The same instruction issued OUTSIDE the compiler's bookkeeping (inline asm).  hipcc tracks a builtin LDS-DMA as a pending LDS
+// write and puts s_waitcnt vmcnt(0) in front of the next LDS read it cannot prove disjoint (every ds_read_b64_tr_b16, for one):
+// a ring of tiles requested two iterations ahead then waits for its newest request before the first operand read of every
+// iteration.  With this form the CALLER owns the ordering: s_waitcnt vmcnt(n) by hand (vector-memory loads complete in order)
+// and a barrier before another wave reads the data.  rsrc = fdn_raw_rsrc(...), lds_addr = fdn_lds_addr(pointer), wave-uniform.
+typedef int fdn_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ fdn_i32x4 fdn_raw_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    return (fdn_i32x4){(int)(unsigned)a, (int)(unsigned)((a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+}
+__device__ __forceinline__ unsigned fdn_lds_addr(const void* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+__device__ __forceinline__ void fdn_lds_dma16_untracked(fdn_i32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");      // (m0 is a reserved register: hipcc rewrites it before each of its own uses)
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a fence + s_barrier and hipcc drains EVERY counter in front of
+// it -- s_waitcnt vmcnt(0) included, so global loads a software pipeline issued a few instructions earlier (register prefetches of
+// a later tile, LDS-DMA into an area only the issuing wave reads back) stall all waves of the workgroup for a full memory latency.
+// Here only the LDS queue is drained; vector-memory loads stay in flight (the compiler's own waitcnt bookkeeping for their
+// destination registers is unaffected).  Use it ONLY where nothing another wave reads after the barrier comes from a pending
+// vector-memory operation.
+__device__ __forceinline__ void fdn_barrier_lds() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 void fdn_set_error(const char* fmt, ...);
 
 // hipFuncAttributeMaxDynamicSharedMemorySize, set once per (device, kernel) under a lock: the C-ABI is re-entrant per

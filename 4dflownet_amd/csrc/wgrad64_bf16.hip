@@ -33,7 +33,13 @@ struct Wgrad64BfArgs {
     float* partial;
     int N, D, H, W;
     int ntd, nth, ntw, ntiles, S;
+    int seg_len, nseg;       // LDS-DMA kernel: walk units are (n, th, tw) columns cut into nseg depth segments of seg_len planes
+    unsigned bytes;          // size of x (= of dz) in bytes (the LDS-DMA kernel addresses both through buffer resources: < 4 GB)
+    int dbg;                 // ablation bits (test build): 1 = no staging loads, 2 = no LDS operand reads, 4 = no barrier, 8 = every tile reads the same cache-resident rows
 };
+
+FDN_HOOK_VAR(int, fdn_wgrad64bf_dbg, 0);
+FDN_HOOK_VAR(int, fdn_wgrad64bf_variant, 0);      // test build: 1 = the register-staged kernel (two planes per tile) for every size
 
 namespace {
 constexpr int TD = 2, TH = 8, TW = 8;
@@ -239,8 +245,227 @@ __global__ __launch_bounds__(256, 2) void wgrad64_bf16_kernel(Wgrad64BfArgs p) {
         }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant (round 4): the same contraction, staged by `buffer_load_dwordx4 ... lds` into a ring of THREE one-plane
+// tiles.  The register-staged kernel above holds the next tile in 44 VGPRs, can therefore only look ONE tile ahead, and
+// spends a barrier + 11 ds_write_b128 + a barrier per tile between its MFMA phases: at (4,128^3) a workgroup issued MFMAs
+// for a fifth of its tile period and two workgroups per CU could not cover each other (MFMA busy 0.55).  Here
+//   * tile = 1 x 8 x 8 voxels: 100 x halo rows (+ 4 rows the last w 8-11 read runs over) + 64 dz rows = 21 pieces of 1 KB
+//     (8 rows x 128 B, the lane-linear image of one DMA instruction); three buffers = 63 KB, two workgroups per CU;
+//   * the LDS image is the register kernel's (64-B halves swapped on rows with bit 1 set): lane (row, slot) of a piece
+//     fetches chunk slot ^ (row bit 1) << 2, i.e. the swizzle moves to the source side;
+//   * tile i + 2 is requested at the top of iteration i, right behind the single barrier of the iteration (which also
+//     says that buffer (i + 2) % 3 = (i - 1) % 3 is no longer read), and awaited two iterations later with
+//     s_waitcnt vmcnt(<pieces of tile i + 1>): two tiles of latency cover, no data registers, no ds_write;
+//   * a tile whose halo box lies inside its plane costs no vector ALU work for addresses: per-thread constants + one
+//     scalar offset per operand (as in wgrad64_wino.hip); border tiles clamp (x) / read past the range (dz -> zeros).
+namespace {
+constexpr int DXROWS = XH * XW;                    // 100 halo rows of one plane
+constexpr int DXSLOTS = (DXROWS + 2 + 7) / 8;      // 13 pieces
+constexpr int DZSLOTS = TH * TW / 8;               // 8 pieces
+constexpr int DSLOTS = DXSLOTS + DZSLOTS;          // 21
+constexpr int DBUFB = DSLOTS * 1024;
+constexpr int DNBUF = 3;
+constexpr int DJ = (DSLOTS + 3) / 4;               // pieces per wave: 6 (wave 0) or 5
+constexpr int DLDS_BYTES = DNBUF * DBUFB;
+}  // namespace
+
+__global__ __launch_bounds__(256, 2) void wgrad64_bf16_dma_kernel(Wgrad64BfArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const int li = lane & 31;
+    const int kh = lane >> 5;
+    const int mq = wave & 1, nq = wave >> 1;
+    const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3;
+    const int a = rr % 3;            // kernel-depth tap
+    const int kk = rr / 3;           // walk index inside the XCD, 0 .. S/8 - 1
+    const int split = kk * 8 + xcd;
+    const int spx = p.S >> 3;        // walks per XCD
+    // Walk units: (n, th, tw) columns cut into depth segments, walked along d.  The three depth-tap workgroups of a walk sit on the
+    // same column at the same time: tap a reads x plane d + a - 1, so a plane requested by tap 2 is requested again by tap 1 one
+    // tile later and by tap 0 two tiles later (L2 hits), and all three share the dz tile.  The concurrent walks of an XCD are on
+    // DIFFERENT columns (h / w neighbours), not on one column at plane-stride distances.
+    const int nunits = p.N * p.nth * p.ntw * p.nseg;
+    const int tq = nunits >> 3, trem = nunits & 7;
+    const int u_begin = xcd * tq + (xcd < trem ? xcd : trem), u_end = u_begin + tq + (xcd < trem ? 1 : 0);
+    const int u0 = u_begin + kk;
+    int nt = 0;
+    for (int u = u0; u < u_end; u += spx) { const int sg = u % p.nseg; nt += min(p.seg_len, p.D - sg * p.seg_len); }
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // ---- per-lane addresses of the transposing reads at h-pair 0 (see the register kernel) ----
+    const int g = lane >> 4, pq = lane & 15;
+    const int chan_b = (g & 1) * 32 + (pq & 3) * 8;
+    int xoff[3][3], zoff[2];
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int row = ((g >> 1) + b) * XW + 4 * q + (pq >> 2);
+            xoff[b][q] = row * 128 + (((mq ^ (row >> 1)) & 1) << 6) + chan_b;
+        }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int row = (g >> 1) * TW + 4 * q + (pq >> 2);
+        zoff[q] = DXSLOTS * 1024 + row * 128 + (((nq ^ (row >> 1)) & 1) << 6) + chan_b;
+    }
+
+    // ---- this thread's part of the (up to) DJ pieces of its wave: piece 4 j + wave; x pieces 0..12, dz pieces 13..20.
+    // Straight-line address arithmetic per piece (row / column of the box + tile origin, clamped for x, range-checked for dz:
+    // 6 VALU) instead of an interior fast path: the branches of the fast path cost more scalar instructions than they saved. ----
+    int zh1[DJ], zw1[DJ];        // row / column inside the box, halo shift (-1) included for x
+    unsigned cb[DJ];             // chunk byte offset
+#pragma unroll
+    for (int j = 0; j < DJ; ++j) {
+        const int slot = 4 * j + wave;
+        const int prow = (lane >> 3) + 8 * (slot < DXSLOTS ? slot : slot - DXSLOTS);     // row of the LDS image (of its operand)
+        const int c = (lane & 7) ^ (((prow >> 1) & 1) << 2);                           // chunk that lives at this position
+        int zh, zw;
+        if (slot < DXSLOTS) { const int r = prow < DXROWS ? prow : DXROWS - 1; zh = r / XW; zw = r - zh * XW - 1; zh -= 1; }
+        else { zh = prow / TW; zw = prow - zh * TW; }
+        zh1[j] = zh; zw1[j] = zw;
+        cb[j] = (unsigned)(c * 16);
+    }
+    const fdn_i32x4 xrs = fdn_raw_rsrc(p.x, p.bytes), zrs = fdn_raw_rsrc(p.dz, p.bytes);
+    const unsigned lds0 = fdn_lds_addr(smem);
+
+    // ---- cursor: unit u = ((n * nth + th) * ntw + tw) * nseg + seg, plane td inside the segment; units advance by spx, decoded
+    // incrementally (scalar work only) ----
+    const int per_h = p.ntw * p.nseg, per_n = p.nth * per_h;
+    int tn, th, tw, sg, td, dend, sn, sh, sw, ss;
+    {
+        int b = u0;
+        tn = b / per_n; b -= tn * per_n;
+        th = b / per_h; b -= th * per_h;
+        tw = b / p.nseg; sg = b - tw * p.nseg;
+        b = spx;
+        sn = b / per_n; b -= sn * per_n;
+        sh = b / per_h; b -= sh * per_h;
+        sw = b / p.nseg; ss = b - sw * p.nseg;
+        td = sg * p.seg_len; dend = min(td + p.seg_len, p.D);
+    }
+    // requests the cursor tile into buffer `buf` and moves the cursor on
+    auto request = [&](int buf) {
+        if (FDN_DBG_BITS(p) & 1) return;
+        const bool fixed = (FDN_DBG_BITS(p) & 8) != 0;          // ablation: every request reads the same (cache-resident) tile
+        const int p0h = (fixed ? 1 : th) * TH, p0w = (fixed ? 1 + (split & 7) : tw) * TW;
+        const int tdd = fixed ? 1 : td, tnn = fixed ? 0 : tn;
+        const int qd = min(max(tdd + a - 1, 0), p.D - 1);
+        const unsigned xplane = (unsigned)((tnn * p.D + qd) * p.H * p.W) * 128u;
+        const unsigned zplane = (unsigned)((tnn * p.D + tdd) * p.H * p.W) * 128u;
+        const unsigned dst = lds0 + (unsigned)(buf * DBUFB);
+#pragma unroll
+        for (int j = 0; j < DJ; ++j) {
+            // piece 4 j + wave: x for j < 3, x (wave 0) / dz for j = 3, dz for j = 4, dz (wave 0) / none for j = 5
+            const bool isx = 4 * j + 3 < DXSLOTS || (4 * j < DXSLOTS && 4 * j + wave_s < DXSLOTS);
+            const bool isz = !isx && (4 * j + 3 < DSLOTS || (4 * j < DSLOTS && 4 * j + wave_s < DSLOTS));
+            const int qh = p0h + zh1[j], qw = p0w + zw1[j];
+            if (isx) {
+                const int ch = min(max(qh, 0), p.H - 1), cw = min(max(qw, 0), p.W - 1);
+                fdn_lds_dma16_untracked(xrs, dst + (unsigned)((4 * j + wave_s) * 1024), (unsigned)((ch * p.W + cw) * 128) + cb[j], xplane);
+            } else if (isz) {
+                const unsigned vo = qh < p.H && qw < p.W ? (unsigned)((qh * p.W + qw) * 128) + cb[j] : 0xffffffffu;   // past the range: zeros
+                fdn_lds_dma16_untracked(zrs, dst + (unsigned)((4 * j + wave_s) * 1024), vo, zplane);
+            }
+        }
+        if (++td == dend) {          // next unit
+            sg += ss; if (sg >= p.nseg) { sg -= p.nseg; ++tw; }
+            tw += sw; if (tw >= p.ntw) { tw -= p.ntw; ++th; }
+            th += sh; if (th >= p.nth) { th -= p.nth; ++tn; }
+            tn += sn;
+            td = sg * p.seg_len; dend = min(td + p.seg_len, p.D);
+        }
+    };
+
+    if (nt > 0) request(0);
+    if (nt > 1) request(1);
+    int buf = 0;
+#pragma unroll 1
+    for (int i = 0; i < nt; ++i) {
+        // tile i has landed (this wave's pieces; the barrier collects the other waves'), tile i + 1 may still be on its way
+        if (i + 1 < nt) {
+            if (wave_s == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (!(FDN_DBG_BITS(p) & 4)) fdn_barrier_lds();
+        const int b2 = buf == 0 ? 2 : buf - 1;          // (i + 2) % 3: the buffer tile i - 1 was read from
+        if (i + 2 < nt) request(b2);
+        const char* xs = smem + buf * DBUFB;
+
+        // ---- 4 k-steps of 16 voxels (h-pairs), each 3 groups (b) of 3 MFMAs; halo-row ring as in the register kernel ----
+        u32x2 gq[2][3], zq[2][2];
+        auto reuse = [](int q) { return q % 3 == 0 && q != 0; };            // b == 0 and not the first h-pair
+        auto slot = [&](int q) { int s_ = 0; for (int k = 1; k <= q; ++k) if (!reuse(k)) s_ ^= 1; return s_; };
+        auto issue = [&](int q, u32x2 (&gg)[3], u32x2 (&z)[2]) {            // q = hp * 3 + b
+            if (FDN_DBG_BITS(p) & 2) return;
+            const int hp = q / 3, b = q % 3;
+            const int dX = hp * 2 * XW * 128;
+            if (!reuse(q)) {
+                gg[0] = tr_read(xs + xoff[b][0] + dX); gg[1] = tr_read(xs + xoff[b][1] + dX); gg[2] = tr_read(xs + xoff[b][2] + dX);
+            }
+            if (b == 0) {
+                const int dZ = hp * 2 * TW * 128;
+                z[0] = tr_read(xs + zoff[0] + dZ); z[1] = tr_read(xs + zoff[1] + dZ);
+            }
+        };
+        if (FDN_DBG_BITS(p) & 2) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                for (int v = 0; v < 3; ++v) gq[u][v] = (u32x2){0x3f803f80u, 0x3f803f80u};
+                zq[u][0] = zq[u][1] = (u32x2){0x3f803f80u, 0x3f803f80u};
+            }
+        }
+        issue(0, gq[0], zq[0]);
+        bf16x8 bv;
+#pragma unroll
+        for (int q = 0; q < (TH / 2) * 3; ++q) {
+            const int b = q % 3;
+            if (q + 1 < (TH / 2) * 3) issue(q + 1, gq[slot(q + 1)], zq[((q + 1) / 3) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const u32x2 g0 = gq[slot(q)][0], g1 = gq[slot(q)][1], g2 = gq[slot(q)][2];
+            if (b == 0) {
+                const u32x2 z0 = zq[(q / 3) & 1][0], z1 = zq[(q / 3) & 1][1];
+                bv = __builtin_bit_cast(bf16x8, (u32x4){z0.x, z0.y, z1.x, z1.y});
+            }
+            const bf16x8 a0 = __builtin_bit_cast(bf16x8, (u32x4){g0.x, g0.y, g1.x, g1.y});
+            const bf16x8 a1 = __builtin_bit_cast(
+                bf16x8, (u32x4){__builtin_amdgcn_alignbit(g0.y, g0.x, 16), __builtin_amdgcn_alignbit(g1.x, g0.y, 16),
+                                __builtin_amdgcn_alignbit(g1.y, g1.x, 16), __builtin_amdgcn_alignbit(g2.x, g1.y, 16)});
+            const bf16x8 a2 = __builtin_bit_cast(bf16x8, (u32x4){g0.y, g1.x, g1.y, g2.x});
+            acc[b * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bv, acc[b * 3 + 0], 0, 0, 0);
+            acc[b * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bv, acc[b * 3 + 1], 0, 0, 0);
+            acc[b * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bv, acc[b * 3 + 2], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+
+    // ---- write this workgroup's partial dW for taps (a, b, c) ----
+    float* out = p.partial + ((size_t)split * 27 + a * 9) * 4096;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = mq * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            out[(size_t)t * 4096 + ci * 64 + nq * 32 + li] = acc[t][r];
+        }
+}
+
 namespace {
 int wgrad64bf_splits(int N, int D, int H, int W) {
+    // (counted in two-plane tiles for both kernels: the one-plane kernel then has >= 4 tiles per walk)
     const long long ntiles = (long long)N * ((D + TD - 1) / TD) * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
     long long S = 168;                 // 3*168 = 504 workgroups ~ 2 per CU; a multiple of 8 (one walk set per XCD)
     while (S > 8 && ntiles / 2 < S) S -= 8;
@@ -257,16 +482,42 @@ int fdn_wgrad64_bf16_launch(const uint16_t* x, const uint16_t* dz, float* dw, vo
     Wgrad64BfArgs a;
     a.x = x; a.dz = dz; a.partial = (float*)ws;
     a.N = N; a.D = D; a.H = H; a.W = W;
-    a.ntd = (D + TD - 1) / TD; a.nth = (H + TH - 1) / TH; a.ntw = (W + TW - 1) / TW;
-    a.ntiles = N * a.ntd * a.nth * a.ntw;
     a.S = wgrad64bf_splits(N, D, H, W);
+    a.dbg = fdn_wgrad64bf_dbg;
     if (ws_bytes < (size_t)a.S * 27 * 4096 * sizeof(float)) {
         fdn_set_error("wgrad64_bf16: workspace too small");
         return FDN_ERR_WORKSPACE;
     }
-    hipLaunchKernelGGL(wgrad64_bf16_kernel, dim3(3 * a.S), dim3(256), LDS_BYTES, s, a);
-    FDN_CHECK_LAUNCH("wgrad64_bf16_kernel");
+    a.nth = (H + TH - 1) / TH; a.ntw = (W + TW - 1) / TW;
+    // the LDS-DMA kernel addresses x / dz through 32-bit buffer offsets; tensors of 4 GB and more keep the register-staged kernel
+    const long long bytes = (long long)N * D * H * W * 128;
+    if (bytes < (1ll << 32) - 4096 && !fdn_wgrad64bf_variant) {
+        a.bytes = (unsigned)bytes;
+        a.ntd = D;
+        a.ntiles = N * a.ntd * a.nth * a.ntw;
+        // depth segments: long enough for the plane reuse between the taps (<= 32 planes), short enough that every walk of
+        // every XCD gets >= ~4 units
+        int want = (int)((long long)a.ntiles / ((long long)a.S * 4));
+        want = want < 1 ? 1 : (want > 32 ? 32 : want);
+        a.nseg = (D + want - 1) / want;
+        a.seg_len = (D + a.nseg - 1) / a.nseg;
+        a.nseg = (D + a.seg_len - 1) / a.seg_len;
+        if (int rc = fdn_func_max_lds((const void*)wgrad64_bf16_dma_kernel, DLDS_BYTES, "wgrad64_bf16")) return rc;
+        hipLaunchKernelGGL(wgrad64_bf16_dma_kernel, dim3(3 * a.S), dim3(256), DLDS_BYTES, s, a);
+        FDN_CHECK_LAUNCH("wgrad64_bf16_dma_kernel");
+    } else {
+        a.bytes = 0;
+        a.ntd = (D + TD - 1) / TD;
+        a.ntiles = N * a.ntd * a.nth * a.ntw;
+        hipLaunchKernelGGL(wgrad64_bf16_kernel, dim3(3 * a.S), dim3(256), LDS_BYTES, s, a);
+        FDN_CHECK_LAUNCH("wgrad64_bf16_kernel");
+    }
     hipLaunchKernelGGL(wgrad64_reduce_kernel, dim3(27 * 1024 / 64), dim3(256), 0, s, (const float*)ws, dw, a.S);
     FDN_CHECK_LAUNCH("wgrad64_reduce_kernel");
     return FDN_OK;
 }
+
+#ifdef FDN_TEST_HOOKS
+extern "C" int fdn_debug_set_wgrad64_bf16_dbg(int bits) { fdn_wgrad64bf_dbg = bits; return FDN_OK; }
+extern "C" int fdn_debug_set_wgrad64_bf16_variant(int v) { fdn_wgrad64bf_variant = v; return FDN_OK; }
+#endif

@@ -45,7 +45,7 @@ struct WgWinoArgs {
     int DT;                      // depth units of the tile walk: D planes, or D / 2 plane pairs (DEP)
     int nth, ntw, ntiles, S;
     unsigned bytes;              // size of x (= of dz) in bytes; < 4 GB (checked by the launcher)
-    int dbg;                     // ablation bits (test build): 1 = no raw loads, 2 = no transform / LDS writes, 4 = no LDS operand reads, 8 = no XCD placement, 16 = depth-fastest tile order
+    int dbg;                     // ablation bits (test build): 1 = no raw loads, 2 = no transform / LDS writes, 4 = no LDS operand reads, 8 = no XCD placement, 16 = depth-fastest tile order, 32 = no tile walk (every iteration on the first tiles)
 };
 
 FDN_HOOK_VAR(int, fdn_wgrad64_wino_dbg, 0);
@@ -87,8 +87,12 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
     const int c16 = tid & 15;        // 16-B chunk (4 channels) of a 256-B row
     const int ig = (tid >> 4) & 1;   // group of this thread's transform item
     const int il = (tid >> 5) & 7;   // line of the item: waves 0-3: x halo lines 0..7; waves 4-6: dz lines 0..5
-    const bool xitem = tid < 256;    // wave-uniform
-    const bool zitem = tid >= 256 && il < WTH;
+    // transform items are whole waves (x: waves 0-3, lines 0..7; dz: waves 4-6, lines 0..5; wave 7 has none): the flags are
+    // formed from the scalar wave id so that the item code sits behind scalar branches, not exec masks
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const bool xitem = wave_s < 4;
+    const bool zitem = wave_s >= 4 && wave_s < 7;
+    static_assert(WTH == 6 && WTG == 2, "item-to-wave map above");
 
     f32x16 acc[3][3];
 #pragma unroll
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
             if (s == 2) combine_z();
             if (s < 2) write_v(s, nxt);
             else if (s < 4) write_z(s - 2, nxt);
-            if (s == kLocSlot) { advance(); locate(); }
+            if (s == kLocSlot && !(FDN_DBG_BITS(p) & 32)) { advance(); locate(); }
             if (s >= kXSlot && s < kXSlot + 6) load_x(s - kXSlot);
             if (s >= kZSlot && s < kZSlot + 4) load_z(s - kZSlot);
             acc[b][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vp[(q + b) & 3].x, Zp[q & 1].x, acc[b][0], 0, 0, 0);
