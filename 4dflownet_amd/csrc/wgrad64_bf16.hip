@@ -269,6 +269,7 @@ constexpr int DBUFB = DSLOTS * 1024;
 constexpr int DNBUF = 3;
 constexpr int DJ = (DSLOTS + 3) / 4;               // pieces per wave: 6 (wave 0) or 5
 constexpr int DLDS_BYTES = DNBUF * DBUFB;
+static_assert(DSLOTS == 21 && DJ == 6, "the s_waitcnt vmcnt(n) of the tile loop counts 6 pieces on wave 0 and 5 on waves 1-3");
 }  // namespace
 
 __global__ __launch_bounds__(256, 2) void wgrad64_bf16_dma_kernel(Wgrad64BfArgs p) {

@@ -114,15 +114,25 @@ def test_conv64_dgrad_fused_bf16(bops, fdn, shape, mt):
                 lib.fdn_debug_set_conv64_bf16_mode2(1)
 
 
-@pytest.mark.parametrize("shape", [(2, 8, 8, 8), (1, 5, 7, 9), (1, 10, 12, 16), (3, 4, 4, 2), (2, 16, 16, 16), (1, 1, 1, 1)])
-def test_conv64_wgrad_bf16(bops, shape):
-    """fp32 result from bf16 operands: products exact, accumulation fp32 -> fp32-level agreement with the oracle."""
+@pytest.mark.parametrize("variant", [0, 1])      # 0 = planner (the LDS-DMA kernel below 4 GB), 1 = the register-staged kernel (the >= 4 GB fallback)
+@pytest.mark.parametrize("shape", [(2, 8, 8, 8), (1, 5, 7, 9), (1, 10, 12, 16), (3, 4, 4, 2), (2, 16, 16, 16), (1, 1, 1, 1),
+                                   (1, 3, 20, 11), (1, 17, 9, 12), (2, 33, 8, 24)])
+def test_conv64_wgrad_bf16(bops, fdn, shape, variant):
+    """fp32 result from bf16 operands: products exact, accumulation fp32 -> fp32-level agreement with the oracle.
+    (2, 33, 8, 24): depth segments of unequal length in the LDS-DMA kernel's unit walk."""
     rng = np.random.default_rng(13)
     N, D, H, W = shape
     x = rb(rng.normal(size=(N, D, H, W, 64)))
     dz = rb(rng.normal(size=(N, D, H, W, 64)))
     ref = O.conv3d_wgrad(x, dz, 3)
-    dw, db = bops.conv3d_wgrad(devb(x), devb(dz), 3, 64, 64, want_bias=True)
+    with variant_lib(fdn, variant) as lib:
+        if lib is not None:
+            lib.fdn_debug_set_wgrad64_bf16_variant(1)
+        try:
+            dw, db = bops.conv3d_wgrad(devb(x), devb(dz), 3, 64, 64, want_bias=True)
+        finally:
+            if lib is not None:
+                lib.fdn_debug_set_wgrad64_bf16_variant(0)
     close_f32(dw, ref, name="wgrad64 bf16")
     close_f32(db, O.bias_grad(dz), name="bias grad 64 bf16")
 
