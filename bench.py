@@ -401,7 +401,7 @@ def secondary_runs(trainer, parallel, device, P, R, B, LB, HB, sustained_steps=3
                             "train_step_tflops": steps * B4 / dt * 3.0 * f4 / 1e12,
                             "roofline": roofline_obj(timer, "conv", True, "conv64_bf16_kernel (3x3x3 64->64 fwd + dgrad launches)",
                                                      CFG4_TRAFFIC),
-                            "roofline_wgrad": roofline_obj(timer, "wgrad", True, "wgrad64_bf16_kernel (3x3x3 64->64 weight gradient)",
+                            "roofline_wgrad": roofline_obj(timer, "wgrad", True, "wgrad64_bf16_dma_kernel (3x3x3 64->64 weight gradient)",
                                                            CFG4_TRAFFIC)}
         del tc, batch
     except Exception as e:
@@ -671,7 +671,7 @@ def main():
                                  % (("conv64_bf16_kernel", "", "") if bf16 else
                                     ("conv64_wino2d_kernel", " inner-box", "; 2-D Winograd F(2,3) along H x F(4,3) along W")), tr),
         "roofline_wgrad": roofline_obj(timer, "wgrad", bf16, "%s (3x3x3 64->64 weight gradient + partial reduction%s)"
-                                       % (("wgrad64_bf16_kernel", "") if bf16 else ("wgrad64_wino_kernel", "; Winograd F(3,2) along D x F(3,4) along W")), tr),
+                                       % (("wgrad64_bf16_dma_kernel", "") if bf16 else ("wgrad64_wino_kernel", "; Winograd F(3,2) along D x F(3,4) along W")), tr),
         "roofline_dgrad_shell": None if bf16 else roofline_obj(timer, "shell", False, "conv64_wino_kernel (shell faces of the fused dgrad: "
                                                                "d / h faces F(4,3) along W, w faces one Winograd coordinate)", tr),
         "train_step_tflops": args.steps * B * world / dt * 3.0 * fwd_flop / 1e12,

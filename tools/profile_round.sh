@@ -19,6 +19,7 @@ cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_kernel_
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pf -- $B --steps 2 --warmup 1 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pw -- $B --steps 2 --warmup 1 > /dev/null 2>&1
 python $R/tools/pmc_traffic.py /tmp/pf /tmp/pw $OUT/${TAG}_pmc_traffic.json > $OUT/${TAG}_pmc_traffic.txt
+cp $OUT/${TAG}_pmc_traffic.json $R/profiles/${TAG}_pmc_traffic.json    # (box-local copy) the bench lines below quote THIS run's counters
 rm -rf /tmp/pf /tmp/pw /tmp/kt
 : > $OUT/${TAG}_pmc_sq.txt
 i=0
@@ -38,6 +39,7 @@ if [ "$2" != "nocfg4" ]; then
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pf4 -- $B4 --steps 1 --warmup 1 > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pw4 -- $B4 --steps 1 --warmup 1 > /dev/null 2>&1
   python $R/tools/pmc_traffic.py /tmp/pf4 /tmp/pw4 $OUT/${TAG}_cfg4_pmc_traffic.json > $OUT/${TAG}_cfg4_pmc_traffic.txt
+  cp $OUT/${TAG}_cfg4_pmc_traffic.json $R/profiles/${TAG}_cfg4_pmc_traffic.json
   rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d /tmp/pq4 -- $B4 --steps 1 --warmup 1 > /dev/null 2>&1
   echo "# cfg4: GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES" > $OUT/${TAG}_cfg4_pmc_sq.txt
   python $R/tools/pmc_dump.py /tmp/pq4 | grep -i "bf16\|head_" >> $OUT/${TAG}_cfg4_pmc_sq.txt
