@@ -439,6 +439,29 @@ def secondary_runs(trainer, parallel, device, P, R, B, LB, HB, sustained_steps=3
     return sec
 
 
+def guarded(fn, line, rank, seconds):
+    """Runs fn() under a watchdog.  If it has not returned after `seconds`, rank 0 prints the headline `line` with the failure
+    recorded in `secondary` and every rank leaves the process (os._exit: a rank stuck inside a collective cannot unwind)."""
+    import threading
+    done = threading.Event()
+
+    def fire():
+        if done.is_set():
+            return
+        if rank == 0 and line is not None:
+            line["secondary"] = {"error": "the N > 1 secondary legs did not finish within %.0f s; headline unaffected (measured before)" % seconds}
+            print(json.dumps(line), flush=True)
+        os._exit(0)
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    try:
+        return fn()
+    finally:
+        done.set()
+        t.cancel()
+
+
 def secondary_runs_dp(trainer, parallel, device, P, R, B, LB, HB, rank, world):
     """N > 1: the two secondary legs that have a data-parallel form, run by ALL ranks (collectives inside), barrier + synchronize on
     both sides, max over ranks -- same timing rule as the headline.
@@ -627,62 +650,61 @@ def main():
     waits = [e0.elapsed_time(e1) for e0, e1 in tc.allreduce_wait_events]
     mine[rank] = float(np.mean(waits)) if waits else 0.0
     per_rank_wait = parallel.allreduce_sum_host(mine)
+    # rank 0 assembles the headline object BEFORE the N > 1 secondary legs run: those legs use point-to-point RCCL traffic that no
+    # multi-GPU box has exercised yet, and a watchdog prints the headline (with the failure noted) rather than lose it to a hang
+    line = None
+    if rank == 0:
+        fwd_flop = fwd_flop_per_patch(tc.model.specs, P, R, LB)
+        tr = CFG4_TRAFFIC if args.config == "cfg4" else ([] if bf16 else CFG2_TRAFFIC)
+        line = {
+            "metric": "3D patches/sec (train step, patch=%d, res×%d)" % (P, R),
+            "value": args.steps * B * world / dt,
+            "unit": "patches/s",
+            "n_gpus": rccl_ranks,
+            "rccl_ranks": rccl_ranks,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16" if bf16 else "f32",
+            "data": "synthetic (SURVEY 8d: default_rng(1234+rank) inputs, Glorot-uniform default_rng(0) weights)",
+            "config": {"workload": "%s train_step: patch_size=%d res_increase=%d batch=%d/GPU low_resblock=%d hi_resblock=%d %s"
+                                   % (args.config, P, R, B, LB, HB, "bf16 activations, fp32 accumulation/parameters" if bf16 else "fp32"),
+                       "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "collective": ("none" if world == 1 else
+                                      "gloo, host-staged (OVERSUBSCRIBED launcher self-test: %d ranks on %d GPU -- not a scaling number)" % (world, ngpu)
+                                      if oversub else "RCCL sum all-reduce of the flat fp32 gradient (%d B) per step, %s"
+                                      % (4 * (tc.model.n_params + 1), "3 buckets started inside backward" if tc.bucketed_allreduce
+                                         else "one call after backward"))},
+            "roofline": roofline_obj(timer, "conv", bf16, "%s (3x3x3 64->64 forward + fused-dgrad%s launches%s)"
+                                     % (("conv64_bf16_kernel", "", "") if bf16 else
+                                        ("conv64_wino2d_kernel", " inner-box", "; 2-D Winograd F(2,3) along H x F(4,3) along W")), tr),
+            "roofline_wgrad": roofline_obj(timer, "wgrad", bf16, "%s (3x3x3 64->64 weight gradient + partial reduction%s)"
+                                           % (("wgrad64_bf16_dma_kernel", "") if bf16 else ("wgrad64_wino_kernel", "; Winograd F(3,2) along D x F(3,4) along W")), tr),
+            "roofline_dgrad_shell": None if bf16 else roofline_obj(timer, "shell", False, "conv64_wino_kernel (shell faces of the fused dgrad: "
+                                                                   "d / h faces F(4,3) along W, w faces one Winograd coordinate)", tr),
+            "train_step_tflops": args.steps * B * world / dt * 3.0 * fwd_flop / 1e12,
+            "lib_source_stamp": build.source_stamp()[:16],          # sha256 prefix of csrc/ + include/fdn.h + flags the binary was built from
+        }
+        if world > 1:
+            line["per_rank_ms_per_step"] = per_rank_ms
+            line["allreduce_exposed_ms"] = {"per_rank_mean": per_rank_wait, "max": max(per_rank_wait),
+                                            "how": "HIP events on the compute stream around allreduce_wait (trainer.train_step), mean over the timed steps"}
+        if oversub:
+            line["oversubscribed"] = True
     sec_dp = None
     if world > 1 and not bf16 and args.config == "cfg2" and not args.no_secondary:
-        specs_keep = tc.model.specs
-        n_params_keep, bucketed_keep = tc.model.n_params, tc.bucketed_allreduce
         del tc, batch
         torch.cuda.empty_cache()
-        sec_dp = secondary_runs_dp(trainer, parallel, device, P, R, B, LB, HB, rank, world)
+        sec_dp = guarded(lambda: secondary_runs_dp(trainer, parallel, device, P, R, B, LB, HB, rank, world), line, rank,
+                         float(os.environ.get("FDN_BENCH_SECONDARY_TIMEOUT", "300")))
+        tc = batch = None
     if rank != 0:
         if parallel.is_dist():
             parallel.barrier()
         return
-    if sec_dp is not None:
-        class _Keep:                                          # the headline controller was released before the secondary legs
-            pass
-        tc = _Keep(); tc.model = _Keep(); tc.model.specs = specs_keep; tc.model.n_params = n_params_keep; tc.bucketed_allreduce = bucketed_keep
-        batch = None
-    fwd_flop = fwd_flop_per_patch(tc.model.specs, P, R, LB)
-    tr = CFG4_TRAFFIC if args.config == "cfg4" else ([] if bf16 else CFG2_TRAFFIC)
-    line = {
-        "metric": "3D patches/sec (train step, patch=%d, res×%d)" % (P, R),
-        "value": args.steps * B * world / dt,
-        "unit": "patches/s",
-        "n_gpus": rccl_ranks,
-        "rccl_ranks": rccl_ranks,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "bf16" if bf16 else "f32",
-        "data": "synthetic (SURVEY 8d: default_rng(1234+rank) inputs, Glorot-uniform default_rng(0) weights)",
-        "config": {"workload": "%s train_step: patch_size=%d res_increase=%d batch=%d/GPU low_resblock=%d hi_resblock=%d %s"
-                               % (args.config, P, R, B, LB, HB, "bf16 activations, fp32 accumulation/parameters" if bf16 else "fp32"),
-                   "global_batch": B * world, "parallelism": "dp%d" % world,
-                   "collective": ("none" if world == 1 else
-                                  "gloo, host-staged (OVERSUBSCRIBED launcher self-test: %d ranks on %d GPU -- not a scaling number)" % (world, ngpu)
-                                  if oversub else "RCCL sum all-reduce of the flat fp32 gradient (%d B) per step, %s"
-                                  % (4 * (tc.model.n_params + 1), "3 buckets started inside backward" if tc.bucketed_allreduce
-                                     else "one call after backward"))},
-        "roofline": roofline_obj(timer, "conv", bf16, "%s (3x3x3 64->64 forward + fused-dgrad%s launches%s)"
-                                 % (("conv64_bf16_kernel", "", "") if bf16 else
-                                    ("conv64_wino2d_kernel", " inner-box", "; 2-D Winograd F(2,3) along H x F(4,3) along W")), tr),
-        "roofline_wgrad": roofline_obj(timer, "wgrad", bf16, "%s (3x3x3 64->64 weight gradient + partial reduction%s)"
-                                       % (("wgrad64_bf16_dma_kernel", "") if bf16 else ("wgrad64_wino_kernel", "; Winograd F(3,2) along D x F(3,4) along W")), tr),
-        "roofline_dgrad_shell": None if bf16 else roofline_obj(timer, "shell", False, "conv64_wino_kernel (shell faces of the fused dgrad: "
-                                                               "d / h faces F(4,3) along W, w faces one Winograd coordinate)", tr),
-        "train_step_tflops": args.steps * B * world / dt * 3.0 * fwd_flop / 1e12,
-        "lib_source_stamp": build.source_stamp()[:16],          # sha256 prefix of csrc/ + include/fdn.h + flags the binary was built from
-    }
-    if world > 1:
-        line["per_rank_ms_per_step"] = per_rank_ms
-        line["allreduce_exposed_ms"] = {"per_rank_mean": per_rank_wait, "max": max(per_rank_wait),
-                                        "how": "HIP events on the compute stream around allreduce_wait (trainer.train_step), mean over the timed steps"}
-    if oversub:
-        line["oversubscribed"] = True
     if sec_dp is not None:
         line["secondary"] = sec_dp
     del tc, batch

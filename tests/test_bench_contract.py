@@ -107,3 +107,19 @@ def test_executed_flop_pricing_follows_the_kernel_the_planner_picks():
     # the shell against the inner box's executed work: 18 % at 24^3, 9 % at 48^3
     assert 0.17 < shell / b.executed_conv64_flop(8, D, H, W) < 0.20
     assert 0.08 < b.executed_shell_flop(8, 48, 48, 48) / b.executed_conv64_flop(8, 48, 48, 48) < 0.10
+
+
+def test_secondary_watchdog_prints_the_headline_and_leaves():
+    """bench.guarded(): the N > 1 secondary legs run after the headline has been measured; if they hang (point-to-point RCCL traffic
+    no multi-GPU box has exercised), rank 0 still prints the ONE JSON line -- with the failure recorded -- and exits 0."""
+    import subprocess
+    code = ("import sys, time; sys.path.insert(0, %r); import bench; "
+            "bench.guarded(lambda: time.sleep(30), {'metric': 'm', 'value': 1.0}, 0, 0.5)" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-500:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["value"] == 1.0 and "did not finish" in line["secondary"]["error"]
+    # and a leg that returns in time is passed through untouched
+    code = ("import sys; sys.path.insert(0, %r); import bench; print(bench.guarded(lambda: {'ok': 1}, {}, 0, 30))" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("{'ok': 1}")
