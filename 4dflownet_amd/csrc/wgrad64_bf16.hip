@@ -249,8 +249,7 @@ __global__ __launch_bounds__(256, 2) void wgrad64_bf16_kernel(Wgrad64BfArgs p) {
 // ---------------------------------------------------------------------------------------------------------------------
 // LDS-DMA variant (round 4): the same contraction, staged by `buffer_load_dwordx4 ... lds` into a ring of THREE one-plane
 // tiles.  The register-staged kernel above holds the next tile in 44 VGPRs, can therefore only look ONE tile ahead, and
-// spends a barrier + 11 ds_write_b128 + a barrier per tile between its MFMA phases: at (4,128^3) a workgroup issued MFMAs
-// for a fifth of its tile period and two workgroups per CU could not cover each other (MFMA busy 0.55).  Here
+// spends a barrier + 11 ds_write_b128 + a barrier per tile between its MFMA phases (MFMA busy 0.55 at (4,128^3)).  Here
 //   * tile = 1 x 8 x 8 voxels: 100 x halo rows (+ 4 rows the last w 8-11 read runs over) + 64 dz rows = 21 pieces of 1 KB
 //     (8 rows x 128 B, the lane-linear image of one DMA instruction); three buffers = 63 KB, two workgroups per CU;
 //   * the LDS image is the register kernel's (64-B halves swapped on rows with bit 1 set): lane (row, slot) of a piece
@@ -258,8 +257,13 @@ __global__ __launch_bounds__(256, 2) void wgrad64_bf16_kernel(Wgrad64BfArgs p) {
 //   * tile i + 2 is requested at the top of iteration i, right behind the single barrier of the iteration (which also
 //     says that buffer (i + 2) % 3 = (i - 1) % 3 is no longer read), and awaited two iterations later with
 //     s_waitcnt vmcnt(<pieces of tile i + 1>): two tiles of latency cover, no data registers, no ds_write;
-//   * a tile whose halo box lies inside its plane costs no vector ALU work for addresses: per-thread constants + one
-//     scalar offset per operand (as in wgrad64_wino.hip); border tiles clamp (x) / read past the range (dz -> zeros).
+//   * the DMA is issued from inline asm (fdn_lds_dma16_untracked): hipcc puts s_waitcnt vmcnt(0) between a BUILTIN LDS-DMA
+//     and the next ds_read_b64_tr_b16, which would wait for the newest request at the top of every K loop;
+//   * addresses are straight-line per piece (box row / column + tile origin, clamped for x, past the range for dz -> the
+//     DMA stores zeros): an interior fast path cost more scalar branches than it saved;
+//   * walk units are (n, th, tw) columns cut into depth segments and walked along d (see the kernel): the three depth-tap
+//     workgroups of a walk share x planes and dz tiles in their XCD's L2.
+// Measured at (4,128^3), same box: 1.56 ms vs 1.63 ms (tools/abl_wgrad_bf16.py); cfg4 step 63.9 -> 61.3 ms.
 namespace {
 constexpr int DXROWS = XH * XW;                    // 100 halo rows of one plane
 constexpr int DXSLOTS = (DXROWS + 2 + 7) / 8;      // 13 pieces
