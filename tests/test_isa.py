@@ -1,0 +1,98 @@
+"""Properties of the gfx950 code the product library ships, read from its code objects (no GPU needed): every kernel is free of
+register spills and scratch, the hot kernels use the instructions DESIGN.md says they do, and the LDS-DMA weight-gradient kernel's
+tile loop is not re-serialised by a compiler-inserted s_waitcnt vmcnt(0) (hipcc puts one between a builtin LDS-DMA and
+the next transposing LDS read; the kernel issues its DMA from inline asm to keep two tiles in flight)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+LIB = os.path.join(ROOT, "4dflownet_amd", "lib4dflow_hip.so")
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+@pytest.fixture(scope="module")
+def code_objects(tmp_path_factory):
+    tools = [os.path.join(LLVM, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf", "llvm-objdump")]
+    if not (os.path.exists(LIB) and all(os.path.exists(t) for t in tools)):
+        pytest.skip("library or LLVM binutils not present")
+    d = tmp_path_factory.mktemp("isa")
+    fat = str(d / "fat.bin")
+    subprocess.run([tools[0], "--dump-section", ".hip_fatbin=" + fat, LIB, str(d / "copy.so")], check=True, capture_output=True)
+    blob = open(fat, "rb").read()
+    starts = [m.start() for m in re.finditer(re.escape(MAGIC), blob)]
+    assert starts, "no offload bundles in .hip_fatbin"
+    out = []
+    for i, s in enumerate(starts):                          # one bundle per translation unit
+        part = str(d / ("bundle%d.bin" % i))
+        open(part, "wb").write(blob[s:starts[i + 1] if i + 1 < len(starts) else len(blob)])
+        co = str(d / ("co%d.o" % i))
+        subprocess.run([tools[1], "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + part,
+                        "--output=" + co], check=True, capture_output=True)
+        notes = subprocess.run([tools[2], "--notes", co], check=True, capture_output=True, text=True).stdout
+        asm = subprocess.run([tools[3], "-d", co], check=True, capture_output=True, text=True).stdout
+        out.append((notes, asm))
+    return out
+
+
+def _kernels(notes):
+    """{kernel name: {metadata key: int}} from the AMDGPU metadata note."""
+    res, cur = {}, None
+    block = {}
+    for line in notes.splitlines():
+        m = re.match(r"\s*-?\s*\.(\w+):\s+(.*)$", line)
+        if not m:
+            continue
+        k, v = m.group(1), m.group(2).strip()
+        if k == "agpr_count" and line.lstrip().startswith("-"):       # first key of a kernel entry
+            block = {}
+        if k == "name" and "kernel" in v:
+            cur = v
+            res[cur] = block
+        if v.isdigit():
+            block[k] = int(v)
+    return res
+
+
+def _function(asm, name_part):
+    m = re.search(r"^[0-9a-f]+ <([^>]*%s[^>]*)>:\n(.*?)(?=^\S|\Z)" % re.escape(name_part), asm, re.S | re.M)
+    return m.group(2) if m else None
+
+
+def test_no_kernel_spills_or_uses_scratch(code_objects):
+    seen = 0
+    for notes, _ in code_objects:
+        for name, md in _kernels(notes).items():
+            seen += 1
+            assert md.get("vgpr_spill_count", 0) == 0, (name, md)       # (SGPR spills go to VGPR lanes: no memory traffic)
+            assert md.get("private_segment_fixed_size", 0) == 0, (name, md)
+    assert seen >= 60, "expected the whole kernel set, saw %d" % seen
+
+
+def test_hot_kernels_use_the_instructions_the_design_names(code_objects):
+    asm = "\n".join(a for _, a in code_objects)
+    want = {"20conv64_wino2d_kernelILb0": "v_mfma_f32_16x16x4_f32", "19wgrad64_wino_kernelILb1": "v_mfma_f32_32x32x2_f32",
+            "18conv64_bf16_kernelILi8ELi2": "v_mfma_f32_32x32x16_bf16", "23wgrad64_bf16_dma_kernel": "ds_read_b64_tr_b16"}
+    for kern, ins in want.items():
+        body = _function(asm, kern)
+        assert body is not None, kern
+        assert ins in body, (kern, ins)
+    assert re.search(r"buffer_load_dwordx4 .* lds", _function(asm, "23wgrad64_bf16_dma_kernel")), "LDS-DMA staging"
+    assert re.search(r"buffer_load_dwordx4 .* lds", _function(asm, "19wgrad64_wino_kernelILb1")), "LDS-DMA second plane"
+
+
+def test_dma_wgrad_tile_loop_keeps_two_tiles_in_flight(code_objects):
+    asm = "\n".join(a for _, a in code_objects)
+    body = _function(asm, "23wgrad64_bf16_dma_kernel")
+    lines = body.splitlines()
+    first_tr = [i for i, l in enumerate(lines) if "ds_read_b64_tr_b16" in l]
+    mfma = [i for i, l in enumerate(lines) if "v_mfma_f32_32x32x16_bf16" in l]
+    assert len(mfma) == 36 and first_tr
+    # between the first transposing read and the last MFMA of the loop body: counted waits only
+    window = lines[first_tr[0] - 12:mfma[-1]]
+    full = [l for l in window if re.search(r"s_waitcnt\s+vmcnt\(0\)", l)]
+    assert not full, "the compiler waits for every outstanding load inside the K loop:\n" + "\n".join(full)
+    assert any(re.search(r"s_waitcnt\s+vmcnt\(6\)", l) for l in lines) and any(re.search(r"s_waitcnt\s+vmcnt\(5\)", l) for l in lines)
