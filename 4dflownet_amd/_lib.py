@@ -63,6 +63,7 @@ DEBUG_SIGNATURES = {
     "fdn_debug_set_conv64_dbg": (c_i, [c_i]),
     "fdn_debug_set_conv64_shell_slabs": (c_i, [c_i]),
     "fdn_debug_set_conv64_wface_direct": (c_i, [c_i]),
+    "fdn_debug_set_conv64_split_dgrad": (c_i, [c_i]),
     "fdn_debug_set_conv64_bf16_mt": (c_i, [c_i]),
     "fdn_debug_set_conv64_bf16_dbg": (c_i, [c_i]),
     "fdn_debug_set_conv64_bf16_mode2": (c_i, [c_i]),

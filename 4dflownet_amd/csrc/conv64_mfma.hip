@@ -35,6 +35,7 @@
 // test/bench hooks: compile-time constants in the product library, settable through fdn_debug_* in the test build only
 FDN_HOOK_VAR(int, fdn_conv64_force_layout, 0);   // 0 = auto, 1..6 = index into the variant table below
 FDN_HOOK_VAR(int, fdn_conv64_dbg, 0);            // ablation bits, see Conv64Args::dbg
+FDN_HOOK_VAR(int, fdn_conv64_split_dgrad, 0);    // fused dgrad, 2-D Winograd path: 1 = inner box and shell faces as two launches (until round 4's last change)
 FDN_HOOK_VAR(int, fdn_conv64_wface_direct, 0);   // fused dgrad, Winograd path: 1 = the w faces as a separate direct-kernel launch (round 2), 0 = a region of the Winograd launch
 FDN_HOOK_VAR(int, fdn_conv64_shell_slabs, 1);    // fused dgrad: 1 = inner box + 6 shell slabs, 0 = one launch over the padded grid
 
@@ -657,8 +658,16 @@ int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, 
         int count = ((parts & 1) ? 1 : 0) + ((parts & 2) ? (wface_direct ? 4 : 5) : 0);
         if ((parts & 1) && wino2 && fdn_conv64_wino2d_ok(ID, IH, IW, ID, IH, IW)) {
             // round 4: the inner box (all 27 taps, fused-fold epilogue; 95 % / 91 % of the positions at 48^3 / 24^3) on the 2-D Winograd
-            // kernel, the shell faces as a launch of their own on the 1-D kernel (their single depth / height / width tap has nothing to
-            // transform along that axis)
+            // body, the shell faces on the 1-D body (their single depth / height / width tap has nothing to transform along that axis)
+            if ((parts & 2) && !wface_direct && !fdn_conv64_split_dgrad) {
+                // both parts: ONE launch, the shell faces behind the inner box's workgroups (conv64_wino2d_shell_kernel, conv64_wino.hip)
+                FdnWino2dPrepared inner;
+                if (int rc = fdn_conv64_wino2d_prepare(x, upack2, bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, 1, 1, 1, ID,
+                                                       IH, IW, off, zero_mode, act, alpha, &inner))
+                    return rc;
+                return fdn_conv64_wino_launch_boxes(x, upack, bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, wb + 1, count - 1,
+                                                    off, zero_mode, act, alpha, s, &inner);
+            }
             if (int rc = fdn_conv64_wino2d_launch(x, upack2, bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, 1, 1, 1, ID, IH,
                                                   IW, off, zero_mode, act, alpha, s))
                 return rc;
@@ -702,4 +711,5 @@ extern "C" int fdn_debug_set_conv64_mt(int layout) { fdn_conv64_force_layout = l
 extern "C" int fdn_debug_set_conv64_dbg(int bits) { fdn_conv64_dbg = bits; return FDN_OK; }
 extern "C" int fdn_debug_set_conv64_shell_slabs(int on) { fdn_conv64_shell_slabs = on; return FDN_OK; }
 extern "C" int fdn_debug_set_conv64_wface_direct(int on) { fdn_conv64_wface_direct = on; return FDN_OK; }
+extern "C" int fdn_debug_set_conv64_split_dgrad(int on) { fdn_conv64_split_dgrad = on; return FDN_OK; }
 #endif

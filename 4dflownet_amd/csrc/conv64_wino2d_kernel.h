@@ -1,0 +1,357 @@
+// Device side of conv64_wino2d.hip (2-D Winograd F(2,3) along H x F(4,3) along W): argument struct, constants and the kernel body, shared
+// with conv64_wino.hip (conv64_wino2d_shell_kernel: the fused-dgrad launch = this body on the inner box + the 1-D body on the shell).
+// See conv64_wino2d.hip for the design notes.
+#pragma once
+#include "fdn_common.h"
+#include "conv64_pack.h"
+
+namespace {
+
+struct Wino2Args {
+    const float* x;
+    const float* up;        // 2-D Winograd operand stream (third part of the pack)
+    const float* bias;
+    const float* res;
+    float* y;
+    const float* fskip;     // fused fold (dgrad mode): see conv64_args.h
+    const float* fy;
+    float* fout;
+    int N, ID, IH, IW, OD, OH, OW;
+    int off, zero_mode, act;
+    float alpha;
+    int dbg;                // ablation bits (test build only): 1 = weight stream stride 0, 4 = no staging, 8 = no epilogue, 128 = no XCD remap
+    int obd, obh, obw, ebd, ebh, ebw;      // output box (h extent even, w extent a multiple of 4)
+    int td, ch, cw, ntd, nth, ntw;         // tile in (depth planes, cell rows, cell columns) and tile counts
+    int cpp, rows, items;                  // cells per plane, staged rows = (td + 2) * cpp, rows * 16
+    unsigned mg_cpp, mg_cw;
+    unsigned mg_tpn_hi, mg_tpn_lo, mg_thw_hi, mg_thw_lo, mg_ntw_hi, mg_ntw_lo;
+};
+
+
+constexpr int kW2Rows = 40;                 // staged cell-planes per tile
+constexpr int kW2Row = 288;                 // bytes per LDS row: 64 cin + 32-B pad (conflict-free ds_read_b128 over 16 consecutive rows)
+constexpr int kW2Plane = kW2Rows * kW2Row + 64;
+constexpr int kW2Lds = 6 * kW2Plane + 96 * 4 + kW2Rows * 48;
+constexpr int kW2UA = 3;                    // transform items per thread (<= 640 items = 40 rows x 16 chunks)
+constexpr int kW2RDB = 6;                   // weight-fragment ring depth
+constexpr int kW2RDA = 3;                   // cell-fragment ring depth
+constexpr int kW2Dep = 1;                   // staging: items (12 x 16-B loads each) in flight per thread
+constexpr unsigned kW2Big = 0x40000000u;    // "reads zero": any sum containing it is >= 2^30 > the sample's bytes
+
+// (a __device__ body + thin __global__ wrappers: conv64_wino.hip runs it as the head of the fused-dgrad launch that also carries the shell)
+template <bool FUSED>
+__device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int block_id, char* const smem) {
+    constexpr int RDB = kW2RDB, RDA = kW2RDA, UA = kW2UA, SPT = 24;
+    static_assert(SPT % RDB == 0 && SPT % RDA == 0, "ring slots must be compile-time");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;               // = cout block
+    const int c = lane & 15;
+    const int q = lane >> 4;
+    int* mtab = (int*)(smem + 6 * kW2Plane);    // [0,32): output index of the cell's first voxel or -1; [32,64): fused-fold index or -1;
+                                                // [64,96): (h | w << 16) of the cell's first voxel (fused mode)
+
+    // ---- which tile (scalar multiply-shift divisions, host-made magics; XCD-aware order as in conv64_wino.hip) ----
+    const int tiles_per_n = p.ntd * p.nth * p.ntw;
+    int b = block_id;
+    if (!(FDN_DBG_BITS(p) & 128)) {
+        const int T = p.N * tiles_per_n, qq = T >> 3, r = T & 7, xcd = b & 7;
+        b = xcd * qq + min(xcd, r) + (b >> 3);
+    }
+    const int n = fdn_udiv40(b, p.mg_tpn_hi, p.mg_tpn_lo);
+    b -= n * tiles_per_n;
+    const int tdi = fdn_udiv40(b, p.mg_thw_hi, p.mg_thw_lo);
+    b -= tdi * (p.nth * p.ntw);
+    const int thi = fdn_udiv40(b, p.mg_ntw_hi, p.mg_ntw_lo);
+    const int p0d = p.obd + tdi * p.td, p0h = p.obh + thi * p.ch * 2, p0w = p.obw + (b - thi * p.ntw) * p.cw * 4;
+    const int ng = p.td * p.cpp;
+
+    if (tid < 32) {
+        int g = -1, gf = -1, hw = 0;
+        if (tid < ng) {
+            const int md = fdn_div20(tid, p.mg_cpp);
+            const int j = tid - md * p.cpp;
+            const int mh = fdn_div20(j, p.mg_cw);
+            const int pd = p0d + md, ph = p0h + 2 * mh, pw = p0w + 4 * (j - mh * p.cw);
+            if (pd < p.obd + p.ebd && ph < p.obh + p.ebh && pw < p.obw + p.ebw) {
+                g = ((n * p.OD + pd) * p.OH + ph) * p.OW + pw;
+                hw = ph | (pw << 16);
+                if (FUSED) {
+                    const int id = pd - 1;
+                    if (id >= 1 && id <= p.ID - 2) gf = ((n * p.ID + id) * p.IH + (ph - 1)) * p.IW + (pw - 1);
+                }
+            }
+        }
+        mtab[tid] = g; mtab[32 + tid] = gf; mtab[64 + tid] = hw;
+    }
+
+    // ---- this lane's two cell rows (tap 0, plane xw = 0) ----
+    int abase[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        int m = mb * 16 + c;
+        m = m < ng ? m : ng - 1;
+        abase[mb] = m * kW2Row + q * 16;
+    }
+
+    // ---- staging plan, once per tile, in LDS: per staged cell-plane r the byte offsets (from the sample's first voxel) of its 4 input
+    // rows and 6 input columns with the boundary rule applied (kW2Big = reads zero: any sum containing it is out of the buffer's range).
+    // ptab[r] = {row 0..3, column 0..5, -, -} (48 B); a transform item adds its channel chunk.  Keeping the plan out of the register
+    // file is what lets a thread hold two items' input rows in flight (24 x 16 B) beside the 64 output accumulators.
+    unsigned* ptab = (unsigned*)(smem + 6 * kW2Plane + 96 * 4);
+    if (tid < p.rows) {
+        const int r = tid;
+        const int zd = fdn_div20(r, p.mg_cpp);
+        const int j = r - zd * p.cpp;
+        const int mh = fdn_div20(j, p.mg_cw);
+        const int q0d = p0d - 1 + p.off, q0h = p0h - 1 + p.off + 2 * mh, q0w = p0w - 1 + p.off + 4 * (j - mh * p.cw);
+        int qd = q0d + zd;
+        bool okd = true;
+        if (p.zero_mode) okd = (unsigned)qd < (unsigned)p.ID;
+        else qd = min(max(qd, 0), p.ID - 1);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            int qh = q0h + jj;
+            bool ok = okd;
+            if (p.zero_mode) ok = ok && (unsigned)qh < (unsigned)p.IH;
+            else qh = min(max(qh, 0), p.IH - 1);
+            ptab[r * 12 + jj] = ok ? (unsigned)((qd * p.IH + qh) * p.IW) * 256u : kW2Big;
+        }
+#pragma unroll
+        for (int ii = 0; ii < 6; ++ii) {
+            int qw = q0w + ii;
+            bool ok = true;
+            if (p.zero_mode) ok = (unsigned)qw < (unsigned)p.IW;
+            else qw = min(max(qw, 0), p.IW - 1);
+            ptab[r * 12 + 4 + ii] = ok ? (unsigned)qw * 256u : kW2Big;
+        }
+    }
+    int vrow[UA], prow[UA];                                   // LDS offsets of the item's output row / plan row; chunk offset
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+        const int i = u * 256 + tid;
+        const int r = i >> 4;
+        vrow[u] = r < p.rows ? r * kW2Row + (i & 15) * 16 : -1;
+        prow[u] = (r < p.rows ? r : 0) * 48;
+    }
+    const unsigned chunkb = (unsigned)(tid & 15) * 16u;
+    __syncthreads();                                          // mtab + ptab visible
+    const unsigned sample_bytes = (unsigned)(p.ID * p.IH * p.IW) * 256u;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.x + (size_t)n * p.ID * p.IH * p.IW * 64), 0, sample_bytes, 0x00020000);
+
+    // weight stream: unit (1024 B) index = ((nb*4 + xh)*3 + kd)*24 + xw*4 + g
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.up, 0, 72 * 64 * 64 * 4, 0x00020000);
+    const int wvoff = wave * (288 * 1024) + lane * 16;
+    const int bmul = (FDN_DBG_BITS(p) & 1) ? 0 : 1024;
+    f32x4 A[RDA][2], B[RDB];
+    auto ldb = [&](int slot, int xh, int kd, int j) {
+        B[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, ((xh * 3 + kd) * 24 + j) * bmul, 0));
+    };
+    auto lda = [&](int slot, int tapb, int j) {             // tapb: byte offset of the depth tap's rows
+        const int o = tapb + (j >> 2) * kW2Plane + (j & 3) * 64;
+        A[slot][0] = *(const f32x4*)(smem + abase[0] + o);
+        A[slot][1] = *(const f32x4*)(smem + abase[1] + o);
+    };
+
+    f32x4 Y[2][4][2];                                        // [output row][output column][M-block]: cout 16w + 4q .. + 3 of that voxel
+#pragma unroll
+    for (int hr = 0; hr < 2; ++hr)
+#pragma unroll
+        for (int wi = 0; wi < 4; ++wi)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) Y[hr][wi][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int tapstep = p.cpp * kW2Row;
+
+#pragma unroll 1
+    for (int xh = 0; xh < 4; ++xh) {
+        if (xh) __syncthreads();                             // everyone finished reading the previous stage's planes
+        // ---- stage xh: V = x[ra] + sgn * x[rb], rows (0,2,-) (1,2,+) (1,2,-) (1,3,-); then B_w^T; all 64 cin ----
+        {
+            const float sgn = xh == 1 ? 1.f : -1.f;
+            // a wave whose 64 items of a pass all lie past the tile's last item requests nothing in that pass (640 items: waves 2, 3 of pass 2)
+            const int items_eff = ((FDN_DBG_BITS(p) & 4) ? 0 : p.items) - __builtin_amdgcn_readfirstlane(wave) * 64;
+            constexpr int DEP = kW2Dep;                       // items in flight per thread
+            f32x4 xa[DEP][6], xb[DEP][6];
+            auto issue = [&](int u, int buf) {
+                const unsigned* pr = (const unsigned*)((const char*)ptab + prow[u]);
+                const unsigned ha = (xh == 0 ? pr[0] : pr[1]) + chunkb;
+                const unsigned hb = (xh == 3 ? pr[3] : pr[2]) + chunkb;
+                const unsigned wo[6] = {pr[4], pr[5], pr[6], pr[7], pr[8], pr[9]};
+#pragma unroll
+                for (int ii = 0; ii < 6; ++ii) {
+                    xa[buf][ii] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ha + wo[ii], 0, 0));
+                    xb[buf][ii] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, hb + wo[ii], 0, 0));
+                }
+            };
+#pragma unroll
+            for (int u = 0; u < DEP - 1; ++u)
+                if (u * 256 < items_eff) issue(u, u);
+#pragma unroll
+            for (int u = 0; u < UA; ++u) {
+                if (u * 256 >= items_eff) break;
+                if (u + DEP - 1 < UA && (u + DEP - 1) * 256 < items_eff) issue(u + DEP - 1, (u + DEP - 1) % DEP);
+                if (vrow[u] < 0) continue;
+                const int bf = u % DEP;
+                // B^T of F(4,3): rows (4,0,-5,0,1,0) (0,-4,-4,1,1,0) (0,4,-4,-1,1,0) (0,-2,-1,2,1,0) (0,2,-1,-2,1,0) (0,4,0,-5,0,1)
+                const f32x4 x0 = xa[bf][0] + sgn * xb[bf][0], x1 = xa[bf][1] + sgn * xb[bf][1], x2 = xa[bf][2] + sgn * xb[bf][2];
+                const f32x4 x3 = xa[bf][3] + sgn * xb[bf][3], x4 = xa[bf][4] + sgn * xb[bf][4], x5 = xa[bf][5] + sgn * xb[bf][5];
+                const f32x4 t1 = x4 - 4.f * x2, t2 = x3 - 4.f * x1;
+                const f32x4 t3 = x4 - x2, t4 = 2.f * (x3 - x1);
+                char* vp = smem + vrow[u];
+                *(f32x4*)(vp) = 4.f * x0 - 5.f * x2 + x4;
+                *(f32x4*)(vp + kW2Plane) = t1 + t2;
+                *(f32x4*)(vp + 2 * kW2Plane) = t1 - t2;
+                *(f32x4*)(vp + 3 * kW2Plane) = t3 + t4;
+                *(f32x4*)(vp + 4 * kW2Plane) = t3 - t4;
+                *(f32x4*)(vp + 5 * kW2Plane) = 4.f * x1 - 5.f * x3 + x5;
+            }
+        }
+        // the weight ring is primed per stage, behind the staging (its registers are free for the input rows meanwhile) and
+        // ahead of the barrier (whose wait covers the L2 round trip)
+#pragma unroll
+        for (int j = 0; j < RDB - 1; ++j) ldb(j, xh, 0, j);
+        __syncthreads();
+
+        // ---- K loop of the stage: 3 depth taps x (6 xw x 4 cin groups) ----
+        f32x4 acc[6][2];
+#pragma unroll
+        for (int xi = 0; xi < 6; ++xi) {
+            acc[xi][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc[xi][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < RDA - 1; ++j) lda(j, 0, j);
+#pragma unroll 1
+        for (int kd = 0; kd < 3; ++kd) {
+            const bool last = kd == 2;
+            const int tapb = kd * tapstep;
+            const int tapb_n = last ? tapb : tapb + tapstep;
+            const int kd_n = last ? kd : kd + 1;             // the last tap re-requests its own first units (never used)
+#pragma unroll
+            for (int j = 0; j < SPT; ++j) {
+                const int sb = j % RDB, sa = j % RDA;
+                const int xi = j >> 2;
+                acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(B[sb][0], A[sa][0][0], acc[xi][0], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    const int jb = j + RDB - 1, ja = j + RDA - 1;
+                    if (jb < SPT) ldb(jb % RDB, xh, kd, jb);
+                    else ldb(jb % RDB, xh, kd_n, jb - SPT);
+                    if (ja < SPT) lda(ja % RDA, tapb, ja);
+                    else lda(ja % RDA, tapb_n, ja - SPT);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(B[sb][0], A[sa][1][0], acc[xi][1], 0, 0, 0);
+#pragma unroll
+                for (int s = 1; s < 4; ++s) {
+                    acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(B[sb][s], A[sa][0][s], acc[xi][0], 0, 0, 0);
+                    acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(B[sb][s], A[sa][1][s], acc[xi][1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+
+        // ---- fold the stage: t = A_w^T M[xh] (A_w^T = (1,1,1,1,1,0) (0,1,-1,2,-2,0) (0,1,1,4,4,0) (0,1,-1,8,-8,1)), then the F(2,3)
+        // output transform A_h^T = (1,1,1,0) (0,1,-1,-1) as Y_h0 += c0 t, Y_h1 += c1 t ----
+        const float c0 = xh < 3 ? 1.f : 0.f;
+        const float c1 = xh == 0 ? 0.f : (xh == 1 ? 1.f : -1.f);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            const f32x4 s12 = acc[1][mb] + acc[2][mb], d12 = acc[1][mb] - acc[2][mb];
+            const f32x4 s34 = acc[3][mb] + acc[4][mb], d34 = acc[3][mb] - acc[4][mb];
+            f32x4 t[4];
+            t[0] = acc[0][mb] + s12 + s34;
+            t[1] = d12 + 2.f * d34;
+            t[2] = s12 + 4.f * s34;
+            t[3] = d12 + 8.f * d34 + acc[5][mb];
+#pragma unroll
+            for (int wi = 0; wi < 4; ++wi) {
+                Y[0][wi][mb] += c0 * t[wi];
+                Y[1][wi][mb] += c1 * t[wi];
+            }
+        }
+    }
+
+    if (FDN_DBG_BITS(p) & 8) return;
+    // ---- epilogue: lane = cell c of each M-block x cout 16w + 4q .. + 3; 8 voxels per cell ----
+    const int cofs = wave * 16 + q * 4;
+    const float slope = p.act == FDN_ACT_RELU ? 0.f : (p.act == FDN_ACT_LEAKY ? p.alpha : 1.f);
+    // Both M-blocks' operand loads (skip / y, or the residual) are requested before the first store: the stores of block 0 may alias
+    // the loads of block 1 as far as the compiler can tell (skip may BE the output), so left to itself it serialises two memory round
+    // trips at the end of every tile.  A lane reads exactly the addresses it writes, so hoisting the reads is safe.
+    int g0[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) g0[mb] = mtab[mb * 16 + c];
+    if (FUSED) {
+        // dgrad on the inner box of the padded grid: voxels strictly inside the volume get exactly one contribution and are finished
+        // here (dz_prev = (dgrad + skip) * act'(y)); surface voxels go to the padded scratch for the border fold.  Branch-free per
+        // voxel: a surface voxel (or a cell outside the box) reads row 0 of the tensor, which nobody writes in this launch, and
+        // discards it; value and destination are selected afterwards.
+        int fi[2][2][4];                      // voxel index into skip / y / dz_prev, or -1 (surface voxel, cell outside the box)
+        f32x4 sk[2][2][4], ym[2][2][4];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            const int gf0 = mtab[32 + mb * 16 + c];
+            const int hw = mtab[64 + mb * 16 + c];
+            const int ph = hw & 0xffff, pw = hw >> 16;                    // padded coordinates of the cell's first voxel
+#pragma unroll
+            for (int hr = 0; hr < 2; ++hr)
+#pragma unroll
+                for (int wi = 0; wi < 4; ++wi) {
+                    const int ih = ph + hr - 1, iw = pw + wi - 1;
+                    const bool in = g0[mb] >= 0 && gf0 >= 0 && ih >= 1 && ih <= p.IH - 2 && iw >= 1 && iw <= p.IW - 2;
+                    fi[mb][hr][wi] = in ? gf0 + hr * p.IW + wi : -1;
+                    const size_t o = (size_t)(in ? fi[mb][hr][wi] : 0) * 64 + cofs;
+                    sk[mb][hr][wi] = p.fskip ? *(const f32x4*)(p.fskip + o) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    ym[mb][hr][wi] = p.fy ? *(const f32x4*)(p.fy + o) : (f32x4){1.f, 1.f, 1.f, 1.f};
+                }
+        }
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            if (g0[mb] < 0) continue;
+#pragma unroll
+            for (int hr = 0; hr < 2; ++hr)
+#pragma unroll
+                for (int wi = 0; wi < 4; ++wi) {
+                    const f32x4 z = Y[hr][wi][mb];
+                    const bool in = fi[mb][hr][wi] >= 0;
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = in ? (z[e] + sk[mb][hr][wi][e]) * (ym[mb][hr][wi][e] > 0.f ? 1.f : slope) : z[e];
+                    float* dst = in ? p.fout + (size_t)fi[mb][hr][wi] * 64 + cofs : p.y + (size_t)(g0[mb] + hr * p.OW + wi) * 64 + cofs;
+                    *(f32x4*)dst = v;
+                }
+        }
+    } else {
+        f32x4 rv[2][2][4];
+        if (p.res) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int hr = 0; hr < 2; ++hr)
+#pragma unroll
+                    for (int wi = 0; wi < 4; ++wi)
+                        rv[mb][hr][wi] = *(const f32x4*)(p.res + (size_t)((g0[mb] >= 0 ? g0[mb] : 0) + hr * p.OW + wi) * 64 + cofs);
+        }
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bv = *(const f32x4*)(p.bias + cofs);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            if (g0[mb] < 0) continue;
+#pragma unroll
+            for (int hr = 0; hr < 2; ++hr)
+#pragma unroll
+                for (int wi = 0; wi < 4; ++wi) {
+                    f32x4 v = Y[hr][wi][mb] + bv;
+                    if (p.res) v += rv[mb][hr][wi];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], slope * v[e]);          // relu / leaky / none: slope in [0,1]
+                    *(f32x4*)(p.y + (size_t)(g0[mb] + hr * p.OW + wi) * 64 + cofs) = v;
+                }
+        }
+    }
+}
+
+}  // namespace

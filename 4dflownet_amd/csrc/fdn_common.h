@@ -177,12 +177,13 @@ int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, 
 // Winograd F(4,3)-along-W variant of the 64->64 conv (conv64_wino.hip): one output box with all 27 taps
 // output box + its non-zero (kd, kh) tap ranges.  wface = 1: the pair of w faces of a fused dgrad's shell (box = the (d,h) range of the
 // padded grid, ow = 0, ew = 4: one "group" per (d,h) position; see conv64_wino.hip)
+struct FdnWino2dPrepared;
 struct FdnWinoBox { int od, oh, ow, ed, eh, ew, ta0, ta1, tb0, tb1, wface; };
 bool fdn_conv64_wino_ok(int ebd, int ebh, int ebw);
 int fdn_conv64_wino_launch_boxes(const float* x, const float* upack, const float* bias, const float* residual, float* y,
                                  const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
                                  int OW, const FdnWinoBox* boxes, int nbox, int off, int zero_mode, int act, float alpha,
-                                 hipStream_t s);
+                                 hipStream_t s, const struct FdnWino2dPrepared* inner = nullptr);
 int fdn_conv64_wino_launch(const float* x, const float* upack, const float* bias, const float* residual, float* y,
                            const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
                            int OW, int obd, int obh, int obw, int ebd, int ebh, int ebw, int off, int zero_mode, int act,
@@ -190,6 +191,13 @@ int fdn_conv64_wino_launch(const float* x, const float* upack, const float* bias
 int fdn_pack_conv64_wino_launch(const float* w, float* uf, float* ud, hipStream_t s);
 // 2-D Winograd variant (conv64_wino2d.hip): F(2,3) along H x F(4,3) along W; one output box with all 27 taps
 bool fdn_conv64_wino2d_ok(int ebd, int ebh, int ebw, int ID, int IH, int IW);
+// A planned, not yet launched 2-D launch (the kernel's argument block, opaque outside conv64_wino2d_kernel.h): fdn_conv64_wino_launch_boxes
+// takes one as `inner` and issues it together with its own regions as ONE launch (conv64_wino2d_shell_kernel: the fused dgrad).
+struct FdnWino2dPrepared { alignas(8) unsigned char args[320]; int blocks; int lds; };
+int fdn_conv64_wino2d_prepare(const float* x, const float* upack2, const float* bias, const float* residual, float* y,
+                              const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
+                              int OW, int obd, int obh, int obw, int ebd, int ebh, int ebw, int off, int zero_mode, int act,
+                              float alpha, FdnWino2dPrepared* out);
 int fdn_conv64_wino2d_launch(const float* x, const float* upack2, const float* bias, const float* residual, float* y,
                              const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
                              int OW, int obd, int obh, int obw, int ebd, int ebh, int ebw, int off, int zero_mode, int act,

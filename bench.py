@@ -62,7 +62,7 @@ class LaunchTimer:
 
     def __init__(self, ops):
         self.ops = ops
-        self.records = {"conv": [], "shell": [], "wgrad": []}
+        self.records = {"conv": [], "wgrad": []}
         self.enabled = False
         self._orig = {}
 
@@ -92,13 +92,10 @@ class LaunchTimer:
             if dz.dtype != torch.float32 or "parts" in k:
                 # bf16 mode: ONE launch covers the inner box and the shell (conv64_bf16.hip); priced as algorithmic work
                 return bracket("conv", N * D * H * W, N * D * H * W * FLOP_PER_VOXEL_CONV64, lambda: dgf(dz, *a, **k))
-            # fp32: the entry point issues the inner box and the shell faces as two launches of two kernels (conv64_wino2d_kernel /
-            # conv64_wino_kernel); issue them through the same entry point as the two `parts` they are, so that each kernel gets its own
-            # HIP-event bracket -- same launches, same order, same stream
-            out = bracket("conv", N * D * H * W, executed_conv64_flop(N, D, H, W, dz.dtype, k.get("algo", 0)),
-                          lambda: dgf(dz, *a, parts=1, **k))
-            bracket("shell", 0, executed_shell_flop(N, D, H, W), lambda: dgf(dz, *a, parts=2, **k))
-            return out
+            # fp32: ONE launch (conv64_wino2d_shell_kernel): the inner box on the 2-D Winograd body, the shell faces behind it on the 1-D
+            # body -- executed FLOPs = both
+            return bracket("conv", N * D * H * W, executed_conv64_flop(N, D, H, W, dz.dtype, k.get("algo", 0)) + executed_shell_flop(N, D, H, W),
+                           lambda: dgf(dz, *a, **k))
 
         def conv3d_wgrad(x, dz, K, Cin, Cout, *a, **k):
             if not self.enabled or (K, Cin, Cout) != (3, 64, 64):
@@ -223,9 +220,6 @@ def roofline_obj(timer, kind, bf16, kernel, traffic_files):
     achieved = avg_exec / (avg_ms * 1e-3) / 1e12              # FLOPs issued on the matrix pipe per second
     algorithmic = avg_flop / (avg_ms * 1e-3) / 1e12           # direct-convolution FLOPs per second
     traffic, tfile = pmc_traffic_bytes(traffic_files, kernel.split(" ")[0])
-    if kind == "shell":                                       # no algorithmic work of its own: part of the fused dgrad
-        return {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                "traffic": traffic, "launches_timed": n_launch, "avg_launch_ms": avg_ms, "executed_gflop_per_launch": avg_exec / 1e9}
     vox = avg_flop / FLOP_PER_VOXEL_CONV64
     esz = 2.0 if bf16 else 4.0
     # conv: in + out rows + the weight stream; wgrad: x + dz rows + the dW it writes (fp32)
@@ -680,11 +674,10 @@ def main():
                                          else "one call after backward"))},
             "roofline": roofline_obj(timer, "conv", bf16, "%s (3x3x3 64->64 forward + fused-dgrad%s launches%s)"
                                      % (("conv64_bf16_kernel", "", "") if bf16 else
-                                        ("conv64_wino2d_kernel", " inner-box", "; 2-D Winograd F(2,3) along H x F(4,3) along W")), tr),
+                                        ("conv64_wino2d", "", ": conv64_wino2d_kernel forward, conv64_wino2d_shell_kernel fused dgrad = inner box + shell faces in one "
+                                         "launch; 2-D Winograd F(2,3) along H x F(4,3) along W, the faces F(4,3) along W")), tr),
             "roofline_wgrad": roofline_obj(timer, "wgrad", bf16, "%s (3x3x3 64->64 weight gradient + partial reduction%s)"
                                            % (("wgrad64_bf16_dma_kernel", "") if bf16 else ("wgrad64_wino_kernel", "; Winograd F(3,2) along D x F(3,4) along W")), tr),
-            "roofline_dgrad_shell": None if bf16 else roofline_obj(timer, "shell", False, "conv64_wino_kernel (shell faces of the fused dgrad: "
-                                                                   "d / h faces F(4,3) along W, w faces one Winograd coordinate)", tr),
             "train_step_tflops": args.steps * B * world / dt * 3.0 * fwd_flop / 1e12,
             "lib_source_stamp": build.source_stamp()[:16],          # sha256 prefix of csrc/ + include/fdn.h + flags the binary was built from
         }

@@ -188,6 +188,41 @@ def test_conv64_dgrad_fused_fold(ops, fdn, shape, layout):
                 lib.fdn_debug_set_conv64_wface_direct(0)
 
 
+@pytest.mark.parametrize("shape", [(1, 5, 8, 12), (2, 9, 2, 24), (1, 1, 2, 4), (3, 24, 24, 24), (1, 11, 14, 28)])
+def test_conv64_dgrad_fused_one_launch_equals_two(ops, fdn, shape):
+    """The fused dgrad of the 2-D Winograd path is ONE launch (conv64_wino2d_shell_kernel: inner box on the 2-D body, shell faces behind
+    it on the 1-D body).  It must be bit-identical to the same two bodies as two launches (test-build switch), and to the two `parts` a
+    caller may issue on its own (network.overlap_shell)."""
+    rng = np.random.default_rng(61)
+    N, D, H, W = shape
+    dz = dev(rng.normal(size=(N, D, H, W, 64)).astype(np.float32))
+    w = (rng.normal(size=(3, 3, 3, 64, 64)) * 0.05).astype(np.float32)
+    y = dev(rng.normal(size=(N, D, H, W, 64)).astype(np.float32))
+    skip = dev(rng.normal(size=(N, D, H, W, 64)).astype(np.float32))
+    _, wd = ops.pack_conv64_weights(dev(w))
+
+    def run(**kw):
+        pad = torch.full((N, D + 2, H + 2, W + 2, 64), float("nan"), device="cuda")
+        out = torch.full((N, D, H, W, 64), float("nan"), device="cuda")
+        if kw.get("two_parts"):
+            ops.conv3d_dgrad_fused(dz, wd, pad, out, skip=skip, y_prev=y, act=O.ACT_LEAKY, parts=ops.DGRAD_SHELL)
+            ops.conv3d_dgrad_fused(dz, wd, pad, out, skip=skip, y_prev=y, act=O.ACT_LEAKY, parts=ops.DGRAD_INNER)
+        else:
+            ops.conv3d_dgrad_fused(dz, wd, pad, out, skip=skip, y_prev=y, act=O.ACT_LEAKY)
+        return pad.clone(), out.clone()          # (before the border fold: the raw products of the launch(es))
+    pad1, out1 = run()
+    pad2, out2 = run(two_parts=True)
+    with fdn._lib.test_build() as lib:
+        lib.fdn_debug_set_conv64_split_dgrad(1)
+        try:
+            pad3, out3 = run()
+        finally:
+            lib.fdn_debug_set_conv64_split_dgrad(0)
+    for name, (p_, o_) in (("parts", (pad2, out2)), ("two launches", (pad3, out3))):
+        assert torch.equal(torch.nan_to_num(pad1, nan=-7.0), torch.nan_to_num(p_, nan=-7.0)), name + ": padded scratch differs"
+        assert torch.equal(torch.nan_to_num(out1, nan=-7.0), torch.nan_to_num(o_, nan=-7.0)), name + ": interior differs"
+
+
 @pytest.mark.parametrize("shape", SHAPES + [(2, 16, 16, 16), (1, 1, 1, 1), (1, 2, 3, 1), (1, 3, 20, 33), (5, 9, 8, 24), (2, 24, 24, 24),
                                             (1, 7, 6, 8), (1, 2, 13, 7)])
 @pytest.mark.parametrize("direct", [0, 1, 2])    # 0 = product library, FDN_ALGO_AUTO: Winograd F(3,4) along W, + F(3,2) along D when D is even;
