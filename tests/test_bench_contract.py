@@ -56,7 +56,8 @@ def test_pmc_traffic_summaries_are_readable_and_skip_metadata(tmp_path):
     # every committed summary parses; "_meta" (commit / source stamp) is not mistaken for a kernel row
     for name in b.CFG2_TRAFFIC + b.CFG4_TRAFFIC:
         if os.path.exists(os.path.join(ROOT, "profiles", name)):
-            kern = "conv64_bf16_kernel" if "cfg4" in name else ("conv64_wino_kernel" if not name.startswith("r1_") else "conv64_mfma_kernel")
+            kern = "conv64_bf16_kernel" if "cfg4" in name else ("conv64_mfma_kernel" if name.startswith("r1_") else
+                                                                    ("conv64_wino_kernel" if name[:2] in ("r2", "r3") else "conv64_wino2d"))
             v, f = b.pmc_traffic_bytes([name], kern)
             assert f == name and v > 1e6, (name, v)
 
