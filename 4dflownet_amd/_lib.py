@@ -73,6 +73,7 @@ DEBUG_SIGNATURES = {
     "fdn_debug_set_conv64_wino_tile": (c_i, [c_i]),
     "fdn_debug_set_conv64_wino2d_dbg": (c_i, [c_i]),
     "fdn_debug_set_conv64_wino2d_tile": (c_i, [c_i]),
+    "fdn_debug_set_conv64_wino2d_variant": (c_i, [c_i]),
     "fdn_debug_set_cin3_mfma": (c_i, [c_i]),
     "fdn_debug_set_conv1x1_mfma": (c_i, [c_i]),
     "fdn_debug_set_wgrad64_wino_dbg": (c_i, [c_i]),

@@ -456,18 +456,22 @@ __global__ void pack_conv64_kernel(const float* __restrict__ w, float* __restric
 
 // every 64->64 layer of the network in ONE launch: blockIdx.y = layer, packs[layer][fwd|dgrad][direct | winograd]
 __global__ void pack_conv64_batch_kernel(const float* __restrict__ w_base, const int64_t* __restrict__ w_offsets, float* __restrict__ packs) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over 153*64*64 packed elements per direction
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over 261*64*64 packed elements per direction
     const float* w = w_base + w_offsets[blockIdx.y];
     float* pf = packs + (size_t)blockIdx.y * 2 * FDN_CONV64_PACK_FLOATS;
     float* pd = pf + FDN_CONV64_PACK_FLOATS;
     if (idx < 27 * 64 * 64) fdn_pack_direct_one(w, pf, pd, idx);
     else if (idx < 81 * 64 * 64) fdn_pack_wino_one(w, pf + 27 * 64 * 64, pd + 27 * 64 * 64, idx - 27 * 64 * 64);
     else if (idx < 153 * 64 * 64) fdn_pack_wino2d_one(w, pf + 81 * 64 * 64, pd + 81 * 64 * 64, idx - 81 * 64 * 64);
+    else if (idx < 261 * 64 * 64) fdn_pack_wino44_one(w, pf + 153 * 64 * 64, pd + 153 * 64 * 64, idx - 153 * 64 * 64);
 }
 
-// pack = [direct stream, 27*64*64 floats | Winograd F(4,3) stream, 54*64*64 | 2-D F(2,3)xF(4,3) stream, 72*64*64]  (FDN_CONV64_PACK_FLOATS in fdn.h)
+// pack = [direct stream, 27*64*64 floats | Winograd F(4,3) stream, 54*64*64 | 2-D F(2,3)xF(4,3) stream, 72*64*64 | 2-D F(4,3)xF(4,3)
+// stream, 108*64*64]  (FDN_CONV64_PACK_FLOATS in fdn.h)
 constexpr int kDirectPackFloats = 27 * 64 * 64;
 constexpr int kWino1PackFloats = 54 * 64 * 64;
+constexpr int kWino2PackFloats = 72 * 64 * 64;
+static_assert(kDirectPackFloats + kWino1PackFloats + kWino2PackFloats + 108 * 64 * 64 == FDN_CONV64_PACK_FLOATS, "pack layout");
 
 extern "C" int fdn_pack_conv64_weights(const float* w, float* wp_fwd, float* wp_dgrad, void* stream) {
     FDN_REQUIRE(w != nullptr, "fdn_pack_conv64_weights: w is NULL");
@@ -619,12 +623,19 @@ int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, 
     const bool wino = algo != FDN_ALGO_DIRECT && (fdn_conv64_force_layout == 0 || fdn_conv64_force_layout == 7);
     const float* upack = wpack + kDirectPackFloats;
     const float* upack2 = upack + kWino1PackFloats;
-    // 2-D Winograd (conv64_wino2d.hip: F(2,3) along H on top of F(4,3) along W, a third fewer multiplies again) when H is even too
+    // 2-D Winograd (conv64_wino2d.hip): F(4,3) along H on top of F(4,3) along W (6.75 of the 27 tap-equivalents) when H is a multiple
+    // of 4, F(2,3) along H (9 tap-equivalents; FDN_ALGO_WINO_H2 forces it) when H is even
     const bool wino2 = wino && algo != FDN_ALGO_WINO_W && fdn_conv64_force_layout == 0;
+    auto hm_for = [&](int eh, int ew) {                           // output rows per cell of the 2-D kernel for an (eh, ew) box, 0 = not applicable
+        if (!wino2) return 0;
+        if (algo != FDN_ALGO_WINO_H2 && fdn_conv64_wino2d_ok(1, eh, ew, ID, IH, IW, 4)) return 4;
+        return fdn_conv64_wino2d_ok(1, eh, ew, ID, IH, IW, 2) ? 2 : 0;
+    };
+    auto upack_hm = [&](int hm) { return hm == 4 ? upack2 + kWino2PackFloats : upack2; };
     if (!(fout && zero_mode && off == -1 && fdn_conv64_shell_slabs)) {
-        if (wino2 && fdn_conv64_wino2d_ok(OD, OH, OW, ID, IH, IW))
-            return fdn_conv64_wino2d_launch(x, upack2, bias, residual, y, nullptr, nullptr, nullptr, N, ID, IH, IW, OD, OH, OW, 0, 0, 0,
-                                            OD, OH, OW, off, zero_mode, act, alpha, s);
+        if (const int hm = fout ? 0 : hm_for(OH, OW))             // (a fused fold outside the slab path is the 1-D / direct kernels' business)
+            return fdn_conv64_wino2d_launch(x, upack_hm(hm), bias, residual, y, nullptr, nullptr, nullptr, N, ID, IH, IW, OD, OH, OW, 0, 0, 0,
+                                            OD, OH, OW, off, zero_mode, act, alpha, hm, s);
         if (wino && fdn_conv64_wino_ok(OD, OH, OW))
             return fdn_conv64_wino_launch(x, upack, bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, 0, 0, 0, OD, OH,
                                           OW, off, zero_mode, act, alpha, s);
@@ -656,20 +667,20 @@ int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, 
         const bool wface_direct = fdn_conv64_wface_direct != 0;       // test build: the round-2 path (direct-kernel slab launch)
         int first = (parts & 1) ? 0 : 1;
         int count = ((parts & 1) ? 1 : 0) + ((parts & 2) ? (wface_direct ? 4 : 5) : 0);
-        if ((parts & 1) && wino2 && fdn_conv64_wino2d_ok(ID, IH, IW, ID, IH, IW)) {
+        if (const int hm = (parts & 1) ? hm_for(IH, IW) : 0) {
             // round 4: the inner box (all 27 taps, fused-fold epilogue; 95 % / 91 % of the positions at 48^3 / 24^3) on the 2-D Winograd
             // body, the shell faces on the 1-D body (their single depth / height / width tap has nothing to transform along that axis)
             if ((parts & 2) && !wface_direct && !fdn_conv64_split_dgrad) {
                 // both parts: ONE launch, the shell faces behind the inner box's workgroups (conv64_wino2d_shell_kernel, conv64_wino.hip)
                 FdnWino2dPrepared inner;
-                if (int rc = fdn_conv64_wino2d_prepare(x, upack2, bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, 1, 1, 1, ID,
-                                                       IH, IW, off, zero_mode, act, alpha, &inner))
+                if (int rc = fdn_conv64_wino2d_prepare(x, upack_hm(hm), bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, 1, 1, 1, ID,
+                                                       IH, IW, off, zero_mode, act, alpha, hm, &inner))
                     return rc;
                 return fdn_conv64_wino_launch_boxes(x, upack, bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, wb + 1, count - 1,
                                                     off, zero_mode, act, alpha, s, &inner);
             }
-            if (int rc = fdn_conv64_wino2d_launch(x, upack2, bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, 1, 1, 1, ID, IH,
-                                                  IW, off, zero_mode, act, alpha, s))
+            if (int rc = fdn_conv64_wino2d_launch(x, upack_hm(hm), bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, 1, 1, 1, ID, IH,
+                                                  IW, off, zero_mode, act, alpha, hm, s))
                 return rc;
             first = 1; count -= 1;
             if (count == 0) return FDN_OK;

@@ -100,3 +100,44 @@ __device__ __forceinline__ void fdn_pack_wino2d_one(const float* __restrict__ w,
         ud[idx] = v;
     }
 }
+
+// 2-D Winograd stream with F(4,3) along H as well (conv64_wino2d.hip, HM = 4): U = G g G^T over the (kh, kw) taps, per depth tap kd, with
+// the G of F(4,3) above on both sides (no sign games: the kernel forms the input coordinates with B^T's own coefficients).
+// layout [nb = cout/16][xh 0..5][kd][xw 0..5][g = cin/16][q][i][s], the 1-KB unit as in fdn_pack_wino2d_one; 108 * 64 * 64 floats.
+__device__ __forceinline__ void fdn_pack_wino44_one(const float* __restrict__ w, float* __restrict__ uf, float* __restrict__ ud, int idx) {
+    const int s = idx & 3;
+    const int i = (idx >> 2) & 15;
+    const int q = (idx >> 6) & 3;
+    const int g = (idx >> 8) & 3;
+    int rest = idx >> 10;                // ((nb*6 + xh)*3 + kd)*6 + xw
+    const int xw = rest % 6; rest /= 6;
+    const int kd = rest % 3; rest /= 3;
+    const int xh = rest % 6;
+    const int nb = rest / 6;
+    const int k = 16 * g + 4 * q + s;
+    const int cj = 16 * nb + i;
+    const float G[6][3] = {{0.25f, 0.f, 0.f}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
+                           {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
+    if (uf) {
+        float v = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            float r = 0.f;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) r = __builtin_fmaf(G[xw][t], w[(((kd * 3 + kh) * 3 + t) * 64 + k) * 64 + cj], r);
+            v = __builtin_fmaf(G[xh][kh], r, v);
+        }
+        uf[idx] = v;
+    }
+    if (ud) {
+        float v = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            float r = 0.f;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) r = __builtin_fmaf(G[xw][t], w[((26 - ((kd * 3 + kh) * 3 + t)) * 64 + cj) * 64 + k], r);
+            v = __builtin_fmaf(G[xh][kh], r, v);
+        }
+        ud[idx] = v;
+    }
+}

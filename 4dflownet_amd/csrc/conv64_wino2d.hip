@@ -41,15 +41,30 @@ namespace {
 FDN_HOOK_VAR(int, fdn_conv64_wino2d_dbg, 0);
 FDN_HOOK_VAR(int, fdn_conv64_wino2d_tile, 0);          // test build: force the tile, td | ch << 8 | cw << 16 (0 = planner)
 
-template <bool FUSED>
+template <bool FUSED, int HM>
 __global__ __launch_bounds__(256, 2) void conv64_wino2d_kernel(Wino2Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    conv64_wino2d_body<FUSED>(p, (int)blockIdx.x, smem);
+    conv64_wino2d_body<FUSED, HM>(p, (int)blockIdx.x, smem);
 }
 
+#ifdef FDN_TEST_HOOKS
+// Occupancy experiment: the same forward body at ONE workgroup per CU -- __launch_bounds__(256, 1) gives a
+// wave the whole 512-register file (256 VGPR + 256 AGPR), the launch asks for more than half a CU's LDS so that a second workgroup
+// cannot become resident -- with the product rings and with deeper ones.  Selected by fdn_debug_set_conv64_wino2d_variant.
+FDN_HOOK_VAR(int, fdn_conv64_wino2d_variant, 0);
+constexpr int kW2LdsOcc1 = 84 * 1024;
+template <int RDB, int RDA, int DEP>
+__global__ __launch_bounds__(256, 1) void conv64_wino2d_occ1_kernel(Wino2Args p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    conv64_wino2d_body<false, 2, RDB, RDA, DEP>(p, (int)blockIdx.x, smem);
+}
+#endif
+
+// both 2-D streams of one layer: [F(2,3) x F(4,3): 72 * 4096 floats | F(4,3) x F(4,3): 108 * 4096]
 __global__ void pack_conv64_wino2d_kernel(const float* __restrict__ w, float* __restrict__ uf, float* __restrict__ ud) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < 72 * 64 * 64) fdn_pack_wino2d_one(w, uf, ud, idx);
+    else if (idx < 180 * 64 * 64) fdn_pack_wino44_one(w, uf ? uf + 72 * 64 * 64 : nullptr, ud ? ud + 72 * 64 * 64 : nullptr, idx - 72 * 64 * 64);
 }
 
 struct Wino2Plan { int td, ch, cw; double cost; };
@@ -77,8 +92,8 @@ Wino2Plan wino2d_plan(int N, int ed, int ech, int ecw) {
 // Is the 2-D Winograd kernel applicable to this output box of this input grid?  (H extent even, W extent a multiple of 4, a sample
 // addressable with 30-bit byte offsets -- the staging plan adds a row offset and a column offset, each of which may be the
 // "reads zero" marker 2^30.)
-bool fdn_conv64_wino2d_ok(int ebd, int ebh, int ebw, int ID, int IH, int IW) {
-    return ebd > 0 && ebh >= 2 && (ebh & 1) == 0 && ebw >= 4 && (ebw & 3) == 0 && (long long)ID * IH * IW <= (1ll << 22);
+bool fdn_conv64_wino2d_ok(int ebd, int ebh, int ebw, int ID, int IH, int IW, int hm) {
+    return (hm == 2 || hm == 4) && ebd > 0 && ebh >= hm && ebh % hm == 0 && ebw >= 4 && (ebw & 3) == 0 && (long long)ID * IH * IW <= (1ll << 22);
 }
 
 static_assert(sizeof(Wino2Args) <= sizeof(FdnWino2dPrepared::args), "FdnWino2dPrepared::args too small");
@@ -86,16 +101,17 @@ static_assert(sizeof(Wino2Args) <= sizeof(FdnWino2dPrepared::args), "FdnWino2dPr
 int fdn_conv64_wino2d_prepare(const float* x, const float* upack2, const float* bias, const float* residual, float* y,
                               const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
                               int OW, int obd, int obh, int obw, int ebd, int ebh, int ebw, int off, int zero_mode, int act,
-                              float alpha, FdnWino2dPrepared* out) {
-    FDN_REQUIRE(fdn_conv64_wino2d_ok(ebd, ebh, ebw, ID, IH, IW), "conv64 (2-D winograd): box %dx%dx%d of a %dx%dx%d grid is not supported",
-                ebd, ebh, ebw, ID, IH, IW);
+                              float alpha, int hm, FdnWino2dPrepared* out) {
+    FDN_REQUIRE(fdn_conv64_wino2d_ok(ebd, ebh, ebw, ID, IH, IW, hm), "conv64 (2-D winograd, F(%d,3) along H): box %dx%dx%d of a %dx%dx%d grid is not supported",
+                hm, ebd, ebh, ebw, ID, IH, IW);
     FDN_REQUIRE(!fout || (zero_mode && off == -1 && obd == 1 && obh == 1 && obw == 1), "conv64 (2-D winograd): the fused fold belongs to the inner box of a padded dgrad");
     Wino2Args a;
     a.x = x; a.up = upack2; a.bias = bias; a.res = residual; a.y = y; a.fskip = fskip; a.fy = fy; a.fout = fout;
     a.N = N; a.ID = ID; a.IH = IH; a.IW = IW; a.OD = OD; a.OH = OH; a.OW = OW;
     a.off = off; a.zero_mode = zero_mode; a.act = act; a.alpha = alpha; a.dbg = fdn_conv64_wino2d_dbg;
+    a.hm = hm;
     a.obd = obd; a.obh = obh; a.obw = obw; a.ebd = ebd; a.ebh = ebh; a.ebw = ebw;
-    const int ech = ebh / 2, ecw = ebw / 4;
+    const int ech = ebh / hm, ecw = ebw / 4;
     Wino2Plan pl = wino2d_plan(N, ebd, ech, ecw);
     if (fdn_conv64_wino2d_tile) {
         pl.td = fdn_conv64_wino2d_tile & 255; pl.ch = (fdn_conv64_wino2d_tile >> 8) & 255; pl.cw = (fdn_conv64_wino2d_tile >> 16) & 255;
@@ -120,27 +136,42 @@ int fdn_conv64_wino2d_prepare(const float* x, const float* upack2, const float* 
 int fdn_conv64_wino2d_launch(const float* x, const float* upack2, const float* bias, const float* residual, float* y,
                              const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
                              int OW, int obd, int obh, int obw, int ebd, int ebh, int ebw, int off, int zero_mode, int act,
-                             float alpha, hipStream_t s) {
+                             float alpha, int hm, hipStream_t s) {
     FdnWino2dPrepared pr;
     if (int rc = fdn_conv64_wino2d_prepare(x, upack2, bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, obd, obh, obw, ebd,
-                                           ebh, ebw, off, zero_mode, act, alpha, &pr))
+                                           ebh, ebw, off, zero_mode, act, alpha, hm, &pr))
         return rc;
     Wino2Args a;
     memcpy(&a, pr.args, sizeof(a));
     const long long blocks = pr.blocks;
-    if (fout) {
-        if (int rc = fdn_func_max_lds((const void*)conv64_wino2d_kernel<true>, kW2Lds, "conv64_wino2d")) return rc;
-        hipLaunchKernelGGL((conv64_wino2d_kernel<true>), dim3((unsigned)blocks), dim3(256), kW2Lds, s, a);
-    } else {
-        if (int rc = fdn_func_max_lds((const void*)conv64_wino2d_kernel<false>, kW2Lds, "conv64_wino2d")) return rc;
-        hipLaunchKernelGGL((conv64_wino2d_kernel<false>), dim3((unsigned)blocks), dim3(256), kW2Lds, s, a);
+    const void* fn = fout ? (hm == 4 ? (const void*)conv64_wino2d_kernel<true, 4> : (const void*)conv64_wino2d_kernel<true, 2>)
+                          : (hm == 4 ? (const void*)conv64_wino2d_kernel<false, 4> : (const void*)conv64_wino2d_kernel<false, 2>);
+    int lds = kW2Lds;
+#ifdef FDN_TEST_HOOKS
+    if (fdn_conv64_wino2d_variant && !fout && hm == 2) {
+        switch (fdn_conv64_wino2d_variant) {
+            case 1: fn = (const void*)conv64_wino2d_occ1_kernel<6, 3, 1>; break;
+            case 2: fn = (const void*)conv64_wino2d_occ1_kernel<12, 6, 1>; break;
+            case 3: fn = (const void*)conv64_wino2d_occ1_kernel<12, 6, 3>; break;
+            case 4: fn = (const void*)conv64_wino2d_occ1_kernel<8, 4, 2>; break;
+            case 5: fn = (const void*)conv64_wino2d_occ1_kernel<24, 6, 3>; break;
+            default: FDN_REQUIRE(false, "conv64 (2-D winograd): unknown variant %d", fdn_conv64_wino2d_variant);
+        }
+        lds = kW2LdsOcc1;
     }
-    FDN_CHECK_LAUNCH("conv64_wino2d_kernel");
+#endif
+    if (int rc = fdn_func_max_lds(fn, lds, "conv64_wino2d")) return rc;
+    void* kargs[] = {(void*)&a};
+    const hipError_t e = hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(256), kargs, lds, s);
+    if (e != hipSuccess) {
+        fdn_set_error("conv64_wino2d_kernel: launch failed: %s", hipGetErrorString(e));
+        return FDN_ERR_HIP;
+    }
     return FDN_OK;
 }
 
 int fdn_pack_conv64_wino2d_launch(const float* w, float* uf, float* ud, hipStream_t s) {
-    hipLaunchKernelGGL(pack_conv64_wino2d_kernel, dim3((72 * 64 * 64 + 255) / 256), dim3(256), 0, s, w, uf, ud);
+    hipLaunchKernelGGL(pack_conv64_wino2d_kernel, dim3((180 * 64 * 64 + 255) / 256), dim3(256), 0, s, w, uf, ud);
     FDN_CHECK_LAUNCH("pack_conv64_wino2d_kernel");
     return FDN_OK;
 }
@@ -148,4 +179,5 @@ int fdn_pack_conv64_wino2d_launch(const float* w, float* uf, float* ud, hipStrea
 #ifdef FDN_TEST_HOOKS
 extern "C" int fdn_debug_set_conv64_wino2d_dbg(int bits) { fdn_conv64_wino2d_dbg = bits; return FDN_OK; }
 extern "C" int fdn_debug_set_conv64_wino2d_tile(int packed) { fdn_conv64_wino2d_tile = packed; return FDN_OK; }
+extern "C" int fdn_debug_set_conv64_wino2d_variant(int v) { fdn_conv64_wino2d_variant = v; return FDN_OK; }
 #endif

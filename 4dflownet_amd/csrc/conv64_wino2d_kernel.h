@@ -1,6 +1,6 @@
-// Device side of conv64_wino2d.hip (2-D Winograd F(2,3) along H x F(4,3) along W): argument struct, constants and the kernel body, shared
-// with conv64_wino.hip (conv64_wino2d_shell_kernel: the fused-dgrad launch = this body on the inner box + the 1-D body on the shell).
-// See conv64_wino2d.hip for the design notes.
+// Device side of conv64_wino2d.hip (2-D Winograd F(HM,3) along H x F(4,3) along W, HM = 2 or 4): argument struct, constants and the
+// kernel body, shared with conv64_wino.hip (conv64_wino2d_shell_kernel: the fused-dgrad launch = this body on the inner box + the 1-D
+// body on the shell).  See conv64_wino2d.hip for the design notes.
 #pragma once
 #include "fdn_common.h"
 #include "conv64_pack.h"
@@ -20,8 +20,9 @@ struct Wino2Args {
     int off, zero_mode, act;
     float alpha;
     int dbg;                // ablation bits (test build only): 1 = weight stream stride 0, 4 = no staging, 8 = no epilogue, 128 = no XCD remap
-    int obd, obh, obw, ebd, ebh, ebw;      // output box (h extent even, w extent a multiple of 4)
-    int td, ch, cw, ntd, nth, ntw;         // tile in (depth planes, cell rows, cell columns) and tile counts
+    int hm;                 // output rows per cell: 2 = F(2,3) along H, 4 = F(4,3) along H (selects the kernel instantiation; host side only)
+    int obd, obh, obw, ebd, ebh, ebw;      // output box (h extent a multiple of hm, w extent a multiple of 4)
+    int td, ch, cw, ntd, nth, ntw;         // tile in (depth planes, cell rows, cell columns) and tile counts; a cell = hm x 4 voxels (h, w)
     int cpp, rows, items;                  // cells per plane, staged rows = (td + 2) * cpp, rows * 16
     unsigned mg_cpp, mg_cw;
     unsigned mg_tpn_hi, mg_tpn_lo, mg_thw_hi, mg_thw_lo, mg_ntw_hi, mg_ntw_lo;
@@ -39,9 +40,15 @@ constexpr int kW2Dep = 1;                   // staging: items (12 x 16-B loads e
 constexpr unsigned kW2Big = 0x40000000u;    // "reads zero": any sum containing it is >= 2^30 > the sample's bytes
 
 // (a __device__ body + thin __global__ wrappers: conv64_wino.hip runs it as the head of the fused-dgrad launch that also carries the shell)
-template <bool FUSED>
+// RDB / RDA / DEP: weight-fragment ring, cell-fragment ring, staging items in flight per thread (the product values are the defaults;
+// the one-workgroup-per-CU occupancy experiment of conv64_wino2d.hip instantiates deeper ones)
+// HM: output rows per cell = the F(HM,3) transform along H (NS = HM + 2 sequential stages, Y = HM x 4 voxels per cell)
+template <bool FUSED, int HM = 2, int RDB = kW2RDB, int RDA = kW2RDA, int DEP = kW2Dep>
 __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int block_id, char* const smem) {
-    constexpr int RDB = kW2RDB, RDA = kW2RDA, UA = kW2UA, SPT = 24;
+    constexpr int UA = kW2UA, SPT = 24;
+    constexpr int NS = HM + 2;                                // stages = Winograd coordinates along H = input rows per cell
+    static_assert(HM == 2 || HM == 4, "F(2,3) or F(4,3) along H");
+    static_assert(HM == 2 || DEP == 1, "the F(4,3) staging holds one item in flight");
     static_assert(SPT % RDB == 0 && SPT % RDA == 0, "ring slots must be compile-time");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -63,7 +70,7 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
     const int tdi = fdn_udiv40(b, p.mg_thw_hi, p.mg_thw_lo);
     b -= tdi * (p.nth * p.ntw);
     const int thi = fdn_udiv40(b, p.mg_ntw_hi, p.mg_ntw_lo);
-    const int p0d = p.obd + tdi * p.td, p0h = p.obh + thi * p.ch * 2, p0w = p.obw + (b - thi * p.ntw) * p.cw * 4;
+    const int p0d = p.obd + tdi * p.td, p0h = p.obh + thi * p.ch * HM, p0w = p.obw + (b - thi * p.ntw) * p.cw * 4;
     const int ng = p.td * p.cpp;
 
     if (tid < 32) {
@@ -72,7 +79,7 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
             const int md = fdn_div20(tid, p.mg_cpp);
             const int j = tid - md * p.cpp;
             const int mh = fdn_div20(j, p.mg_cw);
-            const int pd = p0d + md, ph = p0h + 2 * mh, pw = p0w + 4 * (j - mh * p.cw);
+            const int pd = p0d + md, ph = p0h + HM * mh, pw = p0w + 4 * (j - mh * p.cw);
             if (pd < p.obd + p.ebd && ph < p.obh + p.ebh && pw < p.obw + p.ebw) {
                 g = ((n * p.OD + pd) * p.OH + ph) * p.OW + pw;
                 hw = ph | (pw << 16);
@@ -96,7 +103,7 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
 
     // ---- staging plan, once per tile, in LDS: per staged cell-plane r the byte offsets (from the sample's first voxel) of its 4 input
     // rows and 6 input columns with the boundary rule applied (kW2Big = reads zero: any sum containing it is out of the buffer's range).
-    // ptab[r] = {row 0..3, column 0..5, -, -} (48 B); a transform item adds its channel chunk.  Keeping the plan out of the register
+    // ptab[r] = {row 0..NS-1, column 0..5, ..} (48 B); a transform item adds its channel chunk.  Keeping the plan out of the register
     // file is what lets a thread hold two items' input rows in flight (24 x 16 B) beside the 64 output accumulators.
     unsigned* ptab = (unsigned*)(smem + 6 * kW2Plane + 96 * 4);
     if (tid < p.rows) {
@@ -104,13 +111,13 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
         const int zd = fdn_div20(r, p.mg_cpp);
         const int j = r - zd * p.cpp;
         const int mh = fdn_div20(j, p.mg_cw);
-        const int q0d = p0d - 1 + p.off, q0h = p0h - 1 + p.off + 2 * mh, q0w = p0w - 1 + p.off + 4 * (j - mh * p.cw);
+        const int q0d = p0d - 1 + p.off, q0h = p0h - 1 + p.off + HM * mh, q0w = p0w - 1 + p.off + 4 * (j - mh * p.cw);
         int qd = q0d + zd;
         bool okd = true;
         if (p.zero_mode) okd = (unsigned)qd < (unsigned)p.ID;
         else qd = min(max(qd, 0), p.ID - 1);
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
+        for (int jj = 0; jj < NS; ++jj) {
             int qh = q0h + jj;
             bool ok = okd;
             if (p.zero_mode) ok = ok && (unsigned)qh < (unsigned)p.IH;
@@ -123,7 +130,7 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
             bool ok = true;
             if (p.zero_mode) ok = (unsigned)qw < (unsigned)p.IW;
             else qw = min(max(qw, 0), p.IW - 1);
-            ptab[r * 12 + 4 + ii] = ok ? (unsigned)qw * 256u : kW2Big;
+            ptab[r * 12 + NS + ii] = ok ? (unsigned)qw * 256u : kW2Big;
         }
     }
     int vrow[UA], prow[UA];                                   // LDS offsets of the item's output row / plan row; chunk offset
@@ -140,9 +147,9 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.x + (size_t)n * p.ID * p.IH * p.IW * 64), 0, sample_bytes, 0x00020000);
 
-    // weight stream: unit (1024 B) index = ((nb*4 + xh)*3 + kd)*24 + xw*4 + g
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.up, 0, 72 * 64 * 64 * 4, 0x00020000);
-    const int wvoff = wave * (288 * 1024) + lane * 16;
+    // weight stream: unit (1024 B) index = ((nb*NS + xh)*3 + kd)*24 + xw*4 + g
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.up, 0, NS * 18 * 64 * 64 * 4, 0x00020000);
+    const int wvoff = wave * (NS * 72 * 1024) + lane * 16;
     const int bmul = (FDN_DBG_BITS(p) & 1) ? 0 : 1024;
     f32x4 A[RDA][2], B[RDB];
     auto ldb = [&](int slot, int xh, int kd, int j) {
@@ -154,9 +161,9 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
         A[slot][1] = *(const f32x4*)(smem + abase[1] + o);
     };
 
-    f32x4 Y[2][4][2];                                        // [output row][output column][M-block]: cout 16w + 4q .. + 3 of that voxel
+    f32x4 Y[HM][4][2];                                       // [output row][output column][M-block]: cout 16w + 4q .. + 3 of that voxel
 #pragma unroll
-    for (int hr = 0; hr < 2; ++hr)
+    for (int hr = 0; hr < HM; ++hr)
 #pragma unroll
         for (int wi = 0; wi < 4; ++wi)
 #pragma unroll
@@ -164,15 +171,27 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
 
     const int tapstep = p.cpp * kW2Row;
 
+    // B_w^T of F(4,3) on the six column chunks of one item, written as the six xw planes of the item's LDS row:
+    // rows (4,0,-5,0,1,0) (0,-4,-4,1,1,0) (0,4,-4,-1,1,0) (0,-2,-1,2,1,0) (0,2,-1,-2,1,0) (0,4,0,-5,0,1)
+    auto wtransform = [&](char* vp, const f32x4 x0, const f32x4 x1, const f32x4 x2, const f32x4 x3, const f32x4 x4, const f32x4 x5) {
+        const f32x4 t1 = x4 - 4.f * x2, t2 = x3 - 4.f * x1;
+        const f32x4 t3 = x4 - x2, t4 = 2.f * (x3 - x1);
+        *(f32x4*)(vp) = 4.f * x0 - 5.f * x2 + x4;
+        *(f32x4*)(vp + kW2Plane) = t1 + t2;
+        *(f32x4*)(vp + 2 * kW2Plane) = t1 - t2;
+        *(f32x4*)(vp + 3 * kW2Plane) = t3 + t4;
+        *(f32x4*)(vp + 4 * kW2Plane) = t3 - t4;
+        *(f32x4*)(vp + 5 * kW2Plane) = 4.f * x1 - 5.f * x3 + x5;
+    };
+
 #pragma unroll 1
-    for (int xh = 0; xh < 4; ++xh) {
+    for (int xh = 0; xh < NS; ++xh) {
         if (xh) __syncthreads();                             // everyone finished reading the previous stage's planes
-        // ---- stage xh: V = x[ra] + sgn * x[rb], rows (0,2,-) (1,2,+) (1,2,-) (1,3,-); then B_w^T; all 64 cin ----
-        {
+        // a wave whose 64 items of a pass all lie past the tile's last item requests nothing in that pass (640 items: waves 2, 3 of pass 2)
+        const int items_eff = ((FDN_DBG_BITS(p) & 4) ? 0 : p.items) - __builtin_amdgcn_readfirstlane(wave) * 64;
+        if constexpr (HM == 2) {
+            // ---- stage xh: V = x[ra] + sgn * x[rb], rows (0,2,-) (1,2,+) (1,2,-) (1,3,-); then B_w^T; all 64 cin ----
             const float sgn = xh == 1 ? 1.f : -1.f;
-            // a wave whose 64 items of a pass all lie past the tile's last item requests nothing in that pass (640 items: waves 2, 3 of pass 2)
-            const int items_eff = ((FDN_DBG_BITS(p) & 4) ? 0 : p.items) - __builtin_amdgcn_readfirstlane(wave) * 64;
-            constexpr int DEP = kW2Dep;                       // items in flight per thread
             f32x4 xa[DEP][6], xb[DEP][6];
             auto issue = [&](int u, int buf) {
                 const unsigned* pr = (const unsigned*)((const char*)ptab + prow[u]);
@@ -194,18 +213,50 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
                 if (u + DEP - 1 < UA && (u + DEP - 1) * 256 < items_eff) issue(u + DEP - 1, (u + DEP - 1) % DEP);
                 if (vrow[u] < 0) continue;
                 const int bf = u % DEP;
-                // B^T of F(4,3): rows (4,0,-5,0,1,0) (0,-4,-4,1,1,0) (0,4,-4,-1,1,0) (0,-2,-1,2,1,0) (0,2,-1,-2,1,0) (0,4,0,-5,0,1)
-                const f32x4 x0 = xa[bf][0] + sgn * xb[bf][0], x1 = xa[bf][1] + sgn * xb[bf][1], x2 = xa[bf][2] + sgn * xb[bf][2];
-                const f32x4 x3 = xa[bf][3] + sgn * xb[bf][3], x4 = xa[bf][4] + sgn * xb[bf][4], x5 = xa[bf][5] + sgn * xb[bf][5];
-                const f32x4 t1 = x4 - 4.f * x2, t2 = x3 - 4.f * x1;
-                const f32x4 t3 = x4 - x2, t4 = 2.f * (x3 - x1);
-                char* vp = smem + vrow[u];
-                *(f32x4*)(vp) = 4.f * x0 - 5.f * x2 + x4;
-                *(f32x4*)(vp + kW2Plane) = t1 + t2;
-                *(f32x4*)(vp + 2 * kW2Plane) = t1 - t2;
-                *(f32x4*)(vp + 3 * kW2Plane) = t3 + t4;
-                *(f32x4*)(vp + 4 * kW2Plane) = t3 - t4;
-                *(f32x4*)(vp + 5 * kW2Plane) = 4.f * x1 - 5.f * x3 + x5;
+                wtransform(smem + vrow[u], xa[bf][0] + sgn * xb[bf][0], xa[bf][1] + sgn * xb[bf][1], xa[bf][2] + sgn * xb[bf][2],
+                           xa[bf][3] + sgn * xb[bf][3], xa[bf][4] + sgn * xb[bf][4], xa[bf][5] + sgn * xb[bf][5]);
+            }
+        } else {
+            // ---- stage xh of F(4,3) along H: V = sum_j B_h^T[xh][j] x[row j] over the cell-plane's six input rows, B_h^T =
+            //   xh 0: ( 4, 0,-5, 0, 1, 0)    1: (0,-4,-4, 1, 1, 0)    2: (0, 4,-4,-1, 1, 0)
+            //   xh 3: ( 0,-2,-1, 2, 1, 0)    4: (0, 2,-1,-2, 1, 0)    5: (0, 4, 0,-5, 0, 1)
+            // three rows (stages 0, 5) or four; two rows (12 chunks) are in flight at a time, combined into V, then the next two
+            // (or the last one): the item's 18 / 24 chunks never sit in registers together (Y holds 128 of the wave's 256). ----
+            const bool ends = xh == 0 || xh == 5;            // scalar
+            const int ia = xh == 0 ? 0 : 1, ib = ends ? ia + 2 : 2, ic = ends ? ia + 4 : 3;
+            const float ca = ends ? 4.f : (xh == 1 ? -4.f : (xh == 2 ? 4.f : (xh == 3 ? -2.f : 2.f)));
+            const float cb = ends ? -5.f : (xh <= 2 ? -4.f : -1.f);
+            const float cc = ends ? 1.f : (xh == 1 ? 1.f : (xh == 2 ? -1.f : (xh == 3 ? 2.f : -2.f)));
+#pragma unroll
+            for (int u = 0; u < UA; ++u) {
+                if (u * 256 >= items_eff) break;
+                const unsigned* pr = (const unsigned*)((const char*)ptab + prow[u]);
+                const unsigned ha = pr[ia] + chunkb, hb = pr[ib] + chunkb, hc = pr[ic] + chunkb, hd = pr[4] + chunkb;
+                const unsigned wo[6] = {pr[6], pr[7], pr[8], pr[9], pr[10], pr[11]};
+                f32x4 xa[6], xb[6], v[6];
+#pragma unroll
+                for (int ii = 0; ii < 6; ++ii) {
+                    xa[ii] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ha + wo[ii], 0, 0));
+                    xb[ii] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, hb + wo[ii], 0, 0));
+                }
+#pragma unroll
+                for (int ii = 0; ii < 6; ++ii) v[ii] = ca * xa[ii] + cb * xb[ii];
+                if (ends) {
+#pragma unroll
+                    for (int ii = 0; ii < 6; ++ii) xa[ii] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, hc + wo[ii], 0, 0));
+#pragma unroll
+                    for (int ii = 0; ii < 6; ++ii) v[ii] += xa[ii];
+                } else {
+#pragma unroll
+                    for (int ii = 0; ii < 6; ++ii) {
+                        xa[ii] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, hc + wo[ii], 0, 0));
+                        xb[ii] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, hd + wo[ii], 0, 0));
+                    }
+#pragma unroll
+                    for (int ii = 0; ii < 6; ++ii) v[ii] += cc * xa[ii] + xb[ii];
+                }
+                if (vrow[u] < 0) continue;
+                wtransform(smem + vrow[u], v[0], v[1], v[2], v[3], v[4], v[5]);
             }
         }
         // the weight ring is primed per stage, behind the staging (its registers are free for the input rows meanwhile) and
@@ -253,10 +304,22 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
             }
         }
 
-        // ---- fold the stage: t = A_w^T M[xh] (A_w^T = (1,1,1,1,1,0) (0,1,-1,2,-2,0) (0,1,1,4,4,0) (0,1,-1,8,-8,1)), then the F(2,3)
-        // output transform A_h^T = (1,1,1,0) (0,1,-1,-1) as Y_h0 += c0 t, Y_h1 += c1 t ----
-        const float c0 = xh < 3 ? 1.f : 0.f;
-        const float c1 = xh == 0 ? 0.f : (xh == 1 ? 1.f : -1.f);
+        // ---- fold the stage: t = A_w^T M[xh] (A_w^T = (1,1,1,1,1,0) (0,1,-1,2,-2,0) (0,1,1,4,4,0) (0,1,-1,8,-8,1)), then the output
+        // transform along H as Y_hr += A_h^T[hr][xh] t: F(2,3) A_h^T = (1,1,1,0) (0,1,-1,-1) (coordinate 2 is staged negated, see the
+        // pack), F(4,3) A_h^T = A_w^T ----
+        float ch[HM];
+        if constexpr (HM == 2) {
+            ch[0] = xh < 3 ? 1.f : 0.f;
+            ch[1] = xh == 0 ? 0.f : (xh == 1 ? 1.f : -1.f);
+        } else {
+            const float sg = (xh & 1) ? 1.f : -1.f;          // coordinates 1, 3 = the points +1, +2; 2, 4 = -1, -2
+            const float m = xh <= 2 ? 1.f : 2.f;
+            const bool mid = xh >= 1 && xh <= 4;
+            ch[0] = xh < 5 ? 1.f : 0.f;
+            ch[1] = mid ? sg * m : 0.f;
+            ch[2] = mid ? m * m : 0.f;
+            ch[3] = mid ? sg * m * m * m : (xh == 5 ? 1.f : 0.f);
+        }
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
             const f32x4 s12 = acc[1][mb] + acc[2][mb], d12 = acc[1][mb] - acc[2][mb];
@@ -267,20 +330,23 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
             t[2] = s12 + 4.f * s34;
             t[3] = d12 + 8.f * d34 + acc[5][mb];
 #pragma unroll
-            for (int wi = 0; wi < 4; ++wi) {
-                Y[0][wi][mb] += c0 * t[wi];
-                Y[1][wi][mb] += c1 * t[wi];
-            }
+            for (int wi = 0; wi < 4; ++wi)
+#pragma unroll
+                for (int hr = 0; hr < HM; ++hr) Y[hr][wi][mb] += ch[hr] * t[wi];
         }
     }
 
     if (FDN_DBG_BITS(p) & 8) return;
-    // ---- epilogue: lane = cell c of each M-block x cout 16w + 4q .. + 3; 8 voxels per cell ----
+    // ---- epilogue: lane = cell c of each M-block x cout 16w + 4q .. + 3; HM x 4 voxels per cell ----
     const int cofs = wave * 16 + q * 4;
     const float slope = p.act == FDN_ACT_RELU ? 0.f : (p.act == FDN_ACT_LEAKY ? p.alpha : 1.f);
-    // Both M-blocks' operand loads (skip / y, or the residual) are requested before the first store: the stores of block 0 may alias
-    // the loads of block 1 as far as the compiler can tell (skip may BE the output), so left to itself it serialises two memory round
-    // trips at the end of every tile.  A lane reads exactly the addresses it writes, so hoisting the reads is safe.
+    // The outputs leave in GROUPS of HG rows of one M-block, and a group's operand loads (skip / y, or the residual) are requested one
+    // group ahead of the stores: the stores of group g may alias the loads of group g + 1 as far as the compiler can tell (skip may BE
+    // the output), so left to itself it serialises a memory round trip per group at the end of every tile.  A lane reads exactly the
+    // addresses it writes, so hoisting the reads is safe.  F(2,3): two groups = the two M-blocks, i.e. every load ahead of the first
+    // store; F(4,3): four groups of 2 rows (forward) or eight of one row (fused dgrad: two operands per voxel) -- what fits beside Y.
+    constexpr int HG = HM == 2 ? 2 : (FUSED ? 1 : 2);
+    constexpr int GPB = HM / HG, NG = 2 * GPB;                // groups per M-block, groups
     int g0[2];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) g0[mb] = mtab[mb * 16 + c];
@@ -289,66 +355,74 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
         // here (dz_prev = (dgrad + skip) * act'(y)); surface voxels go to the padded scratch for the border fold.  Branch-free per
         // voxel: a surface voxel (or a cell outside the box) reads row 0 of the tensor, which nobody writes in this launch, and
         // discards it; value and destination are selected afterwards.
-        int fi[2][2][4];                      // voxel index into skip / y / dz_prev, or -1 (surface voxel, cell outside the box)
-        f32x4 sk[2][2][4], ym[2][2][4];
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
+        int fi[2][HG][4];                     // voxel index into skip / y / dz_prev, or -1 (surface voxel, cell outside the box)
+        f32x4 sk[2][HG][4], ym[2][HG][4];
+        auto fload = [&](int g, int buf) {
+            const int mb = g / GPB, h0 = (g % GPB) * HG;
             const int gf0 = mtab[32 + mb * 16 + c];
             const int hw = mtab[64 + mb * 16 + c];
             const int ph = hw & 0xffff, pw = hw >> 16;                    // padded coordinates of the cell's first voxel
 #pragma unroll
-            for (int hr = 0; hr < 2; ++hr)
+            for (int hr = 0; hr < HG; ++hr)
 #pragma unroll
                 for (int wi = 0; wi < 4; ++wi) {
-                    const int ih = ph + hr - 1, iw = pw + wi - 1;
+                    const int ih = ph + h0 + hr - 1, iw = pw + wi - 1;
                     const bool in = g0[mb] >= 0 && gf0 >= 0 && ih >= 1 && ih <= p.IH - 2 && iw >= 1 && iw <= p.IW - 2;
-                    fi[mb][hr][wi] = in ? gf0 + hr * p.IW + wi : -1;
-                    const size_t o = (size_t)(in ? fi[mb][hr][wi] : 0) * 64 + cofs;
-                    sk[mb][hr][wi] = p.fskip ? *(const f32x4*)(p.fskip + o) : (f32x4){0.f, 0.f, 0.f, 0.f};
-                    ym[mb][hr][wi] = p.fy ? *(const f32x4*)(p.fy + o) : (f32x4){1.f, 1.f, 1.f, 1.f};
+                    fi[buf][hr][wi] = in ? gf0 + (h0 + hr) * p.IW + wi : -1;
+                    const size_t o = (size_t)(in ? fi[buf][hr][wi] : 0) * 64 + cofs;
+                    sk[buf][hr][wi] = p.fskip ? *(const f32x4*)(p.fskip + o) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    ym[buf][hr][wi] = p.fy ? *(const f32x4*)(p.fy + o) : (f32x4){1.f, 1.f, 1.f, 1.f};
                 }
-        }
+        };
+        auto fstore = [&](int g, int buf) {
+            const int mb = g / GPB, h0 = (g % GPB) * HG;
+            if (g0[mb] < 0) return;
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
-            if (g0[mb] < 0) continue;
-#pragma unroll
-            for (int hr = 0; hr < 2; ++hr)
+            for (int hr = 0; hr < HG; ++hr)
 #pragma unroll
                 for (int wi = 0; wi < 4; ++wi) {
-                    const f32x4 z = Y[hr][wi][mb];
-                    const bool in = fi[mb][hr][wi] >= 0;
+                    const f32x4 z = Y[h0 + hr][wi][mb];
+                    const bool in = fi[buf][hr][wi] >= 0;
                     f32x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = in ? (z[e] + sk[mb][hr][wi][e]) * (ym[mb][hr][wi][e] > 0.f ? 1.f : slope) : z[e];
-                    float* dst = in ? p.fout + (size_t)fi[mb][hr][wi] * 64 + cofs : p.y + (size_t)(g0[mb] + hr * p.OW + wi) * 64 + cofs;
+                    for (int e = 0; e < 4; ++e) v[e] = in ? (z[e] + sk[buf][hr][wi][e]) * (ym[buf][hr][wi][e] > 0.f ? 1.f : slope) : z[e];
+                    float* dst = in ? p.fout + (size_t)fi[buf][hr][wi] * 64 + cofs : p.y + (size_t)(g0[mb] + (h0 + hr) * p.OW + wi) * 64 + cofs;
                     *(f32x4*)dst = v;
                 }
+        };
+        fload(0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) fload(g + 1, (g + 1) & 1);
+            fstore(g, g & 1);
         }
     } else {
-        f32x4 rv[2][2][4];
-        if (p.res) {
+        f32x4 rv[2][HG][4];
+        auto rload = [&](int g, int buf) {
+            const int mb = g / GPB, h0 = (g % GPB) * HG;
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
+            for (int hr = 0; hr < HG; ++hr)
 #pragma unroll
-                for (int hr = 0; hr < 2; ++hr)
-#pragma unroll
-                    for (int wi = 0; wi < 4; ++wi)
-                        rv[mb][hr][wi] = *(const f32x4*)(p.res + (size_t)((g0[mb] >= 0 ? g0[mb] : 0) + hr * p.OW + wi) * 64 + cofs);
-        }
+                for (int wi = 0; wi < 4; ++wi)
+                    rv[buf][hr][wi] = *(const f32x4*)(p.res + (size_t)((g0[mb] >= 0 ? g0[mb] : 0) + (h0 + hr) * p.OW + wi) * 64 + cofs);
+        };
+        if (p.res) rload(0, 0);
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
         if (p.bias) bv = *(const f32x4*)(p.bias + cofs);
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
+        for (int g = 0; g < NG; ++g) {
+            if (p.res && g + 1 < NG) rload(g + 1, (g + 1) & 1);
+            const int mb = g / GPB, h0 = (g % GPB) * HG, buf = g & 1;
             if (g0[mb] < 0) continue;
 #pragma unroll
-            for (int hr = 0; hr < 2; ++hr)
+            for (int hr = 0; hr < HG; ++hr)
 #pragma unroll
                 for (int wi = 0; wi < 4; ++wi) {
-                    f32x4 v = Y[hr][wi][mb] + bv;
-                    if (p.res) v += rv[mb][hr][wi];
+                    f32x4 v = Y[h0 + hr][wi][mb] + bv;
+                    if (p.res) v += rv[buf][hr][wi];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], slope * v[e]);          // relu / leaky / none: slope in [0,1]
-                    *(f32x4*)(p.y + (size_t)(g0[mb] + hr * p.OW + wi) * 64 + cofs) = v;
+                    *(f32x4*)(p.y + (size_t)(g0[mb] + (h0 + hr) * p.OW + wi) * 64 + cofs) = v;
                 }
         }
     }

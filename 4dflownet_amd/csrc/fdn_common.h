@@ -190,18 +190,19 @@ int fdn_conv64_wino_launch(const float* x, const float* upack, const float* bias
                            float alpha, hipStream_t s);
 int fdn_pack_conv64_wino_launch(const float* w, float* uf, float* ud, hipStream_t s);
 // 2-D Winograd variant (conv64_wino2d.hip): F(2,3) along H x F(4,3) along W; one output box with all 27 taps
-bool fdn_conv64_wino2d_ok(int ebd, int ebh, int ebw, int ID, int IH, int IW);
+// (hm = output rows per cell: 2 = F(2,3) along H, stream at pack + 81*4096; 4 = F(4,3) along H, stream at pack + 153*4096)
+bool fdn_conv64_wino2d_ok(int ebd, int ebh, int ebw, int ID, int IH, int IW, int hm);
 // A planned, not yet launched 2-D launch (the kernel's argument block, opaque outside conv64_wino2d_kernel.h): fdn_conv64_wino_launch_boxes
 // takes one as `inner` and issues it together with its own regions as ONE launch (conv64_wino2d_shell_kernel: the fused dgrad).
 struct FdnWino2dPrepared { alignas(8) unsigned char args[320]; int blocks; int lds; };
 int fdn_conv64_wino2d_prepare(const float* x, const float* upack2, const float* bias, const float* residual, float* y,
                               const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
                               int OW, int obd, int obh, int obw, int ebd, int ebh, int ebw, int off, int zero_mode, int act,
-                              float alpha, FdnWino2dPrepared* out);
+                              float alpha, int hm, FdnWino2dPrepared* out);
 int fdn_conv64_wino2d_launch(const float* x, const float* upack2, const float* bias, const float* residual, float* y,
                              const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
                              int OW, int obd, int obh, int obw, int ebd, int ebh, int ebw, int off, int zero_mode, int act,
-                             float alpha, hipStream_t s);
+                             float alpha, int hm, hipStream_t s);
 int fdn_pack_conv64_wino2d_launch(const float* w, float* uf, float* ud, hipStream_t s);
 int fdn_fold_halo_border_launch(const float* s0, const float* s1, const float* s2, int nsrc, const float* skip,
                                 const float* yprev, int act, float alpha, float* out, int N, int D, int H, int W,

@@ -161,7 +161,7 @@ class FlowNetModel:
         """See __init__.  Takes effect from the next forward()."""
         if conv_algo is None:
             conv_algo = os.environ.get("FDN_CONV_ALGO", "auto")
-        names = {"auto": ops.ALGO_AUTO, "winograd": ops.ALGO_AUTO, "direct": ops.ALGO_DIRECT, "winograd_w": ops.ALGO_WINO_W}
+        names = {"auto": ops.ALGO_AUTO, "winograd": ops.ALGO_AUTO, "direct": ops.ALGO_DIRECT, "winograd_w": ops.ALGO_WINO_W, "winograd_h2": ops.ALGO_WINO_H2}
         per_layer = {}
         if isinstance(conv_algo, dict):
             per_layer, conv_algo = conv_algo, conv_algo.get("*", "auto")

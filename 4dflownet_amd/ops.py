@@ -9,9 +9,9 @@ from ._lib import FdnError, check
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 # FDN_ALGO_*: per-call algorithm of the 64->64 3x3x3 entry points (AUTO = Winograd along W when W % 4 == 0, DIRECT = never)
-ALGO_AUTO, ALGO_DIRECT, ALGO_WINO_W = 0, 1, 2
+ALGO_AUTO, ALGO_DIRECT, ALGO_WINO_W, ALGO_WINO_H2 = 0, 1, 2, 3
 LEAKY_ALPHA = 0.2
-CONV64_PACK_FLOATS = 153 * 64 * 64    # FDN_CONV64_PACK_FLOATS: direct stream (27 taps) + Winograd F(4,3) stream (54) + 2-D F(2,3)xF(4,3) stream (72)
+CONV64_PACK_FLOATS = 261 * 64 * 64    # FDN_CONV64_PACK_FLOATS: direct stream (27 taps) + Winograd F(4,3) stream (54) + 2-D F(2,3)xF(4,3) stream (72)
 
 
 def _p(t, name="tensor", allow_none=False):

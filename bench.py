@@ -89,13 +89,14 @@ class LaunchTimer:
             if not self.enabled:
                 return dgf(dz, *a, **k)
             N, D, H, W = shp(dz)
-            if dz.dtype != torch.float32 or "parts" in k:
+            if dz.dtype != torch.float32:
                 # bf16 mode: ONE launch covers the inner box and the shell (conv64_bf16.hip); priced as algorithmic work
                 return bracket("conv", N * D * H * W, N * D * H * W * FLOP_PER_VOXEL_CONV64, lambda: dgf(dz, *a, **k))
             # fp32: ONE launch (conv64_wino2d_shell_kernel): the inner box on the 2-D Winograd body, the shell faces behind it on the 1-D
-            # body -- executed FLOPs = both
-            return bracket("conv", N * D * H * W, executed_conv64_flop(N, D, H, W, dz.dtype, k.get("algo", 0)) + executed_shell_flop(N, D, H, W),
-                           lambda: dgf(dz, *a, **k))
+            # body -- executed FLOPs = both; a caller-issued part (network.overlap_shell) is priced as that part alone
+            parts = k.get("parts", 3)
+            ex = (executed_conv64_flop(N, D, H, W, dz.dtype, k.get("algo", 0)) if parts & 1 else 0.0) + (executed_shell_flop(N, D, H, W) if parts & 2 else 0.0)
+            return bracket("conv", N * D * H * W if parts & 1 else 0, ex, lambda: dgf(dz, *a, **k))
 
         def conv3d_wgrad(x, dz, K, Cin, Cout, *a, **k):
             if not self.enabled or (K, Cin, Cout) != (3, 64, 64):
@@ -124,14 +125,15 @@ class LaunchTimer:
 
 def executed_conv64_flop(N, D, H, W, dtype=None, algo=0):
     """FLOPs the matrix pipe executes for one 64->64 3x3x3 forward (or fused-dgrad inner box) over N x D x H x W voxels, by the kernel
-    FDN_ALGO_AUTO picks (conv64_mfma.hip: fdn_conv64_launch_ex): 2-D Winograd F(2,3)xF(4,3) = 9 of the 27 tap-equivalents per
-    voxel when H is even and W a multiple of 4, 1-D Winograd F(4,3) along W = 13.5 when only W qualifies, else all 27."""
+    FDN_ALGO_AUTO picks (conv64_mfma.hip: fdn_conv64_launch_ex): 2-D Winograd F(4,3)xF(4,3) = 3 x 36 / 16 = 6.75 of the 27
+    tap-equivalents per voxel when H and W are multiples of 4, F(2,3)xF(4,3) = 9 when H is only even (or FDN_ALGO_WINO_H2), 1-D
+    Winograd F(4,3) along W = 13.5 when only W qualifies (or FDN_ALGO_WINO_W), else all 27."""
     taps = 27.0
     if (dtype is None or dtype == torch.float32) and algo != 1:
         if W % 4 == 0:
             taps = 13.5
-            if H % 2 == 0 and algo == 0:
-                taps = 9.0
+            if H % 2 == 0 and algo in (0, 3):
+                taps = 6.75 if H % 4 == 0 and algo == 0 else 9.0
     return N * D * H * W * taps * 2.0 * 64 * 64
 
 
@@ -675,7 +677,7 @@ def main():
             "roofline": roofline_obj(timer, "conv", bf16, "%s (3x3x3 64->64 forward + fused-dgrad%s launches%s)"
                                      % (("conv64_bf16_kernel", "", "") if bf16 else
                                         ("conv64_wino2d", "", ": conv64_wino2d_kernel forward, conv64_wino2d_shell_kernel fused dgrad = inner box + shell faces in one "
-                                         "launch; 2-D Winograd F(2,3) along H x F(4,3) along W, the faces F(4,3) along W")), tr),
+                                         "launch; 2-D Winograd F(4,3) along H x F(4,3) along W, the faces F(4,3) along W")), tr),
             "roofline_wgrad": roofline_obj(timer, "wgrad", bf16, "%s (3x3x3 64->64 weight gradient + partial reduction%s)"
                                            % (("wgrad64_bf16_dma_kernel", "") if bf16 else ("wgrad64_wino_kernel", "; Winograd F(3,2) along D x F(3,4) along W")), tr),
             "train_step_tflops": args.steps * B * world / dt * 3.0 * fwd_flop / 1e12,

@@ -44,17 +44,23 @@ extern "C" {
 
 /* Algorithm selector of the 64->64 3x3x3 entry points (fdn_conv3d_fwd / _dgrad / _dgrad_fused[_part] / _wgrad; ignored by
  * every other (Cin,Cout,K)).  Per call, no global state.
- *   FDN_ALGO_AUTO   : the planner's choice.  Forward / dgrad: 2-D Winograd, F(2,3) along H x F(4,3) along W (a third of the
- *                     direct multiplies) when H is even and W a multiple of 4, else 1-D Winograd along W (F(4,3): half the
- *                     multiplies) when W is a multiple of 4, else direct.  wgrad: F(3,4) along W when W is a multiple of 4.
- *                     fp32 error a few 1e-7 of sum|x||w| instead of ~1e-7;
+ *   FDN_ALGO_AUTO   : the planner's choice.  Forward / dgrad: 2-D Winograd, F(4,3) along H x F(4,3) along W (a quarter of the
+ *                     direct multiplies) when H and W are multiples of 4, F(2,3) along H x F(4,3) along W (a third) when H is
+ *                     only even, else 1-D Winograd along W (F(4,3): half the multiplies) when W is a multiple of 4, else
+ *                     direct.  wgrad: F(3,4) along W when W is a multiple of 4 (+ F(3,2) along D when D is even).
+ *                     fp32 error up to ~1e-6 of sum|x||w| (F(4,3) x F(4,3)) instead of ~1e-7;
  *   FDN_ALGO_DIRECT : always the direct convolution (plain fp32 FMA chains over the 27 taps, no transform) -- for
  *                     parity-critical runs and for layers whose operands are too ill-conditioned for the transform;
- *   FDN_ALGO_WINO_W : Winograd along W only (the 1-D kernels), never the H transform. */
+ *   FDN_ALGO_WINO_W : Winograd along W only (the 1-D kernels), never the H transform;
+ *   FDN_ALGO_WINO_H2: like AUTO, but never more than F(2,3) along H (round 4's kernels; a third of the error of F(4,3) x F(4,3)). */
 #define FDN_ALGO_AUTO 0
 #define FDN_ALGO_DIRECT 1
 #define FDN_ALGO_WINO_W 2
+#define FDN_ALGO_WINO_H2 3
 
+/* Version of this header; fdn_version() returns the version the library was built from.  A caller must see the two equal:
+ * 140 -> 150 grew FDN_CONV64_PACK_FLOATS (a pack buffer sized by an older header is too small for this library). */
+#define FDN_VERSION 150
 int fdn_version(void);
 const char* fdn_last_error(void);
 
@@ -67,9 +73,10 @@ int fdn_input_features(const float* u, const float* v, const float* w, const flo
  * fdn_conv3d_fwd (wp_fwd) and fdn_conv3d_dgrad / fdn_conv3d_dgrad_fused (wp_dgrad: taps flipped,
  * Cin/Cout swapped).  Each output is FDN_CONV64_PACK_FLOATS floats: the direct-convolution stream
  * (27 taps), the Winograd F(4,3)-along-W stream U = G g (9 (kd,kh) taps x 6 transform coordinates)
- * and the 2-D stream U = Gh g Gw^T (3 kd taps x 4 x 6 coordinates); the conv entry points select
- * among them by the extents (see FDN_ALGO_*).  Either output may be NULL. */
-#define FDN_CONV64_PACK_FLOATS (153 * 64 * 64)
+ * and the two 2-D streams U = Gh g Gw^T (3 kd taps x 4 x 6 coordinates for F(2,3) along H, 3 x 6 x 6
+ * for F(4,3) along H); the conv entry points select among them by the extents (see FDN_ALGO_*).
+ * Either output may be NULL. */
+#define FDN_CONV64_PACK_FLOATS (261 * 64 * 64)
 int fdn_pack_conv64_weights(const float* w, float* wp_fwd, float* wp_dgrad, void* stream);
 /* The same for n_layers kernels in ONE launch (after every optimizer step): layer i lives at
  * w_base + w_offsets[i] (w_offsets: DEVICE array of n_layers float offsets), its two streams at

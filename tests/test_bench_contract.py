@@ -94,24 +94,27 @@ def test_bench_frac_agrees_with_the_pmc_busy_counter():
 
 
 def test_executed_flop_pricing_follows_the_kernel_the_planner_picks():
-    """bench.py prices `achieved` / `frac` with the multiplies the selected kernel EXECUTES (include/fdn.h, FDN_ALGO_*): 9 of 27
-    tap-equivalents per voxel for the 2-D Winograd conv kernel (H even, W % 4 == 0), 13.5 for W-only Winograd, 27 direct; the
-    shell launch of a fused dgrad: 4.5 per d/h-face position, 9 per w-face position."""
+    """bench.py prices `achieved` / `frac` with the multiplies the selected kernel EXECUTES (include/fdn.h, FDN_ALGO_*): 6.75 of 27
+    tap-equivalents per voxel for the 2-D Winograd conv kernel with F(4,3) along H (H % 4 == 0, W % 4 == 0), 9 with F(2,3) along H
+    (H even, or FDN_ALGO_WINO_H2), 13.5 for W-only Winograd, 27 direct; the shell launch of a fused dgrad: 4.5 per d/h-face position,
+    9 per w-face position."""
     b = _bench()
     per_tap = 2.0 * 64 * 64
     vox = 8 * 48 ** 3
-    assert b.executed_conv64_flop(8, 48, 48, 48) == vox * 9 * per_tap
+    assert b.executed_conv64_flop(8, 48, 48, 48) == vox * 6.75 * per_tap
+    assert b.executed_conv64_flop(8, 48, 48, 48, algo=3) == vox * 9 * per_tap             # FDN_ALGO_WINO_H2
+    assert b.executed_conv64_flop(1, 5, 10, 12) == 5 * 10 * 12 * 9 * per_tap                # H even, not a multiple of 4
     assert b.executed_conv64_flop(8, 48, 48, 48, algo=2) == vox * 13.5 * per_tap          # FDN_ALGO_WINO_W
     assert b.executed_conv64_flop(8, 48, 48, 48, algo=1) == vox * 27 * per_tap            # FDN_ALGO_DIRECT
     assert b.executed_conv64_flop(1, 5, 7, 12) == 5 * 7 * 12 * 13.5 * per_tap               # odd H: 1-D kernel
     assert b.executed_conv64_flop(1, 5, 7, 9) == 5 * 7 * 9 * 27 * per_tap                   # W % 4 != 0: direct
-    assert abs(b.executed_conv64_flop(8, 48, 48, 48) / (vox * b.FLOP_PER_VOXEL_CONV64) - 1.0 / 3) < 1e-12
+    assert abs(b.executed_conv64_flop(8, 48, 48, 48) / (vox * b.FLOP_PER_VOXEL_CONV64) - 0.25) < 1e-12
     D = H = W = 24
     shell = b.executed_shell_flop(8, D, H, W)
     assert shell == 8 * ((2 * (H + 2) * W + 2 * D * W) * 4.5 + 2 * (D + 2) * (H + 2) * 9.0) * per_tap
-    # the shell against the inner box's executed work: 18 % at 24^3, 9 % at 48^3
-    assert 0.17 < shell / b.executed_conv64_flop(8, D, H, W) < 0.20
-    assert 0.08 < b.executed_shell_flop(8, 48, 48, 48) / b.executed_conv64_flop(8, 48, 48, 48) < 0.10
+    # the shell against the inner box's executed work: 24 % at 24^3, 12 % at 48^3
+    assert 0.22 < shell / b.executed_conv64_flop(8, D, H, W) < 0.26
+    assert 0.11 < b.executed_shell_flop(8, 48, 48, 48) / b.executed_conv64_flop(8, 48, 48, 48) < 0.13
 
 
 def test_secondary_watchdog_prints_the_headline_and_leaves():

@@ -77,12 +77,15 @@ def test_conv64_fwd(ops, fdn, shape, mt):
 
 # H even and W a multiple of 4 -> FDN_ALGO_AUTO takes the 2-D Winograd kernel (F(2,3) along H x F(4,3) along W, conv64_wino2d.hip).
 # Shapes: one partial tile, ragged tile grids in d / h / w, the smallest grid (1,2,4), H = 2, a multi-tile launch at the cfg2 low-res grid.
-WINO2D_SHAPES = [(1, 5, 8, 12), (3, 4, 4, 4), (2, 9, 2, 24), (1, 1, 2, 4), (1, 17, 10, 8), (2, 24, 24, 24), (1, 3, 6, 20), (1, 11, 14, 28)]
+# H a multiple of 4 as well -> F(4,3) along H (round 5; cells of 4 x 4 voxels): (1,5,8,12), (3,4,4,4), (2,24,24,24), a single cell (1,1,4,4),
+# ragged cell-row / cell-column tile grids (1,7,12,20), (1,19,20,12), (2,3,28,4).
+WINO2D_SHAPES = [(1, 5, 8, 12), (3, 4, 4, 4), (2, 9, 2, 24), (1, 1, 2, 4), (1, 17, 10, 8), (2, 24, 24, 24), (1, 3, 6, 20), (1, 11, 14, 28),
+                 (1, 1, 4, 4), (1, 7, 12, 20), (1, 19, 20, 12), (2, 3, 28, 4)]
 
 
 @pytest.mark.parametrize("shape,tile", [(sh, 0) for sh in WINO2D_SHAPES] +
                          [((2, 24, 24, 24), t) for t in (8 | 1 << 8 | 4 << 16, 8 | 4 << 8 | 1 << 16, 16 | 2 << 8 | 1 << 16, 5 | 2 << 8 | 2 << 16, 32 | 1 << 8 | 1 << 16)] +
-                         [((1, 17, 10, 8), 3 | 1 << 8 | 2 << 16)])
+                         [((1, 17, 10, 8), 3 | 1 << 8 | 2 << 16), ((1, 19, 20, 12), 3 | 2 << 8 | 1 << 16), ((1, 19, 20, 12), 30 | 1 << 8 | 1 << 16)])
 def test_conv64_fwd_wino2d(ops, fdn, shape, tile):
     """2-D Winograd forward == oracle, with every epilogue variant; == the 1-D Winograd and direct kernels to fp32 rounding.
     tile != 0: a forced (td, ch, cw) tile through the test build (tiles the planner would not pick at this size)."""
@@ -102,7 +105,7 @@ def test_conv64_fwd_wino2d(ops, fdn, shape, tile):
                 got = ops.conv3d_fwd(dev(x), dev(w), None if bias is None else dev(bias), act, 0.2,
                                      None if r is None else dev(r), algo=ops.ALGO_AUTO)
                 close(got, ref, name="conv64 fwd 2-D winograd act=%d" % act)
-                for algo in (ops.ALGO_WINO_W, ops.ALGO_DIRECT):
+                for algo in (ops.ALGO_WINO_H2, ops.ALGO_WINO_W, ops.ALGO_DIRECT):
                     other = ops.conv3d_fwd(dev(x), dev(w), None if bias is None else dev(bias), act, 0.2,
                                            None if r is None else dev(r), algo=algo)
                     close(got, other.cpu().numpy(), name="2-D winograd vs algo %d" % algo)
@@ -173,6 +176,11 @@ def test_conv64_dgrad_fused_fold(ops, fdn, shape, layout):
             ops.conv3d_dgrad_fused(dev(dz), wd, pad, out, skip=dev(skip), y_prev=dev(y), act=O.ACT_LEAKY)
             ops.fold_halo_border([pad], out, dev(skip), dev(y), O.ACT_LEAKY)
             close(out, O.act_bwd_from_output(dx + skip, y, O.ACT_LEAKY), name="fused dgrad+border")
+            if layout == 0 and H % 4 == 0 and W % 4 == 0:    # FDN_ALGO_AUTO ran F(4,3) along H: the F(2,3)-along-H inner box (round 4) beside it
+                pad.fill_(float("nan")); out.fill_(float("nan"))
+                ops.conv3d_dgrad_fused(dev(dz), wd, pad, out, skip=dev(skip), y_prev=dev(y), act=O.ACT_LEAKY, algo=ops.ALGO_WINO_H2)
+                ops.fold_halo_border([pad], out, dev(skip), dev(y), O.ACT_LEAKY)
+                close(out, O.act_bwd_from_output(dx + skip, y, O.ACT_LEAKY), name="fused dgrad+border, F(2,3) along H")
             # fan-in of three consumers chained through the output buffer (skip aliases out), mask on the last
             acc = torch.full((N, D, H, W, 64), float("nan"), device="cuda")
             pads = [torch.empty_like(pad) for _ in range(3)]
@@ -188,8 +196,9 @@ def test_conv64_dgrad_fused_fold(ops, fdn, shape, layout):
                 lib.fdn_debug_set_conv64_wface_direct(0)
 
 
-@pytest.mark.parametrize("shape", [(1, 5, 8, 12), (2, 9, 2, 24), (1, 1, 2, 4), (3, 24, 24, 24), (1, 11, 14, 28)])
-def test_conv64_dgrad_fused_one_launch_equals_two(ops, fdn, shape):
+@pytest.mark.parametrize("shape,algo", [(sh, 0) for sh in [(1, 5, 8, 12), (2, 9, 2, 24), (1, 1, 2, 4), (3, 24, 24, 24), (1, 11, 14, 28), (1, 7, 12, 20), (1, 1, 4, 4)]] +
+                         [(sh, 3) for sh in [(1, 5, 8, 12), (3, 24, 24, 24)]])       # algo 3 = FDN_ALGO_WINO_H2 where AUTO takes F(4,3) along H
+def test_conv64_dgrad_fused_one_launch_equals_two(ops, fdn, shape, algo):
     """The fused dgrad of the 2-D Winograd path is ONE launch (conv64_wino2d_shell_kernel: inner box on the 2-D body, shell faces behind
     it on the 1-D body).  It must be bit-identical to the same two bodies as two launches (test-build switch), and to the two `parts` a
     caller may issue on its own (network.overlap_shell)."""
@@ -205,10 +214,10 @@ def test_conv64_dgrad_fused_one_launch_equals_two(ops, fdn, shape):
         pad = torch.full((N, D + 2, H + 2, W + 2, 64), float("nan"), device="cuda")
         out = torch.full((N, D, H, W, 64), float("nan"), device="cuda")
         if kw.get("two_parts"):
-            ops.conv3d_dgrad_fused(dz, wd, pad, out, skip=skip, y_prev=y, act=O.ACT_LEAKY, parts=ops.DGRAD_SHELL)
-            ops.conv3d_dgrad_fused(dz, wd, pad, out, skip=skip, y_prev=y, act=O.ACT_LEAKY, parts=ops.DGRAD_INNER)
+            ops.conv3d_dgrad_fused(dz, wd, pad, out, skip=skip, y_prev=y, act=O.ACT_LEAKY, parts=ops.DGRAD_SHELL, algo=algo)
+            ops.conv3d_dgrad_fused(dz, wd, pad, out, skip=skip, y_prev=y, act=O.ACT_LEAKY, parts=ops.DGRAD_INNER, algo=algo)
         else:
-            ops.conv3d_dgrad_fused(dz, wd, pad, out, skip=skip, y_prev=y, act=O.ACT_LEAKY)
+            ops.conv3d_dgrad_fused(dz, wd, pad, out, skip=skip, y_prev=y, act=O.ACT_LEAKY, algo=algo)
         return pad.clone(), out.clone()          # (before the border fold: the raw products of the launch(es))
     pad1, out1 = run()
     pad2, out2 = run(two_parts=True)
@@ -446,22 +455,28 @@ def test_winograd_kernels_equal_direct_kernels_on_random_shapes(ops, fdn):
         xg = torch.randn((N, D, H, Wg, 64), device="cuda", generator=g)
         dzg = torch.randn((N, D, H, Wg, 64), device="cuda", generator=g)
 
-        def run():
-            y = ops.conv3d_fwd(x, w, b, ops.ACT_LEAKY, 0.2, res, wpack=wf)
+        def run(algo=ops.ALGO_AUTO):
+            y = ops.conv3d_fwd(x, w, b, ops.ACT_LEAKY, 0.2, res, wpack=wf, algo=algo)
             pad = torch.zeros((N, D + 2, H + 2, W + 2, 64), device="cuda")
             out = torch.zeros_like(x)
-            ops.conv3d_dgrad_fused(dz, wd, pad, out, skip=res, y_prev=yfix, act=ops.ACT_LEAKY)
+            ops.conv3d_dgrad_fused(dz, wd, pad, out, skip=res, y_prev=yfix, act=ops.ACT_LEAKY, algo=algo)
             ops.fold_halo_border([pad], out, res, yfix, ops.ACT_LEAKY)
-            dw, _ = ops.conv3d_wgrad(xg, dzg, 3, 64, 64)
+            dw, _ = ops.conv3d_wgrad(xg, dzg, 3, 64, 64, algo=algo)
             return y, out, dw
 
         got = run()
+        got_h2 = run(ops.ALGO_WINO_H2)
         with fdn._lib.test_build() as lib:
             lib.fdn_debug_set_conv64_mt(5); lib.fdn_debug_set_wgrad64_direct(1)
             try:
                 ref = run()
             finally:
                 lib.fdn_debug_set_conv64_mt(0); lib.fdn_debug_set_wgrad64_direct(0)
-        for name, a, r in zip(("fwd", "dgrad", "wgrad"), got, ref):
-            err = (a - r).abs().max().item() / max(r.abs().max().item(), 1e-30)
-            assert err <= 1e-5, (name, (N, D, H, W, Wg), err)
+        # max error over max |reference|: F(2,3) along H keeps round 4's bound; F(4,3) x F(4,3) (H a multiple of 4) has transform
+        # entries up to 8 x 8 instead of 1 x 8 and measures up to 1.1e-5 on these operands (2.5e-5 allowed: 40x inside north_star's 1e-3)
+        hm4 = H % 4 == 0
+        for name, a, a2, r in zip(("fwd", "dgrad", "wgrad"), got, got_h2, ref):
+            scale = max(r.abs().max().item(), 1e-30)
+            err, err2 = (a - r).abs().max().item() / scale, (a2 - r).abs().max().item() / scale
+            assert err2 <= 1e-5, (name, "F(2,3) along H", (N, D, H, W, Wg), err2)
+            assert err <= (2.5e-5 if hm4 and name != "wgrad" else 1e-5), (name, "auto", (N, D, H, W, Wg), err)

@@ -36,25 +36,25 @@ def main():
         res = torch.randn(N, P, P, P, 64, device="cuda", generator=g)
         out = torch.empty_like(x)
         flop = 2.0 * 27 * 64 * 64 * N * P ** 3
-        for name, algo in (("2-D F(2,3)xF(4,3)", ops.ALGO_AUTO), ("1-D F(4,3)", ops.ALGO_WINO_W), ("direct", ops.ALGO_DIRECT)):
+        for name, algo in (("2-D F(4,3)xF(4,3)", ops.ALGO_AUTO), ("2-D F(2,3)xF(4,3)", ops.ALGO_WINO_H2), ("1-D F(4,3)", ops.ALGO_WINO_W), ("direct", ops.ALGO_DIRECT)):
             t = timeit(lambda: ops.conv3d_fwd(x, w, None, ops.ACT_RELU, wpack=wp, out=out, algo=algo))
             t2 = timeit(lambda: ops.conv3d_fwd(x, w, None, ops.ACT_LEAKY, residual=res, wpack=wp, out=out, algo=algo))
             print("fwd %-20s N=%d P=%d : %.3f ms (%.1f TF algorithmic)   +res+leaky %.3f ms" % (name, N, P, t, flop / t / 1e9, t2), flush=True)
         pad = torch.empty(N, P + 2, P + 2, P + 2, 64, device="cuda")
         dxo = torch.empty_like(x)
-        for name, algo in (("2-D inner + 1-D shell, one launch", ops.ALGO_AUTO), ("1-D F(4,3), one launch", ops.ALGO_WINO_W)):
+        for name, algo in (("F(4,3)^2 inner + 1-D shell", ops.ALGO_AUTO), ("F(2,3)xF(4,3) inner + 1-D shell", ops.ALGO_WINO_H2), ("1-D F(4,3), one launch", ops.ALGO_WINO_W)):
             t = timeit(lambda: (ops.conv3d_dgrad_fused(x, wd, pad, dxo, skip=res, y_prev=out, act=ops.ACT_LEAKY, algo=algo),
                                 ops.fold_halo_border([pad], dxo, res, out, ops.ACT_LEAKY)))
             ti = timeit(lambda: ops.conv3d_dgrad_fused(x, wd, pad, dxo, skip=res, y_prev=out, act=ops.ACT_LEAKY, parts=1, algo=algo))
             ts = timeit(lambda: ops.conv3d_dgrad_fused(x, wd, pad, dxo, skip=res, y_prev=out, act=ops.ACT_LEAKY, parts=2, algo=algo))
             t2l = None
-            if algo == ops.ALGO_AUTO:                      # the same with inner box and shell as two launches (until round 4's last change)
+            if algo == ops.ALGO_AUTO and "--split" in sys.argv:     # the same with inner box and shell as two launches (until round 4's last change)
                 with fdn._lib.test_build() as tlib:
                     tlib.fdn_debug_set_conv64_split_dgrad(1)
                     t2l = timeit(lambda: (ops.conv3d_dgrad_fused(x, wd, pad, dxo, skip=res, y_prev=out, act=ops.ACT_LEAKY, algo=algo),
                                           ops.fold_halo_border([pad], dxo, res, out, ops.ACT_LEAKY)))
                     tlib.fdn_debug_set_conv64_split_dgrad(0)
-            print("dgrad fused+border %-24s N=%d P=%d : %.3f ms   (inner box alone %.3f, shell alone %.3f%s)"
+            print("dgrad fused+border %-32s N=%d P=%d : %.3f ms   (inner box alone %.3f, shell alone %.3f%s)"
                   % (name, N, P, t, ti, ts, "" if t2l is None else "; as two launches %.3f" % t2l), flush=True)
         for name, algo in (("F(3,2)_D x F(3,4)_W", ops.ALGO_AUTO), ("F(3,4)_W", ops.ALGO_WINO_W), ("direct", ops.ALGO_DIRECT)):
             ws = torch.empty(ops.wgrad_workspace_bytes(N, P, P, P, 64, 64, 3) // 4 + 1, device="cuda")
