@@ -101,8 +101,12 @@ __device__ __forceinline__ void fdn_pack_wino2d_one(const float* __restrict__ w,
     }
 }
 
-// 2-D Winograd stream with F(4,3) along H as well (conv64_wino2d.hip, HM = 4): U = G g G^T over the (kh, kw) taps, per depth tap kd, with
-// the G of F(4,3) above on both sides (no sign games: the kernel forms the input coordinates with B^T's own coefficients).
+// 2-D Winograd stream with F(4,3) along H as well (conv64_wino2d.hip, HM = 4): U = G g G^T over the (kh, kw) taps, per depth tap kd, G of
+// F(4,3) on the points 0, +-3/4, +-3/2, inf (conv64_wino2d_kernel.h; G[k][j] = p_k^j / prod_{l != k} (p_k - p_l)):
+//   (64/81, 0, 0) (-128/243, -+32/81, -8/27) (32/243, +-16/81, 8/27) (0, 0, 1)
+// The entries are not fp32 numbers, so the stream is formed in double precision and rounded ONCE: U's rounding is the one error of the
+// algorithm that is the same for every voxel (a fixed perturbation of the layer's kernel), and it should be half an ulp, not the three
+// or four of an fp32 fma chain over rounded constants.
 // layout [nb = cout/16][xh 0..5][kd][xw 0..5][g = cin/16][q][i][s], the 1-KB unit as in fdn_pack_wino2d_one; 108 * 64 * 64 floats.
 __device__ __forceinline__ void fdn_pack_wino44_one(const float* __restrict__ w, float* __restrict__ uf, float* __restrict__ ud, int idx) {
     const int s = idx & 3;
@@ -116,28 +120,22 @@ __device__ __forceinline__ void fdn_pack_wino44_one(const float* __restrict__ w,
     const int nb = rest / 6;
     const int k = 16 * g + 4 * q + s;
     const int cj = 16 * nb + i;
-    const float G[6][3] = {{0.25f, 0.f, 0.f}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
-                           {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
+    const double G[6][3] = {{64.0 / 81, 0.0, 0.0}, {-128.0 / 243, -32.0 / 81, -8.0 / 27}, {-128.0 / 243, 32.0 / 81, -8.0 / 27},
+                            {32.0 / 243, 16.0 / 81, 8.0 / 27}, {32.0 / 243, -16.0 / 81, 8.0 / 27}, {0.0, 0.0, 1.0}};
     if (uf) {
-        float v = 0.f;
+        double v = 0.0;
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            float r = 0.f;
+        for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) r = __builtin_fmaf(G[xw][t], w[(((kd * 3 + kh) * 3 + t) * 64 + k) * 64 + cj], r);
-            v = __builtin_fmaf(G[xh][kh], r, v);
-        }
-        uf[idx] = v;
+            for (int t = 0; t < 3; ++t) v += G[xh][kh] * G[xw][t] * (double)w[(((kd * 3 + kh) * 3 + t) * 64 + k) * 64 + cj];
+        uf[idx] = (float)v;
     }
     if (ud) {
-        float v = 0.f;
+        double v = 0.0;
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            float r = 0.f;
+        for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) r = __builtin_fmaf(G[xw][t], w[((26 - ((kd * 3 + kh) * 3 + t)) * 64 + cj) * 64 + k], r);
-            v = __builtin_fmaf(G[xh][kh], r, v);
-        }
-        ud[idx] = v;
+            for (int t = 0; t < 3; ++t) v += G[xh][kh] * G[xw][t] * (double)w[((26 - ((kd * 3 + kh) * 3 + t)) * 64 + cj) * 64 + k];
+        ud[idx] = (float)v;
     }
 }

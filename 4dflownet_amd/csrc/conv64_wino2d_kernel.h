@@ -37,6 +37,12 @@ constexpr int kW2UA = 3;                    // transform items per thread (<= 64
 constexpr int kW2RDB = 6;                   // weight-fragment ring depth
 constexpr int kW2RDA = 3;                   // cell-fragment ring depth
 constexpr int kW2Dep = 1;                   // staging: items (12 x 16-B loads each) in flight per thread
+// F(4,3) x F(4,3) (HM = 4) uses the interpolation points 0, +-3/4, +-3/2, inf instead of Lavin & Gray's 0, +-1, +-2, inf: the same even / odd
+// structure (b = 2a), every constant exact in fp32, and a quarter of the fp32 error (transform entries up to 3.4 instead of 8; measured
+// e_cond 3e-7 vs 1.3e-6 on dz-like operands -- level with F(2,3) x F(4,3) on the classic points).  a = 3/4, b = 3/2:
+constexpr float kPa = 0.75f, kPb = 1.5f, kPa2 = 0.5625f, kPb2 = 2.25f, kPa3 = 0.421875f, kPb3 = 3.375f;
+constexpr float kPab2 = 1.6875f, kPa2b = 0.84375f;           // a b^2, a^2 b
+constexpr float kPs = 2.8125f, kPp = 1.265625f;              // a^2 + b^2, a^2 b^2
 constexpr unsigned kW2Big = 0x40000000u;    // "reads zero": any sum containing it is >= 2^30 > the sample's bytes
 
 // (a __device__ body + thin __global__ wrappers: conv64_wino.hip runs it as the head of the fused-dgrad launch that also carries the shell)
@@ -133,15 +139,24 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
             ptab[r * 12 + NS + ii] = ok ? (unsigned)qw * 256u : kW2Big;
         }
     }
-    int vrow[UA], prow[UA];                                   // LDS offsets of the item's output row / plan row; chunk offset
+    // LDS offsets of item u's output row (-1: past the tile's rows) / plan row; chunk offset.  F(2,3): held in registers; F(4,3): Y takes
+    // 128 of the 256 registers, so the six values are recomputed at every stage (a dozen VALU per stage) instead of living through the K loops
+    // (F(4,3): the thread id is re-derived from the scalar wave id and mbcnt where it is needed late -- staging items, epilogue -- so that
+    // neither it nor the lane's cell / quarter indices occupy registers through the K loops; hipcc spilled exactly those three)
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    auto tid_now = [&]() { return HM == 2 ? tid : wave_s * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); };
+    auto item_vrow = [&](int u) { const int i = u * 256 + tid_now(), r = i >> 4; return r < p.rows ? r * kW2Row + (i & 15) * 16 : -1; };
+    auto item_prow = [&](int u) { const int r = (u * 256 + tid_now()) >> 4; return (r < p.rows ? r : 0) * 48; };
+    int vrow[HM == 2 ? UA : 1], prow[HM == 2 ? UA : 1];
+    if constexpr (HM == 2) {
 #pragma unroll
-    for (int u = 0; u < UA; ++u) {
-        const int i = u * 256 + tid;
-        const int r = i >> 4;
-        vrow[u] = r < p.rows ? r * kW2Row + (i & 15) * 16 : -1;
-        prow[u] = (r < p.rows ? r : 0) * 48;
+        for (int u = 0; u < UA; ++u) {
+            vrow[u] = item_vrow(u);
+            prow[u] = item_prow(u);
+        }
     }
-    const unsigned chunkb = (unsigned)(tid & 15) * 16u;
+    const unsigned chunkb_held = (unsigned)(tid & 15) * 16u;
+    auto chunkb_now = [&]() { return HM == 2 ? chunkb_held : (unsigned)(tid_now() & 15) * 16u; };
     __syncthreads();                                          // mtab + ptab visible
     const unsigned sample_bytes = (unsigned)(p.ID * p.IH * p.IW) * 256u;
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -171,17 +186,28 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
 
     const int tapstep = p.cpp * kW2Row;
 
-    // B_w^T of F(4,3) on the six column chunks of one item, written as the six xw planes of the item's LDS row:
-    // rows (4,0,-5,0,1,0) (0,-4,-4,1,1,0) (0,4,-4,-1,1,0) (0,-2,-1,2,1,0) (0,2,-1,-2,1,0) (0,4,0,-5,0,1)
+    // B_w^T of F(4,3) on the six column chunks of one item, written as the six xw planes of the item's LDS row.  Points 0, +-a, +-b, inf:
+    //   rows (a2b2, 0, -(a2+b2), 0, 1, 0)  (0, -+a b2, -b2, +-a, 1, 0)  (0, -+a2 b, -a2, +-b, 1, 0)  (0, a2b2, 0, -(a2+b2), 0, 1)
+    // HM = 2: a = 1, b = 2 -- (4,0,-5,0,1,0) (0,-4,-4,1,1,0) (0,4,-4,-1,1,0) (0,-2,-1,2,1,0) (0,2,-1,-2,1,0) (0,4,0,-5,0,1); HM = 4: a = 3/4, b = 3/2
     auto wtransform = [&](char* vp, const f32x4 x0, const f32x4 x1, const f32x4 x2, const f32x4 x3, const f32x4 x4, const f32x4 x5) {
-        const f32x4 t1 = x4 - 4.f * x2, t2 = x3 - 4.f * x1;
-        const f32x4 t3 = x4 - x2, t4 = 2.f * (x3 - x1);
-        *(f32x4*)(vp) = 4.f * x0 - 5.f * x2 + x4;
+        f32x4 t1, t2, t3, t4, o0, o5;
+        if constexpr (HM == 2) {
+            t1 = x4 - 4.f * x2; t2 = x3 - 4.f * x1;
+            t3 = x4 - x2; t4 = 2.f * (x3 - x1);
+            o0 = 4.f * x0 - 5.f * x2 + x4;
+            o5 = 4.f * x1 - 5.f * x3 + x5;
+        } else {
+            t1 = x4 - kPb2 * x2; t2 = kPa * x3 - kPab2 * x1;
+            t3 = x4 - kPa2 * x2; t4 = kPb * x3 - kPa2b * x1;
+            o0 = kPp * x0 - kPs * x2 + x4;
+            o5 = kPp * x1 - kPs * x3 + x5;
+        }
+        *(f32x4*)(vp) = o0;
         *(f32x4*)(vp + kW2Plane) = t1 + t2;
         *(f32x4*)(vp + 2 * kW2Plane) = t1 - t2;
         *(f32x4*)(vp + 3 * kW2Plane) = t3 + t4;
         *(f32x4*)(vp + 4 * kW2Plane) = t3 - t4;
-        *(f32x4*)(vp + 5 * kW2Plane) = 4.f * x1 - 5.f * x3 + x5;
+        *(f32x4*)(vp + 5 * kW2Plane) = o5;
     };
 
 #pragma unroll 1
@@ -195,8 +221,8 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
             f32x4 xa[DEP][6], xb[DEP][6];
             auto issue = [&](int u, int buf) {
                 const unsigned* pr = (const unsigned*)((const char*)ptab + prow[u]);
-                const unsigned ha = (xh == 0 ? pr[0] : pr[1]) + chunkb;
-                const unsigned hb = (xh == 3 ? pr[3] : pr[2]) + chunkb;
+                const unsigned ha = (xh == 0 ? pr[0] : pr[1]) + chunkb_held;
+                const unsigned hb = (xh == 3 ? pr[3] : pr[2]) + chunkb_held;
                 const unsigned wo[6] = {pr[4], pr[5], pr[6], pr[7], pr[8], pr[9]};
 #pragma unroll
                 for (int ii = 0; ii < 6; ++ii) {
@@ -217,20 +243,21 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
                            xa[bf][3] + sgn * xb[bf][3], xa[bf][4] + sgn * xb[bf][4], xa[bf][5] + sgn * xb[bf][5]);
             }
         } else {
-            // ---- stage xh of F(4,3) along H: V = sum_j B_h^T[xh][j] x[row j] over the cell-plane's six input rows, B_h^T =
-            //   xh 0: ( 4, 0,-5, 0, 1, 0)    1: (0,-4,-4, 1, 1, 0)    2: (0, 4,-4,-1, 1, 0)
-            //   xh 3: ( 0,-2,-1, 2, 1, 0)    4: (0, 2,-1,-2, 1, 0)    5: (0, 4, 0,-5, 0, 1)
+            // ---- stage xh of F(4,3) along H: V = sum_j B_h^T[xh][j] x[row j] over the cell-plane's six input rows, B_h^T (a = 3/4, b = 3/2) =
+            //   xh 0: (a2b2, 0, -(a2+b2), 0, 1, 0)    1: (0, -a b2, -b2,  a, 1, 0)    2: (0,  a b2, -b2, -a, 1, 0)
+            //   xh 5: (0, a2b2, 0, -(a2+b2), 0, 1)    3: (0, -a2 b, -a2,  b, 1, 0)    4: (0,  a2 b, -a2, -b, 1, 0)
             // three rows (stages 0, 5) or four; two rows (12 chunks) are in flight at a time, combined into V, then the next two
             // (or the last one): the item's 18 / 24 chunks never sit in registers together (Y holds 128 of the wave's 256). ----
             const bool ends = xh == 0 || xh == 5;            // scalar
             const int ia = xh == 0 ? 0 : 1, ib = ends ? ia + 2 : 2, ic = ends ? ia + 4 : 3;
-            const float ca = ends ? 4.f : (xh == 1 ? -4.f : (xh == 2 ? 4.f : (xh == 3 ? -2.f : 2.f)));
-            const float cb = ends ? -5.f : (xh <= 2 ? -4.f : -1.f);
-            const float cc = ends ? 1.f : (xh == 1 ? 1.f : (xh == 2 ? -1.f : (xh == 3 ? 2.f : -2.f)));
+            const float ca = ends ? kPp : (xh == 1 ? -kPab2 : (xh == 2 ? kPab2 : (xh == 3 ? -kPa2b : kPa2b)));
+            const float cb = ends ? -kPs : (xh <= 2 ? -kPb2 : -kPa2);
+            const float cc = ends ? 1.f : (xh == 1 ? kPa : (xh == 2 ? -kPa : (xh == 3 ? kPb : -kPb)));
+            const unsigned chunkb = chunkb_now();
 #pragma unroll
             for (int u = 0; u < UA; ++u) {
                 if (u * 256 >= items_eff) break;
-                const unsigned* pr = (const unsigned*)((const char*)ptab + prow[u]);
+                const unsigned* pr = (const unsigned*)((const char*)ptab + item_prow(u));
                 const unsigned ha = pr[ia] + chunkb, hb = pr[ib] + chunkb, hc = pr[ic] + chunkb, hd = pr[4] + chunkb;
                 const unsigned wo[6] = {pr[6], pr[7], pr[8], pr[9], pr[10], pr[11]};
                 f32x4 xa[6], xb[6], v[6];
@@ -255,8 +282,9 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
 #pragma unroll
                     for (int ii = 0; ii < 6; ++ii) v[ii] += cc * xa[ii] + xb[ii];
                 }
-                if (vrow[u] < 0) continue;
-                wtransform(smem + vrow[u], v[0], v[1], v[2], v[3], v[4], v[5]);
+                const int vr = item_vrow(u);
+                if (vr < 0) continue;
+                wtransform(smem + vr, v[0], v[1], v[2], v[3], v[4], v[5]);
             }
         }
         // the weight ring is primed per stage, behind the staging (its registers are free for the input rows meanwhile) and
@@ -304,16 +332,16 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
             }
         }
 
-        // ---- fold the stage: t = A_w^T M[xh] (A_w^T = (1,1,1,1,1,0) (0,1,-1,2,-2,0) (0,1,1,4,4,0) (0,1,-1,8,-8,1)), then the output
-        // transform along H as Y_hr += A_h^T[hr][xh] t: F(2,3) A_h^T = (1,1,1,0) (0,1,-1,-1) (coordinate 2 is staged negated, see the
-        // pack), F(4,3) A_h^T = A_w^T ----
+        // ---- fold the stage: t = A_w^T M[xh] (A_w^T = (1,1,1,1,1,0) (0,a,-a,b,-b,0) (0,a2,a2,b2,b2,0) (0,a3,-a3,b3,-b3,1); HM = 2: a = 1, b = 2),
+        // then the output transform along H as Y_hr += A_h^T[hr][xh] t: F(2,3) A_h^T = (1,1,1,0) (0,1,-1,-1) (coordinate 2 is staged
+        // negated, see the pack), F(4,3) A_h^T = A_w^T ----
         float ch[HM];
         if constexpr (HM == 2) {
             ch[0] = xh < 3 ? 1.f : 0.f;
             ch[1] = xh == 0 ? 0.f : (xh == 1 ? 1.f : -1.f);
         } else {
-            const float sg = (xh & 1) ? 1.f : -1.f;          // coordinates 1, 3 = the points +1, +2; 2, 4 = -1, -2
-            const float m = xh <= 2 ? 1.f : 2.f;
+            const float sg = (xh & 1) ? 1.f : -1.f;          // coordinates 1, 3 = the points +a, +b; 2, 4 = -a, -b
+            const float m = xh <= 2 ? kPa : kPb;
             const bool mid = xh >= 1 && xh <= 4;
             ch[0] = xh < 5 ? 1.f : 0.f;
             ch[1] = mid ? sg * m : 0.f;
@@ -326,9 +354,15 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
             const f32x4 s34 = acc[3][mb] + acc[4][mb], d34 = acc[3][mb] - acc[4][mb];
             f32x4 t[4];
             t[0] = acc[0][mb] + s12 + s34;
-            t[1] = d12 + 2.f * d34;
-            t[2] = s12 + 4.f * s34;
-            t[3] = d12 + 8.f * d34 + acc[5][mb];
+            if constexpr (HM == 2) {
+                t[1] = d12 + 2.f * d34;
+                t[2] = s12 + 4.f * s34;
+                t[3] = d12 + 8.f * d34 + acc[5][mb];
+            } else {
+                t[1] = kPa * d12 + kPb * d34;
+                t[2] = kPa2 * s12 + kPb2 * s34;
+                t[3] = kPa3 * d12 + kPb3 * d34 + acc[5][mb];
+            }
 #pragma unroll
             for (int wi = 0; wi < 4; ++wi)
 #pragma unroll
@@ -338,7 +372,9 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
 
     if (FDN_DBG_BITS(p) & 8) return;
     // ---- epilogue: lane = cell c of each M-block x cout 16w + 4q .. + 3; HM x 4 voxels per cell ----
-    const int cofs = wave * 16 + q * 4;
+    const int lane_e = HM == 2 ? lane : (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int c_e = HM == 2 ? c : (lane_e & 15);
+    const int cofs = (HM == 2 ? wave : wave_s) * 16 + (HM == 2 ? q : (lane_e >> 4)) * 4;
     const float slope = p.act == FDN_ACT_RELU ? 0.f : (p.act == FDN_ACT_LEAKY ? p.alpha : 1.f);
     // The outputs leave in GROUPS of HG rows of one M-block, and a group's operand loads (skip / y, or the residual) are requested one
     // group ahead of the stores: the stores of group g may alias the loads of group g + 1 as far as the compiler can tell (skip may BE
@@ -349,7 +385,7 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
     constexpr int GPB = HM / HG, NG = 2 * GPB;                // groups per M-block, groups
     int g0[2];
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) g0[mb] = mtab[mb * 16 + c];
+    for (int mb = 0; mb < 2; ++mb) g0[mb] = mtab[mb * 16 + c_e];
     if (FUSED) {
         // dgrad on the inner box of the padded grid: voxels strictly inside the volume get exactly one contribution and are finished
         // here (dz_prev = (dgrad + skip) * act'(y)); surface voxels go to the padded scratch for the border fold.  Branch-free per
@@ -359,8 +395,8 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
         f32x4 sk[2][HG][4], ym[2][HG][4];
         auto fload = [&](int g, int buf) {
             const int mb = g / GPB, h0 = (g % GPB) * HG;
-            const int gf0 = mtab[32 + mb * 16 + c];
-            const int hw = mtab[64 + mb * 16 + c];
+            const int gf0 = mtab[32 + mb * 16 + c_e];
+            const int hw = mtab[64 + mb * 16 + c_e];
             const int ph = hw & 0xffff, pw = hw >> 16;                    // padded coordinates of the cell's first voxel
 #pragma unroll
             for (int hr = 0; hr < HG; ++hr)

@@ -33,8 +33,39 @@ def _up(x, R):
     return F.interpolate(x.permute(0, 4, 1, 2, 3), scale_factor=R, mode="trilinear", align_corners=True).permute(0, 2, 3, 4, 1)
 
 
-def t_forward(params, inputs, R, LB, HB):
-    """params: [(w, b_or_None)] in creation order.  SR4DFlowNet.py:7-51."""
+class _ActWithMask(torch.autograd.Function):
+    """relu / leaky-relu whose BACKWARD takes the side of the kink from a given mask (True = positive side) instead of the sign of its
+    own input.  The piecewise-linear network is differentiated in the linear region another evaluation (the fp32 GPU forward) landed in:
+    a unit whose pre-activation is within rounding of 0 may sit on either side, and a single such unit moves gradient elements by
+    1e-4..1e-3 of their scale -- with the mask given, what is left between the two gradients is arithmetic error only."""
+
+    @staticmethod
+    def forward(ctx, z, slope, mask):
+        ctx.slope = slope
+        ctx.save_for_backward(mask)
+        return torch.where(z > 0, z, z * slope)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (m,) = ctx.saved_tensors
+        return torch.where(m, gy, gy * ctx.slope), None, None
+
+
+def t_forward(params, inputs, R, LB, HB, masks=None, zs=None):
+    """params: [(w, b_or_None)] in creation order.  SR4DFlowNet.py:7-51.
+    masks (optional): one bool tensor per activation, in call order (the 6 stem convs, (h, out) of every ResBlock, the 3 head convs) --
+    the side of the kink the backward pass differentiates on (_ActWithMask); zs (optional list): receives every pre-activation."""
+    if masks is not None or zs is not None:
+        it = iter(masks) if masks is not None else None
+
+        def act(z, slope):
+            if zs is not None:
+                zs.append(z.detach())
+            return _ActWithMask.apply(z, slope, next(it) if it is not None else z > 0)
+        relu = lambda z: act(z, 0.0)
+        leaky = lambda z, s: act(z, s)
+    else:
+        relu, leaky = F.relu, F.leaky_relu
     u, v, w, mu, mv, mw = inputs
     speed = (u ** 2 + v ** 2 + w ** 2) ** 0.5
     mag = (mu ** 2 + mv ** 2 + mw ** 2) ** 0.5
@@ -42,22 +73,22 @@ def t_forward(params, inputs, R, LB, HB):
     phase = torch.cat([u, v, w], -1)
     pc = torch.cat([pcmr, mag, speed], -1)
     P = params
-    pc = F.relu(t_conv(pc, *P[0])); pc = F.relu(t_conv(pc, *P[1]))
-    ph = F.relu(t_conv(phase, *P[2])); ph = F.relu(t_conv(ph, *P[3]))
-    x = F.relu(t_conv(torch.cat([ph, pc], -1), *P[4]))
-    x = F.relu(t_conv(x, *P[5]))
+    pc = relu(t_conv(pc, *P[0])); pc = relu(t_conv(pc, *P[1]))
+    ph = relu(t_conv(phase, *P[2])); ph = relu(t_conv(ph, *P[3]))
+    x = relu(t_conv(torch.cat([ph, pc], -1), *P[4]))
+    x = relu(t_conv(x, *P[5]))
     li = 6
     for i in range(LB + HB):
         if i == LB and R > 1:
             x = _up(x, R)
-        h = F.leaky_relu(t_conv(x, P[li][0]), 0.2)
-        x = F.leaky_relu(x + t_conv(h, P[li + 1][0]), 0.2)
+        h = leaky(t_conv(x, P[li][0]), 0.2)
+        x = leaky(x + t_conv(h, P[li + 1][0]), 0.2)
         li += 2
     if HB == 0 and R > 1:
         x = _up(x, R)
     outs = []
     for _ in range(3):
-        g = F.relu(t_conv(x, *P[li]))
+        g = relu(t_conv(x, *P[li]))
         outs.append(t_conv(g, *P[li + 1]))
         li += 2
     return torch.cat(outs, -1)
