@@ -72,26 +72,29 @@ class _VolumeCache:
         return (os.path.realpath(path), st.st_mtime_ns, st.st_size)
 
     def get(self, path, name):
-        with self._lock:
-            return self._get(path, name)
-
-    def _get(self, path, name):
+        """The lock covers the dictionary only; the file read runs outside it, so the loader's n_parallel workers decode different
+        datasets concurrently (two workers missing on the same key both read it; the second result is dropped)."""
         fid = self._file_id(path)
         key = fid + (name,)
-        if key in self._d:
-            self._d.move_to_end(key)
-            return self._d[key]
-        for k in [k for k in self._d if k[0] == fid[0] and k[:3] != fid]:      # same file, older contents
-            self._bytes -= 0 if self._d[k] is None else self._d[k].nbytes
-            del self._d[k]
+        with self._lock:
+            if key in self._d:
+                self._d.move_to_end(key)
+                return self._d[key]
         with h5io.open_read(path) as f:
             obj = f.get(name)
             arr = None if obj is None else np.asarray(obj[...] if hasattr(obj, "id") else obj.read())
-        self._d[key] = arr
-        self._bytes += 0 if arr is None else arr.nbytes
-        while self._bytes > self.max_bytes and len(self._d) > 1:
-            _, old = self._d.popitem(last=False)
-            self._bytes -= 0 if old is None else old.nbytes
+        with self._lock:
+            if key in self._d:                      # another worker was faster
+                self._d.move_to_end(key)
+                return self._d[key]
+            for k in [k for k in self._d if k[0] == fid[0] and k[:3] != fid]:      # same file, older contents
+                self._bytes -= 0 if self._d[k] is None else self._d[k].nbytes
+                del self._d[k]
+            self._d[key] = arr
+            self._bytes += 0 if arr is None else arr.nbytes
+            while self._bytes > self.max_bytes and len(self._d) > 1:
+                _, old = self._d.popitem(last=False)
+                self._bytes -= 0 if old is None else old.nbytes
         return arr
 
 
@@ -104,8 +107,10 @@ class _BatchedDataset:
     on `n_parallel` worker threads (the `map` parallelism: None = min(4, cores), as AUTOTUNE would pick; <= 1 = in the producer
     thread).  pinned=True (scripts/trainer.py with FDN_HOST_LOADER=1; FDN_LOADER_PINNED=1) stacks the samples straight into PINNED
     host buffers, so the consumer's host-to-device copy is one DMA per tensor instead of a pageable copy; those buffers form a
-    ring of prefetch + 2 batches, i.e. a batch is valid only until the consumer has asked for two more (the training loop's
-    pattern) -- the default hands out fresh arrays the caller may keep, like tf.data does."""
+    ring of prefetch + 3 batches owned by the iterator: while the consumer works on batch k (and may still hold batch k - 1, e.g.
+    for a non-blocking copy), the producer has at most batches k + 1 .. k + prefetch queued and k + prefetch + 1 under assembly --
+    prefetch + 3 distinct slots, so a batch stays untouched until the consumer has asked for TWO more.  The default hands out
+    fresh arrays the caller may keep, like tf.data does."""
 
     def __init__(self, handler, indexes, shuffle, seed, shard, n_parallel=None, prefetch=None, pinned=None):
         self.h = handler
@@ -115,41 +120,41 @@ class _BatchedDataset:
         self.n_parallel = min(4, os.cpu_count() or 1) if n_parallel is None else int(n_parallel)
         self.prefetch = int(os.environ.get("FDN_LOADER_PREFETCH", "2")) if prefetch is None else int(prefetch)
         self.pinned = (os.environ.get("FDN_LOADER_PINNED", "0") not in ("", "0")) if pinned is None else bool(pinned)
-        self._ring = None
 
     def __len__(self):
         return len(self.sampler)
 
-    def _slots(self):
-        """Ring of pinned batch buffers (plain numpy without a GPU): slot -> 11 arrays of the full batch shape."""
-        if self._ring is None:
-            P, H, B = self.h.patch_size, self.h.patch_size * self.h.res_increase, self.h.batch_size
-            shapes = [(B, P, P, P, 1)] * 6 + [(B, H, H, H, 1)] * 3 + [(B,), (B, H, H, H)]
-            pin = False
-            try:
+    def _nslot(self):
+        return max(self.prefetch, 0) + 3
+
+    def _new_ring(self):
+        """Ring of pinned batch buffers (plain numpy without a GPU) for ONE iterator: slot -> 11 arrays of the full batch shape.
+        (Per iterator: an abandoned iterator's producer may still be assembling when the next epoch's iterator starts.)"""
+        P, H, B = self.h.patch_size, self.h.patch_size * self.h.res_increase, self.h.batch_size
+        shapes = [(B, P, P, P, 1)] * 6 + [(B, H, H, H, 1)] * 3 + [(B,), (B, H, H, H)]
+        pin = False
+        try:
+            import torch
+            pin = torch.cuda.is_available()
+        except Exception:
+            pass
+
+        def alloc(shape):
+            if pin:
                 import torch
-                pin = torch.cuda.is_available()
-            except Exception:
-                pass
+                return torch.empty(shape, dtype=torch.float32).pin_memory().numpy()
+            return np.empty(shape, np.float32)
+        return [[alloc(sh) for sh in shapes] for _ in range(self._nslot())]
 
-            def alloc(shape):
-                if pin:
-                    import torch
-                    return torch.empty(shape, dtype=torch.float32).pin_memory().numpy()
-                return np.empty(shape, np.float32)
-            self._ring = [[alloc(sh) for sh in shapes] for _ in range(max(self.prefetch, 0) + 2)]
-        return self._ring
-
-    def _assemble(self, rows, pool, slot):
+    def _assemble(self, rows, pool, bufs):
         if len(rows) == 0:
             P, H = self.h.patch_size, self.h.patch_size * self.h.res_increase
             z = lambda *s: np.zeros(s, np.float32)
             return tuple([z(0, P, P, P, 1)] * 6 + [z(0, H, H, H, 1)] * 3 + [z(0), z(0, H, H, H)])
         load = lambda r: self.h.load_patches_from_index_file(self.indexes[r])
         samples = list(pool.map(load, rows)) if pool is not None else [load(r) for r in rows]
-        if not self.pinned:
+        if bufs is None:
             return tuple(np.stack([s_[i] for s_ in samples], axis=0) for i in range(11))
-        bufs = self._slots()[slot]
         out = []
         for i in range(11):
             dst = bufs[i][:len(samples)]
@@ -164,11 +169,13 @@ class _BatchedDataset:
     def __iter__(self):
         from concurrent.futures import ThreadPoolExecutor
         pool = ThreadPoolExecutor(self.n_parallel) if self.n_parallel > 1 else None
-        nslot = max(self.prefetch, 0) + 2
+        nslot = self._nslot()
+        ring = self._new_ring() if self.pinned else None
+        slot = lambda k: None if ring is None else ring[k % nslot]
         if self.prefetch <= 0:
             try:
                 for k, rows in enumerate(self.sampler):
-                    yield self._assemble(rows, pool, k % nslot)
+                    yield self._assemble(rows, pool, slot(k))
             finally:
                 if pool is not None:
                     pool.shutdown(wait=False)
@@ -178,21 +185,23 @@ class _BatchedDataset:
         q = queue.Queue(maxsize=self.prefetch)
         stop = threading.Event()
 
+        def put(msg):                                       # every put gives up once the consumer is gone: no producer is left blocked
+            while not stop.is_set():
+                try:
+                    q.put(msg, timeout=0.1)
+                    return True
+                except queue.Full:
+                    pass
+            return False
+
         def produce():
             try:
                 for k, rows in enumerate(self.sampler):
-                    item = self._assemble(rows, pool, k % nslot)
-                    while not stop.is_set():
-                        try:
-                            q.put(("batch", item), timeout=0.1)
-                            break
-                        except queue.Full:
-                            pass
-                    if stop.is_set():
+                    if stop.is_set() or not put(("batch", self._assemble(rows, pool, slot(k)))):
                         return
-                q.put(("end", None))
+                put(("end", None))
             except BaseException as e:                      # surfaces in the consumer, not in a dead thread
-                q.put(("error", e))
+                put(("error", e))
 
         t = threading.Thread(target=produce, name="fdn-loader", daemon=True)
         t.start()
@@ -206,8 +215,9 @@ class _BatchedDataset:
                 yield item
         finally:
             stop.set()
+            t.join()                                        # the producer leaves within one put timeout (or one batch assembly) ...
             if pool is not None:
-                pool.shutdown(wait=False)
+                pool.shutdown(wait=False)                   # ... and only then does its worker pool go away
 
 
 class PatchHandler3D:

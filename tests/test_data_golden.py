@@ -223,9 +223,31 @@ def test_prefetching_loader_yields_the_same_batches(n_parallel, prefetch, pinned
             assert len(got) == len(ref) == 3
             for g, r in zip(got, ref):
                 assert all(np.array_equal(x, y) and x.dtype == y.dtype for x, y in zip(g, r))
-    it = iter(ds)                                   # an abandoned iterator must not leave the producer stuck
+    import threading
+    it = iter(ds)                                   # an abandoned iterator must not leave its producer thread behind
     next(it)
-    del it
+    it.close()
+    assert not any(t.name == "fdn-loader" and t.is_alive() for t in threading.enumerate())
+
+
+def test_pinned_ring_keeps_a_batch_until_two_more_were_requested():
+    """The documented contract of the pinned staging ring (prefetch + 3 slots): the consumer may still hold batch k - 1 (a non-blocking
+    copy in flight) while it works on batch k, whatever the producer does meanwhile.  The dataset is walked several times over so that
+    the ring wraps; the producer gets time to run ahead before every check."""
+    import time
+    idx = data.load_indexes(os.path.join(DATA, "validate.csv"))
+    idx = np.concatenate([idx] * 4, axis=0)
+    ref = [tuple(np.array(a) for a in b) for b in
+           data.PatchHandler3D(DATA, 16, 2, 2, 0.6).initialize_dataset(idx, shuffle=False, shard=(0, 1), n_parallel=1, prefetch=0)]
+    ds = data.PatchHandler3D(DATA, 16, 2, 2, 0.6).initialize_dataset(idx, shuffle=False, shard=(0, 1), n_parallel=2, prefetch=1, pinned=True)
+    held = []
+    for k, b in enumerate(ds):
+        held.append(b)
+        time.sleep(0.05)                            # the producer fills every slot it may
+        for j in (k - 1, k):                        # the previous batch and this one are both intact
+            if j >= 0:
+                assert all(np.array_equal(x, y) for x, y in zip(held[j], ref[j])), (k, j)
+    assert len(held) == len(ref) >= 8
 
 
 def test_loader_errors_surface_in_the_consumer():

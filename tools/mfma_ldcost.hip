@@ -30,6 +30,9 @@ __global__ __launch_bounds__(64 * WAVES) void k(float* out, const float* in, int
             if (KIND == 6) asm volatile("s_mul_i32 %0, %0, 3" : "+s"(sc[q & 7]));
             if (KIND == 7) { unsigned lo = laddr; asm volatile("" : "+v"(lo)); r4[q & 15] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lo + (q * 256 % 4096), 0, 0)); }
             if (KIND == 8) asm volatile("v_add_u32 %0, %0, %1" : "+v"(va[q & 7]) : "v"(laddr));
+            if (KIND == 9) { unsigned lo = laddr; asm volatile("" : "+v"(lo));       // direct-to-LDS: no VGPR write-back
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)((char*)lds + (q & 15) * 1024 + (threadIdx.x >> 6) * 16384 % 32768), 16, (int)lo + (q * 256 % 4096), 0, 0, 0); }
+            if (KIND == 10) asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(laddr), "v"(r4[0]), "n"(q * 1024) : "memory");
         }
 #pragma unroll
         for (int u = 1; u < 15; ++u) acc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[u & 3], 0, 0, 0);
@@ -67,7 +70,7 @@ void table(float* d, float* in) {
 #define ROW(KIND, K, name) { float t = run<KIND, K, WAVES>(d, in, IT); printf("  + %2d %-20s %.3f ms  -> %.1f cycles per load\n", K, name, t, (t / base - 1.0) * cyc / K / (WAVES / 4)); }
     ROW(1, 8, "ds_read_b32") ROW(1, 16, "ds_read_b32") ROW(2, 4, "ds_read_b128") ROW(2, 8, "ds_read_b128")
     ROW(4, 8, "global_load_dword") ROW(3, 4, "global_load_dwordx4") ROW(3, 8, "global_load_dwordx4")
-    ROW(7, 4, "buffer_load_dwordx4") ROW(7, 8, "buffer_load_dwordx4") ROW(5, 32, "s_add_u32") ROW(5, 64, "s_add_u32") ROW(6, 32, "s_mul_i32") ROW(8, 32, "v_add_u32") ROW(8, 64, "v_add_u32")
+    ROW(7, 4, "buffer_load_dwordx4") ROW(7, 8, "buffer_load_dwordx4") ROW(9, 4, "buffer_load_dwordx4 lds") ROW(9, 8, "buffer_load_dwordx4 lds") ROW(10, 4, "ds_write_b128") ROW(10, 8, "ds_write_b128") ROW(5, 32, "s_add_u32") ROW(5, 64, "s_add_u32") ROW(6, 32, "s_mul_i32") ROW(8, 32, "v_add_u32") ROW(8, 64, "v_add_u32")
 }
 
 int main() {
