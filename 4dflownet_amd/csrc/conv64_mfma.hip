@@ -593,11 +593,13 @@ int launch_boxes(Conv64Args& a, const Box* boxes, int nbox, hipStream_t s) {
     }
     switch (v) {
         case 1: return launch_conv64<2, 1, 2>(a, boxes, nbox, s);
-        case 2: return launch_conv64<2, 1, 4>(a, boxes, nbox, s);
         case 3: return launch_conv64<1, 1, 2>(a, boxes, nbox, s);
+#ifdef FDN_TEST_HOOKS                                   // the cs4 layouts are never the planner's choice: test build only (forced layouts)
+        case 2: return launch_conv64<2, 1, 4>(a, boxes, nbox, s);
         case 4: return launch_conv64<1, 1, 4>(a, boxes, nbox, s);
-        case 5: return launch_conv64<1, 2, 2>(a, boxes, nbox, s);
-        default: return launch_conv64<1, 2, 4>(a, boxes, nbox, s);
+        case 6: return launch_conv64<1, 2, 4>(a, boxes, nbox, s);
+#endif
+        default: return launch_conv64<1, 2, 2>(a, boxes, nbox, s);
     }
 }
 

@@ -579,12 +579,16 @@ extern "C" int fdn_debug_set_conv1x1_mfma(int on) { fdn_conv1x1_use_mfma = on; r
 template <typename T>
 int fdn_conv_cin3_fwd_launch(const T* x, const float* w, const float* bias, T* y, int N, int D, int H, int W, int act,
                              float alpha, hipStream_t s) {
-    if (fdn_cin3_use_mfma) return fdn_conv_cin3_fwd_mfma_launch<T>(x, w, bias, y, N, D, H, W, act, alpha, s);
-    const int64_t nvox = (int64_t)N * D * H * W;
-    hipLaunchKernelGGL(conv_cin3_fwd_kernel<T>, dim3((unsigned)((nvox + 63) / 64)), dim3(256), 0, s, x, w, bias, y, N, D, H,
-                       W, act, alpha);
-    FDN_CHECK_LAUNCH("conv_cin3_fwd_kernel");
-    return FDN_OK;
+#ifdef FDN_TEST_HOOKS                                   // (the VALU kernel is compiled into the test build only: A/B reference)
+    if (!fdn_cin3_use_mfma) {
+        const int64_t nvox = (int64_t)N * D * H * W;
+        hipLaunchKernelGGL(conv_cin3_fwd_kernel<T>, dim3((unsigned)((nvox + 63) / 64)), dim3(256), 0, s, x, w, bias, y, N, D, H,
+                           W, act, alpha);
+        FDN_CHECK_LAUNCH("conv_cin3_fwd_kernel");
+        return FDN_OK;
+    }
+#endif
+    return fdn_conv_cin3_fwd_mfma_launch<T>(x, w, bias, y, N, D, H, W, act, alpha, s);
 }
 
 // heads_mfma.hip: the MFMA formulation of the three 64 -> 1 head kernels (default); the VALU kernels of this file stay
@@ -605,32 +609,44 @@ extern "C" int fdn_debug_set_heads_mfma(int on) { fdn_heads_use_mfma = on; retur
 template <typename T>
 int fdn_conv_cout1_fwd_launch(const T* x, const float* w, const float* bias, float* y, int N, int D, int H, int W, int ldy,
                               int y_coff, int act, float alpha, hipStream_t s) {
-    if (fdn_heads_use_mfma) return fdn_head_fwd_launch<T>(x, w, bias, y, N, D, H, W, ldy, y_coff, act, alpha, s, !(fdn_heads_use_mfma & 2));
-    const int64_t nvox = (int64_t)N * D * H * W;
-    hipLaunchKernelGGL(conv_cout1_fwd_kernel<T>, dim3(nblocks_for(nvox, 16, 8192)), dim3(256), 0, s, x, w, bias, y, N, D, H,
-                       W, ldy, y_coff, act, alpha);
-    FDN_CHECK_LAUNCH("conv_cout1_fwd_kernel");
-    return FDN_OK;
+#ifdef FDN_TEST_HOOKS
+    if (!fdn_heads_use_mfma) {
+        const int64_t nvox = (int64_t)N * D * H * W;
+        hipLaunchKernelGGL(conv_cout1_fwd_kernel<T>, dim3(nblocks_for(nvox, 16, 8192)), dim3(256), 0, s, x, w, bias, y, N, D, H,
+                           W, ldy, y_coff, act, alpha);
+        FDN_CHECK_LAUNCH("conv_cout1_fwd_kernel");
+        return FDN_OK;
+    }
+#endif
+    return fdn_head_fwd_launch<T>(x, w, bias, y, N, D, H, W, ldy, y_coff, act, alpha, s, !(fdn_heads_use_mfma & 2));
 }
 
 template <typename T>
 int fdn_conv1x1_fwd_launch(const T* xa, const T* xb, const float* w, const float* bias, T* y, int64_t nvox, int act,
                            float alpha, hipStream_t s) {
-    if (fdn_conv1x1_use_mfma) return fdn_conv1x1_fwd_mfma_launch<T>(xa, xb, w, bias, y, nvox, act, alpha, s);
-    hipLaunchKernelGGL(conv1x1_fwd_kernel<T>, dim3(nblocks_for(nvox, 64, 2048)), dim3(256), 0, s, xa, xb, w, bias, y, nvox,
-                       act, alpha);
-    FDN_CHECK_LAUNCH("conv1x1_fwd_kernel");
-    return FDN_OK;
+#ifdef FDN_TEST_HOOKS
+    if (!fdn_conv1x1_use_mfma) {
+        hipLaunchKernelGGL(conv1x1_fwd_kernel<T>, dim3(nblocks_for(nvox, 64, 2048)), dim3(256), 0, s, xa, xb, w, bias, y, nvox,
+                           act, alpha);
+        FDN_CHECK_LAUNCH("conv1x1_fwd_kernel");
+        return FDN_OK;
+    }
+#endif
+    return fdn_conv1x1_fwd_mfma_launch<T>(xa, xb, w, bias, y, nvox, act, alpha, s);
 }
 
 template <typename T>
 int fdn_conv1x1_dgrad_launch(const T* dz, const float* w, const T* ya, const T* yb, T* dxa, T* dxb, int64_t nvox,
                              hipStream_t s) {
-    if (fdn_conv1x1_use_mfma) return fdn_conv1x1_dgrad_mfma_launch<T>(dz, w, ya, yb, dxa, dxb, nvox, s);
-    hipLaunchKernelGGL(conv1x1_dgrad_kernel<T>, dim3(nblocks_for(nvox, 32, 2048)), dim3(256), 0, s, dz, w, ya, yb, dxa, dxb,
-                       nvox);
-    FDN_CHECK_LAUNCH("conv1x1_dgrad_kernel");
-    return FDN_OK;
+#ifdef FDN_TEST_HOOKS
+    if (!fdn_conv1x1_use_mfma) {
+        hipLaunchKernelGGL(conv1x1_dgrad_kernel<T>, dim3(nblocks_for(nvox, 32, 2048)), dim3(256), 0, s, dz, w, ya, yb, dxa, dxb,
+                           nvox);
+        FDN_CHECK_LAUNCH("conv1x1_dgrad_kernel");
+        return FDN_OK;
+    }
+#endif
+    return fdn_conv1x1_dgrad_mfma_launch<T>(dz, w, ya, yb, dxa, dxb, nvox, s);
 }
 
 int fdn_conv_cout1_dgrad_launch(const float* dz, const float* w, float* dxpad, int N, int D, int H, int W, int lddz,
@@ -658,18 +674,20 @@ int fdn_wgrad_cin3_launch(const T* x, const T* dz, float* dw, void* ws, size_t, 
 template <typename T>
 int fdn_wgrad_cout1_launch(const T* x, const float* dz, float* dw, void* ws, size_t, int N, int D, int H, int W, int lddz,
                            int dz_coff, hipStream_t s) {
-    if (fdn_heads_use_mfma) {
-        const int nbm = fdn_head_wgrad_blocks(N, D, H, W);          // <= kSmallBlocks partial rows of 27*64
-        const int rc = fdn_head_wgrad_launch<T>(x, dz, (float*)ws, N, D, H, W, lddz, dz_coff, s);
-        if (rc != FDN_OK) return rc;
-        return reduce_partials((const float*)ws, dw, nbm, 27 * 64, s);
+#ifdef FDN_TEST_HOOKS
+    if (!fdn_heads_use_mfma) {
+        const int nrows = N * (D + 2) * (H + 2);
+        const int nb = nrows < kSmallBlocks ? nrows : kSmallBlocks;
+        const size_t lds = (size_t)(((9 * (W + 4) + 3) & ~3) + 4 * 27 * 64) * sizeof(float);
+        hipLaunchKernelGGL(wgrad_cout1_kernel<T>, dim3(nb), dim3(256), lds, s, x, dz, (float*)ws, N, D, H, W, lddz, dz_coff);
+        FDN_CHECK_LAUNCH("wgrad_cout1_kernel");
+        return reduce_partials((const float*)ws, dw, nb, 27 * 64, s);
     }
-    const int nrows = N * (D + 2) * (H + 2);
-    const int nb = nrows < kSmallBlocks ? nrows : kSmallBlocks;
-    const size_t lds = (size_t)(((9 * (W + 4) + 3) & ~3) + 4 * 27 * 64) * sizeof(float);
-    hipLaunchKernelGGL(wgrad_cout1_kernel<T>, dim3(nb), dim3(256), lds, s, x, dz, (float*)ws, N, D, H, W, lddz, dz_coff);
-    FDN_CHECK_LAUNCH("wgrad_cout1_kernel");
-    return reduce_partials((const float*)ws, dw, nb, 27 * 64, s);
+#endif
+    const int nbm = fdn_head_wgrad_blocks(N, D, H, W);          // <= kSmallBlocks partial rows of 27*64
+    const int rc = fdn_head_wgrad_launch<T>(x, dz, (float*)ws, N, D, H, W, lddz, dz_coff, s);
+    if (rc != FDN_OK) return rc;
+    return reduce_partials((const float*)ws, dw, nbm, 27 * 64, s);
 }
 
 template <typename T>
@@ -677,46 +695,50 @@ int fdn_conv_cout1_dgrad_folded_launch(const float* dz, const float* w, const T*
                                        float* dbias_prev, void* workspace, size_t workspace_bytes, int N, int D, int H, int W,
                                        int lddz, int dz_coff, hipStream_t s) {
     FDN_REQUIRE(dz && w && dz_prev && N > 0 && D > 0 && H > 0 && W > 0, "fdn_conv_cout1_dgrad_folded: bad argument");
-    if (fdn_heads_use_mfma) {
-        const int nb = fdn_head_dgrad_blocks(N, D, H, W);
+#ifdef FDN_TEST_HOOKS
+    if (!fdn_heads_use_mfma) {
+        FDN_REQUIRE(W <= 4096, "fdn_conv_cout1_dgrad_folded: W too large for the row stage");
+        const int nrows = N * D * H;
+        const int nb = nrows < 2048 ? nrows : 2048;
         if (dbias_prev && (!workspace || workspace_bytes < (size_t)nb * 64 * sizeof(float))) {
             fdn_set_error("fdn_conv_cout1_dgrad_folded: workspace %zu < %zu bytes", workspace_bytes, (size_t)nb * 64 * sizeof(float));
             return FDN_ERR_WORKSPACE;
         }
-        const int rc = fdn_head_dgrad_launch<T>(dz, w, y_prev, act, alpha, dz_prev, dbias_prev ? (float*)workspace : nullptr, N, D,
-                                                H, W, lddz, dz_coff, s);
-        if (rc != FDN_OK) return rc;
+        const size_t lds = (size_t)(27 * 64 + 9 * W + 16) * sizeof(float);
+        hipLaunchKernelGGL(conv_cout1_dgrad_folded_kernel<T>, dim3(nb), dim3(256), lds, s, dz, w, y_prev, act, alpha, dz_prev,
+                           dbias_prev ? (float*)workspace : nullptr, N, D, H, W, lddz, dz_coff);
+        FDN_CHECK_LAUNCH("conv_cout1_dgrad_folded_kernel");
         if (dbias_prev) return reduce_partials((const float*)workspace, dbias_prev, nb, 64, s);
         return FDN_OK;
     }
-    FDN_REQUIRE(W <= 4096, "fdn_conv_cout1_dgrad_folded: W too large for the row stage");
-    const int nrows = N * D * H;
-    const int nb = nrows < 2048 ? nrows : 2048;
+#endif
+    const int nb = fdn_head_dgrad_blocks(N, D, H, W);
     if (dbias_prev && (!workspace || workspace_bytes < (size_t)nb * 64 * sizeof(float))) {
         fdn_set_error("fdn_conv_cout1_dgrad_folded: workspace %zu < %zu bytes", workspace_bytes, (size_t)nb * 64 * sizeof(float));
         return FDN_ERR_WORKSPACE;
     }
-    const size_t lds = (size_t)(27 * 64 + 9 * W + 16) * sizeof(float);
-    hipLaunchKernelGGL(conv_cout1_dgrad_folded_kernel<T>, dim3(nb), dim3(256), lds, s, dz, w, y_prev, act, alpha, dz_prev,
-                       dbias_prev ? (float*)workspace : nullptr, N, D, H, W, lddz, dz_coff);
-    FDN_CHECK_LAUNCH("conv_cout1_dgrad_folded_kernel");
+    const int rc = fdn_head_dgrad_launch<T>(dz, w, y_prev, act, alpha, dz_prev, dbias_prev ? (float*)workspace : nullptr, N, D,
+                                            H, W, lddz, dz_coff, s);
+    if (rc != FDN_OK) return rc;
     if (dbias_prev) return reduce_partials((const float*)workspace, dbias_prev, nb, 64, s);
     return FDN_OK;
 }
 
 template <typename T>
 int fdn_wgrad_1x1_launch(const T* xa, const T* xb, const T* dz, float* dw, void* ws, size_t, int64_t nvox, hipStream_t s) {
-    if (fdn_conv1x1_use_mfma) {
-        // one workgroup per CU (128 KB of LDS for the cross-wave sum); >= 64 voxel pairs per wave
-        int nbm = (int)((nvox / 2 + 255) / 256);
-        nbm = nbm < 1 ? 1 : (nbm > 256 ? 256 : nbm);
-        if (int rc = fdn_wgrad_1x1_mfma_launch<T>(xa, xb, dz, (float*)ws, nbm, nvox, s)) return rc;
-        return reduce_partials((const float*)ws, dw, nbm, 128 * 64, s);
+#ifdef FDN_TEST_HOOKS
+    if (!fdn_conv1x1_use_mfma) {
+        const int nb = nblocks_for(nvox, 32 * 4, kSmallBlocks);
+        hipLaunchKernelGGL(wgrad_1x1_kernel<T>, dim3(nb), dim3(256), 0, s, xa, xb, dz, (float*)ws, nvox);
+        FDN_CHECK_LAUNCH("wgrad_1x1_kernel");
+        return reduce_partials((const float*)ws, dw, nb, 128 * 64, s);
     }
-    const int nb = nblocks_for(nvox, 32 * 4, kSmallBlocks);
-    hipLaunchKernelGGL(wgrad_1x1_kernel<T>, dim3(nb), dim3(256), 0, s, xa, xb, dz, (float*)ws, nvox);
-    FDN_CHECK_LAUNCH("wgrad_1x1_kernel");
-    return reduce_partials((const float*)ws, dw, nb, 128 * 64, s);
+#endif
+    // one workgroup per CU (128 KB of LDS for the cross-wave sum); >= 64 voxel pairs per wave
+    int nbm = (int)((nvox / 2 + 255) / 256);
+    nbm = nbm < 1 ? 1 : (nbm > 256 ? 256 : nbm);
+    if (int rc = fdn_wgrad_1x1_mfma_launch<T>(xa, xb, dz, (float*)ws, nbm, nvox, s)) return rc;
+    return reduce_partials((const float*)ws, dw, nbm, 128 * 64, s);
 }
 
 template <typename T>

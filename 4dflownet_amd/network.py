@@ -82,10 +82,12 @@ class FlowNetModel:
     def __init__(self, res_increase, low_resblock=8, hi_resblock=4, device=None, seed=0, dtype="float32", conv_algo=None):
         """dtype: storage type of activations and activation gradients -- "float32" (the reference's arithmetic) or
         "bfloat16" (BASELINE.json configs[3]; parameters, their gradients, the prediction and the optimizer stay fp32).
-        conv_algo (fp32 mode): algorithm of the 64->64 3x3x3 layers -- "auto" (FDN_ALGO_AUTO: 2-D Winograd F(2,3)xF(4,3) forward / dgrad
-        where H is even and W a multiple of 4, Winograd along W where only W allows it), "winograd_w" (FDN_ALGO_WINO_W: the 1-D kernels
-        only), "direct" (FDN_ALGO_DIRECT everywhere), or a dict {layer name: "direct"} that pins single layers
-        (forward, dgrad and wgrad of that layer) to the direct kernels; None reads FDN_CONV_ALGO (default "auto")."""
+        conv_algo (fp32 mode): algorithm of the 64->64 3x3x3 layers -- "auto" (FDN_ALGO_AUTO: 2-D Winograd forward / dgrad, F(4,3) along
+        H x F(4,3) along W where H and W are multiples of 4, F(2,3) along H where H is only even, Winograd along W where only W allows
+        it, else direct -- forward() warns once per grid that falls off the 2-D kernels), "winograd_h2" (FDN_ALGO_WINO_H2: never more
+        than F(2,3) along H, round 4's kernels), "winograd_w" (FDN_ALGO_WINO_W: the 1-D kernels only), "direct" (FDN_ALGO_DIRECT
+        everywhere), or a dict {layer name: "direct"} that pins single layers (forward, dgrad and wgrad of that layer) to the direct
+        kernels; None reads FDN_CONV_ALGO (default "auto")."""
         if not torch.cuda.is_available():
             raise FdnError("FlowNetModel needs a ROCm GPU: the hot path is HIP-only (no CPU fallback)")
         dtype = {"float32": "float32", "fp32": "float32", "f32": "float32", torch.float32: "float32",
@@ -155,6 +157,7 @@ class FlowNetModel:
         cut_hi = self.layers[6 + 2 * self.low_resblock].w_off
         cut_mid = self.layers[6 + 2 * (self.low_resblock // 2)].w_off
         self.grad_buckets = [b for b in ((cut_hi, n + 1), (cut_mid, cut_hi), (0, cut_mid)) if b[1] > b[0]]
+        self._slow_warned = set()
         self.glorot_uniform_init(seed)
 
     def set_conv_algo(self, conv_algo=None):
@@ -257,6 +260,25 @@ class FlowNetModel:
             t = torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float32))).to(self.device)
         return t.contiguous()
 
+    def _warn_slow_grid(self, N, D, H, W):
+        """FDN_ALGO_AUTO picks the 64->64 kernel by the grid's extents (include/fdn.h); a grid that falls off the 2-D Winograd kernels is
+        a silent 1.5x - 3x slowdown of every such layer -- say so once per grid (only for launches big enough to matter)."""
+        if self.dtype != "float32" or (D, H, W) in self._slow_warned or N * D * H * W < (1 << 15):
+            return
+        self._slow_warned.add((D, H, W))
+        if not any(a == ops.ALGO_AUTO for a in self.conv_algo.values()):
+            return
+        if W % 4:
+            how = "the direct kernels (about 3x the time of the 2-D Winograd kernels)"
+        elif H % 2:
+            how = "the 1-D Winograd kernels (about 1.5x the time of the 2-D Winograd kernels)"
+        else:
+            return
+        import warnings
+        warnings.warn("4dflownet_amd: the 64->64 3x3x3 layers of the %dx%dx%d grid run on %s: FDN_ALGO_AUTO takes the 2-D Winograd kernels "
+                      "only where W %% 4 == 0 and H is even (fastest: H %% 4 == 0 as well).  patch_size * res_increase (and patch_size "
+                      "itself for the low-res stack) a multiple of 4 avoids this." % (D, H, W, how), RuntimeWarning, stacklevel=3)
+
     def _conv(self, x, L, act, residual=None, x2=None, out=None, ldy=None, y_coff=0):
         return self.ops.conv3d_fwd(x, L.w, L.b, act, ops.LEAKY_ALPHA, residual, x2, L.wp_f, out, ldy, y_coff, algo=self.conv_algo[L.name])
 
@@ -270,6 +292,9 @@ class FlowNetModel:
             B, D, H, W = u.shape
         R = self.res_increase
         Ls = self.layers
+        self._warn_slow_grid(B, D, H, W)
+        if R > 1 and self.hi_resblock > 0:
+            self._warn_slow_grid(B, D * R, H * R, W * R)
         phase = torch.empty((B, D, H, W, 3), device=self.device, dtype=self.act_dtype)
         pc = torch.empty((B, D, H, W, 3), device=self.device, dtype=self.act_dtype)
         self.ops.input_features(u, v, w, mu, mv, mw, phase, pc)

@@ -47,6 +47,24 @@ def test_glorot_init_matches_oracle_seeded_init(fdn):
     assert m.n_params == O.count_params(O.init_params(5, 1, 1))
 
 
+def test_auto_algo_warns_once_when_a_grid_falls_off_the_winograd_kernels(fdn):
+    """FDN_ALGO_AUTO picks the 64->64 kernel by the extents; P = 18 (a legal reference patch size) has W % 4 != 0 -> the direct
+    kernels, ~3x slower: the model says so once per grid.  P = 16 stays silent."""
+    import warnings
+    net = __import__("importlib").import_module("4dflownet_amd.network")
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for P, expect in ((18, True), (16, False)):
+        m = net.FlowNetModel(1, low_resblock=1, hi_resblock=0, seed=0)
+        x = [torch.rand((6, P, P, P, 1), device="cuda", generator=g) for _ in range(6)]
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            m.forward(x); m.forward(x)
+        hits = [i for i in w if issubclass(i.category, RuntimeWarning) and "W % 4 == 0" in str(i.message)]
+        assert len(hits) == (1 if expect else 0), [str(i.message) for i in w]
+        if expect:
+            assert "direct kernels" in str(hits[0].message) and "18x18x18" in str(hits[0].message)
+
+
 def count_flips(cache, rc):
     """Number of activation units whose sign differs between the fp32 GPU forward and the float64 oracle.
     A unit within fp32 rounding of the ReLU/LeakyReLU kink may legitimately land on either side; each such flip

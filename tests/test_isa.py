@@ -72,9 +72,49 @@ def test_no_kernel_spills_or_uses_scratch(code_objects):
     assert seen >= 60, "expected the whole kernel set, saw %d" % seen
 
 
+# Every kernel of the PRODUCT library and the include/fdn.h entry point that reaches it.  Kernels only a fdn_debug_* switch can select
+# (the VALU thin-layer kernels, the cs4 direct layouts, the occupancy variants) are compiled into lib4dflow_hip_test.so only.
+PRODUCT_KERNELS = {
+    "conv64_wino2d_kernel<false, 4>": "fdn_conv3d_fwd / fdn_conv3d_dgrad, 64->64, H % 4 == 0 and W % 4 == 0 (F(4,3) x F(4,3))",
+    "conv64_wino2d_kernel<true, 4>": "fdn_conv3d_dgrad_fused_part(FDN_DGRAD_INNER)",
+    "conv64_wino2d_shell_kernel<4>": "fdn_conv3d_dgrad_fused",
+    "conv64_wino2d_kernel<false, 2>": "... H even only, or FDN_ALGO_WINO_H2 (F(2,3) x F(4,3))",
+    "conv64_wino2d_kernel<true, 2>": "", "conv64_wino2d_shell_kernel<2>": "",
+    "conv64_wino_kernel<4, false>": "... odd H, FDN_ALGO_WINO_W (F(4,3) along W)", "conv64_wino_kernel<4, true>": "... + shell faces (FDN_DGRAD_SHELL)",
+    "conv64_mfma_kernel<2, 1, 2, false>": "... W % 4 != 0, FDN_ALGO_DIRECT: the planner's three direct layouts", "conv64_mfma_kernel<2, 1, 2, true>": "",
+    "conv64_mfma_kernel<1, 1, 2, false>": "", "conv64_mfma_kernel<1, 1, 2, true>": "", "conv64_mfma_kernel<1, 2, 2, false>": "", "conv64_mfma_kernel<1, 2, 2, true>": "",
+    "wgrad64_wino_kernel<true>": "fdn_conv3d_wgrad 64->64, D even", "wgrad64_wino_kernel<false>": "... odd D, FDN_ALGO_WINO_W",
+    "wgrad64_reduce_dep_kernel": "", "wgrad64_reduce_kernel": "", "wgrad64_pipe_kernel<4, 8>": "... W % 4 != 0, FDN_ALGO_DIRECT",
+    "fold_halo_border_kernel": "fdn_fold_halo_border", "fold_halo_kernel": "fdn_fold_halo",
+    "pack_conv64_kernel": "fdn_pack_conv64_weights", "pack_conv64_wino_kernel": "", "pack_conv64_wino2d_kernel": "", "pack_conv64_batch_kernel": "fdn_pack_conv64_weights_batch",
+    "conv_cin3_fwd_mfma_kernel<T>": "fdn_conv3d_fwd 3->64", "wgrad_cin3_mfma_kernel<T>": "fdn_conv3d_wgrad 3->64", "wgrad_cin3_kernel<T>": "... odd W",
+    "conv1x1_fwd_mfma_kernel<T>": "fdn_conv3d_fwd (64+64)->64 k1", "conv1x1_dgrad_mfma_kernel<T>": "fdn_conv1x1_dgrad", "wgrad_1x1_mfma_kernel<T>": "fdn_conv3d_wgrad k1",
+    "head_fwd_kernel<T>": "fdn_conv3d_fwd 64->1", "head_dgrad_kernel<T>": "fdn_conv_cout1_dgrad_folded", "head_wgrad_kernel<T>": "fdn_conv3d_wgrad 64->1",
+    "conv_cout1_dgrad_kernel": "fdn_conv3d_dgrad 64->1 (padded form)",
+    "bias_grad_kernel<T>": "fdn_bias_grad", "reduce_partials_kernel": "", "sum_partials_kernel": "",
+    "upsample_fwd_kernel<T>": "fdn_upsample_trilinear_fwd", "upsample_bwd_kernel<T>": "fdn_upsample_trilinear_bwd", "input_features_kernel<T>": "fdn_input_features",
+    "loss_main_kernel": "fdn_loss_metrics", "loss_finalize_kernel": "", "mask_sums_kernel": "", "l2_sumsq_kernel": "fdn_l2_sumsq", "adam_kernel": "fdn_adam_step",
+    "gather_patches_kernel": "fdn_gather_patches",
+    "conv64_bf16_kernel<8, 2>": "bf16 mode: fdn_conv3d_fwd_bf16 / dgrad_fused_bf16", "conv64_bf16_kernel<8, 1>": "", "conv64_bf16_kernel<8, 0>": "",
+    "conv64_bf16_kernel<4, 2>": "", "conv64_bf16_kernel<4, 1>": "", "conv64_bf16_kernel<4, 0>": "", "pack_conv64_bf16_kernel": "", "fold_halo_border_bf16_kernel": "",
+    "wgrad64_bf16_dma_kernel": "fdn_conv3d_wgrad_bf16", "wgrad64_bf16_kernel": "... tensors of 4 GB and more",
+}
+
+
+def test_product_library_holds_only_reachable_kernels(code_objects):
+    names = set()
+    for notes, _ in code_objects:
+        for name in _kernels(notes):
+            d = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
+            d = re.sub(r"\(.*$", "", re.sub(r"^void ", "", d.replace("(anonymous namespace)::", "")))
+            names.add(re.sub(r"<(float|unsigned short)>$", "<T>", d))
+    assert names == set(PRODUCT_KERNELS), (sorted(names - set(PRODUCT_KERNELS)), sorted(set(PRODUCT_KERNELS) - names))
+
+
 def test_hot_kernels_use_the_instructions_the_design_names(code_objects):
     asm = "\n".join(a for _, a in code_objects)
-    want = {"20conv64_wino2d_kernelILb0": "v_mfma_f32_16x16x4_f32", "19wgrad64_wino_kernelILb1": "v_mfma_f32_32x32x2_f32",
+    want = {"20conv64_wino2d_kernelILb0ELi4": "v_mfma_f32_16x16x4_f32", "20conv64_wino2d_kernelILb0ELi2": "v_mfma_f32_16x16x4_f32",
+            "19wgrad64_wino_kernelILb1": "v_mfma_f32_32x32x2_f32",
             "18conv64_bf16_kernelILi8ELi2": "v_mfma_f32_32x32x16_bf16", "23wgrad64_bf16_dma_kernel": "ds_read_b64_tr_b16"}
     for kern, ins in want.items():
         body = _function(asm, kern)
