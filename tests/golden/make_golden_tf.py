@@ -11,7 +11,9 @@ here), sets the seeded weights of SURVEY 8(d) by LAYER NAME (conv3d, conv3d_1, .
 of the reference's data/example_data*.h5 rows, and writes tests/golden/tf_golden.npz with, per case:
     inputs (the 11 loader arrays), the weights that were set, pred = model(inputs), the (B,) loss vector incl. L2, mse,
     rel-error, tape.gradient(loss, trainable_variables) (all arrays, in Keras trainable_variables order + their names),
-    the weights after ONE optimizer.apply_gradients step, and optimizer.get_weights() after it (iterations, m..., v...).
+    the weights after ONE optimizer.apply_gradients step, and optimizer.get_weights() after it (iterations, m..., v...);
+    beside the .npz, per case: tf_model_c<i>.h5 = model.save() and tf_optimizer_c<i>.pkl = pickle of optimizer.get_weights(), the two
+    checkpoint files of TrainerController.py:347-363 as real Keras writes them.
 tests/test_tf_golden.py consumes that file when present (CPU: the oracle against it; GPU: the HIP path against it) and
 skips with "parity unpinned" when absent.  Only data leaves this script: inputs and outputs, no reference source.
 
@@ -98,6 +100,12 @@ def main():
         for i, a in enumerate(ow):
             out[k + "opt_%03d" % i] = np.asarray(a)
         out[k + "opt_names"] = np.asarray([w_.name for w_ in tc.optimizer.weights])
+        # the two files the reference itself writes at a checkpoint (TrainerController.py:347-363): model.save()'s HDF5 and the pickled
+        # optimizer.get_weights() -- real Keras files for the built-in reader / restore path (tests/test_tf_golden.py; f1 of SURVEY 8)
+        import pickle
+        tc.model.save(os.path.join(HERE, "tf_model_c%d.h5" % ci))
+        with open(os.path.join(HERE, "tf_optimizer_c%d.pkl" % ci), "wb") as f:
+            pickle.dump(tc.optimizer.get_weights(), f)
     dst = os.path.join(HERE, "tf_golden.npz")
     np.savez_compressed(dst, **out)
     print("wrote", dst, "(%d arrays, TensorFlow %s)" % (len(out), tf.__version__))

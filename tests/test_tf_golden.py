@@ -88,6 +88,28 @@ def test_keras_variable_order_matches_real_tensorflow_names():
 
 
 @needs_npz
+def test_reader_takes_the_checkpoint_files_real_keras_wrote():
+    """tf_model_c<i>.h5 (model.save) and tf_optimizer_c<i>.pkl (pickled optimizer.get_weights()), written beside the .npz: the built-in
+    HDF5 reader returns the weights after the step, and the pickle's slot order is the Keras variable order the restore path assumes."""
+    import pickle
+    h5io = importlib.import_module("4dflownet_amd.h5io")
+    for ci, c in enumerate(load_cases()):
+        h5 = os.path.join(HERE, "golden", "tf_model_c%d.h5" % ci)
+        pkl = os.path.join(HERE, "golden", "tf_optimizer_c%d.pkl" % ci)
+        if not (os.path.exists(h5) and os.path.exists(pkl)):
+            pytest.skip("tf_golden.npz predates the checkpoint files: re-run tests/golden/make_golden_tf.py")
+        got = h5io.read_keras_weights(h5)
+        for n, a in zip(c["names"], c["wnew"]):
+            layer, var = n.split("/")
+            k, b = got[layer]
+            assert np.array_equal(k if var.startswith("kernel") else b, a), n
+        ow = pickle.load(open(pkl, "rb"))
+        nv = len(c["names"])
+        assert len(ow) == 1 + 2 * nv and int(ow[0]) == 1
+        assert [tuple(a.shape) for a in ow[1:1 + nv]] == [tuple(a.shape) for a in c["wnew"]]      # m slots in trainable_variables order
+
+
+@needs_npz
 def test_oracle_reproduces_the_tensorflow_reference():
     for c in load_cases():
         params = O.init_params(0, c["LB"], c["HB"], np.float64)
