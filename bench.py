@@ -38,8 +38,9 @@ PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64
 PEAK_BF16_MFMA_TFLOPS = 2516.6       # dense bf16: 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz
 FLOP_PER_VOXEL_CONV64 = 2.0 * 27 * 64 * 64   # 3.0576 GFLOP per 24^3 patch = 221 184 FLOP/voxel
 # committed PMC traffic summaries (tools/pmc_traffic.py), newest round first
-CFG2_TRAFFIC = ["r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"]
-CFG4_TRAFFIC = ["r4_cfg4_pmc_traffic.json", "r3_cfg4_pmc_traffic.json", "r2_cfg4_pmc_traffic.json", "r1_cfg4_pmc_traffic.json"]
+CFG2_TRAFFIC = ["r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"]
+CFG4_TRAFFIC = ["r5_cfg4_pmc_traffic.json", "r4_cfg4_pmc_traffic.json", "r3_cfg4_pmc_traffic.json", "r2_cfg4_pmc_traffic.json", "r1_cfg4_pmc_traffic.json"]
+PMC_LIVE = None          # --pmc: {kernel name: {...hbm_bytes_per_launch}} measured by two rocprofv3 passes of this very run
 
 
 def synthetic_batch(B, P, R, seed, device):
@@ -147,19 +148,64 @@ def executed_shell_flop(N, D, H, W):
     return N * (dh_faces * 4.5 + w_faces * 9.0) * 2.0 * 64 * 64
 
 
+def _weighted(d, kernel):
+    rows = [(v["launches"], v["hbm_bytes_per_launch"]) for k, v in d.items() if isinstance(v, dict) and "launches" in v and kernel in k]
+    n = sum(r[0] for r in rows)
+    return sum(r[0] * r[1] for r in rows) / n if n else None
+
+
 def pmc_traffic_bytes(fname, kernel):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json, produced by
-    tools/pmc_traffic.py from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command, read side doubled as
-    MI355X_MICROARCH.md prescribes for gfx950).  Launch-weighted over the kernel's variants; None if the file is absent."""
+    """HBM bytes per launch from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command,
+    summarised by tools/pmc_traffic.py, read side doubled as MI355X_MICROARCH.md prescribes for gfx950): measured by THIS run when
+    it was started with --pmc (PMC_LIVE), else quoted from the newest committed profiles/*_pmc_traffic.json.  Launch-weighted over
+    the kernel's variants.  Returns (bytes or None, source description or None)."""
+    if PMC_LIVE is not None:
+        v = _weighted(PMC_LIVE, kernel)
+        if v is not None:
+            return v, "two rocprofv3 --pmc passes of this run (bench.py --pmc)"
     for f in ([fname] if isinstance(fname, str) else fname):
         path = os.path.join(ROOT, "profiles", f)
         if os.path.exists(path):
             d = json.load(open(path))
-            rows = [(v["launches"], v["hbm_bytes_per_launch"]) for k, v in d.items() if isinstance(v, dict) and "launches" in v and kernel in k]
-            n = sum(r[0] for r in rows)
-            if n:
-                return sum(r[0] * r[1] for r in rows) / n, f
+            v = _weighted(d, kernel)
+            if v is not None:
+                stamp = (d.get("_meta") or {}).get("lib_source_stamp", "")
+                try:
+                    cur = importlib.import_module("4dflownet_amd.build").source_stamp()
+                except Exception:
+                    cur = None
+                state = "unstamped" if not stamp else ("measured on this library" if cur and cur.startswith(stamp[:16]) else
+                                                        "STALE: measured on library %s, this one is %s" % (stamp[:16], (cur or "?")[:16]))
+                return v, "profiles/%s (%s)" % (f, state)
     return None, None
+
+
+def pmc_live_passes(argv_tail):
+    """bench.py --pmc: re-run this command (headline only, 2 steps) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate
+    passes, kernel-trace only -- the combination the GPU pool allows) and summarise per kernel.  None when rocprofv3 is missing or a
+    pass fails."""
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_traffic
+    tmp = tempfile.mkdtemp(prefix="fdn_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        dirs = {}
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            dirs[ctr] = os.path.join(tmp, ctr)
+            cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", dirs[ctr], "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-secondary", "--steps", "2", "--warmup", "1"] + argv_tail
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=900)
+            if r.returncode != 0:
+                print("bench.py --pmc: the %s pass failed: %s" % (ctr, r.stderr[-300:]), file=sys.stderr)
+                return None
+        return pmc_traffic.summarise(dirs["FETCH_SIZE"], dirs["WRITE_SIZE"])
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def host_cpu_model():
@@ -172,20 +218,50 @@ def host_cpu_model():
     return "unknown"
 
 
+def one_socket_cores():
+    """One logical CPU per physical core of socket 0 (from /sys topology), or None when the topology cannot be read."""
+    try:
+        seen = {}
+        for cpu in sorted(os.sched_getaffinity(0)):
+            base = "/sys/devices/system/cpu/cpu%d/topology/" % cpu
+            pkg = int(open(base + "physical_package_id").read())
+            core = int(open(base + "core_id").read())
+            if pkg == min([pkg] + [k[0] for k in seen]):
+                seen.setdefault((pkg, core), cpu)
+        pkg0 = min(k[0] for k in seen)
+        cpus = sorted(v for k, v in seen.items() if k[0] == pkg0)
+        return cpus or None
+    except Exception:
+        return None
+
+
 def cpu_baseline(P, R, LB, HB):
     """The same train step (forward + loss + backward + Adam) on the GPU box's host cores, on a bounded sample.
-    Primary figure: torch-CPU (oneDNN conv3d + autograd, float32, all cores torch uses) -- the closest available stand-in
-    for the reference's TensorFlow CPU path, which cannot run here (TensorFlow absent).  Second figure: the numpy oracle."""
+    Primary figure: torch-CPU (oneDNN conv3d + autograd, float32) -- the closest available stand-in for the reference's TensorFlow
+    CPU path, which cannot run here (TensorFlow absent) -- in a child process pinned to the physical cores of ONE socket
+    (sched_setaffinity + OMP_PROC_BIND=close, OMP_PLACES=cores): median of 5 steps after 2 warm-up steps, spread reported (round 4's
+    unpinned best-of-2 on all logical CPUs moved by 37 % between runs).  Second figure: the numpy oracle."""
+    import subprocess
     from oracle import flownet_oracle as O          # checker / baseline only, never on the product path
-    from oracle import torch_cpu as TC
     out = {"unit": "patches/s", "kind": "port", "cpu_model": host_cpu_model(), "logical_cpus": os.cpu_count()}
-    # torch-CPU: warm-up step (oneDNN primitive creation), then the timed one; 1 patch per step
-    dt_warm, threads = TC.time_train_step(P, R, LB, HB, B=1)
-    reps = 2 if dt_warm < 8 else 1
-    dt, threads = TC.time_train_step(P, R, LB, HB, B=1, repeats=reps)
-    out.update({"value": 1.0 / dt, "cores": int(threads),
-                "sample": "1 train step (fwd+loss+bwd+Adam) of 1 patch, P%d/R%d/LB%d/HB%d fp32, torch-CPU %s (oneDNN conv3d + autograd), "
-                          "%d threads, best of %d after one warm-up step: %.2f s" % (P, R, LB, HB, torch.__version__, threads, reps, dt)})
+    cpus = one_socket_cores()
+    env = dict(os.environ, OMP_PROC_BIND="close", OMP_PLACES="cores")
+    if cpus:
+        env["OMP_NUM_THREADS"] = str(len(cpus))
+    cmd = [sys.executable, "-m", "oracle.torch_cpu", str(P), str(R), str(LB), str(HB), "2", "5"] + ([str(len(cpus))] if cpus else [])
+    pin = (lambda: os.sched_setaffinity(0, cpus)) if cpus else None
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, preexec_fn=pin, timeout=1800)
+    if r.returncode != 0:
+        raise RuntimeError("cpu_baseline child failed: " + r.stderr[-500:])
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    ts = sorted(res["times"])
+    med = ts[len(ts) // 2]
+    threads = int(res["threads"])
+    out.update({"value": 1.0 / med, "cores": threads, "spread": {"min_s": ts[0], "median_s": med, "max_s": ts[-1], "steps": len(ts)},
+                "sample": "train steps (fwd+loss+bwd+Adam) of 1 patch, P%d/R%d/LB%d/HB%d fp32, torch-CPU %s (oneDNN conv3d + autograd), %d threads "
+                          "pinned to %s: median of %d after 2 warm-up steps %.2f s (min %.2f, max %.2f)"
+                          % (P, R, LB, HB, torch.__version__, threads, ("the %d physical cores of socket 0" % len(cpus)) if cpus else "all CPUs (topology unreadable)",
+                             len(ts), med, ts[0], ts[-1])})
     try:
         from threadpoolctl import threadpool_info
         blas = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
@@ -228,7 +304,7 @@ def roofline_obj(timer, kind, bf16, kernel, traffic_files):
     alg = vox * 64 * esz * 2 + 27 * 64 * 64 * (4.0 if kind == "wgrad" else esz)
     return {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "traffic": traffic,
-            "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/%s)" % tfile if tfile else None,
+            "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)" if tfile else None, "traffic_source": tfile,
             "algorithmic_bytes_per_launch": alg, "launches_timed": n_launch, "avg_launch_ms": avg_ms,
             "timing": "HIP events on the launch stream around every launch of the sampled timed steps (--event-every)",
             "executed_gflop_per_launch": avg_exec / 1e9,
@@ -237,7 +313,7 @@ def roofline_obj(timer, kind, bf16, kernel, traffic_files):
             "algorithmic_gflop_per_launch": avg_flop / 1e9, "algorithmic_achieved": algorithmic,
             "algorithmic_frac": algorithmic / peak, "algorithmic_speedup": avg_flop / avg_exec,
             "note": None if bf16 else "achieved/frac = FLOPs the Winograd kernel EXECUTES on the fp32 MFMA pipe (forward / dgrad inner box: "
-                                      "2-D F(2,3)xF(4,3), a third of the direct algorithm's multiplies; wgrad: F(3,2) along D x F(3,4) along W, a third) = matrix-pipe "
+                                      "2-D F(4,3)xF(4,3), a quarter of the direct algorithm's multiplies; wgrad: F(3,2) along D x F(3,4) along W, a third) = matrix-pipe "
                                       "utilisation; PMC SQ_VALU_MFMA_BUSY_CYCLES agrees (profiles/README.md).  algorithmic_* prices the same "
                                       "launches with the direct 3x3x3 FLOP count of SURVEY 8d and therefore exceeds the peak"}
 
@@ -577,6 +653,8 @@ def main():
     ap.add_argument("--sustained-steps", type=int, default=300, help="length of the secondary `sustained` run (N=1)")
     ap.add_argument("--single-allreduce", action="store_true",
                     help="N>1: ONE all-reduce of the whole gradient buffer after backward instead of the three buckets started inside it")
+    ap.add_argument("--pmc", action="store_true",
+                    help="N=1: measure roofline.traffic in this run (two extra rocprofv3 --pmc passes of 2 steps) instead of quoting profiles/")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="launcher self-test: allow more ranks than GPUs (ranks share devices, gloo with host staging); not a scaling number")
     args = ap.parse_args()
@@ -599,7 +677,8 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     # the world size the collective actually sees: all-reduce a one per rank
-    rccl_ranks = int(round(parallel.allreduce_sum_(torch.ones(1, device=device)).item()))
+    collective_ranks = int(round(parallel.allreduce_sum_(torch.ones(1, device=device)).item()))
+    backend = "none" if world == 1 else ("gloo" if oversub else "rccl")
 
     # never benchmark a binary older than its sources: (re)build under the build lock (one rank compiles, the others wait), then
     # load -- load() itself re-checks the stamp and fails loudly if the HIP library is missing or stale
@@ -649,6 +728,10 @@ def main():
     # rank 0 assembles the headline object BEFORE the N > 1 secondary legs run: those legs use point-to-point RCCL traffic that no
     # multi-GPU box has exercised yet, and a watchdog prints the headline (with the failure noted) rather than lose it to a hang
     line = None
+    if rank == 0 and args.pmc and world == 1:
+        global PMC_LIVE
+        tail = ["--config", args.config] if args.config != "cfg2" else []
+        PMC_LIVE = pmc_live_passes(tail)
     if rank == 0:
         fwd_flop = fwd_flop_per_patch(tc.model.specs, P, R, LB)
         tr = CFG4_TRAFFIC if args.config == "cfg4" else ([] if bf16 else CFG2_TRAFFIC)
@@ -656,8 +739,12 @@ def main():
             "metric": "3D patches/sec (train step, patch=%d, res×%d)" % (P, R),
             "value": args.steps * B * world / dt,
             "unit": "patches/s",
-            "n_gpus": rccl_ranks,
-            "rccl_ranks": rccl_ranks,
+            # n_gpus = distinct devices the job ran on; collective_ranks = ranks the gradient all-reduce saw, over `backend`;
+            # rccl_ranks counts RCCL peers only: a gloo run (the --oversubscribe launcher self-test) reports 0
+            "n_gpus": min(collective_ranks, ngpu) if oversub else collective_ranks,
+            "collective_ranks": collective_ranks,
+            "backend": backend,
+            "rccl_ranks": 0 if backend == "gloo" else collective_ranks,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,

@@ -136,6 +136,23 @@ def train_step(tp, state, batch, lr, R, LB, HB):
     return loss.detach()
 
 
+def time_train_steps(P, R, LB, HB, B=1, threads=None, warm=2, reps=5):
+    """Seconds of each of `reps` consecutive train steps of B patches (float32) after `warm` untimed ones, and the thread count."""
+    if threads:
+        torch.set_num_threads(int(threads))
+    params = O.init_params(0, LB, HB, np.float32)
+    tp = to_torch_params(params, torch.float32)
+    batch = [torch.from_numpy(np.ascontiguousarray(a)) for a in O.synthetic_batch(B, P, R, seed=1234, dtype=np.float32)]
+    state = {}
+    times = []
+    for i in range(warm + reps):
+        t0 = time.time()
+        train_step(tp, state, batch, 1e-4, R, LB, HB)
+        if i >= warm:
+            times.append(time.time() - t0)
+    return times, torch.get_num_threads()
+
+
 def time_train_step(P, R, LB, HB, B=1, threads=None, repeats=1):
     """Seconds per train step of B patches in float32 on `threads` host threads (default: torch's setting)."""
     if threads:
@@ -151,3 +168,13 @@ def time_train_step(P, R, LB, HB, B=1, threads=None, repeats=1):
         dt = time.time() - t0
         best = dt if best is None else min(best, dt)
     return best, torch.get_num_threads()
+
+
+if __name__ == "__main__":
+    # python -m oracle.torch_cpu P R LB HB warm reps [threads]  -> one JSON line (bench.py's cpu_baseline leg runs this in a child
+    # process whose CPU affinity and OpenMP binding it set beforehand)
+    import json
+    import sys
+    a = [int(v) for v in sys.argv[1:]]
+    ts, n = time_train_steps(a[0], a[1], a[2], a[3], warm=a[4], reps=a[5], threads=a[6] if len(a) > 6 else None)
+    print(json.dumps({"times": ts, "threads": n}))

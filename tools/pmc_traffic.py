@@ -17,15 +17,22 @@ def per_kernel(d, counter):
     return acc
 
 
-fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
-write = per_kernel(sys.argv[2], "WRITE_SIZE")
-out = {}
-for k in sorted(set(fetch) | set(write), key=lambda k: -(sum(fetch.get(k, [0])) + sum(write.get(k, [0])))):
-    nf, nw = len(fetch.get(k, [])), len(write.get(k, []))
-    rd = 2.0 * 1024 * sum(fetch.get(k, [0])) / max(nf, 1)          # gfx950 correction: x2
-    wr = 1024 * sum(write.get(k, [0])) / max(nw, 1)
-    out[k] = {"launches": max(nf, nw), "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
-              "hbm_bytes_per_launch": rd + wr}
-    print("%-64s n=%4d  read %9.2f MB  write %9.2f MB  per launch" % (k[:64], max(nf, nw), rd / 1e6, wr / 1e6))
-if len(sys.argv) > 3:
-    json.dump(out, open(sys.argv[3], "w"), indent=1)
+def summarise(fetch_dir, write_dir, verbose=False):
+    fetch = per_kernel(fetch_dir, "FETCH_SIZE")
+    write = per_kernel(write_dir, "WRITE_SIZE")
+    out = {}
+    for k in sorted(set(fetch) | set(write), key=lambda k: -(sum(fetch.get(k, [0])) + sum(write.get(k, [0])))):
+        nf, nw = len(fetch.get(k, [])), len(write.get(k, []))
+        rd = 2.0 * 1024 * sum(fetch.get(k, [0])) / max(nf, 1)          # gfx950 correction: x2
+        wr = 1024 * sum(write.get(k, [0])) / max(nw, 1)
+        out[k] = {"launches": max(nf, nw), "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
+                  "hbm_bytes_per_launch": rd + wr}
+        if verbose:
+            print("%-64s n=%4d  read %9.2f MB  write %9.2f MB  per launch" % (k[:64], max(nf, nw), rd / 1e6, wr / 1e6))
+    return out
+
+
+if __name__ == "__main__":
+    res = summarise(sys.argv[1], sys.argv[2], verbose=True)
+    if len(sys.argv) > 3:
+        json.dump(res, open(sys.argv[3], "w"), indent=1)
