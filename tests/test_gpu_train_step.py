@@ -228,28 +228,37 @@ def test_linearity_of_conv_at_full_size(fdn):
 
 
 def test_winograd_and_direct_kernels_train_alike(fdn):
-    """The product path (Winograd F(4,3)/F(3,4) kernels for every 64->64 layer) and the round-1 direct MFMA kernels (forced in
-    the test build) run the same 6 training steps from the same weights and batch: per-step losses agree to 1e-5 relative, the
-    first step's gradient to 1e-5 of its scale, and after 6 Adam steps the bulk of the weights has moved identically."""
+    """The product path (2-D Winograd forward / dgrad, depth-transformed Winograd wgrad), the W-only Winograd kernels (FDN_ALGO_WINO_W)
+    and the round-1 direct MFMA kernels (forced in the test build) run the same 6 training steps from the same weights and batch.
+    First-step gradient: the 1-D path keeps round 3's bound (1e-5 of the scale); the product path is held to the same bound whenever
+    its forward put every activation unit on the same side of its kink as the direct forward did -- only a run with counted kink flips
+    (each moves single gradient elements by ~1e-4 of the scale) gets the wider one.  Per-step losses agree to fp32 rounding,
+    and after 6 Adam steps the bulk of the weights has moved identically."""
     trainer_mod = __import__("importlib").import_module("4dflownet_amd.trainer")
     P, R, LB, HB, B = 8, 2, 2, 1, 2
     batch = O.synthetic_batch(B, P, R, seed=77)
 
-    def run(direct):
-        tc = trainer_mod.TrainerController(P, R, initial_learning_rate=1e-4, quicksave_enable=False, low_resblock=LB, hi_resblock=HB, seed=3)
+    def run(algo):
+        tc = trainer_mod.TrainerController(P, R, initial_learning_rate=1e-4, quicksave_enable=False, low_resblock=LB, hi_resblock=HB, seed=3,
+                                           conv_algo=algo)
+        inputs = tc._unpack(batch)[0]
+        tc.model.forward(inputs, training=True)
+        c = tc.model._cache
+        masks = [(t > 0).cpu() for t in [c["a0"], c["a1"], c["p0"], c["p1"], c["c0"], c["c1"]] + [t for blk in c["blocks"] for t in blk[1:]] + list(c["heads"])]
         losses, g0 = [], None
         for step in range(6):
             losses.append(tc.train_step(batch).cpu().numpy().astype(np.float64))
             if step == 0:
                 g0 = tc.model.flat_g.cpu().numpy().astype(np.float64)
-        return np.asarray(losses), g0, tc.model.flat_w.cpu().numpy().astype(np.float64)
+        return np.asarray(losses), g0, tc.model.flat_w.cpu().numpy().astype(np.float64), masks
 
-    l_w, g_w, w_w = run(False)
+    l_w, g_w, w_w, m_w = run("auto")
+    l_1, g_1, w_1, m_1 = run("winograd_w")
     with fdn._lib.test_build() as lib:
         lib.fdn_debug_set_conv64_mt(5)            # direct <1,2,cs2> forward / dgrad kernel
         lib.fdn_debug_set_wgrad64_direct(1)
         try:
-            l_d, g_d, w_d = run(True)
+            l_d, g_d, w_d, m_d = run("auto")
         finally:
             lib.fdn_debug_set_conv64_mt(0)
             lib.fdn_debug_set_wgrad64_direct(0)
@@ -257,16 +266,17 @@ def test_winograd_and_direct_kernels_train_alike(fdn):
     # Adam's +-lr*sign(g) updates of noise-level gradients, which separates the losses by a few 1e-6 per step
     assert np.abs(l_w[0] - l_d[0]).max() <= 1e-6 * np.abs(l_d[0]).max()
     assert np.abs(l_w - l_d).max() <= 3e-5 * np.abs(l_d).max()
-    # first-step gradient: identical weights and batch, two summation orders.  A ReLU / LeakyReLU unit within rounding of its kink may
-    # land on either side, which moves single gradient elements by ~1e-4 of the scale; the bulk agrees to fp32 rounding
-    e_l2 = np.linalg.norm(g_w - g_d) / np.linalg.norm(g_d)
-    e_max = np.abs(g_w - g_d).max() / np.abs(g_d).max()
-    print("\n[train-alike] first-step gradient, Winograd path vs direct kernels: rel L2 %.2e, max %.2e of the scale" % (e_l2, e_max))
-    # measured: 1-D Winograd path < 1e-5 / < 1e-5 (round 3); 2-D forward / dgrad 4.6e-5 / 4.8e-5 -- the same size as either path's
-    # distance to the float64 oracle at these weights (test_gpu_wino_realistic (c'): 2e-4), i.e. kink flips, not kernel error: the
-    # per-kernel errors of the 2-D kernels are at or below the direct kernels' (test_gpu_wino_realistic (a), (b))
-    assert e_l2 <= 1.5e-4 and e_max <= 5e-4
+    for name, g, m in (("W-only Winograd", g_1, m_1), ("product path (2-D Winograd)", g_w, m_w)):
+        flips = sum(int((a != b).sum()) for a, b in zip(m, m_d))
+        e_l2 = np.linalg.norm(g - g_d) / np.linalg.norm(g_d)
+        e_max = np.abs(g - g_d).max() / np.abs(g_d).max()
+        print("\n[train-alike] first-step gradient, %s vs direct kernels: rel L2 %.2e, max %.2e of the scale, %d activation units on the "
+              "other side of the kink" % (name, e_l2, e_max, flips))
+        if flips == 0:
+            assert e_l2 <= 1e-5 and e_max <= 1e-5, (name, e_l2, e_max)
+        else:
+            assert flips <= 8 and e_l2 <= 1.5e-4 and e_max <= 5e-4, (name, flips, e_l2, e_max)
     # Adam moves noise-level gradients by +-lr either way; everything else must coincide
     dw = np.abs(w_w - w_d)
-    # (the share of weights that moved differently at all grows with every gradient element a kink flip touches: 0.19 with the flip above)
+    # (the share of weights that moved differently at all grows with every gradient element a kink flip touches: 0.19 with one flip)
     assert dw.max() <= 6 * 2.1e-4 and np.quantile(dw, 0.99) <= 2e-5 and np.mean(dw > 1e-6) < 0.30
