@@ -32,6 +32,8 @@ SIGNATURES = {
     "fdn_fold_halo_border": (c_i, [c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_f, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "fdn_conv1x1_dgrad": (c_i, [c_fp] * 6 + [c_i64, c_fp]),
     "fdn_conv3d_wgrad_workspace_bytes": (c_sz, [c_i] * 7),
+    "fdn_conv3d_wgrad_batch_workspace_bytes": (c_sz, [c_i] * 5),
+    "fdn_conv3d_wgrad_batch": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_sz] + [c_i] * 5 + [c_fp]),     # (the first four: HOST arrays of device pointers)
     "fdn_conv3d_wgrad": (c_i, [c_fp] * 6 + [c_sz] + [c_i] * 10 + [c_fp]),
     "fdn_upsample_trilinear_fwd": (c_i, [c_fp, c_fp] + [c_i] * 6 + [c_fp]),
     "fdn_upsample_trilinear_bwd": (c_i, [c_fp, c_fp, c_i, c_f, c_fp] + [c_i] * 6 + [c_fp]),

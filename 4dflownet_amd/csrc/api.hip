@@ -192,6 +192,44 @@ extern "C" int fdn_conv3d_wgrad(const float* x, const float* x2, const float* dz
     return FDN_OK;
 }
 
+// Weight gradients of n_layers 64->64 3x3x3 layers that share one grid, in ONE launch (+ one reduction launch) where the kernel allows
+// it (W % 4 == 0, even D, FDN_ALGO_AUTO / _WINO_H2), else layer by layer through fdn_conv3d_wgrad's path: same results either way.
+static bool wgrad_batchable(int n_layers, int D, int W, int algo) {
+    return !fdn_wgrad64_force_direct && (W & 3) == 0 && fdn_wgrad64_wino_batch_ok(n_layers, D, algo);
+}
+extern "C" size_t fdn_conv3d_wgrad_batch_workspace_bytes(int n_layers, int N, int D, int H, int W) {
+    if (n_layers <= 0 || N <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    const size_t one = fdn_conv3d_wgrad_workspace_bytes(N, D, H, W, 64, 64, 3);
+    const size_t all = wgrad_batchable(n_layers, D, W, FDN_ALGO_AUTO) ? fdn_wgrad64_wino_batch_workspace_bytes(n_layers, N, D, H, W) : 0;
+    return all > one ? all : one;
+}
+extern "C" int fdn_conv3d_wgrad_batch(const float* const* x, const float* const* dz, float* const* dw, float* const* dbias, int n_layers,
+                                      void* workspace, size_t workspace_bytes, int N, int D, int H, int W, int algo, void* stream) {
+    FDN_REQUIRE(x && dz && dw && n_layers > 0, "fdn_conv3d_wgrad_batch: NULL table or n_layers <= 0");
+    FDN_REQUIRE(algo >= FDN_ALGO_AUTO && algo <= FDN_ALGO_WINO_H2, "fdn_conv3d_wgrad_batch: bad algo %d", algo);
+    FDN_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "fdn_conv3d_wgrad_batch: bad dims");
+    const size_t need = fdn_conv3d_wgrad_batch_workspace_bytes(n_layers, N, D, H, W);
+    if (workspace_bytes < need || !workspace) {
+        fdn_set_error("fdn_conv3d_wgrad_batch: workspace %zu < %zu bytes", workspace_bytes, need);
+        return FDN_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (wgrad_batchable(n_layers, D, W, algo)) {
+        if (int rc = fdn_wgrad64_wino_batch_launch(x, dz, dw, n_layers, workspace, workspace_bytes, N, D, H, W, s)) return rc;
+    } else {
+        for (int i = 0; i < n_layers; ++i) {
+            FDN_REQUIRE(x[i] && dz[i] && dw[i], "fdn_conv3d_wgrad_batch: NULL pointer for layer %d", i);
+            if (int rc = fdn_conv3d_wgrad(x[i], nullptr, dz[i], dw[i], nullptr, workspace, workspace_bytes, N, D, H, W, 64, 64, 3, 64, 0, algo, stream))
+                return rc;
+        }
+    }
+    if (dbias)                           // (stream-ordered behind the reduction: the workspace is free again)
+        for (int i = 0; i < n_layers; ++i)
+            if (dbias[i])
+                if (int rc = fdn_bias_grad_launch(dz[i], dbias[i], workspace, workspace_bytes, (int64_t)N * D * H * W, 64, 64, 0, s)) return rc;
+    return FDN_OK;
+}
+
 // ---- bf16 activation path ----
 extern "C" int fdn_conv64_fwd_bf16(const uint16_t* x, const uint16_t* wpack, const float* bias, const uint16_t* residual,
                                    uint16_t* y, int N, int D, int H, int W, int act, float alpha, void* stream) {

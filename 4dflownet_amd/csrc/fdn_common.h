@@ -213,6 +213,11 @@ size_t fdn_wgrad64_workspace_bytes(int N, int D, int H, int W);
 int fdn_wgrad64_wino_launch(const float* x, const float* dz, float* dw, void* ws, size_t ws_bytes, int N, int D, int H,
                             int W, hipStream_t s, int algo = FDN_ALGO_AUTO);
 size_t fdn_wgrad64_wino_workspace_bytes(int N, int D, int H, int W);
+// several 64->64 layers of one grid in ONE launch (wgrad64_wino.hip); _ok: applicable (else the caller loops over fdn_wgrad64_wino_launch)
+bool fdn_wgrad64_wino_batch_ok(int n_layers, int D, int algo);
+size_t fdn_wgrad64_wino_batch_workspace_bytes(int n_layers, int N, int D, int H, int W);
+int fdn_wgrad64_wino_batch_launch(const float* const* x, const float* const* dz, float* const* dw, int n_layers, void* ws, size_t ws_bytes,
+                                  int N, int D, int H, int W, hipStream_t s);
 int fdn_wgrad64_reduce_launch(const float* partial, float* dw, int S, hipStream_t s);
 
 // bf16 activation path (conv64_bf16.hip)

@@ -59,10 +59,11 @@ constexpr int kLocSlot = 5, kXSlot = 6, kZSlot = 13;      // pipeline slots: til
 constexpr int XSCRATCH = 6 * 4096;                      // DEP: x chunks of the second plane, [chunk 6][x-thread 256] x 16 B, filled by LDS-DMA
 constexpr int ZSCRATCH = 2 * 3072;                      // DEP: dz chunks 2, 3 of the second plane, [2][dz-thread 192] x 16 B
 
+// (a __device__ body + thin __global__ wrappers: one layer per launch, or several layers of the same grid in ONE launch -- the
+// batched form, wgrad64_wino_batch_kernel below.  q = the workgroup's place in the XCD-aware order of its layer, see wgrad64_place.)
 template <bool DEP>
-__global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
+__device__ __forceinline__ void wgrad64_wino_body(const WgWinoArgs& p, const int q, char* const smem) {
     constexpr int NP = DEP ? 4 : 3;                     // workgroups per split: depth coordinates xd (DEP) or depth taps a
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -76,14 +77,8 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
     // HBM reads 763 -> 553 MB per launch (x + dz = 453 MB), 0.889 -> 0.865 ms.  (A depth-fastest tile order -- the 3 x 10 workgroups of an
     // XCD then share x planes as well -- cuts the reads to 353 MB but runs 0.90 ms: the concurrent tiles then differ by multiples of
     // the plane stride, 9 x 64 KB at 48^3, and pile onto the same memory channels.  Test-build bit 16.)
-    int a, split;
-    {
-        const int G = NP * p.S, qx = G >> 3, rx = G & 7;
-        const int xcd = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
-        const int q = (FDN_DBG_BITS(p) & 8) ? (int)blockIdx.x : xcd * qx + min(xcd, rx) + j;
-        split = q / NP;
-        a = q - NP * split;              // kernel-depth tap, or depth coordinate xd (DEP)
-    }
+    const int split = q / NP;
+    const int a = q - NP * split;        // kernel-depth tap, or depth coordinate xd (DEP)
     const int c16 = tid & 15;        // 16-B chunk (4 channels) of a 256-B row
     const int ig = (tid >> 4) & 1;   // group of this thread's transform item
     const int il = (tid >> 5) & 7;   // line of the item: waves 0-3: x halo lines 0..7; waves 4-6: dz lines 0..5
@@ -387,6 +382,45 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
     }
 }
 
+// workgroup id -> place q in the XCD-aware order of G = NP * S * layers (split, tap) pairs (see the comment at the top of the body)
+__device__ __forceinline__ int wgrad64_place(int block, int G, bool plain) {
+    const int qx = G >> 3, rx = G & 7, xcd = block & 7, j = block >> 3;
+    return plain ? block : xcd * qx + min(xcd, rx) + j;
+}
+
+template <bool DEP>
+__global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(WgWinoArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    wgrad64_wino_body<DEP>(p, wgrad64_place((int)blockIdx.x, (DEP ? 4 : 3) * p.S, (FDN_DBG_BITS(p) & 8) != 0), smem);
+}
+
+// Several layers of the SAME grid in one launch (fdn_conv3d_wgrad_batch): the (split, coordinate) pairs of all layers form one list,
+// placed on the XCDs like a single layer's (the pairs of a layer stay contiguous: neighbours share that layer's rows in L2); a
+// layer gets S = 64 / layers splits, so the launch still fills the chip once, but a workgroup walks layers-times more tiles of ITS layer
+// between the prologue and the output transform, and the partial sums it writes (and the reduction reads) shrink by the same factor.
+// At the cfg2 low-res grid (8 x 24^3: 4.6 tiles per workgroup when a layer has the chip to itself) that is where the time goes.
+constexpr int kWgBatchMax = 32;
+struct WgWinoBatch {
+    WgWinoArgs a;                        // x / dz / partial unused; everything else common to the layers
+    const float* x[kWgBatchMax];
+    const float* dz[kWgBatchMax];
+    int nl;
+};
+struct WgDwTable { float* dw[kWgBatchMax]; };
+
+template <bool DEP>
+__global__ __launch_bounds__(512, 1) void wgrad64_wino_batch_kernel(WgWinoBatch b) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NP = DEP ? 4 : 3;
+    const int per = NP * b.a.S;
+    const int qg = wgrad64_place((int)blockIdx.x, per * b.nl, (FDN_DBG_BITS(b.a) & 8) != 0);
+    const int layer = qg / per;
+    WgWinoArgs p = b.a;
+    p.x = b.x[layer]; p.dz = b.dz[layer];
+    p.partial = b.a.partial + (size_t)layer * b.a.S * (NP * 9) * 4096;
+    wgrad64_wino_body<DEP>(p, qg - layer * per, smem);
+}
+
 // DEP: (D / 2) depth units and 4 workgroups per split
 bool wgrad64_wino_dep_ok(int D) { return D >= 2 && (D & 1) == 0; }
 int wgrad64_wino_splits(int N, int D, int H, int W, bool dep) {
@@ -398,8 +432,10 @@ int wgrad64_wino_splits(int N, int D, int H, int W, bool dep) {
 
 // dw[a][k] = sum_s sum_xd G^T[a][xd] partial[s][xd][k]  (k over the 9 (b,t) taps x 64 x 64), G^T = (1,1/2,1/2,0) (0,1/2,-1/2,0) (0,1/2,1/2,1).
 // Same block shape as wgrad64_reduce_kernel: 64 float4 columns x 4 quarters of S, combined through LDS in a fixed order.
-__global__ __launch_bounds__(256) void wgrad64_reduce_dep_kernel(const float* __restrict__ partial, float* __restrict__ dw, int S) {
+__global__ __launch_bounds__(256) void wgrad64_reduce_dep_kernel(const float* __restrict__ partial_base, WgDwTable dws, int S) {
     __shared__ f32x4 red[3][3][64];
+    const float* partial = partial_base + (size_t)blockIdx.y * S * 36 * 4096;       // blockIdx.y = layer of a batched launch
+    float* dw = dws.dw[blockIdx.y];
     const int col = threadIdx.x & 63, qtr = threadIdx.x >> 6;
     const int e4 = blockIdx.x * 64 + col;                       // 9*1024 float4 columns of one (b,t) block set
     const f32x4* p = (const f32x4*)partial + e4;
@@ -452,7 +488,9 @@ int fdn_wgrad64_wino_launch(const float* x, const float* dz, float* dw, void* ws
         if (int rc = fdn_func_max_lds((const void*)wgrad64_wino_kernel<true>, (int)lds, "wgrad64_wino")) return rc;
         hipLaunchKernelGGL(wgrad64_wino_kernel<true>, dim3(4 * a.S), dim3(512), lds, s, a);
         FDN_CHECK_LAUNCH("wgrad64_wino_kernel");
-        hipLaunchKernelGGL(wgrad64_reduce_dep_kernel, dim3(9 * 1024 / 64), dim3(256), 0, s, (const float*)ws, dw, a.S);
+        WgDwTable t;
+        t.dw[0] = dw;
+        hipLaunchKernelGGL(wgrad64_reduce_dep_kernel, dim3(9 * 1024 / 64), dim3(256), 0, s, (const float*)ws, t, a.S);
         FDN_CHECK_LAUNCH("wgrad64_reduce_dep_kernel");
         return FDN_OK;
     }
@@ -461,6 +499,52 @@ int fdn_wgrad64_wino_launch(const float* x, const float* dz, float* dw, void* ws
     hipLaunchKernelGGL(wgrad64_wino_kernel<false>, dim3(3 * a.S), dim3(512), lds, s, a);
     FDN_CHECK_LAUNCH("wgrad64_wino_kernel");
     return fdn_wgrad64_reduce_launch((const float*)ws, dw, a.S, s);
+}
+
+// ---- several layers of one grid in ONE launch (+ one reduction launch) ----
+// Applicable when the depth-transformed kernel is (D even, FDN_ALGO_AUTO) and the layers' partial sums fit 32-bit tile counts;
+// fdn_conv3d_wgrad_batch (api.hip) falls back to per-layer launches otherwise.
+bool fdn_wgrad64_wino_batch_ok(int n_layers, int D, int algo) {
+    return n_layers >= 2 && n_layers <= kWgBatchMax && wgrad64_wino_dep_ok(D) && algo != FDN_ALGO_WINO_W && algo != FDN_ALGO_DIRECT && !fdn_wgrad64_wino_nodep;
+}
+static int wgrad64_wino_batch_splits(int n_layers, int N, int D, int H, int W) {
+    const long long ntiles = (long long)N * (D / 2) * ((H + WTH - 1) / WTH) * ((W + WTW - 1) / WTW);
+    long long S = 64 / n_layers;         // 4 S n_layers <= 256 workgroups: one per CU, the chip filled once
+    if (S < 1) S = 1;
+    if (ntiles < S) S = ntiles > 0 ? ntiles : 1;
+    return (int)S;
+}
+size_t fdn_wgrad64_wino_batch_workspace_bytes(int n_layers, int N, int D, int H, int W) {
+    return (size_t)n_layers * wgrad64_wino_batch_splits(n_layers, N, D, H, W) * 36 * 4096 * sizeof(float);
+}
+int fdn_wgrad64_wino_batch_launch(const float* const* x, const float* const* dz, float* const* dw, int n_layers, void* ws, size_t ws_bytes,
+                                  int N, int D, int H, int W, hipStream_t s) {
+    FDN_REQUIRE(fdn_wgrad64_wino_batch_ok(n_layers, D, FDN_ALGO_AUTO), "wgrad64 (batched): %d layers at depth %d are not batchable", n_layers, D);
+    FDN_REQUIRE((long long)N * D * H * W * 256 < (1ll << 32), "wgrad64: x of %dx%dx%dx%dx64 floats exceeds the 32-bit buffer addressing", N, D, H, W);
+    WgWinoBatch b;
+    WgDwTable t;
+    b.nl = n_layers;
+    for (int i = 0; i < n_layers; ++i) {
+        FDN_REQUIRE(x[i] && dz[i] && dw[i], "wgrad64 (batched): NULL pointer for layer %d", i);
+        b.x[i] = x[i]; b.dz[i] = dz[i]; t.dw[i] = dw[i];
+    }
+    WgWinoArgs& a = b.a;
+    a.x = nullptr; a.dz = nullptr; a.partial = (float*)ws;
+    a.N = N; a.D = D; a.H = H; a.W = W;
+    a.DT = D / 2;
+    a.nth = (H + WTH - 1) / WTH; a.ntw = (W + WTW - 1) / WTW;
+    a.ntiles = N * a.DT * a.nth * a.ntw;
+    a.S = wgrad64_wino_batch_splits(n_layers, N, D, H, W);
+    FDN_REQUIRE(ws_bytes >= fdn_wgrad64_wino_batch_workspace_bytes(n_layers, N, D, H, W), "wgrad64 (batched): workspace too small");
+    a.bytes = (unsigned)((long long)N * D * H * W * 256);
+    a.dbg = fdn_wgrad64_wino_dbg;
+    const size_t lds = (size_t)3 * WBUFB + XSCRATCH + ZSCRATCH;
+    if (int rc = fdn_func_max_lds((const void*)wgrad64_wino_batch_kernel<true>, (int)lds, "wgrad64_wino_batch")) return rc;
+    hipLaunchKernelGGL(wgrad64_wino_batch_kernel<true>, dim3(4 * a.S * n_layers), dim3(512), lds, s, b);
+    FDN_CHECK_LAUNCH("wgrad64_wino_batch_kernel");
+    hipLaunchKernelGGL(wgrad64_reduce_dep_kernel, dim3(9 * 1024 / 64, n_layers), dim3(256), 0, s, (const float*)ws, t, a.S);
+    FDN_CHECK_LAUNCH("wgrad64_reduce_dep_kernel");
+    return FDN_OK;
 }
 
 #ifdef FDN_TEST_HOOKS

@@ -8,6 +8,7 @@ Parameters live in ONE flat fp32 device buffer in layer CREATION order (kernel, 
 conv3d_35), gradients in a second flat buffer of the same layout, so the data-parallel all-reduce and the Adam step are one
 call each.  Keras' own `trainable_variables` order (depth-sorted layers, keras_layer_order) differs from creation order and
 is what optimizer.pkl uses: keras_variable_order() / trainable_variable_names() translate between the two."""
+import contextlib
 import math
 import os
 
@@ -149,6 +150,12 @@ class FlowNetModel:
         self._side = None              # second HIP stream for the weight-gradient launches
         self.overlap_shell = False     # dgrad shell slabs on a side stream: measured 38.6 -> 39.3 ms per cfg2 step (the two stream joins per
                                        # layer cost more than the tail the slabs fill), so off
+        # weight gradients of 64->64 layers on small grids are collected per gradient bucket and issued as ONE batched launch
+        # (fdn_conv3d_wgrad_batch): at 8 x 24^3 a layer alone on the chip leaves a workgroup 4.6 tiles between prologue and output
+        # transform.  The batch ends where the bucket does, so the data-parallel all-reduce of a bucket starts as early as before.
+        self.batch_wgrad = os.environ.get("FDN_BATCH_WGRAD", "1") not in ("", "0")
+        self.batch_wgrad_max_voxels = 1 << 18          # per launch; the 48^3 layers of cfg2 (8 x 110 592 voxels) fill the chip on their own
+        self._wg_pending = []
         self.overlap_wgrad = False     # measured +0.7 % at cfg2 (kernels already fill the chip); off so per-kernel timings stay clean
         self._cache = None
         # Gradient buckets in the order backward() completes them: slices [lo, hi) of flat_g_ext that are final when the hi-res part
@@ -355,6 +362,10 @@ class FlowNetModel:
         graph (nothing downstream reads them before the optimizer), so they run on a second HIP stream and fill the tails
         of the dgrad chain's kernels; backward() joins the streams before returning."""
         N, D, H, W = x.shape[:4]
+        if (self.batch_wgrad and self.dtype == "float32" and (L.k, L.cin, L.cout) == (3, 64, 64) and x2 is None and lddz is None and
+                N * D * H * W <= self.batch_wgrad_max_voxels and self.conv_algo[L.name] in (ops.ALGO_AUTO, ops.ALGO_WINO_H2)):
+            self._wg_pending.append((x, dz, L, bias))        # issued by _flush_wgrads() at the end of the gradient bucket
+            return
         ws = self._workspace(self.ops.wgrad_workspace_bytes(N, D, H, W, L.cin, L.cout, L.k))
         if not self.overlap_wgrad:
             self.ops.conv3d_wgrad(x, dz, L.k, L.cin, L.cout, x2=x2, dw=L.gw, dbias=L.gb if bias else None, workspace=ws, lddz=lddz,
@@ -370,6 +381,32 @@ class FlowNetModel:
         for t in (x, dz, x2):                             # keep the caching allocator from recycling them too early
             if t is not None:
                 t.record_stream(self._side)
+
+    def _flush_wgrads(self):
+        """Issue the collected weight gradients: layers of one grid and algorithm as one batched launch, a lone layer as before."""
+        pending, self._wg_pending = self._wg_pending, []
+        groups = {}
+        for x, dz, L, bias in pending:
+            groups.setdefault((tuple(x.shape[:4]), self.conv_algo[L.name]), []).append((x, dz, L, bias))
+        for (shape, algo), items in groups.items():
+            N, D, H, W = shape
+            side = self.overlap_wgrad
+            if side:
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=self.device)
+                self._side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side) if side else contextlib.nullcontext():
+                if len(items) == 1:
+                    x, dz, L, bias = items[0]
+                    ws = self._workspace(self.ops.wgrad_workspace_bytes(N, D, H, W, 64, 64, 3))
+                    self.ops.conv3d_wgrad(x, dz, 3, 64, 64, dw=L.gw, dbias=L.gb if bias else None, workspace=ws, algo=algo)
+                else:
+                    ws = self._workspace(self.ops.wgrad_batch_workspace_bytes(len(items), N, D, H, W))
+                    self.ops.conv3d_wgrad_batch([i[0] for i in items], [i[1] for i in items], [i[2].gw for i in items],
+                                                [i[2].gb if i[3] else None for i in items], workspace=ws, algo=algo)
+            if side:
+                for x, dz, _, _ in items:
+                    x.record_stream(self._side); dz.record_stream(self._side)
 
     def _pad_like(self, t):
         N, D, H, W, C = t.shape
@@ -405,6 +442,7 @@ class FlowNetModel:
         grad_ready(lo, hi), if given, is called once per entry of self.grad_buckets, in that order, as soon as every launch that
         writes flat_g_ext[lo:hi] has been enqueued on the current stream."""
         def bucket_done(k):
+            self._flush_wgrads()                            # the batched weight gradients of this bucket's layers
             if grad_ready is not None and k < len(self.grad_buckets):
                 if self._side is not None:
                     torch.cuda.current_stream().wait_stream(self._side)
@@ -481,6 +519,7 @@ class FlowNetModel:
             self._wgrad(x0, dzz, second)
             dz0 = self._dgrad_fold(dzz, second, None, x0, ACT_RELU)
             self._wgrad(c["phase"] if src == "p" else c["pc"], dz0, first)
+        self._flush_wgrads()
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)      # all weight gradients have landed in flat_g
         while done < len(self.grad_buckets):

@@ -107,11 +107,26 @@ class LaunchTimer:
             f = 1.0 if x.dtype != torch.float32 or W % 4 or k.get("algo", 0) == 1 else (1.0 / 3 if D % 2 == 0 and k.get("algo", 0) == 0 else 0.5)
             return bracket("wgrad", N * D * H * W, f * N * D * H * W * FLOP_PER_VOXEL_CONV64, lambda: wg(x, dz, K, Cin, Cout, *a, **k))
 
+        wgb = getattr(ops, "conv3d_wgrad_batch", None)
+        self._orig["conv3d_wgrad_batch"] = wgb
+
+        def conv3d_wgrad_batch(xs, dzs, *a, **k):
+            # ONE launch over len(xs) layers of one grid (the low-res layers of a gradient bucket): priced as that many layers' work
+            if not self.enabled:
+                return wgb(xs, dzs, *a, **k)
+            N, D, H, W = shp(xs[0])
+            f = 1.0 if W % 4 or k.get("algo", 0) == 1 else (1.0 / 3 if D % 2 == 0 else 0.5)
+            vox = len(xs) * N * D * H * W
+            return bracket("wgrad", vox, f * vox * FLOP_PER_VOXEL_CONV64, lambda: wgb(xs, dzs, *a, **k))
+
         ops.conv3d_fwd, ops.conv3d_dgrad_fused, ops.conv3d_wgrad = conv3d_fwd, conv3d_dgrad_fused, conv3d_wgrad
+        if wgb is not None:
+            ops.conv3d_wgrad_batch = conv3d_wgrad_batch
 
     def uninstall(self):
         for name, orig in self._orig.items():
-            setattr(self.ops, name, orig)
+            if orig is not None:
+                setattr(self.ops, name, orig)
 
     def summary(self, kind):
         """(launches, mean ms, mean ALGORITHMIC FLOP per launch = 221 184 x voxels, mean EXECUTED FLOP per launch)"""

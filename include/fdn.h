@@ -147,6 +147,16 @@ int fdn_conv1x1_dgrad(const float* dz, const float* w, const float* ya, const fl
  * dbias != NULL.  Same (Cin,Cout,K) support and x/x2 convention as fdn_conv3d_fwd.
  * workspace: caller-owned scratch of at least fdn_conv3d_wgrad_workspace_bytes(...). */
 size_t fdn_conv3d_wgrad_workspace_bytes(int N, int D, int H, int W, int Cin, int Cout, int K);
+
+/* The weight gradients of n_layers 64->64 3x3x3 layers that share one (N, D, H, W) grid, as ONE launch + one reduction where the
+ * Winograd kernel applies (W % 4 == 0, D even, algo AUTO / WINO_H2), else layer by layer: results identical to n_layers calls of
+ * fdn_conv3d_wgrad.  x, dz, dw (and dbias, which may be NULL or hold NULL entries): HOST arrays of n_layers device pointers
+ * (dz rows dense, 64 channels).  Why: at the low-res grid of cfg2 (8 x 24^3) a layer that has the chip to itself gives a workgroup
+ * 4.6 tiles between its prologue and its output transform; batched, the ResBlock layers of one gradient bucket share the chip and
+ * each workgroup walks n_layers times more tiles of its layer.  src/Network/TrainerController.py:223 (tape.gradient). */
+size_t fdn_conv3d_wgrad_batch_workspace_bytes(int n_layers, int N, int D, int H, int W);
+int fdn_conv3d_wgrad_batch(const float* const* x, const float* const* dz, float* const* dw, float* const* dbias, int n_layers,
+                           void* workspace, size_t workspace_bytes, int N, int D, int H, int W, int algo, void* stream);
 int fdn_conv3d_wgrad(const float* x, const float* x2, const float* dz, float* dw, float* dbias,
                      void* workspace, size_t workspace_bytes, int N, int D, int H, int W, int Cin, int Cout,
                      int K, int lddz, int dz_coff, int algo, void* stream);

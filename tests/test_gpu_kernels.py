@@ -196,6 +196,38 @@ def test_conv64_dgrad_fused_fold(ops, fdn, shape, layout):
                 lib.fdn_debug_set_conv64_wface_direct(0)
 
 
+@pytest.mark.parametrize("shape,nl", [((2, 8, 12, 16), 3), ((8, 24, 24, 24), 8), ((1, 2, 5, 4), 2), ((2, 6, 6, 8), 11), ((1, 7, 6, 8), 3), ((1, 4, 6, 10), 2)])
+def test_conv64_wgrad_batch(ops, shape, nl):
+    """fdn_conv3d_wgrad_batch: the weight (and bias) gradients of nl layers of one grid in ONE launch == the float64 oracle, and == nl
+    calls of fdn_conv3d_wgrad (different split of the voxel sum: equal to fp32 rounding; the fall-back shapes -- odd D, W % 4 != 0 --
+    loop over the single-layer path and are bit-identical)."""
+    N, D, H, W = shape
+    g = torch.Generator(device="cuda").manual_seed(nl * 1000 + D)
+    xs = [torch.randn((N, D, H, W, 64), device="cuda", generator=g) for _ in range(nl)]
+    dzs = [torch.randn((N, D, H, W, 64), device="cuda", generator=g) for _ in range(nl)]
+    dws = [torch.full((3, 3, 3, 64, 64), float("nan"), device="cuda") for _ in range(nl)]
+    dbs = [torch.full((64,), float("nan"), device="cuda") if i % 2 == 0 else None for i in range(nl)]
+    ops.conv3d_wgrad_batch(xs, dzs, dws, dbs)
+    batched = D % 2 == 0 and W % 4 == 0
+    for i in range(nl):
+        one_w, one_b = ops.conv3d_wgrad(xs[i], dzs[i], 3, 64, 64, want_bias=True)
+        scale = one_w.abs().max().item()
+        if batched:
+            assert (dws[i] - one_w).abs().max().item() <= 2e-5 * scale, i      # two splits of an fp32 sum over N D H W voxels (measured 4e-6 at 8 x 24^3)
+        else:
+            assert torch.equal(dws[i], one_w), i
+        if dbs[i] is not None:
+            assert torch.equal(dbs[i], one_b), i
+    if N * D * H * W <= 4096:                      # the float64 oracle on the small cases (first and last layer)
+        for i in (0, nl - 1):
+            ref = O.conv3d_wgrad(xs[i].cpu().numpy().astype(np.float64), dzs[i].cpu().numpy().astype(np.float64), 3)
+            close(dws[i], ref, name="batched wgrad layer %d" % i)
+    with pytest.raises(Exception):
+        ops.conv3d_wgrad_batch(xs, dzs[:-1], dws)                      # ragged lists
+    with pytest.raises(Exception):
+        ops.conv3d_wgrad_batch(xs, dzs, dws, workspace=torch.empty(16, device="cuda"))      # workspace too small: loud
+
+
 @pytest.mark.parametrize("shape,algo", [(sh, 0) for sh in [(1, 5, 8, 12), (2, 9, 2, 24), (1, 1, 2, 4), (3, 24, 24, 24), (1, 11, 14, 28), (1, 7, 12, 20), (1, 1, 4, 4)]] +
                          [(sh, 3) for sh in [(1, 5, 8, 12), (3, 24, 24, 24)]])       # algo 3 = FDN_ALGO_WINO_H2 where AUTO takes F(4,3) along H
 def test_conv64_dgrad_fused_one_launch_equals_two(ops, fdn, shape, algo):

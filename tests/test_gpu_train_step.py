@@ -175,6 +175,43 @@ def test_wgrad_side_stream_gives_identical_gradients(fdn):
     assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
 
 
+def test_batched_wgrad_gives_the_same_gradients(fdn):
+    """batch_wgrad (default on): the 64->64 weight gradients of a gradient bucket's small-grid layers go out as ONE batched launch at
+    the end of the bucket instead of one launch per layer.  Same products, a different split of the voxel sum: every layer's gradient
+    equals the per-layer schedule's to fp32 rounding, everything else (biases, thin layers, hi-res layers) bit for bit -- with and without
+    the side stream, and the bucket callbacks still arrive in order with every gradient of the bucket enqueued."""
+    tc, _ = make(fdn, 8, 2, 2, 1, seed=3)
+    m = tc.model
+    batch = O.synthetic_batch(2, 8, 2, seed=9)
+    grads = {}
+    for key, (bw, ov) in (("ref", (False, False)), ("batched", (True, False)), ("batched+side", (True, True))):
+        m.batch_wgrad, m.overlap_wgrad = bw, ov
+        inputs, hires, venc, mask = tc._unpack(batch)
+        pred = m.forward(inputs, training=True)
+        out, dpred = fdn.ops.loss_metrics(pred, hires[0], hires[1], hires[2], mask)
+        seen = []
+        g = m.backward(dpred, grad_ready=lambda lo, hi: seen.append((lo, hi)))
+        grads[key] = g.clone()
+        torch.cuda.synchronize()
+        assert seen == list(m.grad_buckets) and not m._wg_pending
+    m.batch_wgrad, m.overlap_wgrad = True, False
+    ref = grads["ref"]
+    assert torch.equal(grads["batched"], grads["batched+side"])
+    n64 = 0
+    for L in m.layers:
+        sl = slice(L.w_off, L.w_off + L.w.numel())
+        a, b = grads["batched"][sl], ref[sl]
+        if (L.k, L.cin, L.cout) == (3, 64, 64):
+            n64 += 1
+            assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item(), L.name
+        else:
+            assert torch.equal(a, b), L.name
+        if L.b is not None:
+            sb = slice(L.b_off, L.b_off + L.cout)
+            assert torch.equal(grads["batched"][sb], ref[sb]), L.name
+    assert n64 >= 9
+
+
 def test_full_size_cfg2_patch_matches_oracle(fdn):
     """BASELINE cfg2 network (patch 24, res x2, 8 LR + 4 HR ResBlocks, Glorot init as in bench.py) on ONE synthetic patch:
     prediction, loss and every layer's gradient against the float32 CPU oracle (one ~1 TFLOP CPU train step, 20-60 s).

@@ -83,7 +83,7 @@ PRODUCT_KERNELS = {
     "conv64_wino_kernel<4, false>": "... odd H, FDN_ALGO_WINO_W (F(4,3) along W)", "conv64_wino_kernel<4, true>": "... + shell faces (FDN_DGRAD_SHELL)",
     "conv64_mfma_kernel<2, 1, 2, false>": "... W % 4 != 0, FDN_ALGO_DIRECT: the planner's three direct layouts", "conv64_mfma_kernel<2, 1, 2, true>": "",
     "conv64_mfma_kernel<1, 1, 2, false>": "", "conv64_mfma_kernel<1, 1, 2, true>": "", "conv64_mfma_kernel<1, 2, 2, false>": "", "conv64_mfma_kernel<1, 2, 2, true>": "",
-    "wgrad64_wino_kernel<true>": "fdn_conv3d_wgrad 64->64, D even", "wgrad64_wino_kernel<false>": "... odd D, FDN_ALGO_WINO_W",
+    "wgrad64_wino_kernel<true>": "fdn_conv3d_wgrad 64->64, D even", "wgrad64_wino_batch_kernel<true>": "fdn_conv3d_wgrad_batch", "wgrad64_wino_kernel<false>": "... odd D, FDN_ALGO_WINO_W",
     "wgrad64_reduce_dep_kernel": "", "wgrad64_reduce_kernel": "", "wgrad64_pipe_kernel<4, 8>": "... W % 4 != 0, FDN_ALGO_DIRECT",
     "fold_halo_border_kernel": "fdn_fold_halo_border", "fold_halo_kernel": "fdn_fold_halo",
     "pack_conv64_kernel": "fdn_pack_conv64_weights", "pack_conv64_wino_kernel": "", "pack_conv64_wino2d_kernel": "", "pack_conv64_batch_kernel": "fdn_pack_conv64_weights_batch",

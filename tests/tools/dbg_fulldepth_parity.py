@@ -4,7 +4,7 @@ how many activation units changed side against the float64 forward -- kink flips
 import importlib, os, sys
 import numpy as np
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 fdn = importlib.import_module("4dflownet_amd")
 trainer = importlib.import_module("4dflownet_amd.trainer")
