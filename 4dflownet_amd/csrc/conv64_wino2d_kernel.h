@@ -189,7 +189,7 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
     // B_w^T of F(4,3) on the six column chunks of one item, written as the six xw planes of the item's LDS row.  Points 0, +-a, +-b, inf:
     //   rows (a2b2, 0, -(a2+b2), 0, 1, 0)  (0, -+a b2, -b2, +-a, 1, 0)  (0, -+a2 b, -a2, +-b, 1, 0)  (0, a2b2, 0, -(a2+b2), 0, 1)
     // HM = 2: a = 1, b = 2 -- (4,0,-5,0,1,0) (0,-4,-4,1,1,0) (0,4,-4,-1,1,0) (0,-2,-1,2,1,0) (0,2,-1,-2,1,0) (0,4,0,-5,0,1); HM = 4: a = 3/4, b = 3/2
-    auto wtransform = [&](char* vp, const f32x4 x0, const f32x4 x1, const f32x4 x2, const f32x4 x3, const f32x4 x4, const f32x4 x5) {
+    auto wtransform_ = [&](char* vp, const f32x4 x0, const f32x4 x1, const f32x4 x2, const f32x4 x3, const f32x4 x4, const f32x4 x5, const bool ACC) {
         f32x4 t1, t2, t3, t4, o0, o5;
         if constexpr (HM == 2) {
             t1 = x4 - 4.f * x2; t2 = x3 - 4.f * x1;
@@ -202,12 +202,28 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
             o0 = kPp * x0 - kPs * x2 + x4;
             o5 = kPp * x1 - kPs * x3 + x5;
         }
+        if (ACC) {                                            // add to what the previous stage left in the item's row (same thread wrote it)
+            o0 += *(const f32x4*)(vp);
+            const f32x4 p1 = *(const f32x4*)(vp + kW2Plane), p2 = *(const f32x4*)(vp + 2 * kW2Plane);
+            const f32x4 p3 = *(const f32x4*)(vp + 3 * kW2Plane), p4 = *(const f32x4*)(vp + 4 * kW2Plane);
+            o5 += *(const f32x4*)(vp + 5 * kW2Plane);
+            *(f32x4*)(vp) = o0;
+            *(f32x4*)(vp + kW2Plane) = p1 + (t1 + t2);
+            *(f32x4*)(vp + 2 * kW2Plane) = p2 + (t1 - t2);
+            *(f32x4*)(vp + 3 * kW2Plane) = p3 + (t3 + t4);
+            *(f32x4*)(vp + 4 * kW2Plane) = p4 + (t3 - t4);
+            *(f32x4*)(vp + 5 * kW2Plane) = o5;
+            return;
+        }
         *(f32x4*)(vp) = o0;
         *(f32x4*)(vp + kW2Plane) = t1 + t2;
         *(f32x4*)(vp + 2 * kW2Plane) = t1 - t2;
         *(f32x4*)(vp + 3 * kW2Plane) = t3 + t4;
         *(f32x4*)(vp + 4 * kW2Plane) = t3 - t4;
         *(f32x4*)(vp + 5 * kW2Plane) = o5;
+    };
+    auto wtransform = [&](char* vp, const f32x4 x0, const f32x4 x1, const f32x4 x2, const f32x4 x3, const f32x4 x4, const f32x4 x5) {
+        wtransform_(vp, x0, x1, x2, x3, x4, x5, false);
     };
 
 #pragma unroll 1
@@ -247,13 +263,38 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
             //   xh 0: (a2b2, 0, -(a2+b2), 0, 1, 0)    1: (0, -a b2, -b2,  a, 1, 0)    2: (0,  a b2, -b2, -a, 1, 0)
             //   xh 5: (0, a2b2, 0, -(a2+b2), 0, 1)    3: (0, -a2 b, -a2,  b, 1, 0)    4: (0,  a2 b, -a2, -b, 1, 0)
             // three rows (stages 0, 5) or four; two rows (12 chunks) are in flight at a time, combined into V, then the next two
-            // (or the last one): the item's 18 / 24 chunks never sit in registers together (Y holds 128 of the wave's 256). ----
+            // (or the last one): the item's 18 / 24 chunks never sit in registers together (Y holds 128 of the wave's 256).
+            // Stages 2 and 4 are INCREMENTAL: V[2] = V[1] + 2 a b2 x1 - 2 a x3 and V[4] = V[3] + 2 a2 b x1 - 2 b x3 differ from the stage
+            // before them in rows 1 and 3 only, and B_w^T is linear -- the item loads those two rows (12 chunks instead of 24), transforms
+            // the difference and adds it to the six values it wrote itself a stage earlier (still in its LDS row: the K loop only reads).
+            // A load costs the SIMD ~35 matrix-pipe cycles whatever its width (tools/mfma_ldcost.hip), an LDS read 3-6. ----
             const bool ends = xh == 0 || xh == 5;            // scalar
             const int ia = xh == 0 ? 0 : 1, ib = ends ? ia + 2 : 2, ic = ends ? ia + 4 : 3;
             const float ca = ends ? kPp : (xh == 1 ? -kPab2 : (xh == 2 ? kPab2 : (xh == 3 ? -kPa2b : kPa2b)));
             const float cb = ends ? -kPs : (xh <= 2 ? -kPb2 : -kPa2);
             const float cc = ends ? 1.f : (xh == 1 ? kPa : (xh == 2 ? -kPa : (xh == 3 ? kPb : -kPb)));
             const unsigned chunkb = chunkb_now();
+            const bool incr = (xh == 2 || xh == 4) && !(FDN_DBG_BITS(p) & 16);      // (test build, bit 16: every stage from its own rows)
+            if (incr) {
+                const float c1 = xh == 2 ? 2.f * kPab2 : 2.f * kPa2b, c3 = xh == 2 ? -2.f * kPa : -2.f * kPb;
+#pragma unroll
+                for (int u = 0; u < UA; ++u) {
+                    if (u * 256 >= items_eff) break;
+                    const unsigned* pr = (const unsigned*)((const char*)ptab + item_prow(u));
+                    const unsigned ha = pr[1] + chunkb, hb = pr[3] + chunkb;
+                    const unsigned wo[6] = {pr[6], pr[7], pr[8], pr[9], pr[10], pr[11]};
+                    f32x4 xa[6], xb[6];
+#pragma unroll
+                    for (int ii = 0; ii < 6; ++ii) {
+                        xa[ii] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ha + wo[ii], 0, 0));
+                        xb[ii] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, hb + wo[ii], 0, 0));
+                    }
+                    const int vr = item_vrow(u);
+                    if (vr < 0) continue;
+                    wtransform_(smem + vr, c1 * xa[0] + c3 * xb[0], c1 * xa[1] + c3 * xb[1], c1 * xa[2] + c3 * xb[2], c1 * xa[3] + c3 * xb[3],
+                                c1 * xa[4] + c3 * xb[4], c1 * xa[5] + c3 * xb[5], true);
+                }
+            } else
 #pragma unroll
             for (int u = 0; u < UA; ++u) {
                 if (u * 256 >= items_eff) break;

@@ -63,7 +63,7 @@ def main():
             print("wgrad %-22s N=%d P=%d : %.3f ms (%.1f TF algorithmic)" % (name, N, P, t, flop / t / 1e9), flush=True)
         if "--ablate" in sys.argv:
             with fdn._lib.test_build() as lib:
-                for bits, what in ((0, "full"), (4, "no staging"), (8, "no epilogue"), (1, "weights from one unit"), (13, "K loop only"), (128, "no XCD remap")):
+                for bits, what in ((0, "full"), (4, "no staging"), (8, "no epilogue"), (1, "weights from one unit"), (13, "K loop only"), (128, "no XCD remap"), (16, "stages 2, 4 from own rows")):
                     lib.fdn_debug_set_conv64_wino2d_dbg(bits)
                     t = timeit(lambda: ops.conv3d_fwd(x, w, None, ops.ACT_RELU, wpack=wp, out=out))
                     print("   2-D ablation %-22s: %.3f ms" % (what, t), flush=True)
