@@ -1,6 +1,6 @@
 """One-off soak of the tile / region / XCD-order logic: Winograd kernels of the product library vs the direct MFMA kernels (test build) on many
 random shapes (the same comparison as tests/test_gpu_kernels.py::test_winograd_kernels_equal_direct_kernels_on_random_shapes).
-    python tools/soak_wino.py [count] [seed] [max_extent]"""
+    python tools/soak_wino.py [count] [seed] [max_extent] [h4]      (h4: H a multiple of 4 as well -> the F(4,3) x F(4,3) kernel on every shape)"""
 import importlib, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,10 +8,12 @@ fdn = importlib.import_module("4dflownet_amd"); ops = fdn.ops
 count = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 mx = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+h4 = len(sys.argv) > 4 and sys.argv[4] == "h4"
 rng = np.random.default_rng(seed)
 worst = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
 for k in range(count):
     N, D, H, W = int(rng.integers(1, 5)), int(rng.integers(1, mx + 1)), int(rng.integers(1, mx + 1)), 4 * int(rng.integers(1, mx // 4 + 1))
+    if h4: H = 4 * int(rng.integers(1, mx // 4 + 1))
     if N * D * H * W > 120000: N = 1
     g = torch.Generator(device="cuda").manual_seed(k + 17 * seed)
     x = torch.randn((N, D, H, W, 64), device="cuda", generator=g); res = torch.randn((N, D, H, W, 64), device="cuda", generator=g)
