@@ -68,14 +68,16 @@ __device__ __forceinline__ void ld_bf16x16(const uint16_t* src, float (&z)[16]) 
 //               every line four times; two slices pull it twice.  One buffer means a tile's staging is not hidden behind its own K loop
 //               any more -- the co-resident workgroup's K loop runs meanwhile.
 // MODE 0      : shell slabs / ragged tiles: rolled loop, predicated planes and taps.
+// (a __device__ body + thin __global__ wrappers: conv64_bf16_fused_kernel below runs the MODE 2 body on the inner box of a fused dgrad
+// and the MODE 0 body on its shell slabs in ONE launch.  block / total: this part's workgroup id and count; xcd_remap: the ids are the
+// hardware's own (dealt round-robin to the XCDs), so the XCD-aware order applies.)
 template <int MT, int MODE>
-__global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
+__device__ __forceinline__ void conv64_bf16_body(const Conv64BfArgs& p, const int block, const int total, const bool xcd_remap, char* const smem) {
     constexpr bool FAST = MODE != 0, S2 = MODE == 2;
     constexpr bool GEN = !FAST;
     using C = Conv64BfCfg<MT>;
     constexpr int ROWB = S2 ? 64 : C::ROWB, NP = C::NP;
     constexpr int SPR = ROWB / 16;                         // 16-B slots per LDS row
-    extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -87,9 +89,9 @@ __global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
 
     // ---- XCD-aware tile order: workgroup ids are dealt round-robin to the 8 XCDs; give each XCD one contiguous run of
     // tiles so that neighbouring tiles (shared halo voxels) meet in the same L2 ----
-    int bid = (int)blockIdx.x;
-    if (!(p.dbg & 2)) {
-        const int total = (int)gridDim.x, q = total >> 3, rem = total & 7, x = bid & 7;
+    int bid = block;
+    if (xcd_remap && !(p.dbg & 2)) {
+        const int q = total >> 3, rem = total & 7, x = bid & 7;
         bid = x * q + (x < rem ? x : rem) + (bid >> 3);
     }
     int ri = 0;
@@ -434,6 +436,22 @@ __global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
     }
 }
 
+template <int MT, int MODE>
+__global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    conv64_bf16_body<MT, MODE>(p, (int)blockIdx.x, (int)gridDim.x, true, smem);
+}
+
+// Fused dgrad as ONE launch (round 5, the fp32 path's conv64_wino2d_shell_kernel idea): workgroups [0, n2) run the MODE 2 body on the
+// inner box, the rest the general body on the six shell slabs.  As a launch of their own the slabs -- 1.6 % of the inner box's work at
+// 128^3 -- cost 0.126 ms on an almost empty chip; dispatched last they fill the inner launch's tail.
+template <int MT>
+__global__ __launch_bounds__(256, 2) void conv64_bf16_fused_kernel(Conv64BfArgs p2, Conv64BfArgs p0, int n2) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x < n2) conv64_bf16_body<MT, 2>(p2, (int)blockIdx.x, n2, true, smem);
+    else conv64_bf16_body<MT, 0>(p0, (int)blockIdx.x - n2, (int)gridDim.x - n2, false, smem);
+}
+
 // --------------------------------------------------------------------------------------------
 // border fold (bf16 tensors, fp32 scratch): surface voxels of dz_prev after a fused-fold dgrad launch
 // --------------------------------------------------------------------------------------------
@@ -657,6 +675,25 @@ int launch_bf16(Conv64BfArgs& a, const Box* boxes, int nbox, hipStream_t s) {
                     MT, i, bx.od, bx.oh, bx.ow, bx.ed, bx.eh, bx.ew, bx.ta0, bx.ta1, bx.tb0, bx.tb1, bx.tc0, bx.tc1, t.td, t.th,
                     t.tw, t.ntd, t.nth, t.ntw, r.rows, r.lrows, r.hs, is_fast ? "FAST" : "general");
 #endif
+    }
+    if (fast2.nreg > 0 && slow.nreg > 0 && fast.nreg == 0 && a.fout && !(fdn_conv64bf_dbg & 32)) {
+        // the fused dgrad of a grid with 8 x 8 plane blocks: inner box + shell slabs in ONE launch (test build, bit 32: two launches)
+        int n2 = 0, n0 = 0, max2 = 0, max0 = 0;
+        for (int i = 0; i < fast2.nreg; ++i) {
+            Conv64Region& r = fast2.reg[i];
+            r.first_block = n2; n2 += a.N * r.ntd * r.nth * r.ntw;
+            if (r.lrows_p > max2) max2 = r.lrows_p;
+        }
+        for (int i = 0; i < slow.nreg; ++i) {
+            Conv64Region& r = slow.reg[i];
+            r.first_block = n0; n0 += a.N * r.ntd * r.nth * r.ntw;
+            if (r.lrows_p > max0) max0 = r.lrows_p;
+        }
+        if (int rc = fdn_func_max_lds((const void*)conv64_bf16_fused_kernel<MT>, C::LDS_BUDGET, "conv64_bf16_fused")) return rc;
+        const size_t lds = (size_t)(max2 > max0 ? max2 : max0) * 64 + C::MCAP * 4;
+        hipLaunchKernelGGL((conv64_bf16_fused_kernel<MT>), dim3((unsigned)(n2 + n0)), dim3(256), lds, s, fast2, slow, n2);
+        FDN_CHECK_LAUNCH("conv64_bf16_fused_kernel");
+        return FDN_OK;
     }
     if (int rc = launch_regions<MT, 2>(fast2, s)) return rc;
     if (int rc = launch_regions<MT, 1>(fast, s)) return rc;

@@ -95,7 +95,8 @@ PRODUCT_KERNELS = {
     "upsample_fwd_kernel<T>": "fdn_upsample_trilinear_fwd", "upsample_bwd_kernel<T>": "fdn_upsample_trilinear_bwd", "input_features_kernel<T>": "fdn_input_features",
     "loss_main_kernel": "fdn_loss_metrics", "loss_finalize_kernel": "", "mask_sums_kernel": "", "l2_sumsq_kernel": "fdn_l2_sumsq", "adam_kernel": "fdn_adam_step",
     "gather_patches_kernel": "fdn_gather_patches",
-    "conv64_bf16_kernel<8, 2>": "bf16 mode: fdn_conv3d_fwd_bf16 / dgrad_fused_bf16", "conv64_bf16_kernel<8, 1>": "", "conv64_bf16_kernel<8, 0>": "",
+    "conv64_bf16_kernel<8, 2>": "bf16 mode: fdn_conv64_fwd_bf16", "conv64_bf16_fused_kernel<8>": "fdn_conv64_dgrad_fused_bf16 (inner box + shell slabs, one launch)",
+    "conv64_bf16_fused_kernel<4>": "", "conv64_bf16_kernel<8, 1>": "", "conv64_bf16_kernel<8, 0>": "",
     "conv64_bf16_kernel<4, 2>": "", "conv64_bf16_kernel<4, 1>": "", "conv64_bf16_kernel<4, 0>": "", "pack_conv64_bf16_kernel": "", "fold_halo_border_bf16_kernel": "",
     "wgrad64_bf16_dma_kernel": "fdn_conv3d_wgrad_bf16", "wgrad64_bf16_kernel": "... tensors of 4 GB and more",
 }
