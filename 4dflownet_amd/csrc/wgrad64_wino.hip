@@ -34,6 +34,7 @@
 // kernel has none to spare), dz's second plane in two extra registers.  The depth output transform runs in the reduction kernel
 // (wgrad64_reduce_dep_kernel), which sums the S x 4 partials with the G^T weights.
 #include "fdn_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -142,6 +143,13 @@ __device__ __forceinline__ void wgrad64_wino_body(const WgWinoArgs& p, const int
 
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.dz, 0, p.bytes, 0x00020000);
+    // the same two buffers for the direct-to-LDS loads of the second plane, issued OUTSIDE the compiler's bookkeeping (fdn_common.h):
+    // hipcc counts a builtin LDS-DMA as a pending LDS write and puts s_waitcnt vmcnt(0) in front of the next LDS read it cannot prove
+    // disjoint -- here the operand reads of the very next slot, i.e. a full memory round trip inside the MFMA stream after EVERY raw-row
+    // load.  (Round 4's build happened to escape it; the constants of round 5's interpolation points did not: 0.60 -> 0.75 ms until
+    // the ISA was read.)  The kernel owns the ordering: the scratch is private to the issuing wave, read back behind the explicit
+    // s_waitcnt vmcnt(0) of combine_x / combine_z, and refilled only after those reads have been consumed by the transform.
+    const fdn_i32x4 xrs_raw = fdn_raw_rsrc(p.x, p.bytes), zrs_raw = fdn_raw_rsrc(p.dz, p.bytes);
     f32x4 raw[6];                         // this thread's raw rows: 6 x chunks (waves 0-3) or 4 dz chunks (waves 4-6; DEP: + chunks 0, 1 of the second plane)
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     char* const xscr = smem + 3 * WBUFB + wave_u * 1024;     // DEP: this wave's 1-KB pieces of the x scratch (chunk nn at + nn * 4096)
@@ -197,7 +205,7 @@ __device__ __forceinline__ void wgrad64_wino_body(const WgWinoArgs& p, const int
         const unsigned vo = x_in ? tc0 + (unsigned)(nn * 256) : rowoff + (unsigned)(min(max(tw * WTW + 4 * ig - 1 + nn, 0), p.W - 1) * 256);
         const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)(x_in ? x_so : 0u));   // scalar operand: no waterfall loop
         raw[nn] = bload(xrs, vo, so);
-        if (DEP) fdn_lds_dma16(xrs, xscr + nn * 4096, vo, (int)(so + dxb));       // the same chunk of the second plane -> scratch
+        if (DEP) fdn_lds_dma16_untracked(xrs_raw, fdn_lds_addr(xscr) + (unsigned)(nn * 4096), vo, so + dxb);     // the same chunk of the second plane -> scratch
     };
     auto load_z = [&](int j) {
         if (!zitem || (FDN_DBG_BITS(p) & 1)) return;
@@ -208,7 +216,7 @@ __device__ __forceinline__ void wgrad64_wino_body(const WgWinoArgs& p, const int
         if (DEP && has_zb) {               // second plane: chunks 0, 1 in the two spare registers, chunks 2, 3 through the scratch
             const unsigned vb = vo == 0xffffffffu ? vo : vo + dzb;               // (so + dzb could wrap past a "reads zero" offset)
             if (j < 2) raw[4 + j] = bload(zrs, vb, so);
-            else fdn_lds_dma16(zrs, zscr + (j - 2) * 3072, vb, (int)so);
+            else fdn_lds_dma16_untracked(zrs_raw, fdn_lds_addr(zscr) + (unsigned)((j - 2) * 3072), vb, so);
         }
     };
     // DEP: combine the two planes of an item before its W transform (x: second plane from the scratch this thread's own LDS-DMA filled)
@@ -236,24 +244,29 @@ __device__ __forceinline__ void wgrad64_wino_body(const WgWinoArgs& p, const int
         *(f32x4*)(dst + c16 * 32 + 16) = (f32x4){v0.z, v1.z, v0.w, v1.w};
         *(f32x4*)(dst + 512 + c16 * 16) = v2;
     };
+    // Interpolation points 0, +-a, +-b, inf with a = 3/4, b = 3/2 (round 5; rounds 2-4 used Lavin & Gray's a = 1, b = 2): the same even / odd
+    // structure, every constant below exact in fp32, transform entries up to 3.4 instead of 8 -- a third of the fp32 error on trained
+    // layers (conv64_wino2d_kernel.h has the measurement).  The 1 / N_xi factors of G' (64/81, -128/243, 32/243: not fp32 numbers) are
+    // applied ONCE, to the accumulated matrices in the output transform below, not to every dz chunk.
+    constexpr float pa = 0.75f, pb = 1.5f, pa2 = 0.5625f, pb2 = 2.25f, pa3 = 0.421875f, pb3 = 3.375f;
+    constexpr float pab2 = 1.6875f, pa2b = 0.84375f, ps = 2.8125f, pp = 1.265625f;      // a b^2, a^2 b, a^2 + b^2, a^2 b^2
     auto write_v = [&](int e, char* buf) {
-        // B^T of F(4,3)/F(3,4): (4,0,-5,0,1,0) (0,-4,-4,1,1,0) (0,4,-4,-1,1,0) (0,-2,-1,2,1,0) (0,2,-1,-2,1,0) (0,4,0,-5,0,1)
+        // B^T of F(4,3)/F(3,4): (a2b2,0,-(a2+b2),0,1,0) (0,-+ab2,-b2,+-a,1,0) (0,-+a2b,-a2,+-b,1,0) (0,a2b2,0,-(a2+b2),0,1)
         if (!xitem || (FDN_DBG_BITS(p) & 2)) return;
         char* dst = buf + (il * WTG + ig) * GROWB + e * 768;
         const f32x4 x0 = raw[0], x1 = raw[1], x2 = raw[2], x3 = raw[3], x4 = raw[4], x5 = raw[5];
-        const f32x4 t1 = x4 - 4.f * x2, t2 = x3 - 4.f * x1, t3 = x4 - x2, t4 = 2.f * (x3 - x1);
-        if (e == 0) put(dst, 4.f * x0 - 5.f * x2 + x4, t1 - t2, t3 - t4);          // xi = 0, 2, 4
-        else put(dst, t1 + t2, t3 + t4, 4.f * x1 - 5.f * x3 + x5);                  // xi = 1, 3, 5
+        const f32x4 t1 = x4 - pb2 * x2, t2 = pa * x3 - pab2 * x1, t3 = x4 - pa2 * x2, t4 = pb * x3 - pa2b * x1;
+        if (e == 0) put(dst, pp * x0 - ps * x2 + x4, t1 - t2, t3 - t4);            // xi = 0, 2, 4  (points 0, -a, -b)
+        else put(dst, t1 + t2, t3 + t4, pp * x1 - ps * x3 + x5);                    // xi = 1, 3, 5  (points +a, +b, inf)
     };
     auto write_z = [&](int e, char* buf) {
-        // G' of F(3,4): (1/4,0,0,0) -1/6(1,1,1,1) -1/6(1,-1,1,-1) 1/24(1,2,4,8) 1/24(1,-2,4,-8) (0,0,0,1)
+        // G' of F(3,4) without its 1 / N_xi row factors: (1,0,0,0) (1,+-a,a2,+-a3) (1,+-b,b2,+-b3) (0,0,0,1)
         if (!zitem || (FDN_DBG_BITS(p) & 2)) return;
         char* dst = buf + VBYTES + (il * WTG + ig) * GROWB + e * 768;
         const f32x4 z0 = raw[0], z1 = raw[1], z2 = raw[2], z3 = raw[3];
-        const float s6 = -1.f / 6, s24 = 1.f / 24;
-        const f32x4 e1 = z0 + z2, o1 = z1 + z3, e2 = z0 + 4.f * z2, o2 = 2.f * z1 + 8.f * z3;
-        if (e == 0) put(dst, 0.25f * z0, s6 * (e1 - o1), s24 * (e2 - o2));          // xi = 0, 2, 4
-        else put(dst, s6 * (e1 + o1), s24 * (e2 + o2), z3);                          // xi = 1, 3, 5
+        const f32x4 e1 = z0 + pa2 * z2, o1 = pa * z1 + pa3 * z3, e2 = z0 + pb2 * z2, o2 = pb * z1 + pb3 * z3;
+        if (e == 0) put(dst, z0, e1 - o1, e2 - o2);                                 // xi = 0, 2, 4
+        else put(dst, e1 + o1, e2 + o2, z3);                                         // xi = 1, 3, 5
     };
 
     // ---- prologue: tile 0 -> buffer 0, tile 1 -> registers ----
@@ -295,6 +308,13 @@ __device__ __forceinline__ void wgrad64_wino_body(const WgWinoArgs& p, const int
     int bcur = 0;
     issue_z(smem, 0, 0);
     issue_v(smem, 0, 0);
+    // The tile loop exists three times, one copy per ROLE of the wave (0: transforms x, waves 0-3; 1: transforms dz, waves 4-6; 2: wave 7,
+    // MFMAs only), chosen once by a scalar branch.  With ONE copy and the role tested at every stage, hipcc's wait-count bookkeeping merges
+    // paths no wave can take ("skipped the transform of slot 0 but issues the loads of slot 6") and, depending on nothing more than the
+    // register allocation of the transform code, may decide a raw-row register is still in flight when its slot is reloaded: round 5's
+    // change of constants in write_v / write_z produced s_waitcnt vmcnt(0) after EVERY raw-row load, 0.60 -> 0.75 ms at (8,48^3).
+    auto tile_loop = [&](auto role) {
+    constexpr int ROLE = decltype(role)::value;
 #pragma unroll 1
     for (int k = 0; k < nk; ++k) {
         const int bnxt = bcur == 2 ? 0 : bcur + 1;
@@ -318,13 +338,13 @@ __device__ __forceinline__ void wgrad64_wino_body(const WgWinoArgs& p, const int
             // pipeline stages, pinned to slots: transform + write tile k+1, then load the raw rows of tile k+2
             // (the raw rows of tile k+2 are requested as soon as tile k+1's have been consumed: they are read again a whole tile
             // later, in slots 0-3 of the next iteration -- requested after the barrier, the dz rows came back too late)
-            if (s == 0) combine_x();
-            if (s == 2) combine_z();
-            if (s < 2) write_v(s, nxt);
-            else if (s < 4) write_z(s - 2, nxt);
+            if (ROLE == 0 && s == 0) combine_x();
+            if (ROLE == 1 && s == 2) combine_z();
+            if (ROLE == 0 && s < 2) write_v(s, nxt);
+            if (ROLE == 1 && s >= 2 && s < 4) write_z(s - 2, nxt);
             if (s == kLocSlot && !(FDN_DBG_BITS(p) & 32)) { advance(); locate(); }
-            if (s >= kXSlot && s < kXSlot + 6) load_x(s - kXSlot);
-            if (s >= kZSlot && s < kZSlot + 4) load_z(s - kZSlot);
+            if (ROLE == 0 && s >= kXSlot && s < kXSlot + 6) load_x(s - kXSlot);
+            if (ROLE == 1 && s >= kZSlot && s < kZSlot + 4) load_z(s - kZSlot);
             acc[b][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vp[(q + b) & 3].x, Zp[q & 1].x, acc[b][0], 0, 0, 0);
             acc[b][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vp[(q + b) & 3].y, Zp[q & 1].y, acc[b][1], 0, 0, 0);
             acc[b][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[(q + b) & 3], Zs[q & 1], acc[b][2], 0, 0, 0);
@@ -332,29 +352,41 @@ __device__ __forceinline__ void wgrad64_wino_body(const WgWinoArgs& p, const int
         }
         bcur = bnxt;
     }
+    };
+    if (xitem) tile_loop(std::integral_constant<int, 0>{});
+    else if (zitem) tile_loop(std::integral_constant<int, 1>{});
+    else tile_loop(std::integral_constant<int, 2>{});
 
     // ---- output transform inside the workgroup, then ONE partial dW[a][b][t] per workgroup (half the partial traffic of writing
-    // the 18 Winograd-domain matrices).  dW[t] = sum_xi A'^T[t][xi] M_xi with A'^T = (1,1,1,1,1,0) (0,1,-1,2,-2,0) (0,1,1,4,4,1);
+    // the 18 Winograd-domain matrices).  dW[t] = sum_xi A'^T[t][xi] c_xi M_xi with A'^T = (1,1,1,1,1,0) (0,a,-a,b,-b,0) (0,a2,a2,b2,b2,1)
+    // and c = 1 / N_xi = (64/81, -128/243, -128/243, 32/243, 32/243, 1), the row factors of G' (see write_z);
     // a wave holds one parity of xi, so it forms its share of the three taps in place and the odd-parity wave of each quadrant
     // hands its share to the even one through LDS (the tile buffers are free now), in two rounds of <= 5 of the 9 (b,t) tiles. ----
+    // (lane-level indices re-derived from mbcnt and the scalar wave id: held in registers through the three tile loops they cost a spill)
+    const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int li_e = lane_e & 31, kh_e = lane_e >> 5;
+    const int mq_e = wave_s & 1, nq_e = (wave_s >> 1) & 1, eh_e = wave_s >> 2;
+    {
+        constexpr float c0 = 64.f / 81, ca = -128.f / 243, cb = 32.f / 243;
 #pragma unroll
-    for (int b = 0; b < 3; ++b) {
-        const f32x16 m0 = acc[b][0], m1 = acc[b][1], m2 = acc[b][2];       // xi = eh, 2 + eh, 4 + eh
-        if (eh == 0) {           // xi 0, 2, 4
-            acc[b][0] = m0 + m1 + m2;
-            acc[b][1] = -m1 - 2.f * m2;
-            acc[b][2] = m1 + 4.f * m2;
-        } else {                 // xi 1, 3, 5
-            acc[b][0] = m0 + m1;
-            acc[b][1] = m0 + 2.f * m1;
-            acc[b][2] = m0 + 4.f * m1 + m2;
+        for (int b = 0; b < 3; ++b) {
+            const f32x16 m0 = acc[b][0], m1 = acc[b][1], m2 = acc[b][2];       // xi = eh, 2 + eh, 4 + eh
+            if (eh_e == 0) {           // xi 0, 2, 4: points 0, -a, -b
+                acc[b][0] = c0 * m0 + ca * m1 + cb * m2;
+                acc[b][1] = (-pa * ca) * m1 + (-pb * cb) * m2;
+                acc[b][2] = (pa2 * ca) * m1 + (pb2 * cb) * m2;
+            } else {                 // xi 1, 3, 5: points +a, +b, inf
+                acc[b][0] = ca * m0 + cb * m1;
+                acc[b][1] = (pa * ca) * m0 + (pb * cb) * m1;
+                acc[b][2] = (pa2 * ca) * m0 + (pb2 * cb) * m1 + m2;
+            }
         }
     }
-    float* xch = (float*)smem + (size_t)(wave & 3) * (5 * 16 * 64) + lane;          // per quadrant: [tile 5][r 16][lane 64]
+    float* xch = (float*)smem + (size_t)(wave_s & 3) * (5 * 16 * 64) + lane_e;          // per quadrant: [tile 5][r 16][lane 64]
 #pragma unroll
     for (int round = 0; round < 2; ++round) {
         __syncthreads();                                    // tile buffers / the previous round's exchange are no longer read
-        if (eh == 1) {
+        if (eh_e == 1) {
 #pragma unroll
             for (int k = 0; k < 9; ++k)
                 if ((k < 5) == (round == 0))
@@ -362,7 +394,7 @@ __device__ __forceinline__ void wgrad64_wino_body(const WgWinoArgs& p, const int
                     for (int r = 0; r < 16; ++r) xch[((k - 5 * round) * 16 + r) * 64] = acc[k / 3][k % 3][r];
         }
         __syncthreads();
-        if (eh == 0) {
+        if (eh_e == 0) {
 #pragma unroll
             for (int k = 0; k < 9; ++k)
                 if ((k < 5) == (round == 0))
@@ -370,14 +402,14 @@ __device__ __forceinline__ void wgrad64_wino_body(const WgWinoArgs& p, const int
                     for (int r = 0; r < 16; ++r) acc[k / 3][k % 3][r] += xch[((k - 5 * round) * 16 + r) * 64];
         }
     }
-    if (eh == 0) {
+    if (eh_e == 0) {
         float* out = p.partial + ((size_t)split * (NP * 9) + a * 9) * 4096;     // DEP: [split][xd][b*3+t], mixed into the depth taps by the reduction
 #pragma unroll
         for (int k = 0; k < 9; ++k)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int ci = mq * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                out[(size_t)k * 4096 + ci * 64 + nq * 32 + li] = acc[k / 3][k % 3][r];
+                const int ci = mq_e * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh_e;
+                out[(size_t)k * 4096 + ci * 64 + nq_e * 32 + li_e] = acc[k / 3][k % 3][r];
             }
     }
 }
