@@ -137,3 +137,20 @@ def test_dma_wgrad_tile_loop_keeps_two_tiles_in_flight(code_objects):
     full = [l for l in window if re.search(r"s_waitcnt\s+vmcnt\(0\)", l)]
     assert not full, "the compiler waits for every outstanding load inside the K loop:\n" + "\n".join(full)
     assert any(re.search(r"s_waitcnt\s+vmcnt\(6\)", l) for l in lines) and any(re.search(r"s_waitcnt\s+vmcnt\(5\)", l) for l in lines)
+
+
+def test_fp32_wgrad_tile_loops_do_not_wait_behind_their_raw_row_loads(code_objects):
+    """wgrad64_wino_kernel<true>: three copies of the 54-MFMA tile loop (one per wave role).  The raw rows of tile k + 2 are requested in
+    slots 6..16 and consumed a whole tile later; the only full vector-memory waits allowed are at the top of a loop (slots 0..2: the
+    explicit wait in front of the scratch read-back / the first use of the rows) and at its back edge.  Round 5 saw hipcc put
+    s_waitcnt vmcnt(0) behind EVERY raw-row load after an unrelated change of constants (0.60 -> 0.75 ms at (8,48^3)): this is the tripwire."""
+    asm = "\n".join(a for _, a in code_objects)
+    body = _function(asm, "19wgrad64_wino_kernelILb1")
+    assert body is not None
+    lines = body.splitlines()
+    mfma = [i for i, l in enumerate(lines) if "v_mfma_f32_32x32x2_f32" in l]
+    assert len(mfma) == 3 * 54, len(mfma)
+    for copy in range(3):
+        lo, hi = mfma[copy * 54 + 9], mfma[copy * 54 + 53]          # behind slot 2, up to the last slot
+        full = [l for l in lines[lo:hi] if re.search(r"s_waitcnt\s+vmcnt\(0\)", l)]
+        assert not full, "loop copy %d waits for every outstanding load inside the tile:\n%s" % (copy, "\n".join(full))
