@@ -111,8 +111,10 @@ def test_round3_profiles_carry_the_sources_they_were_measured_on():
     import warnings
     from importlib import import_module
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    files = sorted(f for f in glob.glob(os.path.join(root, "profiles", "r[34]_*"))
-                   if not f.endswith(("_gputest.txt", "_wino2d_fwd_ablation.txt", "_wino2d_fwd_dgrad.txt", "_bf16_ab1.txt", "_fetch_calib.txt")))
+    # (files produced by tools/profile_round.sh + collect_profiles.py; the hand-collected ablation / A-B / soak logs of a round name their tree in words)
+    stamped = ("_bench_kernel_stats.csv", "_bench_line.json", "_bench_line_nosecondary.json", "_pmc_sq.txt", "_pmc_traffic.json", "_pmc_traffic.txt",
+               "_cfg4_bench_line.json", "_cfg4_kernel_stats.csv", "_cfg4_pmc_sq.txt", "_cfg4_pmc_traffic.json", "_cfg4_pmc_traffic.txt")
+    files = sorted(f for f in glob.glob(os.path.join(root, "profiles", "r[3-9]_*")) if f.endswith(stamped))
     if not files:
         pytest.skip("no round-3/4 profiles collected yet")
     stamp = import_module("4dflownet_amd.build").source_stamp()
