@@ -381,10 +381,24 @@ def network_forward(params, inputs, res_increase, low_resblock=8, hi_resblock=4,
     return pred, c
 
 
-def network_backward(params, c, dpred, res_increase, low_resblock=8, hi_resblock=4, f32_coeffs=False, bf16=False):
-    """Gradients of sum_b loss_b w.r.t. every parameter, given dpred.  Returns list of {"w","b"}."""
+def network_backward(params, c, dpred, res_increase, low_resblock=8, hi_resblock=4, f32_coeffs=False, bf16=False, sides=None):
+    """Gradients of sum_b loss_b w.r.t. every parameter, given dpred.  Returns list of {"w","b"}.
+    sides (optional): {"a0","a1","p0","p1","c0","c1": bool array, "blocks": [(h, out) bool arrays], "heads": [bool arrays]} -- the side of
+    the ReLU / LeakyReLU kink (True = positive) ANOTHER evaluation of the same forward landed on, unit by unit.  The network is piecewise
+    linear; given `sides`, the backward pass differentiates in that evaluation's linear region instead of this forward's own (a unit
+    within rounding of 0 may sit on either side, and one such unit moves single gradient elements by 1e-4..1e-3 of their scale), so
+    that what separates the two gradients is arithmetic error only.  The caller checks that the units which changed side are few and tiny."""
     r, wq = _bf16_hooks(bf16)
     P = params
+    if sides is not None:
+        sgn = lambda m: np.where(np.asarray(m), 1.0, -1.0)           # act_bwd_from_output only looks at y > 0
+        c = dict(c)
+        for k in ("a0", "a1", "p0", "p1", "c0", "c1"):
+            c["side_" + k] = sgn(sides[k])
+        c["side_blocks"] = [(sgn(h), sgn(o)) for h, o in sides["blocks"]]
+        c["side_heads"] = [sgn(g) for g in sides["heads"]]
+    side = lambda key, val, idx=None, j=None: (val if sides is None else
+                                               (c["side_" + key] if idx is None else (c["side_" + key][idx] if j is None else c["side_" + key][idx][j])))
     G = [{"w": None, "b": None} for _ in P]
     rb = c["rb"]
     li = len(P) - 6
@@ -395,7 +409,7 @@ def network_backward(params, c, dpred, res_increase, low_resblock=8, hi_resblock
         G[li + 1]["w"] = conv3d_wgrad(g, dz_o, 3)
         G[li + 1]["b"] = bias_grad(dz_o)
         dg = conv3d_dgrad(dz_o, P[li + 1]["w"], g.shape)
-        dz_g = act_bwd_from_output(dg, g, ACT_RELU)
+        dz_g = act_bwd_from_output(dg, side("heads", g, hidx), ACT_RELU)
         G[li]["b"] = bias_grad(dz_g)                 # the HIP path sums this before the store rounds it
         dz_g = r(dz_g)
         G[li]["w"] = conv3d_wgrad(rb, dz_g, 3)
@@ -411,28 +425,28 @@ def network_backward(params, c, dpred, res_increase, low_resblock=8, hi_resblock
     for i in reversed(range(nblocks)):
         x, h, out = c["blocks"][i]
         li -= 2
-        dz_out = r(act_bwd_from_output(d_out, out, ACT_LEAKY))
+        dz_out = r(act_bwd_from_output(d_out, side("blocks", out, i, 1), ACT_LEAKY))
         G[li + 1]["w"] = conv3d_wgrad(h, dz_out, 3)
         dh = conv3d_dgrad(dz_out, wq(P[li + 1]["w"]), h.shape)
-        dz_h = r(act_bwd_from_output(dh, h, ACT_LEAKY))
+        dz_h = r(act_bwd_from_output(dh, side("blocks", h, i, 0), ACT_LEAKY))
         G[li]["w"] = conv3d_wgrad(x, dz_h, 3)
         d_out = conv3d_dgrad(dz_h, wq(P[li]["w"]), x.shape) + dz_out
         if i == low_resblock:
             d_out = r(d_out)          # stored (producer of this block input is the linear upsample) before U^T
             d_out = upsample_trilinear_bwd(d_out, c["up_in"].shape[1:4], res_increase, f32_coeffs)
     assert li == 6
-    dz_c1 = r(act_bwd_from_output(d_out, c["c1"], ACT_RELU))
+    dz_c1 = r(act_bwd_from_output(d_out, side("c1", c["c1"]), ACT_RELU))
     G[5]["w"] = conv3d_wgrad(c["c0"], dz_c1, 3); G[5]["b"] = bias_grad(dz_c1)
-    dz_c0 = r(act_bwd_from_output(conv3d_dgrad(dz_c1, wq(P[5]["w"]), c["c0"].shape), c["c0"], ACT_RELU))
+    dz_c0 = r(act_bwd_from_output(conv3d_dgrad(dz_c1, wq(P[5]["w"]), c["c0"].shape), side("c0", c["c0"]), ACT_RELU))
     G[4]["w"] = conv3d_wgrad(c["cat"], dz_c0, 1); G[4]["b"] = bias_grad(dz_c0)
     dcat = conv3d_dgrad(dz_c0, P[4]["w"], c["cat"].shape)
-    dz_p1 = r(act_bwd_from_output(dcat[..., :64], c["p1"], ACT_RELU))
-    dz_a1 = r(act_bwd_from_output(dcat[..., 64:], c["a1"], ACT_RELU))
+    dz_p1 = r(act_bwd_from_output(dcat[..., :64], side("p1", c["p1"]), ACT_RELU))
+    dz_a1 = r(act_bwd_from_output(dcat[..., 64:], side("a1", c["a1"]), ACT_RELU))
     G[3]["w"] = conv3d_wgrad(c["p0"], dz_p1, 3); G[3]["b"] = bias_grad(dz_p1)
-    dz_p0 = r(act_bwd_from_output(conv3d_dgrad(dz_p1, wq(P[3]["w"]), c["p0"].shape), c["p0"], ACT_RELU))
+    dz_p0 = r(act_bwd_from_output(conv3d_dgrad(dz_p1, wq(P[3]["w"]), c["p0"].shape), side("p0", c["p0"]), ACT_RELU))
     G[2]["w"] = conv3d_wgrad(c["phase"], dz_p0, 3); G[2]["b"] = bias_grad(dz_p0)
     G[1]["w"] = conv3d_wgrad(c["a0"], dz_a1, 3); G[1]["b"] = bias_grad(dz_a1)
-    dz_a0 = r(act_bwd_from_output(conv3d_dgrad(dz_a1, wq(P[1]["w"]), c["a0"].shape), c["a0"], ACT_RELU))
+    dz_a0 = r(act_bwd_from_output(conv3d_dgrad(dz_a1, wq(P[1]["w"]), c["a0"].shape), side("a0", c["a0"]), ACT_RELU))
     G[0]["w"] = conv3d_wgrad(c["pc"], dz_a0, 3); G[0]["b"] = bias_grad(dz_a0)
     for g, p in zip(G, P):
         if p["b"] is None:
@@ -462,7 +476,7 @@ def adam_step_tf(w, g, m, v, t, lr, b1=ADAM_B1, b2=ADAM_B2, eps=ADAM_EPS):
     w[:] = w - lr_t * m / (np.sqrt(v) + eps)
 
 
-def loss_and_grads(params, batch, res_increase, low_resblock=8, hi_resblock=4, f32_coeffs=False, bf16=False):
+def loss_and_grads(params, batch, res_increase, low_resblock=8, hi_resblock=4, f32_coeffs=False, bf16=False, sides=None):
     """batch = (u,v,w,u_mag,v_mag,w_mag,u_hr,v_hr,w_hr,venc,mask) as the loader yields them
     (PatchHandler3D.py:78-81).  Returns dict with per-sample loss (incl. L2), mse, rel-error,
     l2 scalar, pred and the gradient list of sum_b(loss_b) = sum_b mse_b + B*L2."""
@@ -472,7 +486,7 @@ def loss_and_grads(params, batch, res_increase, low_resblock=8, hi_resblock=4, f
     mse, dpred = masked_mse_loss_fwd_bwd(pred, hires, mask)
     rel = relative_error(pred, hires, mask)
     l2 = l2_regularizer(params)
-    grads = network_backward(params, cache, dpred, res_increase, low_resblock, hi_resblock, f32_coeffs, bf16)
+    grads = network_backward(params, cache, dpred, res_increase, low_resblock, hi_resblock, f32_coeffs, bf16, sides=sides)
     B = u.shape[0]
     for g, p in zip(grads, params):
         g["w"] = g["w"] + (B * 2 * L2_LAMBDA) * p["w"]

@@ -15,6 +15,7 @@ import pytest
 import torch
 
 from oracle import flownet_oracle as O
+from _kink import kink_sides
 
 pytestmark = pytest.mark.gpu
 
@@ -47,17 +48,25 @@ def test_bf16_train_step_matches_bf16_oracle(fdn, P, R, LB, HB, B):
     assert tc.model.act_dtype == torch.bfloat16
     batch = O.synthetic_batch(B, P, R, seed=31)
     b64 = tuple(a.astype(np.float64) for a in batch)
-    ref = O.loss_and_grads(params, b64, R, LB, HB, f32_coeffs=True, bf16=True)
     inputs, hires, venc, mask = tc._unpack(batch)
     pred = tc.model.forward(inputs, training=True)
     assert pred.dtype == torch.float32
     cache = tc.model._cache
     assert cache["rb"].t.dtype == torch.bfloat16
+    # the bf16 oracle differentiates in the linear region the GPU forward landed in (a stored activation one bf16 ulp apart can sit on
+    # the other side of its kink: counted here, not forgiven by the tolerance)
+    _, rc = O.network_forward(params, b64[:6], R, LB, HB, f32_coeffs=True, bf16=True)
+    sides, flips, worst_flip = kink_sides(cache, rc)
+    ref = O.loss_and_grads(params, b64, R, LB, HB, f32_coeffs=True, bf16=True, sides=sides)
     out, dpred = fdn.ops.loss_metrics(pred, hires[0], hires[1], hires[2], mask)
     g = tc.model.backward(dpred).cpu().numpy().astype(np.float64)
     assert np.isfinite(g).all()
-    assert l2_rel(pred.cpu().numpy(), ref["pred"]) < 3e-2
-    assert l2_rel(out[:, 0].cpu().numpy(), ref["mse"]) < 3e-2
+    # one bf16 ulp is 4e-3..8e-3 of a value: a stored activation that rounds the other way than the oracle's moves everything downstream
+    # by that much.  Measured 1.5e-3..7.4e-3 on the prediction; with the kink sides handed to the oracle the worst layer gradient is
+    # 3.6e-3..8.1e-3 (round 4, flips forgiven by the tolerance instead: up to 5.5e-2 under a 1.5e-1 bound)
+    assert l2_rel(pred.cpu().numpy(), ref["pred"]) < 1.5e-2
+    assert l2_rel(out[:, 0].cpu().numpy(), ref["mse"]) < 1.5e-2
+    assert worst_flip <= 1e-2, worst_flip            # units that changed side are within a couple of bf16 ulps of zero
     isk = tc.model.is_kernel.cpu().numpy().astype(np.float64)
     g_total = g + B * 2 * O.L2_LAMBDA * tc.model.flat_w.cpu().numpy().astype(np.float64) * isk
     gref = O.flatten(ref["grads"])
@@ -66,12 +75,13 @@ def test_bf16_train_step_matches_bf16_oracle(fdn, P, R, LB, HB, B):
         sl = slice(L.w_off, L.w_off + L.w.numel())
         e = l2_rel(g_total[sl], gref[sl])
         worst = max(worst, e)
-        assert e < 1.5e-1, (L.name, "kernel grad", e)
+        assert e < 2e-2, (L.name, "kernel grad", e)
         if L.b is not None:
             sb = slice(L.b_off, L.b_off + L.cout)
             eb = l2_rel(g_total[sb], gref[sb])
-            assert eb < 1.5e-1, (L.name, "bias grad", eb)
-    print("bf16 vs bf16-oracle: pred %.2e, worst layer grad %.2e" % (l2_rel(pred.cpu().numpy(), ref["pred"]), worst))
+            assert eb < 2e-2, (L.name, "bias grad", eb)
+    print("bf16 vs bf16-oracle: pred %.2e, worst layer grad %.2e (%d activation units on the other side of the kink, largest %.1e of its tensor's scale)"
+          % (l2_rel(pred.cpu().numpy(), ref["pred"]), worst, flips, worst_flip))
     # the full step runs and updates every parameter by at most lr
     w0 = tc.model.flat_w.clone()
     loss = tc.train_step(batch)

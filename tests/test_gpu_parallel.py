@@ -107,7 +107,7 @@ def test_dp2_train_step_equals_single_process_global_batch(fdn):
         assert g0[-1] == (4.0, 2.0)[step]                           # the batch-size slot carries the GLOBAL batch
         # vs the single-process gradient of the global batch: equal up to fp32 effects -- the partial sums are grouped by
         # shard, and the kernel planner may tile N=2 and N=4 launches differently, so a ReLU unit within an ulp of its kink can
-        # land on the other side (each flip moves the gradient by ~1/(B*V) relative; test_gpu_train_step.count_flips).
+        # land on the other side (each flip moves the gradient by ~1/(B*V) relative; test_gpu_train_step.kink_sides).
         # north_star tolerance: 1e-3 relative.
         ref = ref_g[step][:-1].astype(np.float64)
         d = g0[:-1].astype(np.float64) - ref
