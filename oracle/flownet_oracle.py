@@ -486,6 +486,8 @@ def loss_and_grads(params, batch, res_increase, low_resblock=8, hi_resblock=4, f
     mse, dpred = masked_mse_loss_fwd_bwd(pred, hires, mask)
     rel = relative_error(pred, hires, mask)
     l2 = l2_regularizer(params)
+    if callable(sides):                 # sides(cache) -> sides: lets the caller compare its own forward with this one's cache (one oracle forward)
+        sides = sides(cache)
     grads = network_backward(params, cache, dpred, res_increase, low_resblock, hi_resblock, f32_coeffs, bf16, sides=sides)
     B = u.shape[0]
     for g, p in zip(grads, params):

@@ -205,13 +205,16 @@ def test_trained_cfg2_step_winograd_vs_direct_vs_oracle(fdn, trained, oracle, ca
     batch = trained["batch"]
     w_trained = tc.model.get_weights()
 
-    def grads_of(conv_algo, rows):
+    def grads_of(conv_algo, rows, keep_acts=False):
         t = trainer.TrainerController(24, 2, initial_learning_rate=1e-4, quicksave_enable=False, low_resblock=8, hi_resblock=4,
                                       seed=0, conv_algo=conv_algo)
         t.model.set_weights(w_trained)
         sub = tuple(a[rows] for a in batch)
         inputs, hires, venc, mask = t._unpack(sub)
         pred = t.model.forward(inputs, training=True)
+        c = t.model._cache                                 # (backward releases it) host copies of the activations: the kink sides
+        t.kept = None if not keep_acts else {**{k: c[k].cpu() for k in ("a0", "a1", "p0", "p1", "c0", "c1")},
+                                             "blocks": [(None, h.cpu(), o.cpu()) for _, h, o in c["blocks"]], "heads": [g.cpu() for g in c["heads"]]}
         out, dpred = fdn.ops.loss_metrics(pred, hires[0], hires[1], hires[2], mask, want_grad=True)
         t.model.backward(dpred)
         torch.cuda.synchronize()
@@ -233,7 +236,7 @@ def test_trained_cfg2_step_winograd_vs_direct_vs_oracle(fdn, trained, oracle, ca
     assert e_pred <= TOL and e_loss <= TOL and e_grad <= TOL and max(per_layer) <= 10 * TOL
     # one patch against the float64 oracle (CPU restatement of SR4DFlowNet.py:7-120, TrainerController.py:84-156)
     O = oracle
-    p1, l1, g1, _ = grads_of("auto", slice(0, 1))
+    p1, l1, g1, t1 = grads_of("auto", slice(0, 1), keep_acts=True)
     params = O.init_params(0, 8, 4, np.float64)          # list of {"w", "b"} in creation order: fill in the trained values
     it = iter(w_trained)
     for layer in params:
@@ -242,12 +245,22 @@ def test_trained_cfg2_step_winograd_vs_direct_vs_oracle(fdn, trained, oracle, ca
             layer["b"] = np.asarray(next(it), np.float64)
     assert next(it, None) is None
     sub = tuple(np.asarray(a[0:1].cpu() if isinstance(a, torch.Tensor) else a[0:1], np.float64) for a in batch)
-    ref = O.loss_and_grads(params, sub, 2, 8, 4, f32_coeffs=True)
+    # the oracle differentiates in the linear region the GPU forward landed in (tests/_kink.py); the units that changed side are counted
+    from _kink import kink_sides
+    seen = {}
+
+    def sides_of(rc):
+        seen["sides"], seen["flips"], seen["worst"] = kink_sides(t1.kept, rc)
+        return seen["sides"]
+    ref = O.loss_and_grads(params, sub, 2, 8, 4, f32_coeffs=True, sides=sides_of)
     gref = O.flatten(ref["grads"])
     e_l, e_g = float(np.abs(l1 - ref["mse"]).max() / np.abs(ref["mse"]).max()), rel(g1, gref)
     with capsys.disabled():
-        print("[wino-parity c] one patch vs float64 oracle at the trained weights: loss %.2e grad(norm) %.2e" % (e_l, e_g))
-    assert e_l <= 1e-3 and e_g <= 1e-3
+        print("[wino-parity c] one patch vs float64 oracle at the trained weights: loss %.2e grad(norm) %.2e in the GPU's linear region "
+              "(%d activation units on the other side of the kink, largest %.1e of its tensor's scale)" % (e_l, e_g, seen["flips"], seen["worst"]))
+    # (at the trained state the gradient is a small difference of large per-voxel terms: 9e-5 of its norm is arithmetic, measured with
+    # the flips taken out; round 4 asserted 1e-3 here with the flips left in)
+    assert e_l <= TOL and e_g <= 3e-4 and seen["flips"] <= 200 and seen["worst"] <= 2e-5
 
 
 def test_training_with_winograd_tracks_training_with_direct_kernels(fdn, capsys):
