@@ -1,32 +1,34 @@
-// conv3d 3x3x3, 64 -> 64 channels, fp32, NDHWC: 2-D Winograd -- F(2,3) along H on top of F(4,3) along W, direct taps along D --
-// on v_mfma_f32_16x16x4_f32.
+// conv3d 3x3x3, 64 -> 64 channels, fp32, NDHWC: 2-D Winograd -- F(HM,3) along H (HM = 4, or 2 where H is only even) on top of F(4,3)
+// along W, direct taps along D -- on v_mfma_f32_16x16x4_f32.
 //
 // Same contract as conv64_wino.hip / conv64_mfma.hip (tf.pad(SYMMETRIC) + Conv3D + bias + activation + residual of
 // src/Network/SR4DFlowNet.py:93-120 in clamp mode; Conv3DBackpropInputV2 of the same layers in zero mode with the interior
-// MirrorPadGrad fused into the epilogue), with a third fewer multiplies than the 1-D kernel: a CELL of 2 x 4 output voxels (h, w)
-// is computed from its 4 x 6 input patch as
-//     Y = Ah^T [ sum_kd (Gh g Gw^T) .* (Bh^T x Bw) ] Aw             (Lavin & Gray; F(2,3): points 0, +-1, inf; F(4,3): 0, +-1, +-2, inf)
-// i.e. 24 products per (kd, cin, cout) for 8 voxels: 3 * 24 / 8 = 9 tap-equivalents per voxel instead of 13.5 (1-D) or 27 (direct).
-// On MI355X the fp32 matrix rate equals the fp32 vector rate, so fewer multiplies is the only way past the roofline.
+// MirrorPadGrad fused into the epilogue), with fewer multiplies than the 1-D kernel: a CELL of HM x 4 output voxels (h, w) is
+// computed from its (HM+2) x 6 input patch as
+//     Y = Ah^T [ sum_kd (Gh g Gw^T) .* (Bh^T x Bw) ] Aw             (Lavin & Gray)
+// HM = 4: 36 products per (kd, cin, cout) for 16 voxels = 6.75 tap-equivalents per voxel; HM = 2: 24 for 8 voxels = 9 (1-D: 13.5,
+// direct: 27).  On MI355X the fp32 matrix rate equals the fp32 vector rate, so fewer multiplies is the only way past the roofline.
+// HM = 4 uses the interpolation points 0, +-3/4, +-3/2, inf on both axes (conv64_wino2d_kernel.h: a quarter of the fp32 error of the
+// classic 0, +-1, +-2, inf, every constant exact), HM = 2 the classic points of rounds 2-4.
 //
-// The 24 accumulator tiles a cell needs do not fit beside everything else (24 points x 2 M-blocks x 4 registers = 192), so the
-// F(2,3) coordinate xh runs as an OUTER, sequential loop ("stage"): a stage holds the six xw accumulators of its xh only (48
-// registers for 32 cells x 16 cout), runs the whole K loop of that xh (3 depth taps x 64 cin), and folds A_w^T M[xh] into the two
-// output rows with the F(2,3) coefficients (Y_h0 += c0[xh] t, Y_h1 += c1[xh] t; 64 registers).  Because F(2,3)'s B^T rows have two
-// non-zeros, a stage's input is V[xh] = x[ra] +- x[rb] of TWO input rows (xh 0: x0-x2, 1: x1+x2, 2: x1-x2 with the sign folded into
-// the packed weights, 3: x1-x3), staged for all 64 input channels at once -- so the four stages take the place of the four cin
-// slices of the 1-D kernel (same number of barriers) and read each input row twice (L1/L2 hits).
+// The (HM+2) x 6 accumulator tiles a cell needs do not fit beside everything else, so the H coordinate xh runs as an OUTER,
+// sequential loop ("stage"): a stage holds the six xw accumulators of its xh only (48 registers for 32 cells x 16 cout), runs the
+// whole K loop of that xh (3 depth taps x 64 cin), and folds A_w^T M[xh] into the HM output rows with column xh of A_h^T
+// (Y: HM x 4 voxels x 2 M-blocks x 4 = 64 or 128 registers).  A stage's input is V[xh] = sum_j B_h^T[xh][j] x[row j] -- two rows for
+// F(2,3), three or four for F(4,3), two of the middle stages formed incrementally from the stage before them -- staged for all 64
+// input channels at once, so the stages take the place of the cin slices of the 1-D kernel and read each input row several times
+// (L1/L2 hits; what counts is the number of load instructions).
 //
 // Work decomposition:
-//   * M = cells.  Workgroup (4 waves) = a box tile of td x ch x cw cells (<= 32 cells = 256 voxels) x 64 cout; wave w owns all
+//   * M = cells.  Workgroup (4 waves) = a box tile of td x ch x cw cells (<= 32 cells = 256 / 512 voxels) x 64 cout; wave w owns all
 //     32 cells (two 16-cell MFMA blocks) x cout [16w, 16w+16): D[cout][cell] orientation, so a lane (cell c = lane & 15,
 //     q = lane >> 4) holds cout 16w + 4q .. + 3 of one cell = 16-B stores.
-//   * Staging: thread (staged cell-plane r, 16-B channel chunk) loads the 2 x 6 input chunks of its stage (boundary rule through
-//     the staging plan: clamp == SYMMETRIC p=1, or zero through the buffer range check), forms x[ra] +- x[rb], applies B_w^T
-//     (14 VALU per float) and writes 6 xw planes of rows [cell-plane][64 cin + 32-B pad]: the 288-B row stride makes the 16-row
-//     ds_read_b128 lane groups conflict-free.  A tile stages (td + 2) depth planes x ch x cw cells <= 40 rows: 69 KB, 2 workgroups per CU.
-//   * Weights: packed stream U[nb][xh][kd][xw][cin/16][lane][4] (fdn_pack_wino2d_one, 72*64*64 floats per layer and direction),
-//     read straight from L1/L2 by buffer_load_dwordx4.
+//   * Staging: thread (staged cell-plane r, 16-B channel chunk) loads the row chunks of its stage (boundary rule through the staging
+//     plan: clamp == SYMMETRIC p=1, or zero through the buffer range check), forms V, applies B_w^T and writes 6 xw planes of rows
+//     [cell-plane][64 cin + 32-B pad]: the 288-B row stride makes the 16-row ds_read_b128 lane groups conflict-free.  A tile stages
+//     (td + 2) depth planes x ch x cw cells <= 40 rows: 69 KB, 2 workgroups per CU.
+//   * Weights: packed streams U[nb][xh][kd][xw][cin/16][lane][4] (fdn_pack_wino2d_one: 72 * 64 * 64 floats per layer and direction;
+//     fdn_pack_wino44_one: 108 * 64 * 64, formed in double precision), read straight from L1/L2 by buffer_load_dwordx4.
 //   * K loop of a stage: 3 depth taps x 6 xw x 4 cin groups; one step = 2 ds_read_b128 + 1 buffer_load_b128 feeding 8 MFMAs
 //     (2 M-blocks x 4 k-steps, alternating blocks: the 40-cycle dependent latency of v_mfma_f32_16x16x4_f32 is covered);
 //     operands through fragment rings refilled inside the MFMA stream, as in the 1-D kernel.
