@@ -324,7 +324,7 @@ __device__ __forceinline__ void wgrad64_wino_body(const WgWinoArgs& p, const int
 #pragma unroll
         for (int s = 0; s < 18; ++s) {
             const int q = s / 3, b = s % 3;
-            if (s == 12) __syncthreads();       // tile k+1 is complete in `nxt`; every wave is done with tile k-1's buffer
+            if (s == 12 && !(FDN_DBG_BITS(p) & 64)) __syncthreads();       // tile k+1 is complete in `nxt`; every wave is done with tile k-1's buffer  (test build, bit 64: timing without it)
             // read-ahead: operands of the next slot (the first slot of tile k+1 at the end)
             if (s + 1 < 18) {
                 const int ln = (s + 1) / 3 + (s + 1) % 3;                      // x halo line of the next slot: new iff b = 2, or q = 0

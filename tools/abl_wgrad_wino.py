@@ -10,7 +10,7 @@ for P in ([int(sys.argv[2])] if len(sys.argv) > 2 else [48, 24]):
     ws = torch.empty(ops.wgrad_workspace_bytes(N, P, P, P, 64, 64, 3) // 4 + 1, device="cuda"); dw = torch.empty((3, 3, 3, 64, 64), device="cuda")
     flop = 2.0 * 27 * 64 * 64 * N * P ** 3
     for bits, name in ((0, "full (warm-up)"), (0, "full"), (1, "no raw loads"), (2, "no transform / LDS writes"), (3, "no loads, no transform / writes"),
-                       (4, "no LDS operand reads"), (7, "MFMAs + barrier only"), (39, "MFMAs + barrier, no tile walk"), (32, "full, no tile walk"), (0, "full")):
+                       (4, "no LDS operand reads"), (7, "MFMAs + barrier only"), (39, "MFMAs + barrier, no tile walk"), (39 + 64, "MFMAs only, no barrier, no walk"), (64, "full, no barrier (wrong results)"), (32, "full, no tile walk"), (0, "full")):
         lib.fdn_debug_set_wgrad64_wino_dbg(bits)
         for _ in range(3): ops.conv3d_wgrad(x, dz, 3, 64, 64, dw=dw, workspace=ws)
         torch.cuda.synchronize()
