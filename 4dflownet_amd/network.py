@@ -156,7 +156,7 @@ class FlowNetModel:
         self.batch_wgrad = os.environ.get("FDN_BATCH_WGRAD", "1") not in ("", "0")
         self.batch_wgrad_max_voxels = 1 << 18          # per launch; the 48^3 layers of cfg2 (8 x 110 592 voxels) fill the chip on their own
         self._wg_pending = []
-        self.overlap_wgrad = False     # measured +0.7 % at cfg2 (kernels already fill the chip); off so per-kernel timings stay clean
+        self.overlap_wgrad = os.environ.get("FDN_OVERLAP_WGRAD", "0") not in ("", "0")     # measured +0.7 % at cfg2 (kernels already fill the chip); off so per-kernel timings stay clean
         self._cache = None
         # Gradient buckets in the order backward() completes them: slices [lo, hi) of flat_g_ext that are final when the hi-res part
         # (heads + hi-res blocks, together with the trailing batch slot), the upper half of the low-res blocks and the rest are done.
