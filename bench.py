@@ -264,8 +264,12 @@ def cpu_baseline(P, R, LB, HB):
     if cpus:
         env["OMP_NUM_THREADS"] = str(len(cpus))
     cmd = [sys.executable, "-m", "oracle.torch_cpu", str(P), str(R), str(LB), str(HB), "2", "5"] + ([str(len(cpus))] if cpus else [])
-    pin = (lambda: os.sched_setaffinity(0, cpus)) if cpus else None
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, preexec_fn=pin, timeout=1800)
+    def pin():                                      # in the child, before exec: a refused affinity call must not cost the run
+        try:
+            os.sched_setaffinity(0, cpus)
+        except OSError:
+            pass
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, preexec_fn=pin if cpus else None, timeout=1800)
     if r.returncode != 0:
         raise RuntimeError("cpu_baseline child failed: " + r.stderr[-500:])
     res = json.loads(r.stdout.strip().splitlines()[-1])
@@ -810,7 +814,10 @@ def main():
         if not args.no_secondary:
             line["secondary"] = secondary_runs(trainer, parallel, device, P, R, B, LB, HB, args.sustained_steps)
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(P, R, LB, HB)
+            try:                                    # a reported baseline, measured AFTER the headline: it can fail, the line still goes out
+                line["cpu_baseline"] = cpu_baseline(P, R, LB, HB)
+            except Exception as e:
+                line["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, str(e)[-300:]), "kind": "port", "value": None, "unit": "patches/s"}
     print(json.dumps(line), flush=True)
     if parallel.is_dist():
         parallel.barrier()
