@@ -812,7 +812,10 @@ def main():
     torch.cuda.empty_cache()
     if world == 1 and not bf16 and args.config == "cfg2":
         if not args.no_secondary:
-            line["secondary"] = secondary_runs(trainer, parallel, device, P, R, B, LB, HB, args.sustained_steps)
+            try:                                    # secondary legs run after the headline was measured: a failing leg is recorded, not fatal
+                line["secondary"] = secondary_runs(trainer, parallel, device, P, R, B, LB, HB, args.sustained_steps)
+            except Exception as e:
+                line["secondary"] = {"error": "%s: %s" % (type(e).__name__, str(e)[-300:])}
         if not args.no_cpu_baseline:
             try:                                    # a reported baseline, measured AFTER the headline: it can fail, the line still goes out
                 line["cpu_baseline"] = cpu_baseline(P, R, LB, HB)
