@@ -43,6 +43,8 @@ SIGNATURES = {
     "fdn_adam_step": (c_i, [c_fp] * 5 + [c_i64] + [c_f] * 5 + [c_fp, c_fp, c_fp]),
     "fdn_sum_partials": (c_i, [c_fp, c_i, c_fp, c_fp]),
     "fdn_pack_conv64_weights_batch": (c_i, [c_fp, c_fp, c_i, c_fp, c_fp]),
+    "fdn_conv64_pack_streams": (c_i, [c_i] * 6),
+    "fdn_pack_conv64_weights_batch_streams": (c_i, [c_fp, c_fp, c_i, c_fp, c_i, c_i, c_fp]),
     # bf16 activation path
     "fdn_pack_conv64_weights_bf16": (c_i, [c_fp, c_fp, c_fp, c_fp]),
     "fdn_conv64_fwd_bf16": (c_i, [c_fp] * 5 + [c_i] * 5 + [c_f, c_fp]),

@@ -455,15 +455,22 @@ __global__ void pack_conv64_kernel(const float* __restrict__ w, float* __restric
 }
 
 // every 64->64 layer of the network in ONE launch: blockIdx.y = layer, packs[layer][fwd|dgrad][direct | winograd]
-__global__ void pack_conv64_batch_kernel(const float* __restrict__ w_base, const int64_t* __restrict__ w_offsets, float* __restrict__ packs) {
+// sf / sd: the streams to write of the forward / dgrad pack (bit 0 direct, 1 1-D Winograd, 2 F(2,3)xF(4,3), 3 F(4,3)xF(4,3)); a block
+// lies inside one stream (every stream is a multiple of 256 elements), so an unwanted stream costs an early exit
+__global__ void pack_conv64_batch_kernel(const float* __restrict__ w_base, const int64_t* __restrict__ w_offsets, float* __restrict__ packs,
+                                         int sf, int sd) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over 261*64*64 packed elements per direction
+    const int st = idx < 27 * 64 * 64 ? 0 : idx < 81 * 64 * 64 ? 1 : idx < 153 * 64 * 64 ? 2 : 3;
+    if (!(((sf | sd) >> st) & 1) || idx >= 261 * 64 * 64) return;
     const float* w = w_base + w_offsets[blockIdx.y];
     float* pf = packs + (size_t)blockIdx.y * 2 * FDN_CONV64_PACK_FLOATS;
     float* pd = pf + FDN_CONV64_PACK_FLOATS;
-    if (idx < 27 * 64 * 64) fdn_pack_direct_one(w, pf, pd, idx);
-    else if (idx < 81 * 64 * 64) fdn_pack_wino_one(w, pf + 27 * 64 * 64, pd + 27 * 64 * 64, idx - 27 * 64 * 64);
-    else if (idx < 153 * 64 * 64) fdn_pack_wino2d_one(w, pf + 81 * 64 * 64, pd + 81 * 64 * 64, idx - 81 * 64 * 64);
-    else if (idx < 261 * 64 * 64) fdn_pack_wino44_one(w, pf + 153 * 64 * 64, pd + 153 * 64 * 64, idx - 153 * 64 * 64);
+    if (!((sf >> st) & 1)) pf = nullptr;
+    if (!((sd >> st) & 1)) pd = nullptr;
+    if (st == 0) fdn_pack_direct_one(w, pf, pd, idx);
+    else if (st == 1) fdn_pack_wino_one(w, pf ? pf + 27 * 64 * 64 : nullptr, pd ? pd + 27 * 64 * 64 : nullptr, idx - 27 * 64 * 64);
+    else if (st == 2) fdn_pack_wino2d_one(w, pf ? pf + 81 * 64 * 64 : nullptr, pd ? pd + 81 * 64 * 64 : nullptr, idx - 81 * 64 * 64);
+    else fdn_pack_wino44_one(w, pf ? pf + 153 * 64 * 64 : nullptr, pd ? pd + 153 * 64 * 64 : nullptr, idx - 153 * 64 * 64);
 }
 
 // pack = [direct stream, 27*64*64 floats | Winograd F(4,3) stream, 54*64*64 | 2-D F(2,3)xF(4,3) stream, 72*64*64 | 2-D F(4,3)xF(4,3)
@@ -485,12 +492,36 @@ extern "C" int fdn_pack_conv64_weights(const float* w, float* wp_fwd, float* wp_
                                          wp_dgrad ? wp_dgrad + kDirectPackFloats + kWino1PackFloats : nullptr, (hipStream_t)stream);
 }
 
-extern "C" int fdn_pack_conv64_weights_batch(const float* w_base, const int64_t* w_offsets, int n_layers, float* packs, void* stream) {
+extern "C" int fdn_pack_conv64_weights_batch_streams(const float* w_base, const int64_t* w_offsets, int n_layers, float* packs,
+                                                     int streams_fwd, int streams_dgrad, void* stream) {
     FDN_REQUIRE(w_base && w_offsets && packs && n_layers > 0, "fdn_pack_conv64_weights_batch: NULL argument or n_layers<=0");
+    FDN_REQUIRE(!(streams_fwd & ~FDN_PACK_STREAM_ALL) && !(streams_dgrad & ~FDN_PACK_STREAM_ALL), "fdn_pack_conv64_weights_batch_streams: bad stream mask %d / %d",
+                streams_fwd, streams_dgrad);
+    if (!(streams_fwd | streams_dgrad)) return FDN_OK;
     hipLaunchKernelGGL(pack_conv64_batch_kernel, dim3((FDN_CONV64_PACK_FLOATS + 255) / 256, (unsigned)n_layers), dim3(256), 0, (hipStream_t)stream,
-                       w_base, w_offsets, packs);
+                       w_base, w_offsets, packs, streams_fwd, streams_dgrad);
     FDN_CHECK_LAUNCH("fdn_pack_conv64_weights_batch");
     return FDN_OK;
+}
+
+extern "C" int fdn_pack_conv64_weights_batch(const float* w_base, const int64_t* w_offsets, int n_layers, float* packs, void* stream) {
+    return fdn_pack_conv64_weights_batch_streams(w_base, w_offsets, n_layers, packs, FDN_PACK_STREAM_ALL, FDN_PACK_STREAM_ALL, stream);
+}
+
+extern "C" int fdn_conv64_pack_streams(int N, int D, int H, int W, int algo, int role) {
+    FDN_REQUIRE(algo >= FDN_ALGO_AUTO && algo <= FDN_ALGO_WINO_H2, "fdn_conv64_pack_streams: bad algo %d", algo);
+    FDN_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && D <= 1020 && H <= 1020 && W <= 1020, "fdn_conv64_pack_streams: bad dims");
+    FDN_REQUIRE(role >= FDN_ROLE_FWD && role <= FDN_ROLE_DGRAD_FUSED, "fdn_conv64_pack_streams: bad role %d", role);
+    unsigned m = 0;
+    float* const some = reinterpret_cast<float*>(sizeof(float));      // a fused fold is requested by a non-NULL dz_prev; nothing is dereferenced
+    int rc;
+    if (role == FDN_ROLE_FWD)
+        rc = fdn_conv64_launch_ex(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, N, D, H, W, D, H, W, 0, 0, FDN_ACT_NONE, 0.f,
+                                  nullptr, 3, algo, &m);
+    else
+        rc = fdn_conv64_launch_ex(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, role == FDN_ROLE_DGRAD_FUSED ? some : nullptr, N, D, H, W,
+                                  D + 2, H + 2, W + 2, -1, 1, FDN_ACT_NONE, 0.f, nullptr, 3, algo, &m);
+    return rc ? rc : (int)m;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -611,7 +642,9 @@ FdnTile fdn_plan_tile(int N, int OD, int OH, int OW, int max_vox, int max_halo_r
 
 int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, const float* residual, float* y,
                          const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
-                         int OW, int off, int zero_mode, int act, float alpha, hipStream_t s, int parts, int algo) {
+                         int OW, int off, int zero_mode, int act, float alpha, hipStream_t s, int parts, int algo, unsigned* probe) {
+    // probe != nullptr: launch nothing, OR into *probe the streams of the pack this call would read (bit 0 direct, 1 1-D Winograd,
+    // 2 F(2,3)xF(4,3), 3 F(4,3)xF(4,3)) -- fdn_conv64_pack_streams; the selection below is the only statement of the rule.
     // staged rows are addressed with 32-bit byte offsets from the sample's first voxel (256 B per voxel)
     FDN_REQUIRE((long long)ID * IH * IW < (1ll << 24), "conv64: a sample of %dx%dx%d voxels exceeds the 32-bit row addressing", ID, IH, IW);
     Conv64Args a;
@@ -634,13 +667,19 @@ int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, 
         return fdn_conv64_wino2d_ok(1, eh, ew, ID, IH, IW, 2) ? 2 : 0;
     };
     auto upack_hm = [&](int hm) { return hm == 4 ? upack2 + kWino2PackFloats : upack2; };
+    auto stream_bit = [](int hm) { return hm == 4 ? 8u : 4u; };
     if (!(fout && zero_mode && off == -1 && fdn_conv64_shell_slabs)) {
-        if (const int hm = fout ? 0 : hm_for(OH, OW))             // (a fused fold outside the slab path is the 1-D / direct kernels' business)
+        if (const int hm = fout ? 0 : hm_for(OH, OW)) {           // (a fused fold outside the slab path is the 1-D / direct kernels' business)
+            if (probe) { *probe |= stream_bit(hm); return FDN_OK; }
             return fdn_conv64_wino2d_launch(x, upack_hm(hm), bias, residual, y, nullptr, nullptr, nullptr, N, ID, IH, IW, OD, OH, OW, 0, 0, 0,
                                             OD, OH, OW, off, zero_mode, act, alpha, hm, s);
-        if (wino && fdn_conv64_wino_ok(OD, OH, OW))
+        }
+        if (wino && fdn_conv64_wino_ok(OD, OH, OW)) {
+            if (probe) { *probe |= 2u; return FDN_OK; }
             return fdn_conv64_wino_launch(x, upack, bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, 0, 0, 0, OD, OH,
                                           OW, off, zero_mode, act, alpha, s);
+        }
+        if (probe) { *probe |= 1u; return FDN_OK; }
         return launch_boxes(a, &full, 1, s);
     }
     // Fused dgrad on the padded grid (OD = ID+2): padded index p <-> position P = p-1 reads dz[p - 2 + tap], zero outside.
@@ -674,6 +713,7 @@ int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, 
             // body, the shell faces on the 1-D body (their single depth / height / width tap has nothing to transform along that axis)
             if ((parts & 2) && !wface_direct && !fdn_conv64_split_dgrad) {
                 // both parts: ONE launch, the shell faces behind the inner box's workgroups (conv64_wino2d_shell_kernel, conv64_wino.hip)
+                if (probe) { *probe |= stream_bit(hm) | 2u; return FDN_OK; }
                 FdnWino2dPrepared inner;
                 if (int rc = fdn_conv64_wino2d_prepare(x, upack_hm(hm), bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, 1, 1, 1, ID,
                                                        IH, IW, off, zero_mode, act, alpha, hm, &inner))
@@ -681,17 +721,20 @@ int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, 
                 return fdn_conv64_wino_launch_boxes(x, upack, bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, wb + 1, count - 1,
                                                     off, zero_mode, act, alpha, s, &inner);
             }
-            if (int rc = fdn_conv64_wino2d_launch(x, upack_hm(hm), bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, 1, 1, 1, ID, IH,
-                                                  IW, off, zero_mode, act, alpha, hm, s))
+            if (probe) *probe |= stream_bit(hm);
+            else if (int rc = fdn_conv64_wino2d_launch(x, upack_hm(hm), bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, 1, 1, 1, ID, IH,
+                                                       IW, off, zero_mode, act, alpha, hm, s))
                 return rc;
             first = 1; count -= 1;
             if (count == 0) return FDN_OK;
         }
+        if (probe) { *probe |= 2u | (((parts & 2) && wface_direct) ? 1u : 0u); return FDN_OK; }
         if (int rc = fdn_conv64_wino_launch_boxes(x, upack, bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, wb + first,
                                                   count, off, zero_mode, act, alpha, s))
             return rc;
         return ((parts & 2) && wface_direct) ? launch_boxes(a, wfaces, 2, s) : FDN_OK;
     }
+    if (probe) { *probe |= 1u; return FDN_OK; }
     if (parts == 3) return launch_boxes(a, boxes, 7, s);
     if (parts & 1) return launch_boxes(a, boxes, 1, s);
     return (parts & 2) ? launch_boxes(a, boxes + 1, 6, s) : FDN_OK;
@@ -701,7 +744,7 @@ int fdn_conv64_launch(const float* x, const float* wpack, const float* bias, con
                       int ID, int IH, int IW, int OD, int OH, int OW, int off, int zero_mode, int act, float alpha,
                       hipStream_t s, int algo) {
     return fdn_conv64_launch_ex(x, wpack, bias, residual, y, nullptr, nullptr, nullptr, N, ID, IH, IW, OD, OH, OW, off,
-                                zero_mode, act, alpha, s, 3, algo);
+                                zero_mode, act, alpha, s, 3, algo, nullptr);
 }
 
 int fdn_fold_halo_border_launch(const float* s0, const float* s1, const float* s2, int nsrc, const float* skip,

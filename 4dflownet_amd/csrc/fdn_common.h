@@ -173,7 +173,7 @@ int fdn_conv64_launch(const float* x, const float* wpack, const float* bias, con
 int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, const float* residual, float* y,
                          const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
                          int OW, int off, int zero_mode, int act, float alpha, hipStream_t s, int parts = 3,
-                         int algo = FDN_ALGO_AUTO);
+                         int algo = FDN_ALGO_AUTO, unsigned* probe = nullptr);
 // Winograd F(4,3)-along-W variant of the 64->64 conv (conv64_wino.hip): one output box with all 27 taps
 // output box + its non-zero (kd, kh) tap ranges.  wface = 1: the pair of w faces of a fused dgrad's shell (box = the (d,h) range of the
 // padded grid, ow = 0, ew = 4: one "group" per (d,h) position; see conv64_wino.hip)

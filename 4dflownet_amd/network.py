@@ -165,6 +165,12 @@ class FlowNetModel:
         cut_mid = self.layers[6 + 2 * (self.low_resblock // 2)].w_off
         self.grad_buckets = [b for b in ((cut_hi, n + 1), (cut_mid, cut_hi), (0, cut_mid)) if b[1] > b[0]]
         self._slow_warned = set()
+        # streams of the 64->64 packs that are kept current (fp32 mode): [forward packs, dgrad packs].  A pack holds four streams
+        # and a grid reads one or two of them, so the per-step re-pack writes only what forward() has found the grids of this model
+        # to read (_require_pack_streams asks the library's own selection code, widens the set and re-packs when a new grid or
+        # algorithm needs more); nothing else reads the packs.
+        self._pack_streams = [0, 0]
+        self._pack_need_cache = {}
         self.glorot_uniform_init(seed)
 
     def set_conv_algo(self, conv_algo=None):
@@ -201,7 +207,8 @@ class FlowNetModel:
         """Re-derive the MFMA operand streams after any parameter update (Adam step, load_weights)."""
         self.weights_version += 1
         if self.dtype == "float32":
-            ops.pack_conv64_weights_batch(self.flat_w, self._w64_offsets, self._packs)      # all 64->64 layers, one launch
+            if self._w64_offsets.numel():                  # all 64->64 layers, the streams in use, one launch
+                ops.pack_conv64_weights_batch(self.flat_w, self._w64_offsets, self._packs, streams=self._pack_streams)
             return
         for L in self.layers:
             if L.wp_f is not None:
@@ -286,6 +293,26 @@ class FlowNetModel:
                       "only where W %% 4 == 0 and H is even (fastest: H %% 4 == 0 as well).  patch_size * res_increase (and patch_size "
                       "itself for the low-res stack) a multiple of 4 avoids this." % (D, H, W, how), RuntimeWarning, stacklevel=3)
 
+    def _require_pack_streams(self, N, D, H, W, training):
+        """Make sure the pack streams the 64->64 layers read on this grid are current (see __init__)."""
+        if self.dtype != "float32":
+            return
+        algos = tuple(sorted(set(self.conv_algo[L.name] for L in self.layers if L.wp_f is not None)))
+        key = (N, D, H, W, training, algos)
+        need = self._pack_need_cache.get(key)
+        if need is None:
+            f = d = 0
+            for a in algos:
+                f |= ops.conv64_pack_streams(N, D, H, W, a, ops.ROLE_FWD)
+                if training:
+                    d |= ops.conv64_pack_streams(N, D, H, W, a, ops.ROLE_DGRAD_FUSED)
+            need = self._pack_need_cache[key] = (f, d)
+        new = [need[0] & ~self._pack_streams[0], need[1] & ~self._pack_streams[1]]
+        if new[0] or new[1]:
+            self._pack_streams = [self._pack_streams[0] | new[0], self._pack_streams[1] | new[1]]
+            if self._w64_offsets.numel():
+                ops.pack_conv64_weights_batch(self.flat_w, self._w64_offsets, self._packs, streams=new)
+
     def _conv(self, x, L, act, residual=None, x2=None, out=None, ldy=None, y_coff=0):
         return self.ops.conv3d_fwd(x, L.w, L.b, act, ops.LEAKY_ALPHA, residual, x2, L.wp_f, out, ldy, y_coff, algo=self.conv_algo[L.name])
 
@@ -300,8 +327,11 @@ class FlowNetModel:
         R = self.res_increase
         Ls = self.layers
         self._warn_slow_grid(B, D, H, W)
-        if R > 1 and self.hi_resblock > 0:
-            self._warn_slow_grid(B, D * R, H * R, W * R)
+        self._require_pack_streams(B, D, H, W, training)
+        if R > 1:                                          # (the three head convs run on the upsampled grid whatever hi_resblock is)
+            if self.hi_resblock > 0:
+                self._warn_slow_grid(B, D * R, H * R, W * R)
+            self._require_pack_streams(B, D * R, H * R, W * R, training)
         phase = torch.empty((B, D, H, W, 3), device=self.device, dtype=self.act_dtype)
         pc = torch.empty((B, D, H, W, 3), device=self.device, dtype=self.act_dtype)
         self.ops.input_features(u, v, w, mu, mv, mw, phase, pc)

@@ -270,12 +270,25 @@ def sum_partials(partials, out=None):
     return out
 
 
-def pack_conv64_weights_batch(w_flat, w_offsets, packs):
+def pack_conv64_weights_batch(w_flat, w_offsets, packs, streams=None):
     """Every 64->64 kernel of the flat parameter buffer in one launch.  w_offsets: int64 DEVICE tensor of float offsets;
-    packs: (n_layers, 2, CONV64_PACK_FLOATS)."""
+    packs: (n_layers, 2, CONV64_PACK_FLOATS).  streams = (forward mask, dgrad mask) of PACK_STREAM_* bits restricts the launch to
+    those streams of the packs (conv64_pack_streams names the ones a grid reads); None = all."""
     n = w_offsets.numel()
     if w_offsets.dtype != torch.int64 or not w_offsets.is_cuda or packs.numel() != n * 2 * CONV64_PACK_FLOATS:
         raise FdnError("pack_conv64_weights_batch: bad offsets / packs")
-    check(_lib.load().fdn_pack_conv64_weights_batch(_p(w_flat), w_offsets.data_ptr(), n, _p(packs), _stream()),
-          "fdn_pack_conv64_weights_batch")
+    sf, sd = (PACK_STREAM_ALL, PACK_STREAM_ALL) if streams is None else streams
+    check(_lib.load().fdn_pack_conv64_weights_batch_streams(_p(w_flat), w_offsets.data_ptr(), n, _p(packs), int(sf), int(sd), _stream()),
+          "fdn_pack_conv64_weights_batch_streams")
     return packs
+
+
+PACK_STREAM_ALL = 15
+ROLE_FWD, ROLE_DGRAD, ROLE_DGRAD_FUSED = 0, 1, 2
+
+
+def conv64_pack_streams(N, D, H, W, algo=ALGO_AUTO, role=ROLE_FWD):
+    """PACK_STREAM_* bits of the pack streams the 64->64 entry point of `role` reads on an (N,D,H,W) grid (fdn_conv64_pack_streams)."""
+    m = _lib.load().fdn_conv64_pack_streams(int(N), int(D), int(H), int(W), int(algo), int(role))
+    check(min(m, 0), "fdn_conv64_pack_streams")
+    return m

@@ -83,6 +83,25 @@ int fdn_pack_conv64_weights(const float* w, float* wp_fwd, float* wp_dgrad, void
  * packs + i * 2 * FDN_CONV64_PACK_FLOATS (forward stream first, dgrad stream second). */
 int fdn_pack_conv64_weights_batch(const float* w_base, const int64_t* w_offsets, int n_layers, float* packs,
                                   void* stream);
+/* A pack holds four streams and a given grid reads one or two of them.  fdn_conv64_pack_streams says which: the streams
+ * (FDN_PACK_STREAM_* bits) that fdn_conv3d_fwd (role FDN_ROLE_FWD, reads wp_fwd), fdn_conv3d_dgrad (FDN_ROLE_DGRAD) or
+ * fdn_conv3d_dgrad_fused[_part] (FDN_ROLE_DGRAD_FUSED; both read wp_dgrad) read for a 64->64 layer on an (N,D,H,W) grid
+ * under `algo` -- answered by the launcher's own selection code, so it cannot drift from it; negative = error code.
+ * fdn_pack_conv64_weights_batch_streams is fdn_pack_conv64_weights_batch restricted to the named streams of the forward
+ * and of the dgrad packs (the others keep whatever they held: a caller that narrows the set must re-pack before a
+ * grid that needs more).  cfg2 reads F(4,3)xF(4,3) forward and F(4,3)xF(4,3) + 1-D Winograd (shell faces) in dgrad: 270 of
+ * the 522 x 4096 floats per layer.  The per-step re-pack after the optimizer, TrainerController.py:225. */
+#define FDN_PACK_STREAM_DIRECT 1
+#define FDN_PACK_STREAM_WINO_W 2
+#define FDN_PACK_STREAM_WINO_H2 4
+#define FDN_PACK_STREAM_WINO_H4 8
+#define FDN_PACK_STREAM_ALL 15
+#define FDN_ROLE_FWD 0
+#define FDN_ROLE_DGRAD 1
+#define FDN_ROLE_DGRAD_FUSED 2
+int fdn_conv64_pack_streams(int N, int D, int H, int W, int algo, int role);
+int fdn_pack_conv64_weights_batch_streams(const float* w_base, const int64_t* w_offsets, int n_layers, float* packs,
+                                          int streams_fwd, int streams_dgrad, void* stream);
 
 /* y = act(conv3d(sym_pad(x), w) + bias + residual).
  * Replaces tf.pad(SYMMETRIC,p=(K-1)/2) + Conv3D(valid) + BiasAdd + activation, and the

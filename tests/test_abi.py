@@ -163,3 +163,21 @@ def test_tracked_gpu_test_log_matches_the_tree():
     if stale:
         warnings.warn("%s: %s changed since the recorded GPU run -- re-run tools/gputest_round.sh and collect it" %
                       (os.path.basename(logs[-1]), " and ".join(stale)))
+
+
+def test_pack_stream_query_follows_the_launchers_selection(fdn):
+    """fdn_conv64_pack_streams runs the launcher's own selection in probe mode (no GPU needed): the streams named in include/fdn.h's
+    FDN_ALGO_* table.  Bits: 1 direct, 2 1-D Winograd, 4 F(2,3)xF(4,3), 8 F(4,3)xF(4,3)."""
+    q = fdn._lib.load().fdn_conv64_pack_streams
+    FWD, DG, FUSED = 0, 1, 2
+    AUTO, DIRECT, WINO_W, WINO_H2 = 0, 1, 2, 3
+    for shp in ((8, 24, 24, 24), (8, 48, 48, 48), (1, 12, 12, 12)):          # H, W multiples of 4: the cfg2 grids
+        assert q(*shp, AUTO, FWD) == 8 and q(*shp, AUTO, FUSED) == 8 | 2     # dgrad: inner box + the 1-D shell faces
+        assert q(*shp, WINO_H2, FWD) == 4 and q(*shp, WINO_H2, FUSED) == 4 | 2
+        assert q(*shp, WINO_W, FWD) == 2 and q(*shp, WINO_W, FUSED) == 2
+        assert q(*shp, DIRECT, FWD) == 1 and q(*shp, DIRECT, FUSED) == 1 and q(*shp, DIRECT, DG) == 1
+    assert q(2, 8, 6, 8, AUTO, FWD) == 4                                      # H only even
+    assert q(2, 9, 9, 12, AUTO, FWD) == 2 and q(2, 9, 9, 12, AUTO, FUSED) == 2   # odd H: 1-D Winograd
+    assert q(2, 10, 10, 10, AUTO, FWD) == 1 and q(2, 10, 10, 10, AUTO, FUSED) == 1   # W % 4 != 0: direct
+    assert q(2, 10, 10, 10, AUTO, DG) == 8                                    # the padded grid is 12^3
+    assert q(2, 10, 10, 10, 7, FWD) < 0 and q(0, 10, 10, 10, AUTO, FWD) < 0 and q(2, 10, 10, 10, AUTO, 3) < 0

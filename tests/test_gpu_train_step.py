@@ -299,3 +299,48 @@ def test_winograd_and_direct_kernels_train_alike(fdn):
     dw = np.abs(w_w - w_d)
     # (the share of weights that moved differently at all grows with every gradient element a kink flip touches: 0.19 with one flip)
     assert dw.max() <= 6 * 2.1e-4 and np.quantile(dw, 0.99) <= 2e-5 and np.mean(dw > 1e-6) < 0.30
+
+
+def test_per_step_repack_writes_only_the_streams_in_use_and_widens_on_a_new_grid(fdn):
+    """The model re-packs, after every optimizer step, only the pack streams its grids read (fdn_conv64_pack_streams); a grid or
+    algorithm that needs another stream widens the set and re-packs at once.  Checked against a model whose packs are all current:
+    same weights, grids visited in an order that narrows first (P = 8: F(4,3)xF(4,3) + 1-D), then needs the direct stream (P = 10),
+    then F(2,3)xF(4,3) by algorithm."""
+    net = __import__("importlib").import_module("4dflownet_amd.network")
+    ops = __import__("importlib").import_module("4dflownet_amd.ops")
+    g = torch.Generator(device="cuda").manual_seed(3)
+    m = net.FlowNetModel(2, low_resblock=1, hi_resblock=1, seed=0)
+    assert m._pack_streams == [0, 0]
+    full = net.FlowNetModel(2, low_resblock=1, hi_resblock=1, seed=0)
+    full._pack_streams = [ops.PACK_STREAM_ALL, ops.PACK_STREAM_ALL]
+    full.weights_changed()
+
+    def step(P, algo=None):
+        x = [torch.rand((2, P, P, P, 1), device="cuda", generator=g) for _ in range(6)]
+        dp = torch.randn((2, 2 * P, 2 * P, 2 * P, 3), device="cuda", generator=g)
+        out = []
+        for mm in (m, full):
+            if algo is not None:
+                mm.set_conv_algo(algo)
+            pred = mm.forward(x, training=True).clone()
+            grads = mm.backward(dp).clone()
+            mm.flat_w.add_(grads / grads.abs().max(), alpha=-1e-3)            # a (bounded) parameter update, then the per-step re-pack
+            mm.weights_changed()
+            out.append((pred, grads))
+        assert torch.isfinite(out[1][0]).all() and torch.isfinite(out[1][1]).all()
+        assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+
+    step(8)
+    assert m._pack_streams == [8, 8 | 2]
+    step(8)
+    pred_only = m.forward([torch.rand((2, 12, 12, 12, 1), device="cuda", generator=g) for _ in range(6)])   # inference: no dgrad streams asked
+    assert m._pack_streams == [8, 8 | 2] and torch.isfinite(pred_only).all()
+    step(10)                                              # 10^3 -> direct; 20^3 -> F(4,3)xF(4,3)
+    assert m._pack_streams == [8 | 1, 8 | 2 | 1]
+    step(8, algo="winograd_h2")
+    assert m._pack_streams == [8 | 4 | 1, 8 | 4 | 2 | 1]
+    step(10)
+    step(8, algo="auto")
+    # the untouched streams of the narrowed model really are stale: only what the mask names is written
+    stale = m._packs[:, 0, 27 * 4096:81 * 4096]           # forward packs, 1-D Winograd stream: never asked for
+    assert not torch.equal(stale, full._packs[:, 0, 27 * 4096:81 * 4096])
