@@ -47,6 +47,7 @@ SIGNATURES = {
     "fdn_pack_conv64_weights_batch_streams": (c_i, [c_fp, c_fp, c_i, c_fp, c_i, c_i, c_fp]),
     # bf16 activation path
     "fdn_pack_conv64_weights_bf16": (c_i, [c_fp, c_fp, c_fp, c_fp]),
+    "fdn_pack_conv64_weights_bf16_batch": (c_i, [c_fp, c_fp, c_i, c_fp, c_fp]),
     "fdn_conv64_fwd_bf16": (c_i, [c_fp] * 5 + [c_i] * 5 + [c_f, c_fp]),
     "fdn_conv64_dgrad_fused_bf16": (c_i, [c_fp] * 5 + [c_i, c_f, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "fdn_fold_halo_border_bf16": (c_i, [c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_f, c_fp, c_i, c_i, c_i, c_i, c_fp]),

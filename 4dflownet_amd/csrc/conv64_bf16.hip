@@ -540,9 +540,17 @@ __global__ __launch_bounds__(256) void fold_halo_border_bf16_kernel(const float*
 //   cout = 32 (row/32) + sigma(row%32),  sigma(q) = 16 ((q>>2)&1) + (q&3) + 4 (q>>3)   (accumulator row -> lane-contiguous)
 //   dgrad stream: contraction over the layer's cout, rows = the layer's cin, taps flipped.
 // --------------------------------------------------------------------------------------------
-__global__ void pack_conv64_bf16_kernel(const float* __restrict__ w, uint16_t* __restrict__ wf, uint16_t* __restrict__ wd) {
+// w_offsets != nullptr: the batched form -- blockIdx.y = layer, kernel at w + w_offsets[layer], its two streams at wf + layer * 2 * 27*64*64
+// (forward stream first, dgrad stream second), like fdn_pack_conv64_weights_batch
+__global__ void pack_conv64_bf16_kernel(const float* __restrict__ w, uint16_t* __restrict__ wf, uint16_t* __restrict__ wd,
+                                        const int64_t* __restrict__ w_offsets) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= 27 * 64 * 64) return;
+    if (w_offsets) {
+        w += w_offsets[blockIdx.y];
+        wf += (size_t)blockIdx.y * 2 * (27 * 64 * 64);
+        wd = wf + 27 * 64 * 64;
+    }
     const int k = idx & 7;
     const int row = (idx >> 3) & 63;
     const int kh = (idx >> 9) & 1;
@@ -561,8 +569,16 @@ __global__ void pack_conv64_bf16_kernel(const float* __restrict__ w, uint16_t* _
 extern "C" int fdn_pack_conv64_weights_bf16(const float* w, uint16_t* wp_fwd, uint16_t* wp_dgrad, void* stream) {
     FDN_REQUIRE(w != nullptr, "fdn_pack_conv64_weights_bf16: w is NULL");
     hipLaunchKernelGGL(pack_conv64_bf16_kernel, dim3((27 * 64 * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w,
-                       wp_fwd, wp_dgrad);
+                       wp_fwd, wp_dgrad, (const int64_t*)nullptr);
     FDN_CHECK_LAUNCH("fdn_pack_conv64_weights_bf16");
+    return FDN_OK;
+}
+
+extern "C" int fdn_pack_conv64_weights_bf16_batch(const float* w_base, const int64_t* w_offsets, int n_layers, uint16_t* packs, void* stream) {
+    FDN_REQUIRE(w_base && w_offsets && packs && n_layers > 0, "fdn_pack_conv64_weights_bf16_batch: NULL argument or n_layers<=0");
+    hipLaunchKernelGGL(pack_conv64_bf16_kernel, dim3((27 * 64 * 64 + 255) / 256, (unsigned)n_layers), dim3(256), 0, (hipStream_t)stream, w_base,
+                       packs, (uint16_t*)nullptr, w_offsets);
+    FDN_CHECK_LAUNCH("fdn_pack_conv64_weights_bf16_batch");
     return FDN_OK;
 }
 

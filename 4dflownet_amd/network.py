@@ -210,9 +210,8 @@ class FlowNetModel:
             if self._w64_offsets.numel():                  # all 64->64 layers, the streams in use, one launch
                 ops.pack_conv64_weights_batch(self.flat_w, self._w64_offsets, self._packs, streams=self._pack_streams)
             return
-        for L in self.layers:
-            if L.wp_f is not None:
-                self.ops.pack_conv64_weights(L.w, L.wp_f, L.wp_d)
+        if self._w64_offsets.numel():
+            ops_bf16.pack_conv64_weights_batch(self.flat_w, self._w64_offsets, self._packs)   # one launch (37 per-layer launches before)
 
     @property
     def trainable_variables(self):

@@ -59,6 +59,17 @@ def pack_conv64_weights(w, wp_fwd=None, wp_dgrad=None, want_dgrad=True):
     return wp_fwd, wp_dgrad
 
 
+def pack_conv64_weights_batch(w_flat, w_offsets, packs):
+    """Every 64->64 kernel of the flat fp32 parameter buffer in one launch.  w_offsets: int64 DEVICE tensor of float offsets;
+    packs: bf16 (n_layers, 2, 27*64*64)."""
+    n = w_offsets.numel()
+    if w_offsets.dtype != torch.int64 or not w_offsets.is_cuda or packs.dtype != BF16 or packs.numel() != n * 2 * 27 * 64 * 64:
+        raise FdnError("pack_conv64_weights_batch (bf16): bad offsets / packs")
+    check(_lib.load().fdn_pack_conv64_weights_bf16_batch(_pf(w_flat, "w"), w_offsets.data_ptr(), n, _pb(packs), _stream()),
+          "fdn_pack_conv64_weights_bf16_batch")
+    return packs
+
+
 def conv3d_fwd(x, w, bias=None, act=ACT_NONE, alpha=LEAKY_ALPHA, residual=None, x2=None, wpack=None, out=None,
                ldy=None, y_coff=0, algo=0):
     """x bf16 (N,D,H,W,Cin[/2 if x2]); w fp32 Keras layout; output bf16, except Cout == 1 (prediction) -> fp32.

@@ -233,6 +233,10 @@ int fdn_sum_partials(const float* partials, int n, float* out, void* stream);
 
 /* fp32 Keras kernel (27,64,64) -> bf16 operand streams (27*64*64 uint16_t each) for the two entry points below. */
 int fdn_pack_conv64_weights_bf16(const float* w, uint16_t* wp_fwd, uint16_t* wp_dgrad, void* stream);
+/* The same for n_layers kernels in ONE launch (after every optimizer step, TrainerController.py:225): layer i at
+ * w_base + w_offsets[i] (DEVICE array of float offsets), its streams at packs + i * 2 * 27*64*64 (forward, then dgrad). */
+int fdn_pack_conv64_weights_bf16_batch(const float* w_base, const int64_t* w_offsets, int n_layers, uint16_t* packs,
+                                       void* stream);
 
 /* fdn_conv3d_fwd for (Cin,Cout,K) = (64,64,3) with bf16 x / residual / y.  SR4DFlowNet.py:93-120. */
 int fdn_conv64_fwd_bf16(const uint16_t* x, const uint16_t* wpack, const float* bias, const uint16_t* residual,

@@ -199,3 +199,17 @@ def test_upsample_and_features_bf16(bops, R):
     ph, pc = bops.input_features(*[dev(a) for a in batch[:6]])
     rph, rpc = O.input_features(*[a.astype(np.float64) for a in batch[:6]])
     close_bf16(ph, rph, name="phase"); close_bf16(pc, rpc, name="pc")
+
+
+def test_batched_bf16_pack_equals_per_layer_pack(bops):
+    """fdn_pack_conv64_weights_bf16_batch (one launch after every optimizer step) writes the same streams as the per-layer entry point."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    n, sz = 5, 27 * 64 * 64
+    flat = torch.randn(7 + n * (sz + 64), device="cuda", generator=g)
+    offs = torch.tensor([7 + i * (sz + 64) for i in range(n)], device="cuda", dtype=torch.int64)
+    packs = torch.zeros((n, 2, sz), device="cuda", dtype=torch.bfloat16)
+    bops.pack_conv64_weights_batch(flat, offs, packs)
+    for i in range(n):
+        w = flat[7 + i * (sz + 64): 7 + i * (sz + 64) + sz].view(3, 3, 3, 64, 64)
+        wf, wd = bops.pack_conv64_weights(w)
+        assert torch.equal(packs[i, 0], wf) and torch.equal(packs[i, 1], wd)

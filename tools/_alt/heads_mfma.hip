@@ -8,12 +8,8 @@
 //               dx[i][c] = act'(y_prev[i][c]) sum_t A[i][t] w[t][c]      (V x 27) x (27 x 64) GEMM
 //               dW[t][c] = sum_i A[i][t] x[i][c]                         (27 x V) x (V x 64) GEMM
 // so every 64-channel row is touched once (forward: once per tile incl. halo) and the kernels run at the HBM roof.
-// fp32 storage: all three use v_mfma_f32_32x32x2_f32 (K is 64, 27 or the voxel count): fp32 products and accumulation exactly like the
-// VALU kernels they replace.  bf16 storage (T = bf16 bits): forward and input gradient run on v_mfma_f32_32x32x16_bf16 with the fp32
-// operands split into bf16 pairs v = hi + lo (exact to 2^-17; their results are rounded to bf16 anyway); the weight gradient stays on
-// the fp32 MFMAs -- a bf16 variant (exact three-piece split of the scalars, both operands through ds_read_b64_tr_b16: 12 MFMAs of 32
-// cycles per chunk instead of 32 of 64) measured SLOWER in a same-box A/B at (4,128^3), 572 vs 479 us: the kernel is bound by the
-// write -> wait -> read latency chain of its wave-private LDS patches at two waves per SIMD, not by matrix time.
+// All three use v_mfma_f32_32x32x2_f32 (K is 64, 27 or the voxel count): fp32 products and accumulation exactly like the
+// VALU kernels they replace, for both activation storage types T (float / bf16 bits; bf16 -> fp32 is exact).
 #include "fdn_common.h"
 #include <type_traits>
 #include <stdlib.h>
@@ -229,31 +225,12 @@ __global__ __launch_bounds__(256, 2) void head_dgrad_kernel(const float* __restr
     // voxels, and every mask load / store instruction covers whole 128-B lines (32 lanes x 4 B per voxel) instead of 64 scattered
     // 16-B pieces.
     constexpr bool VROW = sizeof(T) == 4;
-    // bf16 storage: the result is rounded to bf16 on the way out, so the 27-tap contraction runs on v_mfma_f32_32x32x16_bf16 with both
-    // operands split into bf16 pairs v = hi + lo (exact to 2^-17): hi*hi + hi*lo + lo*hi, 2 K-blocks of 16 taps x 2 channel tiles x 3 = 12
-    // MFMAs of 32 cycles instead of 28 fp32 MFMAs of 64 (0.19 ms of matrix time per launch at (4,128^3)).  Lane (row li, kb = kh) holds
-    // taps 16 blk + 8 kb + j, j = 0..7, of its row's channel.
-    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-    float wa[VROW ? 2 : 1][VROW ? 14 : 1];
-    bf16x8 wbh[VROW ? 1 : 2][VROW ? 1 : 2], wbl[VROW ? 1 : 2][VROW ? 1 : 2];       // [channel tile][K-block]
+    float wa[2][14];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         const int ch = VROW ? 32 * m + li : 32 * m + 16 * ((li >> 2) & 1) + (li & 3) + 4 * (li >> 3);
-        if constexpr (VROW) {
 #pragma unroll
-            for (int s = 0; s < 14; ++s) wa[m][s] = (2 * s + kh) < 27 ? w[(2 * s + kh) * 64 + ch] : 0.f;
-        } else {
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int t = 16 * blk + 8 * kh + j;
-                    const float wv = t < 27 ? w[t * 64 + ch] : 0.f;
-                    const __bf16 h = (__bf16)wv;
-                    wbh[m][blk][j] = h;
-                    wbl[m][blk][j] = (__bf16)(wv - (float)h);
-                }
-        }
+        for (int s = 0; s < 14; ++s) wa[m][s] = (2 * s + kh) < 27 ? w[(2 * s + kh) * 64 + ch] : 0.f;
     }
     struct TileOrg { int n, d, h, w; };
     auto decode = [&](int tile) {
@@ -402,36 +379,18 @@ __global__ __launch_bounds__(256, 2) void head_dgrad_kernel(const float* __restr
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-            if constexpr (VROW) {
 #pragma unroll
-                for (int s = 0; s < 14; ++s) {
-                    const int t0 = 2 * s, t1 = 2 * s + 1;
-                    const float e0 = nb[t0 / 9][(t0 / 3) % 3][t0 % 3];
-                    const float e1 = t1 < 27 ? nb[t1 / 9][(t1 / 3) % 3][t1 % 3] : 0.f;
-                    const float bv = kh ? e1 : e0;
+            for (int s = 0; s < 14; ++s) {
+                const int t0 = 2 * s, t1 = 2 * s + 1;
+                const float e0 = nb[t0 / 9][(t0 / 3) % 3][t0 % 3];
+                const float e1 = t1 < 27 ? nb[t1 / 9][(t1 / 3) % 3][t1 % 3] : 0.f;
+                const float bv = kh ? e1 : e0;
+                if constexpr (VROW) {
                     acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, wa[0][s], acc[0], 0, 0, 0);
                     acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, wa[1][s], acc[1], 0, 0, 0);
-                }
-            } else {
-#pragma unroll
-                for (int blk = 0; blk < 2; ++blk) {
-                    bf16x8 ah, al;                       // this lane's voxel, taps 16 blk + 8 kh + j
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int t0 = 16 * blk + j, t1 = 16 * blk + 8 + j;
-                        const float e0 = nb[t0 / 9][(t0 / 3) % 3][t0 % 3];
-                        const float e1 = t1 < 27 ? nb[(t1 % 27) / 9][((t1 % 27) / 3) % 3][t1 % 3] : 0.f;
-                        const float av = kh ? e1 : e0;
-                        const __bf16 h = (__bf16)av;
-                        ah[j] = h;
-                        al[j] = (__bf16)(av - (float)h);
-                    }
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) {
-                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wbh[m][blk], ah, acc[m], 0, 0, 0);
-                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wbh[m][blk], al, acc[m], 0, 0, 0);
-                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wbl[m][blk], ah, acc[m], 0, 0, 0);
-                    }
+                } else {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[0][s], bv, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[1][s], bv, acc[1], 0, 0, 0);
                 }
             }
             if constexpr (VROW) {
