@@ -19,7 +19,7 @@ struct Wino2Args {
     int N, ID, IH, IW, OD, OH, OW;
     int off, zero_mode, act;
     float alpha;
-    int dbg;                // ablation bits (test build only): 1 = weight stream stride 0, 4 = no staging, 8 = no epilogue, 128 = no XCD remap
+    int dbg;                // ablation bits (test build only): 1 = weight stream stride 0, 4 = no staging, 8 = no epilogue, 32 = epilogue operands from cache-resident rows, 128 = no XCD remap
     int hm;                 // output rows per cell: 2 = F(2,3) along H, 4 = F(4,3) along H (selects the kernel instantiation; host side only)
     int obd, obh, obw, ebd, ebh, ebw;      // output box (h extent a multiple of hm, w extent a multiple of 4)
     int td, ch, cw, ntd, nth, ntw;         // tile in (depth planes, cell rows, cell columns) and tile counts; a cell = hm x 4 voxels (h, w)
@@ -422,6 +422,12 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
     // the output), so left to itself it serialises a memory round trip per group at the end of every tile.  A lane reads exactly the
     // addresses it writes, so hoisting the reads is safe.  F(2,3): two groups = the two M-blocks, i.e. every load ahead of the first
     // store; F(4,3): four groups of 2 rows (forward) or eight of one row (fused dgrad: two operands per voxel) -- what fits beside Y.
+    // (test build, bit 32: the epilogue's operand rows come from the first 64 KB of their tensors -- cache hits; wrong results, timing only.
+    // It prices what the operands cost BEYOND their instructions: at (8,48^3) a residual costs 0.036 ms of which 0.029 is the latency of rows
+    // that come from HBM (tools/abl_epilogue_ops.py).  Tried and removed: pulling those rows into the L2 one stage early with untracked
+    // direct-to-LDS loads (4 per lane and operand, no registers) -- vector-memory loads retire in order, so the next counted wait of the
+    // wave pays the prefetch's HBM round trip, as much as the epilogue then saves: fwd + residual 0.528 with vs 0.521 ms without.)
+    const int opmask = (FDN_DBG_BITS(p) & 32) ? 255 : -1;
     constexpr int HG = HM == 2 ? 2 : (FUSED ? 1 : 2);
     constexpr int GPB = HM / HG, NG = 2 * GPB;                // groups per M-block, groups
     int g0[2];
@@ -446,7 +452,7 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
                     const int ih = ph + h0 + hr - 1, iw = pw + wi - 1;
                     const bool in = g0[mb] >= 0 && gf0 >= 0 && ih >= 1 && ih <= p.IH - 2 && iw >= 1 && iw <= p.IW - 2;
                     fi[buf][hr][wi] = in ? gf0 + (h0 + hr) * p.IW + wi : -1;
-                    const size_t o = (size_t)(in ? fi[buf][hr][wi] : 0) * 64 + cofs;
+                    const size_t o = (size_t)((in ? fi[buf][hr][wi] : 0) & opmask) * 64 + cofs;
                     sk[buf][hr][wi] = p.fskip ? *(const f32x4*)(p.fskip + o) : (f32x4){0.f, 0.f, 0.f, 0.f};
                     ym[buf][hr][wi] = p.fy ? *(const f32x4*)(p.fy + o) : (f32x4){1.f, 1.f, 1.f, 1.f};
                 }
@@ -481,7 +487,7 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
             for (int hr = 0; hr < HG; ++hr)
 #pragma unroll
                 for (int wi = 0; wi < 4; ++wi)
-                    rv[buf][hr][wi] = *(const f32x4*)(p.res + (size_t)((g0[mb] >= 0 ? g0[mb] : 0) + (h0 + hr) * p.OW + wi) * 64 + cofs);
+                    rv[buf][hr][wi] = *(const f32x4*)(p.res + (size_t)(((g0[mb] >= 0 ? g0[mb] : 0) + (h0 + hr) * p.OW + wi) & opmask) * 64 + cofs);
         };
         if (p.res) rload(0, 0);
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
