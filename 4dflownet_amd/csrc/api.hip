@@ -231,23 +231,35 @@ extern "C" int fdn_conv3d_wgrad_batch(const float* const* x, const float* const*
 }
 
 // ---- bf16 activation path ----
-extern "C" int fdn_conv64_fwd_bf16(const uint16_t* x, const uint16_t* wpack, const float* bias, const uint16_t* residual,
-                                   uint16_t* y, int N, int D, int H, int W, int act, float alpha, void* stream) {
+extern "C" int fdn_conv64_fwd_bf16_mask(const uint16_t* x, const uint16_t* wpack, const float* bias, const uint16_t* residual,
+                                        uint16_t* y, uint16_t* y_mask, int N, int D, int H, int W, int act, float alpha, void* stream) {
     FDN_REQUIRE(x && wpack && y, "fdn_conv64_fwd_bf16: NULL argument");
     FDN_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && D <= 1022 && H <= 1022 && W <= 1022, "fdn_conv64_fwd_bf16: bad dims");
     FDN_REQUIRE(act >= FDN_ACT_NONE && act <= FDN_ACT_LEAKY, "fdn_conv64_fwd_bf16: bad act %d", act);
     return fdn_conv64_bf16_launch(x, wpack, bias, residual, y, nullptr, nullptr, nullptr, nullptr, N, D, H, W, D, H, W, 0, 0,
-                                  act, alpha, (hipStream_t)stream);
+                                  act, alpha, (hipStream_t)stream, y_mask, nullptr);
+}
+
+extern "C" int fdn_conv64_fwd_bf16(const uint16_t* x, const uint16_t* wpack, const float* bias, const uint16_t* residual,
+                                   uint16_t* y, int N, int D, int H, int W, int act, float alpha, void* stream) {
+    return fdn_conv64_fwd_bf16_mask(x, wpack, bias, residual, y, nullptr, N, D, H, W, act, alpha, stream);
+}
+
+extern "C" int fdn_conv64_dgrad_fused_bf16_mask(const uint16_t* dz, const uint16_t* wpack, float* dxpad, const uint16_t* skip,
+                                                const uint16_t* y_prev, const uint16_t* y_mask, int act, float alpha,
+                                                uint16_t* dz_prev, int N, int D, int H, int W, void* stream) {
+    FDN_REQUIRE(dz && wpack && dxpad && dz_prev, "fdn_conv64_dgrad_fused_bf16: NULL argument");
+    FDN_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && D <= 1020 && H <= 1020 && W <= 1020, "fdn_conv64_dgrad_fused_bf16: bad dims");
+    FDN_REQUIRE(act >= FDN_ACT_NONE && act <= FDN_ACT_LEAKY, "fdn_conv64_dgrad_fused_bf16: bad act %d", act);
+    FDN_REQUIRE(!(y_mask && act == FDN_ACT_NONE), "fdn_conv64_dgrad_fused_bf16_mask: a sign mask needs act = RELU or LEAKY");
+    return fdn_conv64_bf16_launch(dz, wpack, nullptr, nullptr, nullptr, dxpad, skip, y_prev, dz_prev, N, D, H, W, D + 2, H + 2,
+                                  W + 2, -1, 1, act, alpha, (hipStream_t)stream, nullptr, y_mask);
 }
 
 extern "C" int fdn_conv64_dgrad_fused_bf16(const uint16_t* dz, const uint16_t* wpack, float* dxpad, const uint16_t* skip,
                                            const uint16_t* y_prev, int act, float alpha, uint16_t* dz_prev, int N, int D,
                                            int H, int W, void* stream) {
-    FDN_REQUIRE(dz && wpack && dxpad && dz_prev, "fdn_conv64_dgrad_fused_bf16: NULL argument");
-    FDN_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && D <= 1020 && H <= 1020 && W <= 1020, "fdn_conv64_dgrad_fused_bf16: bad dims");
-    FDN_REQUIRE(act >= FDN_ACT_NONE && act <= FDN_ACT_LEAKY, "fdn_conv64_dgrad_fused_bf16: bad act %d", act);
-    return fdn_conv64_bf16_launch(dz, wpack, nullptr, nullptr, nullptr, dxpad, skip, y_prev, dz_prev, N, D, H, W, D + 2, H + 2,
-                                  W + 2, -1, 1, act, alpha, (hipStream_t)stream);
+    return fdn_conv64_dgrad_fused_bf16_mask(dz, wpack, dxpad, skip, y_prev, nullptr, act, alpha, dz_prev, N, D, H, W, stream);
 }
 
 extern "C" int fdn_fold_halo_border_bf16(const float* dxpad0, const float* dxpad1, const float* dxpad2, int nsrc,

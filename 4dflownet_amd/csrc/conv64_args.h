@@ -63,6 +63,11 @@ struct Conv64BfArgs {
     const uint16_t* fskip;  // fused fold (dgrad): gradient to add, producer output for act', finished dz_prev
     const uint16_t* fy;
     uint16_t* fout;
+    // sign masks (round 5): 64 bits per voxel, bit c = (the stored bf16 y[c] > 0), as four uint16_t words [voxel][cout / 16].  The forward
+    // writes one beside y (ymask, or null); the fused dgrad reads it INSTEAD of y for act' (fmask, or null: then fy): an eighth of a
+    // 16-B load per lane and plane instead of two 16-B loads -- at (4,128^3) an epilogue operand costs what streaming its 1.07 GB costs
+    uint16_t* ymask;
+    const uint16_t* fmask;
     int N, ID, IH, IW, OD, OH, OW;
     int off, zero_mode;
     int act;

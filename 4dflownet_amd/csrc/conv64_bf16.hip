@@ -391,6 +391,15 @@ __device__ __forceinline__ void conv64_bf16_body(const Conv64BfArgs& p, const in
     const float slope = p.act == FDN_ACT_RELU ? 0.f : (p.act == FDN_ACT_LEAKY ? p.alpha : 1.f);
     const int cofs = wn * 32 + kh * 16;
     const bool act_max = slope <= 1.f;          // act(t) = max(t, slope*t) for slope in [0,1] (relu, leaky, none): 2 VALU, not 3
+    // fused dgrad with a sign mask instead of y: the MT mask words of this lane (2 B each) are requested up front
+    unsigned mk[MT];
+    if (p.fout && p.fmask) {
+#pragma unroll
+        for (int md = 0; md < MT; ++md) {
+            const int g = mtab[md * 64 + wm * 32 + j];
+            mk[md] = (g >= 0 && (g & (1 << 30))) ? (unsigned)p.fmask[(size_t)(g & ~(1 << 30)) * 4 + (cofs >> 4)] : 0u;
+        }
+    }
 #pragma unroll
     for (int md = 0; md < MT; ++md) {
         const int g = mtab[md * 64 + wm * 32 + j];
@@ -403,7 +412,10 @@ __device__ __forceinline__ void conv64_bf16_body(const Conv64BfArgs& p, const in
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { sk[r] = 0.f; ym[r] = 1.f; }
                 if (p.fskip) ld_bf16x16(p.fskip + o, sk);
-                if (p.fy) ld_bf16x16(p.fy + o, ym);
+                if (p.fmask) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ym[r] = ((mk[md] >> r) & 1u) ? 1.f : 0.f;
+                } else if (p.fy) ld_bf16x16(p.fy + o, ym);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) z[r] = (acc[md][r] + sk[r]) * (ym[r] > 0.f ? 1.f : slope);
                 st_bf16x16(p.fout + o, z);
@@ -432,6 +444,12 @@ __device__ __forceinline__ void conv64_bf16_body(const Conv64BfArgs& p, const in
                 for (int r = 0; r < 16; ++r) z[r] = z[r] > 0.f ? z[r] : slope * z[r];
             }
             st_bf16x16(p.y + o, z);
+            if (p.ymask) {                         // bit r = (the bf16 value just stored > 0): what the dgrad's act' asks of y
+                unsigned bits = 0u;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bits |= ((float)(__bf16)z[r] > 0.f ? 1u : 0u) << r;
+                p.ymask[(size_t)g * 4 + (cofs >> 4)] = (uint16_t)bits;
+            }
         }
     }
 }
@@ -733,10 +751,12 @@ int launch_boxes(Conv64BfArgs& a, const Box* boxes, int nbox, hipStream_t s) {
 
 int fdn_conv64_bf16_launch(const uint16_t* x, const uint16_t* wpack, const float* bias, const uint16_t* residual, uint16_t* y,
                            float* ypad, const uint16_t* fskip, const uint16_t* fy, uint16_t* fout, int N, int ID, int IH,
-                           int IW, int OD, int OH, int OW, int off, int zero_mode, int act, float alpha, hipStream_t s) {
+                           int IW, int OD, int OH, int OW, int off, int zero_mode, int act, float alpha, hipStream_t s,
+                           uint16_t* ymask, const uint16_t* fmask) {
     Conv64BfArgs a;
     a.x = x; a.wp = wpack; a.bias = bias; a.res = residual; a.y = y; a.ypad = ypad;
-    a.fskip = fskip; a.fy = fy; a.fout = fout;
+    a.fskip = fskip; a.fy = fmask ? nullptr : fy; a.fout = fout;
+    a.ymask = ymask; a.fmask = fmask;
     a.N = N; a.ID = ID; a.IH = IH; a.IW = IW; a.OD = OD; a.OH = OH; a.OW = OW;
     a.off = off; a.zero_mode = zero_mode; a.act = act; a.alpha = alpha; a.dbg = fdn_conv64bf_dbg;
     const Box full{0, 0, 0, OD, OH, OW, 0, 2, 0, 2, 0, 2, 0};

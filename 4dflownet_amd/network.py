@@ -71,12 +71,14 @@ class _Layer:
 
 
 class _T:
-    """An activation tensor + the activation of the op that produced it (needed to form act'(y) in backward)."""
-    __slots__ = ("t", "act")
+    """An activation tensor + the activation of the op that produced it (needed to form act'(y) in backward) + (bf16 mode, training) the
+    sign mask its 64->64 producer wrote beside it: the fused dgrad reads 8 B per voxel of that instead of the 128-B rows of y (ops_bf16)."""
+    __slots__ = ("t", "act", "mask")
 
-    def __init__(self, t, act):
+    def __init__(self, t, act, mask=None):
         self.t = t
         self.act = act
+        self.mask = mask
 
 
 class FlowNetModel:
@@ -170,6 +172,9 @@ class FlowNetModel:
         # to read (_require_pack_streams asks the library's own selection code, widens the set and re-packs when a new grid or
         # algorithm needs more); nothing else reads the packs.
         self._pack_streams = [0, 0]
+        # bf16 training: 64->64 layers write a sign mask beside their output and the fused dgrad reads it for act' instead of the output
+        # (FDN_BF16_SIGN_MASK=0: read y, the round-4 behaviour -- same results bit for bit, for A/B timing)
+        self.sign_masks = os.environ.get("FDN_BF16_SIGN_MASK", "1") not in ("", "0")
         self._pack_need_cache = {}
         self.glorot_uniform_init(seed)
 
@@ -312,8 +317,17 @@ class FlowNetModel:
             if self._w64_offsets.numel():
                 ops.pack_conv64_weights_batch(self.flat_w, self._w64_offsets, self._packs, streams=new)
 
-    def _conv(self, x, L, act, residual=None, x2=None, out=None, ldy=None, y_coff=0):
+    def _conv(self, x, L, act, residual=None, x2=None, out=None, ldy=None, y_coff=0, mask=None):
+        if mask is not None:                               # bf16 training, 64->64: the output and its sign mask (ops_bf16.conv64_fwd)
+            return ops_bf16.conv64_fwd(x, L.wp_f, L.b, act, ops.LEAKY_ALPHA, residual, out, mask=mask)
         return self.ops.conv3d_fwd(x, L.w, L.b, act, ops.LEAKY_ALPHA, residual, x2, L.wp_f, out, ldy, y_coff, algo=self.conv_algo[L.name])
+
+    def _conv_m(self, x, L, act, residual=None, want_mask=False):
+        """A 64->64 layer and, in bf16 training, the sign mask of its output (else None)."""
+        if want_mask and self.sign_masks and self.dtype == "bfloat16" and act != ACT_NONE:
+            mask = ops_bf16.new_sign_mask(x)
+            return self._conv(x, L, act, residual=residual, mask=mask), mask
+        return self._conv(x, L, act, residual=residual), None
 
     def forward(self, inputs, training=False):
         """inputs: [u, v, w, u_mag, v_mag, w_mag], each (B,P,P,P,1) or (B,P,P,P).  Returns a device tensor
@@ -339,9 +353,10 @@ class FlowNetModel:
         p0 = self._conv(phase, Ls[2], ACT_RELU)
         p1 = self._conv(p0, Ls[3], ACT_RELU)
         c0 = self._conv(p1, Ls[4], ACT_RELU, x2=a1)          # concat [phase, pc] never materialised (:23)
-        c1 = self._conv(c0, Ls[5], ACT_RELU)
-        rb = _T(c1, ACT_RELU)
+        c1, m_c1 = self._conv_m(c0, Ls[5], ACT_RELU, want_mask=training)
+        rb = _T(c1, ACT_RELU, m_c1)
         blocks = []
+        hmasks = []                                        # bf16 training: sign mask of every block's inner activation h (else None)
         up = None
         li = 6
         nb = self.low_resblock + self.hi_resblock
@@ -352,10 +367,11 @@ class FlowNetModel:
                 rb = up_out
             if i == nb:
                 break
-            h = self._conv(rb.t, Ls[li], ACT_LEAKY)
-            out = self._conv(h, Ls[li + 1], ACT_LEAKY, residual=rb.t)
+            h, m_h = self._conv_m(rb.t, Ls[li], ACT_LEAKY, want_mask=training)
+            out, m_out = self._conv_m(h, Ls[li + 1], ACT_LEAKY, residual=rb.t, want_mask=training)
             blocks.append((rb, h, out))
-            rb = _T(out, ACT_LEAKY)
+            hmasks.append(m_h)
+            rb = _T(out, ACT_LEAKY, m_out)
             li += 2
         pred = torch.empty(tuple(rb.t.shape[:4]) + (3,), device=self.device)
         heads = []
@@ -366,7 +382,7 @@ class FlowNetModel:
             li += 2
         if training:
             self._cache = dict(phase=phase, pc=pc, a0=a0, a1=a1, p0=p0, p1=p1, c0=c0, c1=c1, blocks=blocks, up=up,
-                               rb=rb, heads=heads)
+                               rb=rb, heads=heads, hmasks=hmasks)
         return pred
 
     __call__ = forward
@@ -441,11 +457,16 @@ class FlowNetModel:
         N, D, H, W, C = t.shape
         return torch.empty((N, D + 2, H + 2, W + 2, C), device=t.device, dtype=torch.float32)
 
-    def _dgrad_fold(self, dz, L, skip, y_prev, act):
+    def _dgrad_fold(self, dz, L, skip, y_prev, act, mask=None):
         """dz_prev = (MirrorPadGrad(Conv3DBackpropInput(dz)) + skip) * act'(y_prev) for a 64->64 layer: interior voxels
-        are finished by the conv epilogue, the surface by one small border kernel."""
+        are finished by the conv epilogue, the surface by one small border kernel.  mask (bf16 mode): the sign mask of y_prev, read by
+        the conv epilogue instead of y_prev itself."""
         out = torch.empty_like(dz)
         pad = self._pad_like(dz)
+        if mask is not None and y_prev is not None:
+            ops_bf16.conv3d_dgrad_fused(dz, L.wp_d, pad, out, skip=skip, y_prev=y_prev, act=act, mask=mask)
+            self.ops.fold_halo_border([pad], out, skip, y_prev, act)
+            return out
         if self.overlap_shell and self.dtype == "float32":
             # the six 9-tap shell slabs (a short direct-conv launch) run on a second stream next to the Winograd launch of the
             # inner box and fill its tail; both only read dz and write disjoint positions
@@ -506,8 +527,11 @@ class FlowNetModel:
             self._wgrad(rb.t, dz_g, L1, bias=False)
             pad = self._pad_like(rb.t)
             y_m, a_m = act_of(rb) if hidx == 2 else (None, ACT_NONE)
-            self.ops.conv3d_dgrad_fused(dz_g, L1.wp_d, pad, dz, skip=dz if hidx > 0 else None, y_prev=y_m, act=a_m,
-                                        algo=self.conv_algo[L1.name])
+            if y_m is not None and rb.mask is not None:
+                ops_bf16.conv3d_dgrad_fused(dz_g, L1.wp_d, pad, dz, skip=dz if hidx > 0 else None, y_prev=y_m, act=a_m, mask=rb.mask)
+            else:
+                self.ops.conv3d_dgrad_fused(dz_g, L1.wp_d, pad, dz, skip=dz if hidx > 0 else None, y_prev=y_m, act=a_m,
+                                            algo=self.conv_algo[L1.name])
             pads.append(pad)
             del dz_g
             li += 2
@@ -528,14 +552,16 @@ class FlowNetModel:
             if i == 0:
                 break
             x, h, out = c["blocks"][i - 1]
-            c["blocks"][i - 1] = None
+            m_h = c["hmasks"][i - 1]
+            c["blocks"][i - 1] = c["hmasks"][i - 1] = None
             li -= 2
             La, Lb = Ls[li], Ls[li + 1]
             self._wgrad(h, dz, Lb)
-            dz_h = self._dgrad_fold(dz, Lb, None, h, ACT_LEAKY)
+            dz_h = self._dgrad_fold(dz, Lb, None, h, ACT_LEAKY, mask=m_h)
+            del m_h
             self._wgrad(x.t, dz_h, La)
             y_m, a_m = act_of(x)
-            dz = self._dgrad_fold(dz_h, La, dz, y_m, a_m)
+            dz = self._dgrad_fold(dz_h, La, dz, y_m, a_m, mask=x.mask)
             del dz_h
         assert li == 6
         # dz == dz_c1

@@ -91,24 +91,43 @@ def conv3d_fwd(x, w, bias=None, act=ACT_NONE, alpha=LEAKY_ALPHA, residual=None, 
     return out
 
 
-def conv64_fwd(x, wpack, bias=None, act=ACT_NONE, alpha=LEAKY_ALPHA, residual=None, out=None):
+def new_sign_mask(y):
+    """Sign-mask buffer for a bf16 (N,D,H,W,64) tensor: 64 bits per voxel as four int16 words (include/fdn.h)."""
+    return torch.empty(tuple(y.shape[:4]) + (4,), device=y.device, dtype=torch.int16)
+
+
+def _pm(t, name="mask", allow_none=False):
+    if t is None and allow_none:
+        return None
+    if t.dtype != torch.int16 or not t.is_cuda or not t.is_contiguous():
+        raise FdnError("%s: contiguous int16 CUDA tensor (N,D,H,W,4) expected" % name)
+    return t.data_ptr()
+
+
+def conv64_fwd(x, wpack, bias=None, act=ACT_NONE, alpha=LEAKY_ALPHA, residual=None, out=None, mask=None):
+    """mask (new_sign_mask(out)), if given, receives bit c of voxel v = (out[v][c] > 0): what the fused dgrad needs of `out` for act'."""
     N, D, H, W, C = x.shape
     if C != 64:
         raise FdnError("conv64_fwd: 64 input channels expected, got %d" % C)
     if out is None:
         out = torch.empty_like(x)
-    check(_lib.load().fdn_conv64_fwd_bf16(_pb(x, "x"), _pb(wpack, "wpack"), _pf(bias, allow_none=True),
-                                          _pb(residual, allow_none=True), _pb(out, "out"), N, D, H, W, act, float(alpha),
-                                          _stream()), "fdn_conv64_fwd_bf16")
+    if mask is not None and mask.numel() != N * D * H * W * 4:
+        raise FdnError("conv64_fwd: mask needs %d int16 words" % (N * D * H * W * 4))
+    check(_lib.load().fdn_conv64_fwd_bf16_mask(_pb(x, "x"), _pb(wpack, "wpack"), _pf(bias, allow_none=True),
+                                               _pb(residual, allow_none=True), _pb(out, "out"), _pm(mask, allow_none=True), N, D, H, W, act,
+                                               float(alpha), _stream()), "fdn_conv64_fwd_bf16_mask")
     return out
 
 
-def conv3d_dgrad_fused(dz, wpack_dgrad, dxpad, out, skip=None, y_prev=None, act=ACT_NONE, alpha=LEAKY_ALPHA, algo=0):
+def conv3d_dgrad_fused(dz, wpack_dgrad, dxpad, out, skip=None, y_prev=None, act=ACT_NONE, alpha=LEAKY_ALPHA, algo=0, mask=None):
+    """mask: the sign mask the forward wrote beside y_prev (conv64_fwd(mask=...)); read instead of y_prev for act'."""
     N, D, H, W = dz.shape[:4]
-    check(_lib.load().fdn_conv64_dgrad_fused_bf16(_pb(dz, "dz"), _pb(wpack_dgrad, "wpack"), _pf(dxpad, "dxpad"),
-                                                  _pb(skip, allow_none=True), _pb(y_prev, allow_none=True), act,
-                                                  float(alpha), _pb(out, "out"), N, D, H, W, _stream()),
-          "fdn_conv64_dgrad_fused_bf16")
+    if mask is not None and mask.numel() != N * D * H * W * 4:
+        raise FdnError("conv3d_dgrad_fused: mask needs %d int16 words" % (N * D * H * W * 4))
+    check(_lib.load().fdn_conv64_dgrad_fused_bf16_mask(_pb(dz, "dz"), _pb(wpack_dgrad, "wpack"), _pf(dxpad, "dxpad"),
+                                                       _pb(skip, allow_none=True), _pb(y_prev, allow_none=True),
+                                                       _pm(mask, allow_none=True), act, float(alpha), _pb(out, "out"), N, D, H, W,
+                                                       _stream()), "fdn_conv64_dgrad_fused_bf16_mask")
     return out
 
 

@@ -250,6 +250,19 @@ int fdn_conv64_dgrad_fused_bf16(const uint16_t* dz, const uint16_t* wpack, float
 int fdn_fold_halo_border_bf16(const float* dxpad0, const float* dxpad1, const float* dxpad2, int nsrc,
                               const uint16_t* skip, const uint16_t* y_prev, int act, float alpha, uint16_t* dz_prev,
                               int N, int D, int H, int W, void* stream);
+/* Sign masks.  The activation gradient of SR4DFlowNet.py:113,118 (LeakyReLU) / :17-25 (ReLU) needs one bit of the producer's
+ * output: y > 0.  fdn_conv64_fwd_bf16_mask is fdn_conv64_fwd_bf16 that also writes, when y_mask != NULL, 64 bits per voxel
+ * -- four uint16_t words [voxel][cout / 16], bit c % 16 = (the stored bf16 y[c] > 0) -- i.e. (N*D*H*W*4) uint16_t;
+ * fdn_conv64_dgrad_fused_bf16_mask reads that mask for act' instead of the 128-B rows of y_prev when y_mask != NULL
+ * (y_prev may then be NULL; act must be RELU or LEAKY).  Same results bit for bit; at (4,128^3) the launch is 0.14 ms
+ * (8 %) shorter -- an epilogue operand of these kernels costs what streaming its 1.07 GB costs.  The border fold
+ * (fdn_fold_halo_border_bf16) still takes y_prev itself: it touches the surface voxels only. */
+int fdn_conv64_fwd_bf16_mask(const uint16_t* x, const uint16_t* wpack, const float* bias, const uint16_t* residual,
+                             uint16_t* y, uint16_t* y_mask, int N, int D, int H, int W, int act, float alpha,
+                             void* stream);
+int fdn_conv64_dgrad_fused_bf16_mask(const uint16_t* dz, const uint16_t* wpack, float* dxpad, const uint16_t* skip,
+                                     const uint16_t* y_prev, const uint16_t* y_mask, int act, float alpha,
+                                     uint16_t* dz_prev, int N, int D, int H, int W, void* stream);
 
 /* The remaining entry points of the path in bf16 storage: same contracts as the fp32 functions of the same
  * name.  Parameters, parameter gradients, the 64->1 heads' output (the prediction, `y` of Cout=1) and its

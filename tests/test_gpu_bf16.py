@@ -213,3 +213,39 @@ def test_batched_bf16_pack_equals_per_layer_pack(bops):
         w = flat[7 + i * (sz + 64): 7 + i * (sz + 64) + sz].view(3, 3, 3, 64, 64)
         wf, wd = bops.pack_conv64_weights(w)
         assert torch.equal(packs[i, 0], wf) and torch.equal(packs[i, 1], wd)
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 8, 8), (1, 10, 12, 16), (1, 5, 7, 9), (1, 16, 16, 16)])
+@pytest.mark.parametrize("act", [1, 2])
+def test_sign_mask_replaces_y_in_the_fused_dgrad(bops, shape, act):
+    """fdn_conv64_fwd_bf16_mask writes bit c of voxel v = (y[v][c] > 0); fdn_conv64_dgrad_fused_bf16_mask reads it for act' instead of y:
+    same dz_prev and padded scratch bit for bit (MODE 2 tiles, ragged tiles and the shell slabs' general body)."""
+    g = torch.Generator(device="cuda").manual_seed(17)
+    N, D, H, W = shape
+    x = torch.randn((N, D, H, W, 64), device="cuda", generator=g).to(torch.bfloat16)
+    res = torch.randn((N, D, H, W, 64), device="cuda", generator=g).to(torch.bfloat16)
+    w = torch.randn((3, 3, 3, 64, 64), device="cuda", generator=g) * 0.05
+    b = torch.randn(64, device="cuda", generator=g) * 0.1
+    wf, wd = bops.pack_conv64_weights(w)
+    y0 = bops.conv64_fwd(x, wf, b, act, 0.2, res)
+    mask = bops.new_sign_mask(y0)
+    mask.fill_(-1)
+    y1 = bops.conv64_fwd(x, wf, b, act, 0.2, res, mask=mask)
+    assert torch.equal(y0, y1)
+    bits = (mask.to(torch.int32) & 0xffff).unsqueeze(-1) >> torch.arange(16, device="cuda", dtype=torch.int32) & 1     # (N,D,H,W,4,16)
+    assert torch.equal(bits.reshape(N, D, H, W, 64).bool(), y0.float() > 0)
+    assert 0.05 < bits.float().mean().item() < 0.95
+    dz = torch.randn((N, D, H, W, 64), device="cuda", generator=g).to(torch.bfloat16)
+    outs = []
+    for m in (None, mask):
+        pad = torch.zeros((N, D + 2, H + 2, W + 2, 64), device="cuda")
+        out = torch.zeros_like(dz)
+        bops.conv3d_dgrad_fused(dz, wd, pad, out, skip=res, y_prev=y0, act=act, mask=m)
+        bops.fold_halo_border([pad], out, res, y0, act)
+        outs.append((out, pad))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # the mask alone is enough for the conv launch (y_prev may be NULL there)
+    pad = torch.zeros((N, D + 2, H + 2, W + 2, 64), device="cuda"); out = torch.zeros_like(dz)
+    bops.conv3d_dgrad_fused(dz, wd, pad, out, skip=res, y_prev=None, act=act, mask=mask)
+    bops.fold_halo_border([pad], out, res, y0, act)
+    assert torch.equal(out, outs[0][0])
