@@ -413,11 +413,18 @@ __device__ __forceinline__ void conv64_bf16_body(const Conv64BfArgs& p, const in
                 for (int r = 0; r < 16; ++r) { sk[r] = 0.f; ym[r] = 1.f; }
                 if (p.fskip) ld_bf16x16(p.fskip + o, sk);
                 if (p.fmask) {
+                    // act' straight from the bit: sign-extend it to a lane mask and select between the bit patterns of 1 and slope (v_bfe_i32 + v_bfi_b32)
+                    const unsigned oneb = 0x3f800000u, slb = __builtin_bit_cast(unsigned, slope);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) ym[r] = ((mk[md] >> r) & 1u) ? 1.f : 0.f;
-                } else if (p.fy) ld_bf16x16(p.fy + o, ym);
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned t = (unsigned)((int)(mk[md] << (31 - r)) >> 31);
+                        z[r] = (acc[md][r] + sk[r]) * __builtin_bit_cast(float, (t & oneb) | (~t & slb));
+                    }
+                } else {
+                    if (p.fy) ld_bf16x16(p.fy + o, ym);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) z[r] = (acc[md][r] + sk[r]) * (ym[r] > 0.f ? 1.f : slope);
+                    for (int r = 0; r < 16; ++r) z[r] = (acc[md][r] + sk[r]) * (ym[r] > 0.f ? 1.f : slope);
+                }
                 st_bf16x16(p.fout + o, z);
             } else {
                 float* o = p.ypad + (size_t)g * 64 + cofs;

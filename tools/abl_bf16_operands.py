@@ -29,3 +29,9 @@ for rep in range(2):
     d2 = t(lambda: bops.conv64_dgrad_fused(x, wd, pad, out, skip=res, y_prev=None, act=0))
     d3 = t(lambda: bops.conv64_dgrad_fused(x, wd, pad, out, skip=res, y_prev=y, act=2))
     print("bf16 (4,128^3): fwd %.3f  fwd+res %.3f | fused dgrad: none %.3f  y %.3f  skip %.3f  skip+y %.3f ms" % (f0, f1, d0, d1, d2, d3), flush=True)
+    m = bops.new_sign_mask(out)
+    f0m = t(lambda: bops.conv64_fwd(x, wf, None, 2, 0.2, None, out, mask=m))
+    f1m = t(lambda: bops.conv64_fwd(x, wf, None, 2, 0.2, res, out, mask=m))
+    d1m = t(lambda: bops.conv64_dgrad_fused(x, wd, pad, out, skip=None, y_prev=y, act=2, mask=m))
+    d3m = t(lambda: bops.conv64_dgrad_fused(x, wd, pad, out, skip=res, y_prev=y, act=2, mask=m))
+    print("   with sign masks: fwd %.3f  fwd+res %.3f (writing the mask) | fused dgrad: mask %.3f  skip+mask %.3f ms" % (f0m, f1m, d1m, d3m), flush=True)
