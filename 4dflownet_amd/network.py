@@ -318,8 +318,8 @@ class FlowNetModel:
                 ops.pack_conv64_weights_batch(self.flat_w, self._w64_offsets, self._packs, streams=new)
 
     def _conv(self, x, L, act, residual=None, x2=None, out=None, ldy=None, y_coff=0, mask=None):
-        if mask is not None:                               # bf16 training, 64->64: the output and its sign mask (ops_bf16.conv64_fwd)
-            return ops_bf16.conv64_fwd(x, L.wp_f, L.b, act, ops.LEAKY_ALPHA, residual, out, mask=mask)
+        if mask is not None:                               # bf16 training, 64->64: the output and its sign mask (ops_bf16.conv3d_fwd)
+            return self.ops.conv3d_fwd(x, L.w, L.b, act, ops.LEAKY_ALPHA, residual, None, L.wp_f, out, ldy, y_coff, mask=mask)
         return self.ops.conv3d_fwd(x, L.w, L.b, act, ops.LEAKY_ALPHA, residual, x2, L.wp_f, out, ldy, y_coff, algo=self.conv_algo[L.name])
 
     def _conv_m(self, x, L, act, residual=None, want_mask=False):

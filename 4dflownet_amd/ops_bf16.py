@@ -71,11 +71,18 @@ def pack_conv64_weights_batch(w_flat, w_offsets, packs):
 
 
 def conv3d_fwd(x, w, bias=None, act=ACT_NONE, alpha=LEAKY_ALPHA, residual=None, x2=None, wpack=None, out=None,
-               ldy=None, y_coff=0, algo=0):
+               ldy=None, y_coff=0, algo=0, mask=None):
     """x bf16 (N,D,H,W,Cin[/2 if x2]); w fp32 Keras layout; output bf16, except Cout == 1 (prediction) -> fp32.
-    algo is accepted for signature parity with ops.conv3d_fwd and ignored: the bf16 kernels are direct convolutions."""
+    algo is accepted for signature parity with ops.conv3d_fwd and ignored: the bf16 kernels are direct convolutions.
+    mask (64->64 only; new_sign_mask(out)): also receives the sign mask of the output, see conv64_fwd."""
     N, D, H, W = x.shape[:4]
     K, Cin, Cout = w.shape[0], w.shape[3], w.shape[4]
+    if mask is not None:
+        if (K, Cin, Cout) != (3, 64, 64) or x2 is not None or ldy not in (None, 64) or y_coff:
+            raise FdnError("conv3d_fwd (bf16): a sign mask belongs to a dense 64->64 3x3x3 layer")
+        if wpack is None:
+            wpack, _ = pack_conv64_weights(w, want_dgrad=False)
+        return conv64_fwd(x, wpack, bias, act, alpha, residual, out, mask=mask)
     odt = torch.float32 if Cout == 1 else BF16
     if out is None:
         out = torch.empty((N, D, H, W, Cout), device=x.device, dtype=odt)
