@@ -292,6 +292,37 @@ extern "C" int fdn_conv1x1_dgrad_bf16(const uint16_t* dz, const float* w, const 
     return fdn_conv1x1_dgrad_launch<uint16_t>(dz, w, ya, yb, dxa, dxb, nvox, (hipStream_t)stream);
 }
 
+extern "C" size_t fdn_conv3d_wgrad_bf16_batch_workspace_bytes(int n_layers, int N, int D, int H, int W) {
+    if (n_layers <= 0 || N <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    const size_t one = fdn_conv3d_wgrad_bf16_workspace_bytes(N, D, H, W, 64, 64, 3);
+    const size_t all = fdn_wgrad64_bf16_batch_ok(n_layers, N, D, H, W) ? fdn_wgrad64_bf16_batch_workspace_bytes(n_layers, N, D, H, W) : 0;
+    return all > one ? all : one;
+}
+extern "C" int fdn_conv3d_wgrad_bf16_batch(const uint16_t* const* x, const uint16_t* const* dz, float* const* dw, float* const* dbias,
+                                           int n_layers, void* workspace, size_t workspace_bytes, int N, int D, int H, int W, void* stream) {
+    FDN_REQUIRE(x && dz && dw && n_layers > 0, "fdn_conv3d_wgrad_bf16_batch: NULL table or n_layers <= 0");
+    FDN_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "fdn_conv3d_wgrad_bf16_batch: bad dims");
+    const size_t need = fdn_conv3d_wgrad_bf16_batch_workspace_bytes(n_layers, N, D, H, W);
+    if (workspace_bytes < need || !workspace) {
+        fdn_set_error("fdn_conv3d_wgrad_bf16_batch: workspace %zu < %zu bytes", workspace_bytes, need);
+        return FDN_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (fdn_wgrad64_bf16_batch_ok(n_layers, N, D, H, W)) {
+        if (int rc = fdn_wgrad64_bf16_batch_launch(x, dz, dw, n_layers, workspace, workspace_bytes, N, D, H, W, s)) return rc;
+    } else {
+        for (int i = 0; i < n_layers; ++i) {
+            FDN_REQUIRE(x[i] && dz[i] && dw[i], "fdn_conv3d_wgrad_bf16_batch: NULL pointer for layer %d", i);
+            if (int rc = fdn_wgrad64_bf16_launch(x[i], dz[i], dw[i], workspace, workspace_bytes, N, D, H, W, s)) return rc;
+        }
+    }
+    if (dbias)                           // (stream-ordered behind the reduction: the workspace is free again)
+        for (int i = 0; i < n_layers; ++i)
+            if (dbias[i])
+                if (int rc = fdn_bias_grad_launch<uint16_t>(dz[i], dbias[i], workspace, workspace_bytes, (int64_t)N * D * H * W, 64, 64, 0, s)) return rc;
+    return FDN_OK;
+}
+
 extern "C" int fdn_conv_cout1_dgrad_folded_bf16(const float* dz, const float* w, const uint16_t* y_prev, int act, float alpha,
                                                 uint16_t* dz_prev, float* dbias_prev, void* workspace, size_t workspace_bytes,
                                                 int N, int D, int H, int W, int lddz, int dz_coff, void* stream) {

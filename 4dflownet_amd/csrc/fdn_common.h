@@ -231,3 +231,8 @@ int fdn_fold_halo_border_bf16_launch(const float* s0, const float* s1, const flo
 size_t fdn_wgrad64_bf16_workspace_bytes(int N, int D, int H, int W);
 int fdn_wgrad64_bf16_launch(const uint16_t* x, const uint16_t* dz, float* dw, void* ws, size_t ws_bytes, int N, int D, int H,
                             int W, hipStream_t s);
+// several 64->64 layers of one grid per launch (wgrad64_bf16.hip)
+bool fdn_wgrad64_bf16_batch_ok(int n_layers, int N, int D, int H, int W);
+size_t fdn_wgrad64_bf16_batch_workspace_bytes(int n_layers, int N, int D, int H, int W);
+int fdn_wgrad64_bf16_batch_launch(const uint16_t* const* x, const uint16_t* const* dz, float* const* dw, int n_layers, void* ws, size_t ws_bytes,
+                                  int N, int D, int H, int W, hipStream_t s);

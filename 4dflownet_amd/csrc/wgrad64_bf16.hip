@@ -276,8 +276,9 @@ constexpr int DLDS_BYTES = DNBUF * DBUFB;
 static_assert(DSLOTS == 21 && DJ == 6, "the s_waitcnt vmcnt(n) of the tile loop counts 6 pieces on wave 0 and 5 on waves 1-3");
 }  // namespace
 
-__global__ __launch_bounds__(256, 2) void wgrad64_bf16_dma_kernel(Wgrad64BfArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// (a __device__ body + thin __global__ wrappers: one layer per launch, or several layers of one grid in ONE launch -- wgrad64_bf16_dma_batch_kernel
+// below.  block = the workgroup's index among the 3 S workgroups of its layer; 3 S is a multiple of 8, so block & 7 is still its XCD.)
+__device__ __forceinline__ void wgrad64_bf16_dma_body(const Wgrad64BfArgs& p, const int block, char* const smem) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void wgrad64_bf16_dma_kernel(Wgrad64BfArgs 
     const int li = lane & 31;
     const int kh = lane >> 5;
     const int mq = wave & 1, nq = wave >> 1;
-    const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3;
+    const int xcd = block & 7, rr = block >> 3;
     const int a = rr % 3;            // kernel-depth tap
     const int kk = rr / 3;           // walk index inside the XCD, 0 .. S/8 - 1
     const int split = kk * 8 + xcd;
@@ -468,6 +469,54 @@ __global__ __launch_bounds__(256, 2) void wgrad64_bf16_dma_kernel(Wgrad64BfArgs 
         }
 }
 
+__global__ __launch_bounds__(256, 2) void wgrad64_bf16_dma_kernel(Wgrad64BfArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    wgrad64_bf16_dma_body(p, (int)blockIdx.x, smem);
+}
+
+// Several layers of the SAME grid in one launch (fdn_conv3d_wgrad_bf16_batch; the fp32 path's wgrad64_wino_batch_kernel idea): a layer
+// gets S = 168 / layers splits (a multiple of 8), so the launch still fills the chip about once, but a workgroup walks layers-times
+// more tiles of ITS layer between prologue and output stage and the partial sums (and the one batched reduction) shrink by that factor.
+// At the cfg4 low-res grid (4 x 32^3) a layer alone on the chip leaves a walk 12 one-plane tiles.
+constexpr int kWgBfBatchMax = 8;
+struct Wgrad64BfBatch {
+    Wgrad64BfArgs a;                     // x / dz / partial of layer 0; everything else common to the layers
+    const uint16_t* x[kWgBfBatchMax];
+    const uint16_t* dz[kWgBfBatchMax];
+};
+struct WgBfDwTable { float* dw[kWgBfBatchMax]; };
+
+__global__ __launch_bounds__(256, 2) void wgrad64_bf16_dma_batch_kernel(Wgrad64BfBatch b) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int per = 3 * b.a.S;
+    const int layer = (int)blockIdx.x / per;
+    Wgrad64BfArgs p = b.a;
+    p.x = b.x[layer]; p.dz = b.dz[layer];
+    p.partial = b.a.partial + (size_t)layer * b.a.S * 27 * 4096;
+    wgrad64_bf16_dma_body(p, (int)blockIdx.x - layer * per, smem);
+}
+
+// dw[layer] = sum over the S partials of that layer (wgrad64_reduce_kernel with a table of outputs; blockIdx.y = layer)
+__global__ __launch_bounds__(256) void wgrad64_reduce_batch_kernel(const float* __restrict__ partial_base, WgBfDwTable t, int S) {
+    __shared__ f32x4 red[3][64];
+    const float* partial = partial_base + (size_t)blockIdx.y * S * 27 * 4096;
+    const int col = threadIdx.x & 63, qtr = threadIdx.x >> 6;
+    const int e4 = blockIdx.x * 64 + col;
+    const f32x4* p = (const f32x4*)partial + e4;
+    const int s0q = (S * qtr) >> 2, s1q = (S * (qtr + 1)) >> 2;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    int s = s0q;
+    for (; s + 2 <= s1q; s += 2) {
+        s0 += p[(size_t)(s + 0) * (27 * 1024)];
+        s1 += p[(size_t)(s + 1) * (27 * 1024)];
+    }
+    for (; s < s1q; ++s) s0 += p[(size_t)s * (27 * 1024)];
+    const f32x4 v = s0 + s1;
+    if (qtr) red[qtr - 1][col] = v;
+    __syncthreads();
+    if (qtr == 0) ((f32x4*)t.dw[blockIdx.y])[e4] = (v + red[0][col]) + (red[1][col] + red[2][col]);
+}
+
 namespace {
 int wgrad64bf_splits(int N, int D, int H, int W) {
     // (counted in two-plane tiles for both kernels: the one-plane kernel then has >= 4 tiles per walk)
@@ -519,6 +568,64 @@ int fdn_wgrad64_bf16_launch(const uint16_t* x, const uint16_t* dz, float* dw, vo
     }
     hipLaunchKernelGGL(wgrad64_reduce_kernel, dim3(27 * 1024 / 64), dim3(256), 0, s, (const float*)ws, dw, a.S);
     FDN_CHECK_LAUNCH("wgrad64_reduce_kernel");
+    return FDN_OK;
+}
+
+// ---- several layers of one grid: chunks of <= 7 layers, each ONE launch + one reduction (3 S layers ~ 504 workgroups) ----
+static int wgrad64bf_batch_splits(int chunk) { int S = (168 / chunk) & ~7; return S < 8 ? 8 : S; }
+bool fdn_wgrad64_bf16_batch_ok(int n_layers, int N, int D, int H, int W) {
+    const long long tiles1 = (long long)N * D * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);       // one-plane tiles of a layer
+    return n_layers >= 2 && (long long)N * D * H * W * 128 < (1ll << 32) - 4096 && !fdn_wgrad64bf_variant && tiles1 >= 4 * 80;     // every walk of every chunk size gets >= 4 tiles
+}
+size_t fdn_wgrad64_bf16_batch_workspace_bytes(int n_layers, int N, int D, int H, int W) {
+    const size_t one = fdn_wgrad64_bf16_workspace_bytes(N, D, H, W);
+    size_t all = 0;
+    for (int chunk = 2; chunk <= 7 && chunk <= n_layers; ++chunk) {
+        const size_t b = (size_t)chunk * wgrad64bf_batch_splits(chunk) * 27 * 4096 * sizeof(float);
+        if (b > all) all = b;
+    }
+    return all > one ? all : one;
+}
+int fdn_wgrad64_bf16_batch_launch(const uint16_t* const* x, const uint16_t* const* dz, float* const* dw, int n_layers, void* ws, size_t ws_bytes,
+                                  int N, int D, int H, int W, hipStream_t s) {
+    FDN_REQUIRE(fdn_wgrad64_bf16_batch_ok(n_layers, N, D, H, W), "wgrad64_bf16 (batched): %d layers of %dx%dx%dx%d are not batchable", n_layers, N, D, H, W);
+    FDN_REQUIRE(ws_bytes >= fdn_wgrad64_bf16_batch_workspace_bytes(n_layers, N, D, H, W), "wgrad64_bf16 (batched): workspace too small");
+    if (int rc = fdn_func_max_lds((const void*)wgrad64_bf16_dma_batch_kernel, DLDS_BYTES, "wgrad64_bf16_batch")) return rc;
+    for (int first = 0; first < n_layers;) {
+        int chunk = n_layers - first;
+        if (chunk > 7) chunk = (chunk == 8) ? 4 : 7;           // (8 = 4 + 4 rather than 7 + 1)
+        if (chunk == 1) {                                       // a lone layer: the single-layer launch
+            if (int rc = fdn_wgrad64_bf16_launch(x[first], dz[first], dw[first], ws, ws_bytes, N, D, H, W, s)) return rc;
+            first += 1;
+            continue;
+        }
+        Wgrad64BfBatch b;
+        WgBfDwTable t;
+        for (int i = 0; i < chunk; ++i) {
+            FDN_REQUIRE(x[first + i] && dz[first + i] && dw[first + i], "wgrad64_bf16 (batched): NULL pointer for layer %d", first + i);
+            b.x[i] = x[first + i]; b.dz[i] = dz[first + i]; t.dw[i] = dw[first + i];
+        }
+        for (int i = chunk; i < kWgBfBatchMax; ++i) { b.x[i] = nullptr; b.dz[i] = nullptr; t.dw[i] = nullptr; }
+        Wgrad64BfArgs& a = b.a;
+        a.x = b.x[0]; a.dz = b.dz[0]; a.partial = (float*)ws;
+        a.N = N; a.D = D; a.H = H; a.W = W;
+        a.S = wgrad64bf_batch_splits(chunk);
+        a.dbg = fdn_wgrad64bf_dbg;
+        a.nth = (H + TH - 1) / TH; a.ntw = (W + TW - 1) / TW;
+        a.bytes = (unsigned)((long long)N * D * H * W * 128);
+        a.ntd = D;
+        a.ntiles = N * a.ntd * a.nth * a.ntw;
+        int want = (int)((long long)a.ntiles / ((long long)a.S * 4));
+        want = want < 1 ? 1 : (want > 32 ? 32 : want);
+        a.nseg = (D + want - 1) / want;
+        a.seg_len = (D + a.nseg - 1) / a.nseg;
+        a.nseg = (D + a.seg_len - 1) / a.seg_len;
+        hipLaunchKernelGGL(wgrad64_bf16_dma_batch_kernel, dim3(3 * a.S * chunk), dim3(256), DLDS_BYTES, s, b);
+        FDN_CHECK_LAUNCH("wgrad64_bf16_dma_batch_kernel");
+        hipLaunchKernelGGL(wgrad64_reduce_batch_kernel, dim3(27 * 1024 / 64, chunk), dim3(256), 0, s, (const float*)ws, t, a.S);
+        FDN_CHECK_LAUNCH("wgrad64_reduce_batch_kernel");
+        first += chunk;
+    }
     return FDN_OK;
 }
 

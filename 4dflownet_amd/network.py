@@ -407,8 +407,9 @@ class FlowNetModel:
         graph (nothing downstream reads them before the optimizer), so they run on a second HIP stream and fill the tails
         of the dgrad chain's kernels; backward() joins the streams before returning."""
         N, D, H, W = x.shape[:4]
-        if (self.batch_wgrad and self.dtype == "float32" and (L.k, L.cin, L.cout) == (3, 64, 64) and x2 is None and lddz is None and
-                N * D * H * W <= self.batch_wgrad_max_voxels and self.conv_algo[L.name] in (ops.ALGO_AUTO, ops.ALGO_WINO_H2)):
+        if (self.batch_wgrad and (L.k, L.cin, L.cout) == (3, 64, 64) and x2 is None and lddz is None and
+                N * D * H * W <= self.batch_wgrad_max_voxels and
+                (self.dtype != "float32" or self.conv_algo[L.name] in (ops.ALGO_AUTO, ops.ALGO_WINO_H2))):
             self._wg_pending.append((x, dz, L, bias))        # issued by _flush_wgrads() at the end of the gradient bucket
             return
         ws = self._workspace(self.ops.wgrad_workspace_bytes(N, D, H, W, L.cin, L.cout, L.k))

@@ -202,6 +202,33 @@ def conv3d_wgrad(x, dz, K, Cin, Cout, x2=None, want_bias=False, dw=None, dbias=N
     return dw, dbias
 
 
+def wgrad_batch_workspace_bytes(n_layers, N, D, H, W):
+    return int(_lib.load().fdn_conv3d_wgrad_bf16_batch_workspace_bytes(n_layers, N, D, H, W))
+
+
+def conv3d_wgrad_batch(xs, dzs, dws, dbiases=None, workspace=None, algo=0):
+    """Weight gradients of several 64->64 3x3x3 layers that share one grid, up to seven per launch (fdn_conv3d_wgrad_bf16_batch): xs / dzs
+    bf16 (N,D,H,W,64), dws fp32 (3,3,3,64,64); dbiases: None or a list with None / fp32 (64,) entries.  algo: signature parity, ignored."""
+    import ctypes
+    n = len(xs)
+    if not (n and len(dzs) == n and len(dws) == n and (dbiases is None or len(dbiases) == n)):
+        raise ValueError("conv3d_wgrad_batch: xs, dzs, dws (and dbiases) must be lists of one length")
+    N, D, H, W = xs[0].shape[:4]
+    for x, dz in zip(xs, dzs):
+        if tuple(x.shape) != (N, D, H, W, 64) or tuple(dz.shape) != (N, D, H, W, 64):
+            raise ValueError("conv3d_wgrad_batch: every layer must have the grid %s with 64 channels" % ((N, D, H, W),))
+    need = wgrad_batch_workspace_bytes(n, N, D, H, W)
+    if workspace is None:
+        workspace = torch.empty((need + 3) // 4, device=xs[0].device, dtype=torch.float32)
+    tx = (ctypes.c_void_p * n)(*[_pb(t, "x") for t in xs])
+    tz = (ctypes.c_void_p * n)(*[_pb(t, "dz") for t in dzs])
+    tw = (ctypes.c_void_p * n)(*[_pf(t, "dw") for t in dws])
+    tb = (ctypes.c_void_p * n)(*[_pf(t, "dbias", allow_none=True) for t in dbiases]) if dbiases is not None and any(b is not None for b in dbiases) else None
+    check(_lib.load().fdn_conv3d_wgrad_bf16_batch(tx, tz, tw, tb, n, _pf(workspace, "workspace"), workspace.numel() * workspace.element_size(),
+                                                  N, D, H, W, _stream()), "fdn_conv3d_wgrad_bf16_batch")
+    return dws
+
+
 def upsample_trilinear_fwd(x, R, out=None):
     N, D, H, W, C = x.shape
     if out is None:

@@ -115,7 +115,7 @@ class LaunchTimer:
             if not self.enabled:
                 return wgb(xs, dzs, *a, **k)
             N, D, H, W = shp(xs[0])
-            f = 1.0 if W % 4 or k.get("algo", 0) == 1 else (1.0 / 3 if D % 2 == 0 else 0.5)
+            f = 1.0 if xs[0].dtype != torch.float32 or W % 4 or k.get("algo", 0) == 1 else (1.0 / 3 if D % 2 == 0 else 0.5)     # (bf16: direct)
             vox = len(xs) * N * D * H * W
             return bracket("wgrad", vox, f * vox * FLOP_PER_VOXEL_CONV64, lambda: wgb(xs, dzs, *a, **k))
 

@@ -276,6 +276,14 @@ size_t fdn_conv3d_wgrad_bf16_workspace_bytes(int N, int D, int H, int W, int Cin
 int fdn_conv3d_wgrad_bf16(const uint16_t* x, const uint16_t* x2, const void* dz, float* dw, float* dbias, void* workspace,
                           size_t workspace_bytes, int N, int D, int H, int W, int Cin, int Cout, int K, int lddz,
                           int dz_coff, void* stream);
+/* fdn_conv3d_wgrad_batch for bf16 activations: the weight gradients (TrainerController.py:223) of several 64->64 3x3x3 layers of
+ * ONE grid -- x, dz, dw, dbias: HOST arrays of n_layers device pointers (dbias or its entries may be NULL) -- in chunks of up to
+ * seven layers per launch (+ one reduction per chunk) where the grid allows, else layer by layer; results equal
+ * fdn_conv3d_wgrad_bf16 per layer to fp32 rounding (a different split of the voxel sum). */
+size_t fdn_conv3d_wgrad_bf16_batch_workspace_bytes(int n_layers, int N, int D, int H, int W);
+int fdn_conv3d_wgrad_bf16_batch(const uint16_t* const* x, const uint16_t* const* dz, float* const* dw, float* const* dbias,
+                                int n_layers, void* workspace, size_t workspace_bytes, int N, int D, int H, int W,
+                                void* stream);
 int fdn_conv_cout1_dgrad_folded_bf16(const float* dz, const float* w, const uint16_t* y_prev, int act, float alpha,
                                      uint16_t* dz_prev, float* dbias_prev, void* workspace, size_t workspace_bytes,
                                      int N, int D, int H, int W, int lddz, int dz_coff, void* stream);

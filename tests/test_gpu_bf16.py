@@ -249,3 +249,28 @@ def test_sign_mask_replaces_y_in_the_fused_dgrad(bops, shape, act):
     bops.conv3d_dgrad_fused(dz, wd, pad, out, skip=res, y_prev=None, act=act, mask=mask)
     bops.fold_halo_border([pad], out, res, y0, act)
     assert torch.equal(out, outs[0][0])
+
+
+@pytest.mark.parametrize("shape,nl", [((4, 32, 32, 32), 9), ((4, 32, 32, 32), 2), ((1, 40, 24, 16), 8), ((2, 8, 8, 8), 3)])
+def test_batched_bf16_wgrad_equals_per_layer_launches(bops, shape, nl):
+    """fdn_conv3d_wgrad_bf16_batch: several 64->64 layers of one grid in chunks of up to seven per launch (9 = 7 + 2, 8 = 4 + 4); a different
+    split of the voxel sum than the per-layer launch, so equal to fp32 rounding; a grid too small to batch loops over the per-layer path
+    bit-identically."""
+    g = torch.Generator(device="cuda").manual_seed(23)
+    N, D, H, W = shape
+    xs = [torch.randn((N, D, H, W, 64), device="cuda", generator=g).to(torch.bfloat16) for _ in range(nl)]
+    dzs = [(torch.randn((N, D, H, W, 64), device="cuda", generator=g) * (0.3 + i)).to(torch.bfloat16) for i in range(nl)]
+    dws = [torch.full((3, 3, 3, 64, 64), float("nan"), device="cuda") for _ in range(nl)]
+    dbs = [torch.full((64,), float("nan"), device="cuda") if i % 2 else None for i in range(nl)]
+    bops.conv3d_wgrad_batch(xs, dzs, dws, dbs)
+    small = N * D * ((H + 7) // 8) * ((W + 7) // 8) < 320
+    for i in range(nl):
+        dw, db = bops.conv3d_wgrad(xs[i], dzs[i], 3, 64, 64, want_bias=dbs[i] is not None)
+        scale = dw.abs().max().item()
+        assert torch.isfinite(dws[i]).all()
+        if small:
+            assert torch.equal(dws[i], dw)
+        else:
+            assert (dws[i] - dw).abs().max().item() <= 2e-5 * scale, (i, (dws[i] - dw).abs().max().item() / scale)
+        if dbs[i] is not None:
+            assert torch.equal(dbs[i], db)

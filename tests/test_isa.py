@@ -99,6 +99,7 @@ PRODUCT_KERNELS = {
     "conv64_bf16_fused_kernel<4>": "", "conv64_bf16_kernel<8, 1>": "", "conv64_bf16_kernel<8, 0>": "",
     "conv64_bf16_kernel<4, 2>": "", "conv64_bf16_kernel<4, 1>": "", "conv64_bf16_kernel<4, 0>": "", "pack_conv64_bf16_kernel": "", "fold_halo_border_bf16_kernel": "",
     "wgrad64_bf16_dma_kernel": "fdn_conv3d_wgrad_bf16", "wgrad64_bf16_kernel": "... tensors of 4 GB and more",
+    "wgrad64_bf16_dma_batch_kernel": "fdn_conv3d_wgrad_bf16_batch", "wgrad64_reduce_batch_kernel": "",
 }
 
 
@@ -127,16 +128,17 @@ def test_hot_kernels_use_the_instructions_the_design_names(code_objects):
 
 def test_dma_wgrad_tile_loop_keeps_two_tiles_in_flight(code_objects):
     asm = "\n".join(a for _, a in code_objects)
-    body = _function(asm, "23wgrad64_bf16_dma_kernel")
-    lines = body.splitlines()
-    first_tr = [i for i, l in enumerate(lines) if "ds_read_b64_tr_b16" in l]
-    mfma = [i for i, l in enumerate(lines) if "v_mfma_f32_32x32x16_bf16" in l]
-    assert len(mfma) == 36 and first_tr
-    # between the first transposing read and the last MFMA of the loop body: counted waits only
-    window = lines[first_tr[0] - 12:mfma[-1]]
-    full = [l for l in window if re.search(r"s_waitcnt\s+vmcnt\(0\)", l)]
-    assert not full, "the compiler waits for every outstanding load inside the K loop:\n" + "\n".join(full)
-    assert any(re.search(r"s_waitcnt\s+vmcnt\(6\)", l) for l in lines) and any(re.search(r"s_waitcnt\s+vmcnt\(5\)", l) for l in lines)
+    for name in ("23wgrad64_bf16_dma_kernel", "29wgrad64_bf16_dma_batch_kernel"):      # one layer per launch / several (the same body)
+        body = _function(asm, name)
+        lines = body.splitlines()
+        first_tr = [i for i, l in enumerate(lines) if "ds_read_b64_tr_b16" in l]
+        mfma = [i for i, l in enumerate(lines) if "v_mfma_f32_32x32x16_bf16" in l]
+        assert len(mfma) == 36 and first_tr, name
+        # between the first transposing read and the last MFMA of the loop body: counted waits only
+        window = lines[first_tr[0] - 12:mfma[-1]]
+        full = [l for l in window if re.search(r"s_waitcnt\s+vmcnt\(0\)", l)]
+        assert not full, name + ": the compiler waits for every outstanding load inside the K loop:\n" + "\n".join(full)
+        assert any(re.search(r"s_waitcnt\s+vmcnt\(6\)", l) for l in lines) and any(re.search(r"s_waitcnt\s+vmcnt\(5\)", l) for l in lines), name
 
 
 def test_fp32_wgrad_tile_loops_do_not_wait_behind_their_raw_row_loads(code_objects):
