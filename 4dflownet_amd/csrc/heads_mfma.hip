@@ -537,7 +537,7 @@ template int fdn_head_dgrad_launch<uint16_t>(const float*, const float*, const u
 namespace {
 
 template <typename T>
-__global__ __launch_bounds__(256, 2) void head_wgrad_kernel(const T* __restrict__ x, const float* __restrict__ dz,
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void head_wgrad_kernel(const T* __restrict__ x, const float* __restrict__ dz,
                                                             float* __restrict__ partial, int N, int D, int H, int W, int ntd,
                                                             int nth, int ntw, int lddz, int dz_coff) {
     __shared__ float zs[2][H_HV + 8];
@@ -614,8 +614,11 @@ __global__ __launch_bounds__(256, 2) void head_wgrad_kernel(const T* __restrict_
     };
     TileOrg o = decode(blockIdx.x);
     stage(o, zs[0]);
-    u32x4 xv[NLD];
-    if ((int)blockIdx.x < ntiles) load_x(o, wave * 2, xv);
+    u32x4 xv[NLD], xv2[E == 8 ? NLD : 1];          // (bf16 storage: both chunks of a tile are requested a tile ahead)
+    if ((int)blockIdx.x < ntiles) {
+        load_x(o, wave * 2, xv);
+        if constexpr (E == 8) load_x(o, wave * 2 + 1, xv2);
+    }
     int par = 0;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, par ^= 1) {
         __syncthreads();
@@ -626,6 +629,121 @@ __global__ __launch_bounds__(256, 2) void head_wgrad_kernel(const T* __restrict_
 #pragma unroll 1
         for (int q = 0; q < 2; ++q) {
             const int mt = wave * 2 + q;
+            if constexpr (E == 8) {
+                // ---- bf16 storage (round 5): lane = TAP.  C[tap][channel] += A^T[tap][voxel] x[voxel][channel] on v_mfma_f32_32x32x16_bf16: the
+                // row operand of lane (tap li, kb = kh) is that tap's folded scalar at voxels 16 kb2 + 8 kb + j, j = 0..7 (h row 2 kb2 + kb of the
+                // chunk, w = j) -- which the lane forms ITSELF from the staged dz halo: inside the volume A[v][t] is dz at v + 1 - t, one LDS
+                // read per value (16 per lane and chunk; the fp32 path reads 27 per voxel-lane and transposes A through LDS), on the volume's
+                // faces the same per-axis rule as there (tap 0 takes n[+1] plus n[0] on the low face, tap 2 n[-1] plus n[0] on the high face).
+                // The fp32 scalars split exactly into three bf16 pieces (8 + 8 + 8 mantissa bits) and x is bf16, so the products are exact and
+                // the sum is what the fp32 MFMAs give.  x stays bf16 in LDS (128 B per voxel, halves swapped on rows with bit 1 set) and
+                // comes back voxel-strided through ds_read_b64_tr_b16.  12 MFMAs of 32 cycles per chunk instead of 32 of 64, and no
+                // write -> wait -> read round trip for A (the first attempt of this round kept lane = voxel and lost 19 % to that chain). ----
+                typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+                typedef short v4i16 __attribute__((ext_vector_type(4)));
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                // x rows of this chunk -> LDS; the same chunk of the NEXT tile is requested now, a whole tile (two chunks) ahead: with one
+                // chunk of lead (the fp32 path) the 8 waves of a CU keep 32 KB in flight, 3.3 TB/s at 2.5 us of latency whatever the arithmetic costs
+                if (q == 0) {
+#pragma unroll
+                    for (int u = 0; u < NLD; ++u) {
+                        const int row = lane / CPR + (64 / CPR) * u;
+                        *(u32x4*)((char*)xw + row * 128 + (((lane % CPR) * 16) ^ (((row >> 1) & 1) << 6))) = xv[u];
+                    }
+                    if (has_next) load_x(on, wave * 2, xv);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < NLD; ++u) {
+                        const int row = lane / CPR + (64 / CPR) * u;
+                        *(u32x4*)((char*)xw + row * 128 + (((lane % CPR) * 16) ^ (((row >> 1) & 1) << 6))) = xv2[u];
+                    }
+                    if (has_next) load_x(on, wave * 2 + 1, xv2);
+                }
+                const bool tapv = li < 27;                                   // (li >= 27: padding rows of the MFMA, read like the centre tap, zeroed below)
+                const int ta = tapv ? li / 9 : 1, tb = tapv ? (li / 3) % 3 : 1, tc = tapv ? li % 3 : 1;       // this lane's tap
+                // chunk-level (scalar) facts: which axes have a volume face inside this chunk -- only those get the face term n[0] -- and
+                // whether some of its voxels lie outside the volume (ragged last tiles)
+                const int mtu = __builtin_amdgcn_readfirstlane(mt);
+                const int vd = mtu >> 1, hq = 4 * (mtu & 1);
+                const int gd = o.d + vd;
+                const bool needD = gd == 0 || gd >= D - 1, needH = o.h + hq == 0 || o.h + hq + 4 > H - 1, needW = o.w == 0 || o.w + H_TW > W - 1;
+                const bool ragged = gd >= D || o.h + hq + 4 > H || o.w + H_TW > W;
+                const bool d2 = (ta == 0 && gd == 0) || (ta == 2 && gd == D - 1);
+                float av[2][8];
+#pragma unroll
+                for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) av[kb2][jj] = 0.f;
+                // 2 x 2 x 2 source terms per value: per axis the tap's own neighbour (tap 0: n[+1], 1: n[0], 2: n[-1]) and, on a face, n[0] again;
+                // a combination that uses a face term is skipped by a scalar branch unless the chunk touches that face (81 % of the chunks
+                // of a 128^3 grid run combination 0 alone: one LDS read per value)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const bool ud = c & 4, uh = c & 2, uw = c & 1;
+                    if ((ud && !needD) || (uh && !needH) || (uw && !needW)) continue;
+                    const int zb = ((vd + 1 + (ud ? 0 : 1 - ta)) * H_XH + hq + kh + 1 + (uh ? 0 : 1 - tb)) * H_XW + 1 + (uw ? 0 : 1 - tc);
+#pragma unroll
+                    for (int kb2 = 0; kb2 < 2; ++kb2) {
+                        const int gh = o.h + hq + 2 * kb2 + kh;
+                        const bool h2 = (tb == 0 && gh == 0) || (tb == 2 && gh == H - 1);
+                        const bool dh_on = (!ud || d2) && (!uh || h2);
+#pragma unroll
+                        for (int jj = 0; jj < 8; ++jj) {
+                            const bool w2 = (tc == 0 && o.w + jj == 0) || (tc == 2 && o.w + jj == W - 1);
+                            const float zv = z[zb + 2 * kb2 * H_XW + jj];
+                            av[kb2][jj] += (c == 0 || (dh_on && (!uw || w2))) ? zv : 0.f;
+                        }
+                    }
+                }
+                if (ragged) {
+#pragma unroll
+                    for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+                        for (int jj = 0; jj < 8; ++jj)
+                            if (!(gd < D && o.h + hq + 2 * kb2 + kh < H && o.w + jj < W)) av[kb2][jj] = 0.f;
+                }
+                if (!tapv) {
+#pragma unroll
+                    for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+                        for (int jj = 0; jj < 8; ++jj) av[kb2][jj] = 0.f;
+                }
+                bf16x8 ap[2][3];
+#pragma unroll
+                for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float a0 = av[kb2][j];
+                        const __bf16 p0 = (__bf16)a0;
+                        const float r1 = a0 - (float)p0;
+                        const __bf16 p1 = (__bf16)r1;
+                        ap[kb2][0][j] = p0; ap[kb2][1][j] = p1; ap[kb2][2][j] = (__bf16)(r1 - (float)p1);
+                    }
+                __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the x rows are in LDS (wave-private patch)
+                __builtin_amdgcn_wave_barrier();
+                const int g = lane >> 4, pq = lane & 15;
+#pragma unroll
+                for (int kb2 = 0; kb2 < 2; ++kb2) {
+                    const int r0 = 16 * kb2 + 8 * (g >> 1) + (pq >> 2);
+                    const int xo = 32 * (g & 1) + 8 * (pq & 3);
+                    bf16x8 xb[2];
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const char* a0 = (const char*)xw + r0 * 128 + ((64 * m) ^ (((r0 >> 1) & 1) << 6)) + xo;
+                        const char* a1 = (const char*)xw + (r0 + 4) * 128 + ((64 * m) ^ ((((r0 + 4) >> 1) & 1) << 6)) + xo;
+                        const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4i16 __attribute__((address_space(3)))*)a0));
+                        const u32x2 hi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4i16 __attribute__((address_space(3)))*)a1));
+                        xb[m] = __builtin_bit_cast(bf16x8, (u32x4){lo.x, lo.y, hi.x, hi.y});
+                    }
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[kb2][c], xb[0], acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[kb2][c], xb[1], acc[1], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();         // all reads done before the next chunk overwrites the patch
+                continue;
+            }
             // ---- x rows -> LDS (fp32), next chunk's loads in flight ----
 #pragma unroll
             for (int u = 0; u < NLD; ++u) {
@@ -726,16 +844,18 @@ __global__ __launch_bounds__(256, 2) void head_wgrad_kernel(const T* __restrict_
 
 }  // namespace
 
-int fdn_head_wgrad_blocks(int N, int D, int H, int W) {
+// persistent grid = partial rows the caller provides: two workgroups per CU for fp32 storage (54.5 KB of LDS), three for bf16 (37.6 KB, 153 VGPRs)
+int fdn_head_wgrad_blocks(int N, int D, int H, int W, int elem_bytes) {
     const long long ntiles = (long long)N * ((D + H_TD - 1) / H_TD) * ((H + H_TH - 1) / H_TH) * ((W + H_TW - 1) / H_TW);
-    return (int)(ntiles < 512 ? ntiles : 512);
+    const long long cap = elem_bytes == 2 ? 768 : 512;
+    return (int)(ntiles < cap ? ntiles : cap);
 }
 
 template <typename T>
 int fdn_head_wgrad_launch(const T* x, const float* dz, float* partial, int N, int D, int H, int W, int lddz, int dz_coff,
                           hipStream_t s) {
     const int ntd = (D + H_TD - 1) / H_TD, nth = (H + H_TH - 1) / H_TH, ntw = (W + H_TW - 1) / H_TW;
-    hipLaunchKernelGGL(head_wgrad_kernel<T>, dim3((unsigned)fdn_head_wgrad_blocks(N, D, H, W)), dim3(256), 0, s, x, dz, partial, N, D,
+    hipLaunchKernelGGL(head_wgrad_kernel<T>, dim3((unsigned)fdn_head_wgrad_blocks(N, D, H, W, (int)sizeof(T))), dim3(256), 0, s, x, dz, partial, N, D,
                        H, W, ntd, nth, ntw, lddz, dz_coff);
     FDN_CHECK_LAUNCH("head_wgrad_kernel");
     return FDN_OK;

@@ -531,6 +531,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 }
 
 constexpr int kSmallBlocks = 512;   // partial-sum blocks of the thin-layer wgrad / bias kernels
+constexpr int kSmallRows = 768;     // partial rows the workspace holds: the bf16 head wgrad runs three workgroups per CU (heads_mfma.hip)
 
 int reduce_partials(const float* partial, float* out, int nparts, int nelem, hipStream_t s) {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((nelem + 31) / 32), dim3(256), 0, s, partial, out, nparts, nelem);
@@ -550,7 +551,7 @@ int nblocks_for(int64_t items, int per_block, int cap) {
 size_t fdn_small_wgrad_workspace_bytes(int Cin, int Cout, int K) {
     size_t elems = (size_t)K * K * K * Cin * Cout;
     if (elems < 64) elems = 64;
-    return (size_t)kSmallBlocks * elems * sizeof(float);
+    return (size_t)kSmallRows * elems * sizeof(float);
 }
 
 // Launchers, templated on the activation storage type T (float, or uint16_t = bf16 bits); parameters, parameter
@@ -600,7 +601,7 @@ template <typename T> int fdn_head_dgrad_launch(const float* dz, const float* w,
 int fdn_head_dgrad_blocks(int N, int D, int H, int W);
 template <typename T> int fdn_head_wgrad_launch(const T* x, const float* dz, float* partial, int N, int D, int H, int W, int lddz,
                                                 int dz_coff, hipStream_t s);
-int fdn_head_wgrad_blocks(int N, int D, int H, int W);
+int fdn_head_wgrad_blocks(int N, int D, int H, int W, int elem_bytes);
 FDN_HOOK_VAR(int, fdn_heads_use_mfma, 1);
 #ifdef FDN_TEST_HOOKS
 extern "C" int fdn_debug_set_heads_mfma(int on) { fdn_heads_use_mfma = on; return FDN_OK; }
@@ -684,7 +685,7 @@ int fdn_wgrad_cout1_launch(const T* x, const float* dz, float* dw, void* ws, siz
         return reduce_partials((const float*)ws, dw, nb, 27 * 64, s);
     }
 #endif
-    const int nbm = fdn_head_wgrad_blocks(N, D, H, W);          // <= kSmallBlocks partial rows of 27*64
+    const int nbm = fdn_head_wgrad_blocks(N, D, H, W, (int)sizeof(T));          // <= kSmallBlocks partial rows of 27*64
     const int rc = fdn_head_wgrad_launch<T>(x, dz, (float*)ws, N, D, H, W, lddz, dz_coff, s);
     if (rc != FDN_OK) return rc;
     return reduce_partials((const float*)ws, dw, nbm, 27 * 64, s);
