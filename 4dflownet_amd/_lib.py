@@ -60,6 +60,7 @@ SIGNATURES = {
     "fdn_conv3d_wgrad_bf16_batch_workspace_bytes": (c_sz, [c_i] * 5),
     "fdn_conv3d_wgrad_bf16_batch": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_fp, c_sz] + [c_i] * 4 + [c_fp]),     # (the first four: HOST arrays of device pointers)
     "fdn_conv_cout1_dgrad_folded_bf16": (c_i, [c_fp, c_fp, c_fp, c_i, c_f, c_fp, c_fp, c_fp, c_sz, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "fdn_conv_cout1_dgrad_folded_bf16_mask": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_f, c_fp, c_fp, c_fp, c_sz, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "fdn_conv1x1_dgrad_bf16": (c_i, [c_fp] * 6 + [c_i64, c_fp]),
     "fdn_upsample_trilinear_fwd_bf16": (c_i, [c_fp, c_fp] + [c_i] * 6 + [c_fp]),
     "fdn_upsample_trilinear_bwd_bf16": (c_i, [c_fp, c_fp, c_i, c_f, c_fp] + [c_i] * 6 + [c_fp]),

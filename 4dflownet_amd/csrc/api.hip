@@ -55,7 +55,7 @@ template <typename T> int fdn_wgrad_cout1_launch(const T* x, const float* dz, fl
 template <typename T> int fdn_conv_cout1_dgrad_folded_launch(const float* dz, const float* w, const T* y_prev, int act,
                                                              float alpha, T* dz_prev, float* dbias_prev, void* workspace,
                                                              size_t workspace_bytes, int N, int D, int H, int W, int lddz,
-                                                             int dz_coff, hipStream_t s);
+                                                             int dz_coff, hipStream_t s, const uint16_t* ymask = nullptr);
 template <typename T> int fdn_wgrad_1x1_launch(const T* xa, const T* xb, const T* dz, float* dw, void* ws, size_t ws_bytes,
                                                int64_t nvox, hipStream_t s);
 template <typename T> int fdn_bias_grad_launch(const T* dz, float* db, void* ws, size_t ws_bytes, int64_t nvox, int C,
@@ -323,11 +323,20 @@ extern "C" int fdn_conv3d_wgrad_bf16_batch(const uint16_t* const* x, const uint1
     return FDN_OK;
 }
 
+extern "C" int fdn_conv_cout1_dgrad_folded_bf16_mask(const float* dz, const float* w, const uint16_t* y_prev, const uint16_t* y_mask,
+                                                     int act, float alpha, uint16_t* dz_prev, float* dbias_prev, void* workspace,
+                                                     size_t workspace_bytes, int N, int D, int H, int W, int lddz, int dz_coff,
+                                                     void* stream) {
+    FDN_REQUIRE(!(y_mask && act == FDN_ACT_NONE), "fdn_conv_cout1_dgrad_folded_bf16_mask: a sign mask needs act = RELU or LEAKY");
+    return fdn_conv_cout1_dgrad_folded_launch<uint16_t>(dz, w, y_prev, act, alpha, dz_prev, dbias_prev, workspace,
+                                                        workspace_bytes, N, D, H, W, lddz, dz_coff, (hipStream_t)stream, y_mask);
+}
+
 extern "C" int fdn_conv_cout1_dgrad_folded_bf16(const float* dz, const float* w, const uint16_t* y_prev, int act, float alpha,
                                                 uint16_t* dz_prev, float* dbias_prev, void* workspace, size_t workspace_bytes,
                                                 int N, int D, int H, int W, int lddz, int dz_coff, void* stream) {
-    return fdn_conv_cout1_dgrad_folded_launch<uint16_t>(dz, w, y_prev, act, alpha, dz_prev, dbias_prev, workspace,
-                                                        workspace_bytes, N, D, H, W, lddz, dz_coff, (hipStream_t)stream);
+    return fdn_conv_cout1_dgrad_folded_bf16_mask(dz, w, y_prev, nullptr, act, alpha, dz_prev, dbias_prev, workspace, workspace_bytes, N, D, H, W,
+                                                 lddz, dz_coff, stream);
 }
 
 extern "C" int fdn_conv3d_fwd_bf16(const uint16_t* x, const uint16_t* x2, const float* w, const uint16_t* wpack,

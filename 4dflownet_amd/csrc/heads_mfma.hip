@@ -9,11 +9,12 @@
 //               dW[t][c] = sum_i A[i][t] x[i][c]                         (27 x V) x (V x 64) GEMM
 // so every 64-channel row is touched once (forward: once per tile incl. halo) and the kernels run at the HBM roof.
 // fp32 storage: all three use v_mfma_f32_32x32x2_f32 (K is 64, 27 or the voxel count): fp32 products and accumulation exactly like the
-// VALU kernels they replace.  bf16 storage (T = bf16 bits): forward and input gradient run on v_mfma_f32_32x32x16_bf16 with the fp32
-// operands split into bf16 pairs v = hi + lo (exact to 2^-17; their results are rounded to bf16 anyway); the weight gradient stays on
-// the fp32 MFMAs -- a bf16 variant (exact three-piece split of the scalars, both operands through ds_read_b64_tr_b16: 12 MFMAs of 32
-// cycles per chunk instead of 32 of 64) measured SLOWER in a same-box A/B at (4,128^3), 572 vs 479 us: the kernel is bound by the
-// write -> wait -> read latency chain of its wave-private LDS patches at two waves per SIMD, not by matrix time.
+// VALU kernels they replace.  bf16 storage (T = bf16 bits): v_mfma_f32_32x32x16_bf16 on operands split into bf16 pieces -- forward and
+// input gradient on hi + lo pairs (exact to 2^-17; their results are rounded to bf16 anyway), the weight gradient with EXACT products
+// (x is bf16, the fp32 scalars split into three pieces).  The weight gradient took two attempts: with lane = voxel (A transposed through
+// wave-private LDS planes, as in the fp32 path) the bf16 MFMAs made it SLOWER, 479 -> 572 us at (4,128^3) -- the write -> wait -> read
+// chain of the LDS patches, not matrix time, bounds that layout; with lane = TAP (every lane forms its tap's scalars for 16 voxels
+// straight from the dz halo), x requested a tile ahead and three workgroups per CU it runs 490 -> 355 us.
 #include "fdn_common.h"
 #include <type_traits>
 #include <stdlib.h>
@@ -215,7 +216,8 @@ template <typename T>
 __global__ __launch_bounds__(256, 2) void head_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ w,
                                                             const T* __restrict__ yprev, int act, float alpha,
                                                             T* __restrict__ out, float* __restrict__ bpart, int N, int D, int H,
-                                                            int W, int ntd, int nth, int ntw, int lddz, int dz_coff) {
+                                                            int W, int ntd, int nth, int ntw, int lddz, int dz_coff,
+                                                            const uint16_t* __restrict__ ymask) {
     __shared__ float zs[2][H_HV + 8];           // dz halo of the current / next tile
     __shared__ float bred[4][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -340,8 +342,13 @@ __global__ __launch_bounds__(256, 2) void head_dgrad_kernel(const float* __restr
             // requested here for the same reason
             constexpr int EVP = FdnVec<T>::E;
             float yq[VROW ? 1 : 2][VROW ? 1 : 16];
+            unsigned ymk[2] = {0u, 0u};              // bf16 storage with a sign mask (conv64_args.h: [voxel][cout / 16] words): this lane's 16 channels per channel tile = one word
             if constexpr (!VROW) {
-                if (yprev) {
+                if (ymask) {
+                    const size_t voxp = (size_t)o.n * D * H * W + ((size_t)min(gd, D - 1) * H + min(gh, H - 1)) * W + min(gw, W - 1);
+                    ymk[0] = ymask[voxp * 4 + kh];
+                    ymk[1] = ymask[voxp * 4 + 2 + kh];
+                } else if (yprev) {
                     const size_t voxp = (size_t)o.n * D * H * W + ((size_t)min(gd, D - 1) * H + min(gh, H - 1)) * W + min(gw, W - 1);
 #pragma unroll
                     for (int m = 0; m < 2; ++m)
@@ -467,7 +474,10 @@ __global__ __launch_bounds__(256, 2) void head_dgrad_kernel(const float* __restr
                     float v[EV];
 #pragma unroll
                     for (int q = 0; q < EV; ++q) v[q] = acc[m][r0 + q];
-                    if (yprev) {
+                    if (!VROW && ymask) {
+#pragma unroll
+                        for (int q = 0; q < EV; ++q) v[q] *= ((ymk[m] >> (r0 + q)) & 1u) ? 1.f : slope;
+                    } else if (yprev) {
 #pragma unroll
                         for (int q = 0; q < EV; ++q) v[q] *= yq[VROW ? 0 : m][VROW ? 0 : r0 + q] > 0.f ? 1.f : slope;
                     }
@@ -517,15 +527,15 @@ int fdn_head_dgrad_blocks(int N, int D, int H, int W) {
 
 template <typename T>
 int fdn_head_dgrad_launch(const float* dz, const float* w, const T* y_prev, int act, float alpha, T* dz_prev, float* bpart, int N,
-                          int D, int H, int W, int lddz, int dz_coff, hipStream_t s) {
+                          int D, int H, int W, int lddz, int dz_coff, hipStream_t s, const uint16_t* ymask) {
     const int ntd = (D + H_TD - 1) / H_TD, nth = (H + H_TH - 1) / H_TH, ntw = (W + H_TW - 1) / H_TW;
     hipLaunchKernelGGL(head_dgrad_kernel<T>, dim3((unsigned)fdn_head_dgrad_blocks(N, D, H, W)), dim3(256), 0, s, dz, w, y_prev, act,
-                       alpha, dz_prev, bpart, N, D, H, W, ntd, nth, ntw, lddz, dz_coff);
+                       alpha, dz_prev, bpart, N, D, H, W, ntd, nth, ntw, lddz, dz_coff, sizeof(T) == 2 ? ymask : nullptr);
     FDN_CHECK_LAUNCH("head_dgrad_kernel");
     return FDN_OK;
 }
-template int fdn_head_dgrad_launch<float>(const float*, const float*, const float*, int, float, float*, float*, int, int, int, int, int, int, hipStream_t);
-template int fdn_head_dgrad_launch<uint16_t>(const float*, const float*, const uint16_t*, int, float, uint16_t*, float*, int, int, int, int, int, int, hipStream_t);
+template int fdn_head_dgrad_launch<float>(const float*, const float*, const float*, int, float, float*, float*, int, int, int, int, int, int, hipStream_t, const uint16_t*);
+template int fdn_head_dgrad_launch<uint16_t>(const float*, const float*, const uint16_t*, int, float, uint16_t*, float*, int, int, int, int, int, int, hipStream_t, const uint16_t*);
 
 // ---------------------------------------------------------------------------------------------------------------
 // weight gradient of a head:  dW[t][c] = sum_i A[i][t] x[i][c]  with the same folded scalar stencil A as the input gradient

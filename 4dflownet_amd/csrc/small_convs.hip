@@ -597,7 +597,8 @@ int fdn_conv_cin3_fwd_launch(const T* x, const float* w, const float* bias, T* y
 template <typename T> int fdn_head_fwd_launch(const T* x, const float* w, const float* bias, float* y, int N, int D, int H,
                                               int W, int ldy, int y_coff, int act, float alpha, hipStream_t s, int xcd_walk);
 template <typename T> int fdn_head_dgrad_launch(const float* dz, const float* w, const T* y_prev, int act, float alpha, T* dz_prev,
-                                                float* bpart, int N, int D, int H, int W, int lddz, int dz_coff, hipStream_t s);
+                                                float* bpart, int N, int D, int H, int W, int lddz, int dz_coff, hipStream_t s,
+                                                const uint16_t* ymask);
 int fdn_head_dgrad_blocks(int N, int D, int H, int W);
 template <typename T> int fdn_head_wgrad_launch(const T* x, const float* dz, float* partial, int N, int D, int H, int W, int lddz,
                                                 int dz_coff, hipStream_t s);
@@ -694,7 +695,7 @@ int fdn_wgrad_cout1_launch(const T* x, const float* dz, float* dw, void* ws, siz
 template <typename T>
 int fdn_conv_cout1_dgrad_folded_launch(const float* dz, const float* w, const T* y_prev, int act, float alpha, T* dz_prev,
                                        float* dbias_prev, void* workspace, size_t workspace_bytes, int N, int D, int H, int W,
-                                       int lddz, int dz_coff, hipStream_t s) {
+                                       int lddz, int dz_coff, hipStream_t s, const uint16_t* ymask) {
     FDN_REQUIRE(dz && w && dz_prev && N > 0 && D > 0 && H > 0 && W > 0, "fdn_conv_cout1_dgrad_folded: bad argument");
 #ifdef FDN_TEST_HOOKS
     if (!fdn_heads_use_mfma) {
@@ -719,7 +720,7 @@ int fdn_conv_cout1_dgrad_folded_launch(const float* dz, const float* w, const T*
         return FDN_ERR_WORKSPACE;
     }
     const int rc = fdn_head_dgrad_launch<T>(dz, w, y_prev, act, alpha, dz_prev, dbias_prev ? (float*)workspace : nullptr, N, D,
-                                            H, W, lddz, dz_coff, s);
+                                            H, W, lddz, dz_coff, s, ymask);
     if (rc != FDN_OK) return rc;
     if (dbias_prev) return reduce_partials((const float*)workspace, dbias_prev, nb, 64, s);
     return FDN_OK;
@@ -766,7 +767,7 @@ int fdn_bias_grad_launch(const T* dz, float* db, void* ws, size_t ws_bytes, int6
     template int fdn_wgrad_cout1_launch<T>(const T*, const float*, float*, void*, size_t, int, int, int, int, int, int,        \
                                            hipStream_t);                                                                       \
     template int fdn_conv_cout1_dgrad_folded_launch<T>(const float*, const float*, const T*, int, float, T*, float*, void*,    \
-                                                       size_t, int, int, int, int, int, int, hipStream_t);                     \
+                                                       size_t, int, int, int, int, int, int, hipStream_t, const uint16_t*);   \
     template int fdn_wgrad_1x1_launch<T>(const T*, const T*, const T*, float*, void*, size_t, int64_t, hipStream_t);           \
     template int fdn_bias_grad_launch<T>(const T*, float*, void*, size_t, int64_t, int, int, int, hipStream_t);
 FDN_INSTANTIATE_SMALL(float)

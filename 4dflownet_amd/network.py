@@ -375,14 +375,16 @@ class FlowNetModel:
             li += 2
         pred = torch.empty(tuple(rb.t.shape[:4]) + (3,), device=self.device)
         heads = []
+        gmasks = []                                         # bf16 training: sign masks of the three head activations (else None)
         for hidx in range(3):
-            g = self._conv(rb.t, Ls[li], ACT_RELU)
+            g, m_g = self._conv_m(rb.t, Ls[li], ACT_RELU, want_mask=training)
             self._conv(g, Ls[li + 1], ACT_NONE, out=pred, ldy=3, y_coff=hidx)
             heads.append(g)
+            gmasks.append(m_g)
             li += 2
         if training:
             self._cache = dict(phase=phase, pc=pc, a0=a0, a1=a1, p0=p0, p1=p1, c0=c0, c1=c1, blocks=blocks, up=up,
-                               rb=rb, heads=heads, hmasks=hmasks)
+                               rb=rb, heads=heads, hmasks=hmasks, gmasks=gmasks)
         return pred
 
     __call__ = forward
@@ -522,8 +524,12 @@ class FlowNetModel:
             # the folded head dgrad also emits the bias gradient of the 64->64 head conv (sum of dz_g) while it has it in registers
             if self._ws_bias is None:
                 self._ws_bias = torch.empty(2048 * 64, device=self.device, dtype=torch.float32)
+            m_g = c["gmasks"][hidx]
+            mk = {} if m_g is None else {"mask": m_g}          # (bf16 mode: the head activation's sign mask instead of its rows)
             dz_g = self.ops.conv_cout1_dgrad_folded(dpred, L2.w, tuple(g.shape[:4]), g, ACT_RELU, lddz=3, dz_coff=hidx,
-                                               dbias_prev=L1.gb, workspace=self._ws_bias)
+                                               dbias_prev=L1.gb, workspace=self._ws_bias, **mk)
+            c["gmasks"][hidx] = None
+            del m_g, mk
             del g
             self._wgrad(rb.t, dz_g, L1, bias=False)
             pad = self._pad_like(rb.t)

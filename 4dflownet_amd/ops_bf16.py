@@ -151,18 +151,21 @@ def fold_halo_border(dxpads, out, skip=None, y_prev=None, act=ACT_NONE, alpha=LE
 
 
 def conv_cout1_dgrad_folded(dz, w, spatial, y_prev=None, act=ACT_NONE, alpha=LEAKY_ALPHA, lddz=1, dz_coff=0, out=None,
-                            dbias_prev=None, workspace=None):
-    """64->1 head dgrad (dz = fp32 prediction gradient) + halo fold + act'(y_prev): bf16 (N,D,H,W,64)."""
+                            dbias_prev=None, workspace=None, mask=None):
+    """64->1 head dgrad (dz = fp32 prediction gradient) + halo fold + act'(y_prev): bf16 (N,D,H,W,64).
+    mask: the sign mask conv64_fwd(mask=...) wrote beside y_prev; read instead of y_prev for act'."""
     N, D, H, W = spatial
     if out is None:
         out = torch.empty((N, D, H, W, 64), device=dz.device, dtype=BF16)
     if dbias_prev is not None and workspace is None:
         workspace = torch.empty(2048 * 64, device=dz.device, dtype=torch.float32)
+    if mask is not None and mask.numel() != N * D * H * W * 4:
+        raise FdnError("conv_cout1_dgrad_folded: mask needs %d int16 words" % (N * D * H * W * 4))
     wsb = 0 if workspace is None else workspace.numel() * workspace.element_size()
-    check(_lib.load().fdn_conv_cout1_dgrad_folded_bf16(_pf(dz, "dz"), _pf(w, "w"), _pb(y_prev, allow_none=True), act,
-                                                       float(alpha), _pb(out), _pf(dbias_prev, allow_none=True),
-                                                       _pf(workspace, allow_none=True), wsb, N, D, H, W, lddz, dz_coff,
-                                                       _stream()), "fdn_conv_cout1_dgrad_folded_bf16")
+    check(_lib.load().fdn_conv_cout1_dgrad_folded_bf16_mask(_pf(dz, "dz"), _pf(w, "w"), _pb(y_prev, allow_none=True), _pm(mask, allow_none=True),
+                                                            act, float(alpha), _pb(out), _pf(dbias_prev, allow_none=True),
+                                                            _pf(workspace, allow_none=True), wsb, N, D, H, W, lddz, dz_coff,
+                                                            _stream()), "fdn_conv_cout1_dgrad_folded_bf16_mask")
     return out
 
 

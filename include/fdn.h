@@ -287,6 +287,12 @@ int fdn_conv3d_wgrad_bf16_batch(const uint16_t* const* x, const uint16_t* const*
 int fdn_conv_cout1_dgrad_folded_bf16(const float* dz, const float* w, const uint16_t* y_prev, int act, float alpha,
                                      uint16_t* dz_prev, float* dbias_prev, void* workspace, size_t workspace_bytes,
                                      int N, int D, int H, int W, int lddz, int dz_coff, void* stream);
+/* ... with the sign mask of y_prev (written by fdn_conv64_fwd_bf16_mask for the 64->64 head conv that produced it) read for act'
+ * instead of its 128-B rows when y_mask != NULL; same results bit for bit. */
+int fdn_conv_cout1_dgrad_folded_bf16_mask(const float* dz, const float* w, const uint16_t* y_prev, const uint16_t* y_mask,
+                                          int act, float alpha, uint16_t* dz_prev, float* dbias_prev, void* workspace,
+                                          size_t workspace_bytes, int N, int D, int H, int W, int lddz, int dz_coff,
+                                          void* stream);
 int fdn_conv1x1_dgrad_bf16(const uint16_t* dz, const float* w, const uint16_t* ya, const uint16_t* yb, uint16_t* dxa,
                            uint16_t* dxb, int64_t nvox, void* stream);
 int fdn_upsample_trilinear_fwd_bf16(const uint16_t* x, uint16_t* y, int N, int D, int H, int W, int C, int R, void* stream);

@@ -274,3 +274,25 @@ def test_batched_bf16_wgrad_equals_per_layer_launches(bops, shape, nl):
             assert (dws[i] - dw).abs().max().item() <= 2e-5 * scale, (i, (dws[i] - dw).abs().max().item() / scale)
         if dbs[i] is not None:
             assert torch.equal(dbs[i], db)
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 8, 8), (1, 5, 7, 9), (1, 12, 16, 24)])
+def test_sign_mask_replaces_y_in_the_head_dgrad(bops, shape):
+    """fdn_conv_cout1_dgrad_folded_bf16_mask: the 64->1 head's input gradient reads the sign mask of the head activation instead of its rows --
+    same dz_prev and producer bias gradient bit for bit."""
+    g = torch.Generator(device="cuda").manual_seed(29)
+    N, D, H, W = shape
+    x = torch.randn((N, D, H, W, 64), device="cuda", generator=g).to(torch.bfloat16)
+    w = torch.randn((3, 3, 3, 64, 64), device="cuda", generator=g) * 0.05
+    wf, _ = bops.pack_conv64_weights(w)
+    mask = bops.new_sign_mask(x)
+    y = bops.conv64_fwd(x, wf, None, 1, 0.2, None, mask=mask)                      # the head's 64->64 conv (ReLU)
+    w1 = torch.randn((3, 3, 3, 64, 1), device="cuda", generator=g) * 0.1
+    dpred = torch.randn((N, D, H, W, 3), device="cuda", generator=g)
+    outs = []
+    for m in (None, mask):
+        db = torch.zeros(64, device="cuda")
+        out = bops.conv_cout1_dgrad_folded(dpred, w1, (N, D, H, W), y, 1, lddz=3, dz_coff=2, dbias_prev=db, mask=m)
+        outs.append((out, db))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert (outs[0][0] == 0).float().mean().item() > 0.2               # the ReLU mask really bites
