@@ -84,6 +84,7 @@ DEBUG_SIGNATURES = {
     "fdn_debug_set_conv64_wino2d_dbg": (c_i, [c_i]),
     "fdn_debug_set_conv64_wino2d_tile": (c_i, [c_i]),
     "fdn_debug_set_conv64_wino2d_variant": (c_i, [c_i]),
+    "fdn_debug_set_conv64_wino2d_mb": (c_i, [c_i]),
     "fdn_debug_set_cin3_mfma": (c_i, [c_i]),
     "fdn_debug_set_conv1x1_mfma": (c_i, [c_i]),
     "fdn_debug_set_wgrad64_wino_dbg": (c_i, [c_i]),
@@ -95,6 +96,9 @@ DEBUG_SIGNATURES = {
 
 class FdnError(RuntimeError):
     pass
+
+
+FDN_VERSION = 160    # include/fdn.h
 
 
 _product = None
@@ -117,13 +121,23 @@ def _open(path, sigs, test_hooks=False):
     return lib
 
 
+def _check_version(lib, path):
+    """The python mirror of include/fdn.h hard-codes sizes the library trusts (ops.CONV64_PACK_FLOATS: a pack buffer sized for an older
+    header is too small for this library's pack kernel): a library of another version -- FDN_NO_REBUILD with an external build -- is refused."""
+    have = lib.fdn_version()
+    if have != FDN_VERSION:
+        raise FdnError("%s reports fdn_version() = %d, this package mirrors include/fdn.h at FDN_VERSION %d: rebuild (python 4dflownet_amd/build.py)"
+                       % (os.path.basename(path), have, FDN_VERSION))
+    return lib
+
+
 def load():
     """Load the shared library (once) and attach the prototypes.  Raises FdnError if it is not built."""
     global _lib, _product
     if _lib is not None:
         return _lib
     if _product is None:
-        _product = _open(LIB_PATH, SIGNATURES)
+        _product = _check_version(_open(LIB_PATH, SIGNATURES), LIB_PATH)
     _lib = _product
     return _lib
 
@@ -137,7 +151,7 @@ def test_build():
     if _test is None:
         sigs = dict(SIGNATURES)
         sigs.update(DEBUG_SIGNATURES)
-        _test = _open(TEST_LIB_PATH, sigs, test_hooks=True)
+        _test = _check_version(_open(TEST_LIB_PATH, sigs, test_hooks=True), TEST_LIB_PATH)
     prev = _lib
     _lib = _test
     try:

@@ -34,7 +34,7 @@ FDN_HOOK_VAR(int, fdn_wgrad64_force_direct, 0);
 extern "C" int fdn_debug_set_wgrad64_direct(int on) { fdn_wgrad64_force_direct = on; return FDN_OK; }
 #endif
 
-extern "C" int fdn_version(void) { return FDN_VERSION; }   // 150: FDN_CONV64_PACK_FLOATS = 261 * 4096 (F(4,3)xF(4,3) stream), FDN_ALGO_WINO_H2
+extern "C" int fdn_version(void) { return FDN_VERSION; }   // 160: FDN_CONV64_PACK_FLOATS = 423 * 4096 (+ the bf16 x 3 stream), FDN_ALGO_WINO_BF16X3
 extern "C" const char* fdn_last_error(void) { return g_err; }
 
 // small-channel kernels (small_convs.hip), templated on the activation storage type (float / uint16_t = bf16 bits)
@@ -66,7 +66,7 @@ extern "C" int fdn_conv3d_fwd(const float* x, const float* x2, const float* w, c
                               const float* residual, float* y, int N, int D, int H, int W, int Cin, int Cout, int K,
                               int ldy, int y_coff, int act, float alpha, int algo, void* stream) {
     FDN_REQUIRE(x && y, "fdn_conv3d_fwd: x/y is NULL");
-    FDN_REQUIRE(algo >= FDN_ALGO_AUTO && algo <= FDN_ALGO_WINO_H2, "fdn_conv3d_fwd: bad algo %d", algo);
+    FDN_REQUIRE(algo >= FDN_ALGO_AUTO && algo <= FDN_ALGO_LAST, "fdn_conv3d_fwd: bad algo %d", algo);
     FDN_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "fdn_conv3d_fwd: bad dims N=%d D=%d H=%d W=%d", N, D, H, W);
     FDN_REQUIRE(act >= FDN_ACT_NONE && act <= FDN_ACT_LEAKY, "fdn_conv3d_fwd: bad act %d", act);
     hipStream_t s = (hipStream_t)stream;
@@ -96,7 +96,7 @@ extern "C" int fdn_conv3d_fwd(const float* x, const float* x2, const float* w, c
 extern "C" int fdn_conv3d_dgrad(const float* dz, const float* w, const float* wpack, float* dxpad, int N, int D,
                                 int H, int W, int Cin, int Cout, int K, int lddz, int dz_coff, int algo, void* stream) {
     FDN_REQUIRE(dz && dxpad, "fdn_conv3d_dgrad: dz/dxpad is NULL");
-    FDN_REQUIRE(algo >= FDN_ALGO_AUTO && algo <= FDN_ALGO_WINO_H2, "fdn_conv3d_dgrad: bad algo %d", algo);
+    FDN_REQUIRE(algo >= FDN_ALGO_AUTO && algo <= FDN_ALGO_LAST, "fdn_conv3d_dgrad: bad algo %d", algo);
     FDN_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "fdn_conv3d_dgrad: bad dims");
     hipStream_t s = (hipStream_t)stream;
     if (Cin == 64 && Cout == 64 && K == 3) {
@@ -118,7 +118,7 @@ extern "C" int fdn_conv3d_dgrad_fused(const float* dz, const float* wpack, float
                                       const float* y_prev, int act, float alpha, float* dz_prev, int N, int D, int H,
                                       int W, int algo, void* stream) {
     FDN_REQUIRE(dz && wpack && dxpad && dz_prev, "fdn_conv3d_dgrad_fused: NULL argument");
-    FDN_REQUIRE(algo >= FDN_ALGO_AUTO && algo <= FDN_ALGO_WINO_H2, "fdn_conv3d_dgrad_fused: bad algo %d", algo);
+    FDN_REQUIRE(algo >= FDN_ALGO_AUTO && algo <= FDN_ALGO_LAST, "fdn_conv3d_dgrad_fused: bad algo %d", algo);
     FDN_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && D <= 1020 && H <= 1020 && W <= 1020, "fdn_conv3d_dgrad_fused: bad dims");
     FDN_REQUIRE(act >= FDN_ACT_NONE && act <= FDN_ACT_LEAKY, "fdn_conv3d_dgrad_fused: bad act %d", act);
     return fdn_conv64_launch_ex(dz, wpack, nullptr, nullptr, dxpad, skip, y_prev, dz_prev, N, D, H, W, D + 2, H + 2, W + 2,
@@ -129,7 +129,7 @@ extern "C" int fdn_conv3d_dgrad_fused_part(const float* dz, const float* wpack, 
                                            const float* y_prev, int act, float alpha, float* dz_prev, int N, int D, int H,
                                            int W, int parts, int algo, void* stream) {
     FDN_REQUIRE(dz && wpack && dxpad && dz_prev, "fdn_conv3d_dgrad_fused_part: NULL argument");
-    FDN_REQUIRE(algo >= FDN_ALGO_AUTO && algo <= FDN_ALGO_WINO_H2, "fdn_conv3d_dgrad_fused_part: bad algo %d", algo);
+    FDN_REQUIRE(algo >= FDN_ALGO_AUTO && algo <= FDN_ALGO_LAST, "fdn_conv3d_dgrad_fused_part: bad algo %d", algo);
     FDN_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && D <= 1020 && H <= 1020 && W <= 1020, "fdn_conv3d_dgrad_fused_part: bad dims");
     FDN_REQUIRE(act >= FDN_ACT_NONE && act <= FDN_ACT_LEAKY, "fdn_conv3d_dgrad_fused_part: bad act %d", act);
     FDN_REQUIRE(parts >= 1 && parts <= 3, "fdn_conv3d_dgrad_fused_part: parts must be FDN_DGRAD_INNER | FDN_DGRAD_SHELL");
@@ -159,7 +159,7 @@ extern "C" int fdn_conv3d_wgrad(const float* x, const float* x2, const float* dz
                                 void* workspace, size_t workspace_bytes, int N, int D, int H, int W, int Cin, int Cout,
                                 int K, int lddz, int dz_coff, int algo, void* stream) {
     FDN_REQUIRE(x && dz && dw, "fdn_conv3d_wgrad: x/dz/dw is NULL");
-    FDN_REQUIRE(algo >= FDN_ALGO_AUTO && algo <= FDN_ALGO_WINO_H2, "fdn_conv3d_wgrad: bad algo %d", algo);
+    FDN_REQUIRE(algo >= FDN_ALGO_AUTO && algo <= FDN_ALGO_LAST, "fdn_conv3d_wgrad: bad algo %d", algo);
     FDN_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "fdn_conv3d_wgrad: bad dims");
     const size_t need = fdn_conv3d_wgrad_workspace_bytes(N, D, H, W, Cin, Cout, K);
     if (workspace_bytes < need || (need && !workspace)) {
@@ -206,7 +206,7 @@ extern "C" size_t fdn_conv3d_wgrad_batch_workspace_bytes(int n_layers, int N, in
 extern "C" int fdn_conv3d_wgrad_batch(const float* const* x, const float* const* dz, float* const* dw, float* const* dbias, int n_layers,
                                       void* workspace, size_t workspace_bytes, int N, int D, int H, int W, int algo, void* stream) {
     FDN_REQUIRE(x && dz && dw && n_layers > 0, "fdn_conv3d_wgrad_batch: NULL table or n_layers <= 0");
-    FDN_REQUIRE(algo >= FDN_ALGO_AUTO && algo <= FDN_ALGO_WINO_H2, "fdn_conv3d_wgrad_batch: bad algo %d", algo);
+    FDN_REQUIRE(algo >= FDN_ALGO_AUTO && algo <= FDN_ALGO_LAST, "fdn_conv3d_wgrad_batch: bad algo %d", algo);
     FDN_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "fdn_conv3d_wgrad_batch: bad dims");
     const size_t need = fdn_conv3d_wgrad_batch_workspace_bytes(n_layers, N, D, H, W);
     if (workspace_bytes < need || !workspace) {

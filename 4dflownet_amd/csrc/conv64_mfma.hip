@@ -459,9 +459,9 @@ __global__ void pack_conv64_kernel(const float* __restrict__ w, float* __restric
 // lies inside one stream (every stream is a multiple of 256 elements), so an unwanted stream costs an early exit
 __global__ void pack_conv64_batch_kernel(const float* __restrict__ w_base, const int64_t* __restrict__ w_offsets, float* __restrict__ packs,
                                          int sf, int sd) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over 261*64*64 packed elements per direction
-    const int st = idx < 27 * 64 * 64 ? 0 : idx < 81 * 64 * 64 ? 1 : idx < 153 * 64 * 64 ? 2 : 3;
-    if (!(((sf | sd) >> st) & 1) || idx >= 261 * 64 * 64) return;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over 261*64*64 packed elements per direction + the 108*64*64 values of the bf16 x 3 stream
+    const int st = idx < 27 * 64 * 64 ? 0 : idx < 81 * 64 * 64 ? 1 : idx < 153 * 64 * 64 ? 2 : idx < 261 * 64 * 64 ? 3 : 4;
+    if (!(((sf | sd) >> st) & 1) || idx >= 369 * 64 * 64) return;
     const float* w = w_base + w_offsets[blockIdx.y];
     float* pf = packs + (size_t)blockIdx.y * 2 * FDN_CONV64_PACK_FLOATS;
     float* pd = pf + FDN_CONV64_PACK_FLOATS;
@@ -470,15 +470,17 @@ __global__ void pack_conv64_batch_kernel(const float* __restrict__ w_base, const
     if (st == 0) fdn_pack_direct_one(w, pf, pd, idx);
     else if (st == 1) fdn_pack_wino_one(w, pf ? pf + 27 * 64 * 64 : nullptr, pd ? pd + 27 * 64 * 64 : nullptr, idx - 27 * 64 * 64);
     else if (st == 2) fdn_pack_wino2d_one(w, pf ? pf + 81 * 64 * 64 : nullptr, pd ? pd + 81 * 64 * 64 : nullptr, idx - 81 * 64 * 64);
-    else fdn_pack_wino44_one(w, pf ? pf + 153 * 64 * 64 : nullptr, pd ? pd + 153 * 64 * 64 : nullptr, idx - 153 * 64 * 64);
+    else if (st == 3) fdn_pack_wino44_one(w, pf ? pf + 153 * 64 * 64 : nullptr, pd ? pd + 153 * 64 * 64 : nullptr, idx - 153 * 64 * 64);
+    else fdn_pack_wino44s_one(w, pf ? (uint16_t*)(pf + 261 * 64 * 64) : nullptr, pd ? (uint16_t*)(pd + 261 * 64 * 64) : nullptr, idx - 261 * 64 * 64);
 }
 
 // pack = [direct stream, 27*64*64 floats | Winograd F(4,3) stream, 54*64*64 | 2-D F(2,3)xF(4,3) stream, 72*64*64 | 2-D F(4,3)xF(4,3)
-// stream, 108*64*64]  (FDN_CONV64_PACK_FLOATS in fdn.h)
+// stream, 108*64*64 | the same as three bf16 pieces per value, 162*64*64 float-sized slots]  (FDN_CONV64_PACK_FLOATS in fdn.h)
 constexpr int kDirectPackFloats = 27 * 64 * 64;
 constexpr int kWino1PackFloats = 54 * 64 * 64;
 constexpr int kWino2PackFloats = 72 * 64 * 64;
-static_assert(kDirectPackFloats + kWino1PackFloats + kWino2PackFloats + 108 * 64 * 64 == FDN_CONV64_PACK_FLOATS, "pack layout");
+constexpr int kWino44PackFloats = 108 * 64 * 64;
+static_assert(kDirectPackFloats + kWino1PackFloats + kWino2PackFloats + kWino44PackFloats + 162 * 64 * 64 == FDN_CONV64_PACK_FLOATS, "pack layout");
 
 extern "C" int fdn_pack_conv64_weights(const float* w, float* wp_fwd, float* wp_dgrad, void* stream) {
     FDN_REQUIRE(w != nullptr, "fdn_pack_conv64_weights: w is NULL");
@@ -498,7 +500,7 @@ extern "C" int fdn_pack_conv64_weights_batch_streams(const float* w_base, const 
     FDN_REQUIRE(!(streams_fwd & ~FDN_PACK_STREAM_ALL) && !(streams_dgrad & ~FDN_PACK_STREAM_ALL), "fdn_pack_conv64_weights_batch_streams: bad stream mask %d / %d",
                 streams_fwd, streams_dgrad);
     if (!(streams_fwd | streams_dgrad)) return FDN_OK;
-    hipLaunchKernelGGL(pack_conv64_batch_kernel, dim3((FDN_CONV64_PACK_FLOATS + 255) / 256, (unsigned)n_layers), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(pack_conv64_batch_kernel, dim3((369 * 64 * 64 + 255) / 256, (unsigned)n_layers), dim3(256), 0, (hipStream_t)stream,
                        w_base, w_offsets, packs, streams_fwd, streams_dgrad);
     FDN_CHECK_LAUNCH("fdn_pack_conv64_weights_batch");
     return FDN_OK;
@@ -509,7 +511,7 @@ extern "C" int fdn_pack_conv64_weights_batch(const float* w_base, const int64_t*
 }
 
 extern "C" int fdn_conv64_pack_streams(int N, int D, int H, int W, int algo, int role) {
-    FDN_REQUIRE(algo >= FDN_ALGO_AUTO && algo <= FDN_ALGO_WINO_H2, "fdn_conv64_pack_streams: bad algo %d", algo);
+    FDN_REQUIRE(algo >= FDN_ALGO_AUTO && algo <= FDN_ALGO_LAST, "fdn_conv64_pack_streams: bad algo %d", algo);
     FDN_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && D <= 1020 && H <= 1020 && W <= 1020, "fdn_conv64_pack_streams: bad dims");
     FDN_REQUIRE(role >= FDN_ROLE_FWD && role <= FDN_ROLE_DGRAD_FUSED, "fdn_conv64_pack_streams: bad role %d", role);
     unsigned m = 0;
@@ -644,7 +646,7 @@ int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, 
                          const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
                          int OW, int off, int zero_mode, int act, float alpha, hipStream_t s, int parts, int algo, unsigned* probe) {
     // probe != nullptr: launch nothing, OR into *probe the streams of the pack this call would read (bit 0 direct, 1 1-D Winograd,
-    // 2 F(2,3)xF(4,3), 3 F(4,3)xF(4,3)) -- fdn_conv64_pack_streams; the selection below is the only statement of the rule.
+    // 2 F(2,3)xF(4,3), 3 F(4,3)xF(4,3), 4 the same as bf16 x 3) -- fdn_conv64_pack_streams; the selection below is the only statement of the rule.
     // staged rows are addressed with 32-bit byte offsets from the sample's first voxel (256 B per voxel)
     FDN_REQUIRE((long long)ID * IH * IW < (1ll << 24), "conv64: a sample of %dx%dx%d voxels exceeds the 32-bit row addressing", ID, IH, IW);
     Conv64Args a;
@@ -666,13 +668,16 @@ int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, 
         if (algo != FDN_ALGO_WINO_H2 && fdn_conv64_wino2d_ok(1, eh, ew, ID, IH, IW, 4)) return 4;
         return fdn_conv64_wino2d_ok(1, eh, ew, ID, IH, IW, 2) ? 2 : 0;
     };
-    auto upack_hm = [&](int hm) { return hm == 4 ? upack2 + kWino2PackFloats : upack2; };
-    auto stream_bit = [](int hm) { return hm == 4 ? 8u : 4u; };
+    // FDN_ALGO_WINO_BF16X3: F(4,3) x F(4,3) grids read the bf16 x 3 stream and run the SPLIT kernel (hm is passed on as 4 | 8)
+    const bool split = algo == FDN_ALGO_WINO_BF16X3;
+    auto upack_hm = [&](int hm) { return hm == 4 ? (split ? upack2 + kWino2PackFloats + kWino44PackFloats : upack2 + kWino2PackFloats) : upack2; };
+    auto stream_bit = [&](int hm) { return hm == 4 ? (split ? 16u : 8u) : 4u; };
+    auto hm_arg = [&](int hm) { return hm == 4 && split ? 12 : hm; };
     if (!(fout && zero_mode && off == -1 && fdn_conv64_shell_slabs)) {
         if (const int hm = fout ? 0 : hm_for(OH, OW)) {           // (a fused fold outside the slab path is the 1-D / direct kernels' business)
             if (probe) { *probe |= stream_bit(hm); return FDN_OK; }
             return fdn_conv64_wino2d_launch(x, upack_hm(hm), bias, residual, y, nullptr, nullptr, nullptr, N, ID, IH, IW, OD, OH, OW, 0, 0, 0,
-                                            OD, OH, OW, off, zero_mode, act, alpha, hm, s);
+                                            OD, OH, OW, off, zero_mode, act, alpha, hm_arg(hm), s);
         }
         if (wino && fdn_conv64_wino_ok(OD, OH, OW)) {
             if (probe) { *probe |= 2u; return FDN_OK; }
@@ -716,14 +721,14 @@ int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, 
                 if (probe) { *probe |= stream_bit(hm) | 2u; return FDN_OK; }
                 FdnWino2dPrepared inner;
                 if (int rc = fdn_conv64_wino2d_prepare(x, upack_hm(hm), bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, 1, 1, 1, ID,
-                                                       IH, IW, off, zero_mode, act, alpha, hm, &inner))
+                                                       IH, IW, off, zero_mode, act, alpha, hm_arg(hm), &inner))
                     return rc;
                 return fdn_conv64_wino_launch_boxes(x, upack, bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, wb + 1, count - 1,
                                                     off, zero_mode, act, alpha, s, &inner);
             }
             if (probe) *probe |= stream_bit(hm);
             else if (int rc = fdn_conv64_wino2d_launch(x, upack_hm(hm), bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, 1, 1, 1, ID, IH,
-                                                       IW, off, zero_mode, act, alpha, hm, s))
+                                                       IW, off, zero_mode, act, alpha, hm_arg(hm), s))
                 return rc;
             first = 1; count -= 1;
             if (count == 0) return FDN_OK;

@@ -1,6 +1,7 @@
 // Per-element weight re-layout shared by the single-layer and the batched pack kernels (conv64_mfma.hip, conv64_wino.hip).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 
 // Direct stream: Keras (27,64,64)[tap][cin][cout] -> [half][tap][g][kh][row j][s]
 //   row j of a 32-row tile is MFMA row i = j & 31, which lands in accumulator register r = (i&3) + 4(i>>3) of lane half
@@ -137,5 +138,52 @@ __device__ __forceinline__ void fdn_pack_wino44_one(const float* __restrict__ w,
 #pragma unroll
             for (int t = 0; t < 3; ++t) v += G[xh][kh] * G[xw][t] * (double)w[((26 - ((kd * 3 + kh) * 3 + t)) * 64 + cj) * 64 + k];
         ud[idx] = (float)v;
+    }
+}
+
+// The F(4,3) x F(4,3) stream once more, for FDN_ALGO_WINO_BF16X3 (conv64_wino2d_kernel.h, SPLIT): the same U (double precision, rounded once
+// to fp32) split EXACTLY into three bf16 pieces u = hi + mid + lo, laid out as the row operand of v_mfma_f32_16x16x32_bf16:
+// [nb = cout/16][xh 0..5][pass = cin/32][kd][xw 0..5][piece][lane][8]: lane (i = lane & 15, q = lane >> 4), element j <-> cout 16 nb + i,
+// cin 32 pass + 8 q + j.  A wave's (stage, pass, kd, xw) step reads 3 KB: one 16-B load per lane and piece.
+// idx runs over the 108 * 64 * 64 values; the stream is 3 * 108 * 64 * 64 uint16_t = 162 * 64 * 64 float-sized slots.
+__device__ __forceinline__ void fdn_pack_wino44s_one(const float* __restrict__ w, uint16_t* __restrict__ uf, uint16_t* __restrict__ ud, int idx) {
+    const int j = idx & 7;
+    const int lane = (idx >> 3) & 63;
+    int rest = idx >> 9;                 // (((nb*6 + xh)*2 + pass)*3 + kd)*6 + xw
+    const int unit = rest;
+    const int xw = rest % 6; rest /= 6;
+    const int kd = rest % 3; rest /= 3;
+    const int pass = rest & 1; rest >>= 1;
+    const int xh = rest % 6;
+    const int nb = rest / 6;
+    const int k = 32 * pass + 8 * (lane >> 4) + j;
+    const int cj = 16 * nb + (lane & 15);
+    const double G[6][3] = {{64.0 / 81, 0.0, 0.0}, {-128.0 / 243, -32.0 / 81, -8.0 / 27}, {-128.0 / 243, 32.0 / 81, -8.0 / 27},
+                            {32.0 / 243, 16.0 / 81, 8.0 / 27}, {32.0 / 243, -16.0 / 81, 8.0 / 27}, {0.0, 0.0, 1.0}};
+    const size_t o = (size_t)unit * 1536 + lane * 8 + j;
+    auto put = [&](uint16_t* dst, float u) {
+        const __bf16 hi = (__bf16)u;
+        const float r1 = u - (float)hi;
+        const __bf16 mid = (__bf16)r1;
+        const __bf16 lo = (__bf16)(r1 - (float)mid);
+        dst[o] = __builtin_bit_cast(uint16_t, hi);
+        dst[o + 512] = __builtin_bit_cast(uint16_t, mid);
+        dst[o + 1024] = __builtin_bit_cast(uint16_t, lo);
+    };
+    if (uf) {
+        double v = 0.0;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) v += G[xh][kh] * G[xw][t] * (double)w[(((kd * 3 + kh) * 3 + t) * 64 + k) * 64 + cj];
+        put(uf, (float)v);
+    }
+    if (ud) {
+        double v = 0.0;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) v += G[xh][kh] * G[xw][t] * (double)w[((26 - ((kd * 3 + kh) * 3 + t)) * 64 + cj) * 64 + k];
+        put(ud, (float)v);
     }
 }

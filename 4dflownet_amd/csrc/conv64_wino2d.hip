@@ -43,10 +43,12 @@ namespace {
 FDN_HOOK_VAR(int, fdn_conv64_wino2d_dbg, 0);
 FDN_HOOK_VAR(int, fdn_conv64_wino2d_tile, 0);          // test build: force the tile, td | ch << 8 | cw << 16 (0 = planner)
 
-template <bool FUSED, int HM>
+FDN_HOOK_VAR(int, fdn_conv64_wino2d_mb, 0);            // test build: force the M-blocks per wave (1 = half-size tiles, 2 = full; 0 = by the grid)
+
+template <bool FUSED, int HM, int MB = 2, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void conv64_wino2d_kernel(Wino2Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    conv64_wino2d_body<FUSED, HM>(p, (int)blockIdx.x, smem);
+    conv64_wino2d_body<FUSED, HM, kW2RDB, kW2RDA, kW2Dep, MB, SPLIT>(p, (int)blockIdx.x, smem);
 }
 
 #ifdef FDN_TEST_HOOKS
@@ -62,26 +64,29 @@ __global__ __launch_bounds__(256, 1) void conv64_wino2d_occ1_kernel(Wino2Args p)
 }
 #endif
 
-// both 2-D streams of one layer: [F(2,3) x F(4,3): 72 * 4096 floats | F(4,3) x F(4,3): 108 * 4096]
+// the 2-D streams of one layer: [F(2,3) x F(4,3): 72 * 4096 floats | F(4,3) x F(4,3): 108 * 4096 | the same as three bf16 pieces per value: 162 * 4096 slots]
 __global__ void pack_conv64_wino2d_kernel(const float* __restrict__ w, float* __restrict__ uf, float* __restrict__ ud) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < 72 * 64 * 64) fdn_pack_wino2d_one(w, uf, ud, idx);
     else if (idx < 180 * 64 * 64) fdn_pack_wino44_one(w, uf ? uf + 72 * 64 * 64 : nullptr, ud ? ud + 72 * 64 * 64 : nullptr, idx - 72 * 64 * 64);
+    else if (idx < 288 * 64 * 64) fdn_pack_wino44s_one(w, uf ? (uint16_t*)(uf + 180 * 64 * 64) : nullptr, ud ? (uint16_t*)(ud + 180 * 64 * 64) : nullptr, idx - 180 * 64 * 64);
 }
 
 struct Wino2Plan { int td, ch, cw; double cost; };
+constexpr long long kW2HalfBelow = 0;                   // half-size tiles below this many full-size tiles (0: never)
 
 // tile choice: every tile costs the MFMA time of 32 cells whatever its fill, plus the staging work of its rows and a fixed prologue /
 // epilogue; the launch ends with the busiest CU (2 co-resident workgroups per CU share the matrix pipe, so work per CU = its tiles).
-Wino2Plan wino2d_plan(int N, int ed, int ech, int ecw) {
+Wino2Plan wino2d_plan(int N, int ed, int ech, int ecw, int mb) {
     Wino2Plan best{1, 1, 1, 1e30};
+    const int max_rows = mb == 2 ? kW2Rows : kW2RowsH;
     for (int ch = 1; ch <= ech && ch <= 4; ++ch)
         for (int cw = 1; cw <= ecw && ch * cw <= 4; ++cw)
-            for (int td = 1; td <= ed && td * ch * cw <= 32; ++td) {
+            for (int td = 1; td <= ed && td * ch * cw <= 16 * mb; ++td) {
                 const int rows = (td + 2) * ch * cw;
-                if (rows > kW2Rows) continue;
+                if (rows > max_rows) continue;
                 const double tiles = (double)N * ((ed + td - 1) / td) * ((ech + ch - 1) / ch) * ((ecw + cw - 1) / cw);
-                const double per_tile = 32.0 + 0.15 * rows + 2.0;
+                const double per_tile = 16.0 * mb + 0.15 * rows + 2.0;
                 const double rounds = 0.9 * (double)((long long)((tiles + 255) / 256)) + 0.1 * tiles / 256.0;
                 const double cst = rounds * per_tile;
                 if (cst < best.cost) best = {td, ch, cw, cst};
@@ -95,6 +100,7 @@ Wino2Plan wino2d_plan(int N, int ed, int ech, int ecw) {
 // addressable with 30-bit byte offsets -- the staging plan adds a row offset and a column offset, each of which may be the
 // "reads zero" marker 2^30.)
 bool fdn_conv64_wino2d_ok(int ebd, int ebh, int ebw, int ID, int IH, int IW, int hm) {
+    hm &= 7;                                            // (bit 3 of a launcher's hm argument: the bf16 x 3 products, FDN_ALGO_WINO_BF16X3)
     return (hm == 2 || hm == 4) && ebd > 0 && ebh >= hm && ebh % hm == 0 && ebw >= 4 && (ebw & 3) == 0 && (long long)ID * IH * IW <= (1ll << 22);
 }
 
@@ -103,7 +109,10 @@ static_assert(sizeof(Wino2Args) <= sizeof(FdnWino2dPrepared::args), "FdnWino2dPr
 int fdn_conv64_wino2d_prepare(const float* x, const float* upack2, const float* bias, const float* residual, float* y,
                               const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
                               int OW, int obd, int obh, int obw, int ebd, int ebh, int ebw, int off, int zero_mode, int act,
-                              float alpha, int hm, FdnWino2dPrepared* out) {
+                              float alpha, int hm_arg, FdnWino2dPrepared* out) {
+    const int hm = hm_arg & 7;
+    const bool split = (hm_arg & 8) != 0;               // F(4,3) x F(4,3) products as bf16 x 3 (upack2 = that stream)
+    FDN_REQUIRE(!split || hm == 4, "conv64 (2-D winograd): the bf16 x 3 products exist for F(4,3) along H only");
     FDN_REQUIRE(fdn_conv64_wino2d_ok(ebd, ebh, ebw, ID, IH, IW, hm), "conv64 (2-D winograd, F(%d,3) along H): box %dx%dx%d of a %dx%dx%d grid is not supported",
                 hm, ebd, ebh, ebw, ID, IH, IW);
     FDN_REQUIRE(!fout || (zero_mode && off == -1 && obd == 1 && obh == 1 && obw == 1), "conv64 (2-D winograd): the fused fold belongs to the inner box of a padded dgrad");
@@ -111,15 +120,24 @@ int fdn_conv64_wino2d_prepare(const float* x, const float* upack2, const float* 
     a.x = x; a.up = upack2; a.bias = bias; a.res = residual; a.y = y; a.fskip = fskip; a.fy = fy; a.fout = fout;
     a.N = N; a.ID = ID; a.IH = IH; a.IW = IW; a.OD = OD; a.OH = OH; a.OW = OW;
     a.off = off; a.zero_mode = zero_mode; a.act = act; a.alpha = alpha; a.dbg = fdn_conv64_wino2d_dbg;
-    a.hm = hm;
+    a.hm = hm; a.split = split ? 1 : 0;
     a.obd = obd; a.obh = obh; a.obw = obw; a.ebd = ebd; a.ebh = ebh; a.ebw = ebw;
     const int ech = ebh / hm, ecw = ebw / 4;
-    Wino2Plan pl = wino2d_plan(N, ebd, ech, ecw);
+    Wino2Plan pl = wino2d_plan(N, ebd, ech, ecw, 2);
+    // half-size tiles (F(4,3) along H only) where the full-size ones leave CUs with one workgroup or none: kW2HalfBelow full tiles
+    int mb = 2;
+    if (hm == 4 && !split) {
+        const long long full = (long long)N * ((ebd + pl.td - 1) / pl.td) * ((ech + pl.ch - 1) / pl.ch) * ((ecw + pl.cw - 1) / pl.cw);
+        if (full < kW2HalfBelow) mb = 1;
+        if (fdn_conv64_wino2d_mb) mb = fdn_conv64_wino2d_mb;
+        if (mb == 1) pl = wino2d_plan(N, ebd, ech, ecw, 1);
+    }
     if (fdn_conv64_wino2d_tile) {
         pl.td = fdn_conv64_wino2d_tile & 255; pl.ch = (fdn_conv64_wino2d_tile >> 8) & 255; pl.cw = (fdn_conv64_wino2d_tile >> 16) & 255;
-        FDN_REQUIRE(pl.td >= 1 && pl.ch >= 1 && pl.cw >= 1 && pl.td * pl.ch * pl.cw <= 32 && (pl.td + 2) * pl.ch * pl.cw <= kW2Rows,
+        FDN_REQUIRE(pl.td >= 1 && pl.ch >= 1 && pl.cw >= 1 && pl.td * pl.ch * pl.cw <= 16 * mb && (pl.td + 2) * pl.ch * pl.cw <= (mb == 2 ? kW2Rows : kW2RowsH),
                     "conv64 (2-D winograd): forced tile %dx%dx%d does not fit", pl.td, pl.ch, pl.cw);
     }
+    a.mb = mb;
     a.td = pl.td; a.ch = pl.ch; a.cw = pl.cw;
     a.ntd = (ebd + pl.td - 1) / pl.td; a.nth = (ech + pl.ch - 1) / pl.ch; a.ntw = (ecw + pl.cw - 1) / pl.cw;
     a.cpp = pl.ch * pl.cw; a.rows = (pl.td + 2) * a.cpp; a.items = a.rows * 16;
@@ -131,24 +149,26 @@ int fdn_conv64_wino2d_prepare(const float* x, const float* upack2, const float* 
     FDN_REQUIRE(blocks < (1ll << 31), "conv64 (2-D winograd): too many tiles");
     memcpy(out->args, &a, sizeof(a));
     out->blocks = (int)blocks;
-    out->lds = kW2Lds;
+    out->lds = split ? W2Geo<2, true>::lds : (mb == 2 ? kW2Lds : W2Geo<1>::lds);
     return FDN_OK;
 }
 
 int fdn_conv64_wino2d_launch(const float* x, const float* upack2, const float* bias, const float* residual, float* y,
                              const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
                              int OW, int obd, int obh, int obw, int ebd, int ebh, int ebw, int off, int zero_mode, int act,
-                             float alpha, int hm, hipStream_t s) {
+                             float alpha, int hm_arg, hipStream_t s) {
+    const int hm = hm_arg & 7;
     FdnWino2dPrepared pr;
     if (int rc = fdn_conv64_wino2d_prepare(x, upack2, bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, obd, obh, obw, ebd,
-                                           ebh, ebw, off, zero_mode, act, alpha, hm, &pr))
+                                           ebh, ebw, off, zero_mode, act, alpha, hm_arg, &pr))
         return rc;
     Wino2Args a;
     memcpy(&a, pr.args, sizeof(a));
     const long long blocks = pr.blocks;
-    const void* fn = fout ? (hm == 4 ? (const void*)conv64_wino2d_kernel<true, 4> : (const void*)conv64_wino2d_kernel<true, 2>)
-                          : (hm == 4 ? (const void*)conv64_wino2d_kernel<false, 4> : (const void*)conv64_wino2d_kernel<false, 2>);
-    int lds = kW2Lds;
+    const void* fn_split = fout ? (const void*)conv64_wino2d_kernel<true, 4, 2, true> : (const void*)conv64_wino2d_kernel<false, 4, 2, true>;
+    const void* fn = a.split ? fn_split : fout ? (hm == 4 ? (a.mb == 1 ? (const void*)conv64_wino2d_kernel<true, 4, 1> : (const void*)conv64_wino2d_kernel<true, 4>) : (const void*)conv64_wino2d_kernel<true, 2>)
+                          : (hm == 4 ? (a.mb == 1 ? (const void*)conv64_wino2d_kernel<false, 4, 1> : (const void*)conv64_wino2d_kernel<false, 4>) : (const void*)conv64_wino2d_kernel<false, 2>);
+    int lds = pr.lds;
 #ifdef FDN_TEST_HOOKS
     if (fdn_conv64_wino2d_variant && !fout && hm == 2) {
         switch (fdn_conv64_wino2d_variant) {
@@ -173,7 +193,7 @@ int fdn_conv64_wino2d_launch(const float* x, const float* upack2, const float* b
 }
 
 int fdn_pack_conv64_wino2d_launch(const float* w, float* uf, float* ud, hipStream_t s) {
-    hipLaunchKernelGGL(pack_conv64_wino2d_kernel, dim3((180 * 64 * 64 + 255) / 256), dim3(256), 0, s, w, uf, ud);
+    hipLaunchKernelGGL(pack_conv64_wino2d_kernel, dim3((288 * 64 * 64 + 255) / 256), dim3(256), 0, s, w, uf, ud);
     FDN_CHECK_LAUNCH("pack_conv64_wino2d_kernel");
     return FDN_OK;
 }
@@ -182,4 +202,5 @@ int fdn_pack_conv64_wino2d_launch(const float* w, float* uf, float* ud, hipStrea
 extern "C" int fdn_debug_set_conv64_wino2d_dbg(int bits) { fdn_conv64_wino2d_dbg = bits; return FDN_OK; }
 extern "C" int fdn_debug_set_conv64_wino2d_tile(int packed) { fdn_conv64_wino2d_tile = packed; return FDN_OK; }
 extern "C" int fdn_debug_set_conv64_wino2d_variant(int v) { fdn_conv64_wino2d_variant = v; return FDN_OK; }
+extern "C" int fdn_debug_set_conv64_wino2d_mb(int mb) { fdn_conv64_wino2d_mb = mb; return FDN_OK; }
 #endif

@@ -21,6 +21,8 @@ struct Wino2Args {
     float alpha;
     int dbg;                // ablation bits (test build only): 1 = weight stream stride 0, 4 = no staging, 8 = no epilogue, 32 = epilogue operands from cache-resident rows, 128 = no XCD remap
     int hm;                 // output rows per cell: 2 = F(2,3) along H, 4 = F(4,3) along H (selects the kernel instantiation; host side only)
+    int mb;                 // 16-cell M-blocks per wave: 2 = full tiles, 1 = half-size tiles (host side only)
+    int split;              // 1: `up` is the bf16 x 3 stream and the products run on the bf16 pipe (FDN_ALGO_WINO_BF16X3; host side only)
     int obd, obh, obw, ebd, ebh, ebw;      // output box (h extent a multiple of hm, w extent a multiple of 4)
     int td, ch, cw, ntd, nth, ntw;         // tile in (depth planes, cell rows, cell columns) and tile counts; a cell = hm x 4 voxels (h, w)
     int cpp, rows, items;                  // cells per plane, staged rows = (td + 2) * cpp, rows * 16
@@ -33,6 +35,45 @@ constexpr int kW2Rows = 40;                 // staged cell-planes per tile
 constexpr int kW2Row = 288;                 // bytes per LDS row: 64 cin + 32-B pad (conflict-free ds_read_b128 over 16 consecutive rows)
 constexpr int kW2Plane = kW2Rows * kW2Row + 64;
 constexpr int kW2Lds = 6 * kW2Plane + 96 * 4 + kW2Rows * 48;
+// Half-size tiles (MB = 1: ONE 16-cell M-block per wave, <= 16 cells and <= kW2RowsH staged cell-planes per tile) for grids whose full-size
+// tiles do not fill the chip: at (8,24^3) 216 tiles leave 40 CUs idle and the other 216 with a single workgroup, 432 half tiles put two
+// workgroups on most CUs (a workgroup alone on its CU has nobody to cover its staging, barriers and epilogue).  Same LDS image, fewer rows.
+constexpr int kW2RowsH = 24;
+// SPLIT (FDN_ALGO_WINO_BF16X3): the Winograd-domain products on the bf16 matrix pipe.  Both operands are split EXACTLY into three bf16
+// pieces, v = hi + mid + lo (each the round-to-nearest bf16 of what the pieces before it leave: 8 + 8 + 8 significand bits), and the six
+// cross terms hi.hi, mid.hi, lo.hi, hi.mid, mid.mid, hi.lo run on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (a bf16 x bf16 product is
+// exact in fp32; dropped: mid.lo + lo.mid + lo.lo <= 2^-25 |u||v|, under the half ulp an fp32 multiply rounds away).  gfx950's fp32
+// MFMA runs at 1/16 of the bf16 rate, so six terms cost 6/16 of the matrix time, and the bf16 pipe -- unlike the fp32 one -- lets the
+// co-resident workgroup's staging run beside it.  An LDS row holds 32 cin x 3 pieces (64 B each) + 32 B pad = 224 B (conflict-free
+// ds_read_b128 over 16 consecutive rows like the 288-B fp32 rows), so a stage runs as TWO cin passes over the same 54 KB of planes
+// and two workgroups still share a CU.
+constexpr int kW2RowS = 224;
+template <int MB, bool SPLIT = false> struct W2Geo {
+    static constexpr int rows = MB == 2 ? kW2Rows : kW2RowsH;
+    static constexpr int row = SPLIT ? kW2RowS : kW2Row;
+    static constexpr int plane = rows * row + 64;
+    static constexpr int lds = 6 * plane + 96 * 4 + rows * 48;
+};
+typedef __bf16 fdn_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 fdn_bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned fdn_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned fdn_pk_bf16(float a, float b) {       // two round-to-nearest-even bf16 in one dword (v_cvt_pk_bf16_f32)
+    const fdn_bf16x2 t = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, t);
+}
+__device__ __forceinline__ f32x4 fdn_unpk_bf16(fdn_u32x2 h) {
+    return (f32x4){__builtin_bit_cast(float, h.x << 16), __builtin_bit_cast(float, h.x & 0xffff0000u),
+                   __builtin_bit_cast(float, h.y << 16), __builtin_bit_cast(float, h.y & 0xffff0000u)};
+}
+// v = hi + mid + lo exactly (the residual of a round-to-nearest is an fp32 number; the last one has at most 8 significant bits)
+__device__ __forceinline__ void fdn_split3(const f32x4 v, fdn_u32x2& hi, fdn_u32x2& mid, fdn_u32x2& lo) {
+    hi = (fdn_u32x2){fdn_pk_bf16(v.x, v.y), fdn_pk_bf16(v.z, v.w)};
+    f32x4 r = v - fdn_unpk_bf16(hi);
+    mid = (fdn_u32x2){fdn_pk_bf16(r.x, r.y), fdn_pk_bf16(r.z, r.w)};
+    r = r - fdn_unpk_bf16(mid);
+    lo = (fdn_u32x2){fdn_pk_bf16(r.x, r.y), fdn_pk_bf16(r.z, r.w)};
+}
+constexpr int kW2UnitS = 3072;              // bytes of one (stage, pass, kd, xw) step of a wave's split weight stream: 3 pieces x 64 lanes x 16 B
 constexpr int kW2UA = 3;                    // transform items per thread (<= 640 items = 40 rows x 16 chunks)
 constexpr int kW2RDB = 6;                   // weight-fragment ring depth
 constexpr int kW2RDA = 3;                   // cell-fragment ring depth
@@ -49,9 +90,15 @@ constexpr unsigned kW2Big = 0x40000000u;    // "reads zero": any sum containing 
 // RDB / RDA / DEP: weight-fragment ring, cell-fragment ring, staging items in flight per thread (the product values are the defaults;
 // the one-workgroup-per-CU occupancy experiment of conv64_wino2d.hip instantiates deeper ones)
 // HM: output rows per cell = the F(HM,3) transform along H (NS = HM + 2 sequential stages, Y = HM x 4 voxels per cell)
-template <bool FUSED, int HM = 2, int RDB = kW2RDB, int RDA = kW2RDA, int DEP = kW2Dep>
+// MB: 16-cell M-blocks per wave (2 = the full tile; 1 = half-size tiles: each xw keeps TWO accumulators, even / odd k-steps, so that no
+// MFMA waits for its predecessor's result -- the sum over cin is split differently, equal to the full tile to fp32 rounding)
+template <bool FUSED, int HM = 2, int RDB = kW2RDB, int RDA = kW2RDA, int DEP = kW2Dep, int MB = 2, bool SPLIT = false>
 __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int block_id, char* const smem) {
     constexpr int UA = kW2UA, SPT = 24;
+    constexpr int kW2Plane = W2Geo<MB, SPLIT>::plane;       // (shadows the full-tile constants: every row / plane offset below is the variant's own)
+    constexpr int kW2Row = W2Geo<MB, SPLIT>::row;
+    static_assert(MB == 1 || MB == 2, "one or two M-blocks per wave");
+    static_assert(!SPLIT || (HM == 4 && MB == 2), "the bf16 x 3 products exist for full F(4,3) x F(4,3) tiles");
     constexpr int NS = HM + 2;                                // stages = Winograd coordinates along H = input rows per cell
     static_assert(HM == 2 || HM == 4, "F(2,3) or F(4,3) along H");
     static_assert(HM == 2 || DEP == 1, "the F(4,3) staging holds one item in flight");
@@ -79,7 +126,7 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
     const int p0d = p.obd + tdi * p.td, p0h = p.obh + thi * p.ch * HM, p0w = p.obw + (b - thi * p.ntw) * p.cw * 4;
     const int ng = p.td * p.cpp;
 
-    if (tid < 32) {
+    if (tid < 16 * MB) {
         int g = -1, gf = -1, hw = 0;
         if (tid < ng) {
             const int md = fdn_div20(tid, p.mg_cpp);
@@ -99,9 +146,9 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
     }
 
     // ---- this lane's two cell rows (tap 0, plane xw = 0) ----
-    int abase[2];
+    int abase[MB];
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
+    for (int mb = 0; mb < MB; ++mb) {
         int m = mb * 16 + c;
         m = m < ng ? m : ng - 1;
         abase[mb] = m * kW2Row + q * 16;
@@ -166,23 +213,23 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.up, 0, NS * 18 * 64 * 64 * 4, 0x00020000);
     const int wvoff = wave * (NS * 72 * 1024) + lane * 16;
     const int bmul = (FDN_DBG_BITS(p) & 1) ? 0 : 1024;
-    f32x4 A[RDA][2], B[RDB];
+    f32x4 A[SPLIT ? 1 : RDA][MB], B[SPLIT ? 1 : RDB];
     auto ldb = [&](int slot, int xh, int kd, int j) {
         B[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, ((xh * 3 + kd) * 24 + j) * bmul, 0));
     };
     auto lda = [&](int slot, int tapb, int j) {             // tapb: byte offset of the depth tap's rows
         const int o = tapb + (j >> 2) * kW2Plane + (j & 3) * 64;
         A[slot][0] = *(const f32x4*)(smem + abase[0] + o);
-        A[slot][1] = *(const f32x4*)(smem + abase[1] + o);
+        if constexpr (MB == 2) A[slot][1] = *(const f32x4*)(smem + abase[1] + o);
     };
 
-    f32x4 Y[HM][4][2];                                       // [output row][output column][M-block]: cout 16w + 4q .. + 3 of that voxel
+    f32x4 Y[HM][4][MB];                                      // [output row][output column][M-block]: cout 16w + 4q .. + 3 of that voxel
 #pragma unroll
     for (int hr = 0; hr < HM; ++hr)
 #pragma unroll
         for (int wi = 0; wi < 4; ++wi)
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) Y[hr][wi][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int mb = 0; mb < MB; ++mb) Y[hr][wi][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int tapstep = p.cpp * kW2Row;
 
@@ -226,12 +273,86 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
         wtransform_(vp, x0, x1, x2, x3, x4, x5, false);
     };
 
+    // SPLIT: a stage = two cin passes (32 cin each) over the same planes, each folded into Y on its own (the fold is linear; accumulators
+    // that lived through both passes would sit beside the staging rows of the second: 48 registers the staging does not have)
+    constexpr int NPASS = SPLIT ? 2 : 1;
+    fdn_bf16x8 US[SPLIT ? 2 : 1][3], VS[3][2];              // SPLIT operands: weight pieces of this step and the next, cell pieces of this step
+    const int wvoff_s = wave * (NS * 2 * 18 * kW2UnitS) + lane * 16;
+    auto ldu = [&](int slot, int step) {                    // step = ((xh * 2 + pass) * 3 + kd) * 6 + xw of the wave's stream
+        const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void*)p.up, 0, 4 * NS * 2 * 18 * kW2UnitS, 0x00020000);
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+            US[SPLIT ? slot : 0][pc] = __builtin_bit_cast(fdn_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(srs, wvoff_s + pc * 1024, step * ((FDN_DBG_BITS(p) & 1) ? 0 : kW2UnitS), 0));
+    };
+    auto ldv = [&](int pc, int o) {                         // o: byte offset of (depth tap, xw plane)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) VS[pc][mb] = __builtin_bit_cast(fdn_bf16x8, *(const fdn_u32x4*)(smem + abase[mb < MB ? mb : 0] + o + pc * 64));
+    };
 #pragma unroll 1
-    for (int xh = 0; xh < NS; ++xh) {
-        if (xh) __syncthreads();                             // everyone finished reading the previous stage's planes
+    for (int ss = 0; ss < NS * NPASS; ++ss) {
+        const int xh = SPLIT ? ss >> 1 : ss;
+        if (ss) __syncthreads();                             // everyone finished reading the previous stage's planes
         // a wave whose 64 items of a pass all lie past the tile's last item requests nothing in that pass (640 items: waves 2, 3 of pass 2)
         const int items_eff = ((FDN_DBG_BITS(p) & 4) ? 0 : p.items) - __builtin_amdgcn_readfirstlane(wave) * 64;
-        if constexpr (HM == 2) {
+        if constexpr (SPLIT) {
+            // ---- stage xh, cin pass: the same V = sum_j B_h^T[xh][j] x[row j] and B_w^T as below, for 32 of the 64 input channels: items =
+            // (staged cell-plane r, 16-B chunk of 4 cin) = rows x 8 <= 320, i.e. one item per thread and 64 more, which rotate over the waves
+            // with the stage; every value is split into its three bf16 pieces on the way to LDS (row = [piece][32 cin]).  No incremental
+            // stages here: what a stage wrote is overwritten by the next cin pass. ----
+            const bool ends = xh == 0 || xh == 5;
+            const int ia = xh == 0 ? 0 : 1, ib = ends ? ia + 2 : 2, ic = ends ? ia + 4 : 3;
+            const float ca = ends ? kPp : (xh == 1 ? -kPab2 : (xh == 2 ? kPab2 : (xh == 3 ? -kPa2b : kPa2b)));
+            const float cb = ends ? -kPs : (xh <= 2 ? -kPb2 : -kPa2);
+            const float cc = ends ? 1.f : (xh == 1 ? kPa : (xh == 2 ? -kPa : (xh == 3 ? kPb : -kPb)));
+            const int wave_r = (wave_s + ss) & 3;            // scalar: the wave that takes the 64 extra items changes with the stage
+            const int items_s = ((FDN_DBG_BITS(p) & 4) ? 0 : p.rows * 8) - wave_r * 64;
+            const int lane_n = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (u * 256 >= items_s) break;
+                const int i = u * 256 + wave_r * 64 + lane_n, r = i >> 3;
+                const bool valid = r < p.rows;
+                const unsigned* pr = ptab + (valid ? r : 0) * 12;
+                const unsigned chunkb = (unsigned)((ss & 1) * 128 + (i & 7) * 16);
+                const unsigned ha = pr[ia] + chunkb, hb = pr[ib] + chunkb, hc = pr[ic] + chunkb, hd = pr[4] + chunkb;
+                const unsigned wo[6] = {pr[6], pr[7], pr[8], pr[9], pr[10], pr[11]};
+                f32x4 xa[6], xb[6], v[6];
+#pragma unroll
+                for (int ii = 0; ii < 6; ++ii) {
+                    xa[ii] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ha + wo[ii], 0, 0));
+                    xb[ii] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, hb + wo[ii], 0, 0));
+                }
+#pragma unroll
+                for (int ii = 0; ii < 6; ++ii) v[ii] = ca * xa[ii] + cb * xb[ii];
+                if (ends) {
+#pragma unroll
+                    for (int ii = 0; ii < 6; ++ii) xa[ii] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, hc + wo[ii], 0, 0));
+#pragma unroll
+                    for (int ii = 0; ii < 6; ++ii) v[ii] += xa[ii];
+                } else {
+#pragma unroll
+                    for (int ii = 0; ii < 6; ++ii) {
+                        xa[ii] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, hc + wo[ii], 0, 0));
+                        xb[ii] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, hd + wo[ii], 0, 0));
+                    }
+#pragma unroll
+                    for (int ii = 0; ii < 6; ++ii) v[ii] += cc * xa[ii] + xb[ii];
+                }
+                if (!valid) continue;
+                char* vp = smem + r * kW2Row + (i & 7) * 8;
+                const f32x4 t1 = v[4] - kPb2 * v[2], t2 = kPa * v[3] - kPab2 * v[1];
+                const f32x4 t3 = v[4] - kPa2 * v[2], t4 = kPb * v[3] - kPa2b * v[1];
+                const f32x4 o[6] = {kPp * v[0] - kPs * v[2] + v[4], t1 + t2, t1 - t2, t3 + t4, t3 - t4, kPp * v[1] - kPs * v[3] + v[5]};
+#pragma unroll
+                for (int xw = 0; xw < 6; ++xw) {
+                    fdn_u32x2 hi, mid, lo;
+                    fdn_split3(o[xw], hi, mid, lo);
+                    *(fdn_u32x2*)(vp + xw * kW2Plane) = hi;
+                    *(fdn_u32x2*)(vp + xw * kW2Plane + 64) = mid;
+                    *(fdn_u32x2*)(vp + xw * kW2Plane + 128) = lo;
+                }
+            }
+        } else if constexpr (HM == 2) {
             // ---- stage xh: V = x[ra] + sgn * x[rb], rows (0,2,-) (1,2,+) (1,2,-) (1,3,-); then B_w^T; all 64 cin ----
             const float sgn = xh == 1 ? 1.f : -1.f;
             f32x4 xa[DEP][6], xb[DEP][6];
@@ -330,8 +451,11 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
         }
         // the weight ring is primed per stage, behind the staging (its registers are free for the input rows meanwhile) and
         // ahead of the barrier (whose wait covers the L2 round trip)
+        if constexpr (SPLIT) ldu(0, ss * 18);
+        else {
 #pragma unroll
-        for (int j = 0; j < RDB - 1; ++j) ldb(j, xh, 0, j);
+            for (int j = 0; j < RDB - 1; ++j) ldb(j, xh, 0, j);
+        }
         __syncthreads();
 
         // ---- K loop of the stage: 3 depth taps x (6 xw x 4 cin groups) ----
@@ -341,6 +465,45 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
             acc[xi][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
             acc[xi][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
+        if constexpr (SPLIT) {
+            // one step = (kd, xw): 32 cin x 6 terms x 2 M-blocks = 12 MFMAs of 16 cycles, fed by 3 weight pieces (16 B per lane each, L1/L2;
+            // requested a step ahead into the other half of US) and 3 x 2 cell pieces (ds_read_b128; each re-requested right behind its last use)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) ldv(pc, 0);
+#pragma unroll 1
+            for (int kd = 0; kd < 3; ++kd) {
+                const bool last = kd == 2;
+                const int tapb = kd * tapstep, tapb_n = last ? tapb : tapb + tapstep;
+                const int st0 = (ss * 3 + kd) * 6, st0_n = last ? st0 : st0 + 6;       // the last tap re-requests its own first step (never used)
+#pragma unroll
+                for (int xw = 0; xw < 6; ++xw) {
+                    const int su = xw & 1;
+                    const int vo_n = xw < 5 ? tapb + (xw + 1) * kW2Plane : tapb_n;
+                    auto mm = [&](int pu, int pv) {
+                        acc[xw][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(US[su][pu], VS[pv][0], acc[xw][0], 0, 0, 0);
+                        acc[xw][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(US[su][pu], VS[pv][1], acc[xw][1], 0, 0, 0);
+                    };
+                    mm(0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ldu(su ^ 1, xw < 5 ? st0 + xw + 1 : st0_n);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(1, 0);
+                    mm(2, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ldv(0, vo_n);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(0, 1);
+                    mm(1, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ldv(1, vo_n);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(0, 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ldv(2, vo_n);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < RDA - 1; ++j) lda(j, 0, j);
 #pragma unroll 1
@@ -363,14 +526,21 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
                     else lda(ja % RDA, tapb_n, ja - SPT);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(B[sb][0], A[sa][1][0], acc[xi][1], 0, 0, 0);
+                if constexpr (MB == 2) {
+                    acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(B[sb][0], A[sa][1][0], acc[xi][1], 0, 0, 0);
 #pragma unroll
-                for (int s = 1; s < 4; ++s) {
-                    acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(B[sb][s], A[sa][0][s], acc[xi][0], 0, 0, 0);
-                    acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(B[sb][s], A[sa][1][s], acc[xi][1], 0, 0, 0);
+                    for (int s = 1; s < 4; ++s) {
+                        acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(B[sb][s], A[sa][0][s], acc[xi][0], 0, 0, 0);
+                        acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(B[sb][s], A[sa][1][s], acc[xi][1], 0, 0, 0);
+                    }
+                } else {                                     // one M-block: k-steps alternate between the two accumulators of the xw
+                    acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(B[sb][1], A[sa][0][1], acc[xi][1], 0, 0, 0);
+                    acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(B[sb][2], A[sa][0][2], acc[xi][0], 0, 0, 0);
+                    acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(B[sb][3], A[sa][0][3], acc[xi][1], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
         }
 
         // ---- fold the stage: t = A_w^T M[xh] (A_w^T = (1,1,1,1,1,0) (0,a,-a,b,-b,0) (0,a2,a2,b2,b2,0) (0,a3,-a3,b3,-b3,1); HM = 2: a = 1, b = 2),
@@ -389,8 +559,12 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
             ch[2] = mid ? m * m : 0.f;
             ch[3] = mid ? sg * m * m * m : (xh == 5 ? 1.f : 0.f);
         }
+        if constexpr (MB == 1) {
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
+            for (int xi = 0; xi < 6; ++xi) acc[xi][0] += acc[xi][1];
+        }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
             const f32x4 s12 = acc[1][mb] + acc[2][mb], d12 = acc[1][mb] - acc[2][mb];
             const f32x4 s34 = acc[3][mb] + acc[4][mb], d34 = acc[3][mb] - acc[4][mb];
             f32x4 t[4];
@@ -429,10 +603,10 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
     // wave pays the prefetch's HBM round trip, as much as the epilogue then saves: fwd + residual 0.528 with vs 0.521 ms without.)
     const int opmask = (FDN_DBG_BITS(p) & 32) ? 255 : -1;
     constexpr int HG = HM == 2 ? 2 : (FUSED ? 1 : 2);
-    constexpr int GPB = HM / HG, NG = 2 * GPB;                // groups per M-block, groups
-    int g0[2];
+    constexpr int GPB = HM / HG, NG = MB * GPB;               // groups per M-block, groups
+    int g0[MB];
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) g0[mb] = mtab[mb * 16 + c_e];
+    for (int mb = 0; mb < MB; ++mb) g0[mb] = mtab[mb * 16 + c_e];
     if (FUSED) {
         // dgrad on the inner box of the padded grid: voxels strictly inside the volume get exactly one contribution and are finished
         // here (dz_prev = (dgrad + skip) * act'(y)); surface voxels go to the padded scratch for the border fold.  Branch-free per

@@ -158,7 +158,11 @@ class FlowNetModel:
         self.batch_wgrad = os.environ.get("FDN_BATCH_WGRAD", "1") not in ("", "0")
         self.batch_wgrad_max_voxels = 1 << 18          # per launch; the 48^3 layers of cfg2 (8 x 110 592 voxels) fill the chip on their own
         self._wg_pending = []
-        self.overlap_wgrad = os.environ.get("FDN_OVERLAP_WGRAD", "0") not in ("", "0")     # measured +0.7 % at cfg2 (kernels already fill the chip); off so per-kernel timings stay clean
+        # weight gradients on a second HIP stream (they are leaves of the backward graph: they fill the tails of the dgrad launches and
+        # the gaps the thin kernels leave; bit-identical results).  FDN_OVERLAP_WGRAD=0 issues everything on one stream -- what a
+        # per-kernel timing pass wants (bench.py takes its HIP-event pass that way, in steps of its own).
+        self.overlap_wgrad = os.environ.get("FDN_OVERLAP_WGRAD", "1") not in ("", "0")
+        self._ws_side = None           # the side stream's own workspace (allocated and re-allocated under that stream: see _workspace)
         self._cache = None
         # Gradient buckets in the order backward() completes them: slices [lo, hi) of flat_g_ext that are final when the hi-res part
         # (heads + hi-res blocks, together with the trailing batch slot), the upper half of the low-res blocks and the rest are done.
@@ -182,12 +186,13 @@ class FlowNetModel:
         """See __init__.  Takes effect from the next forward()."""
         if conv_algo is None:
             conv_algo = os.environ.get("FDN_CONV_ALGO", "auto")
-        names = {"auto": ops.ALGO_AUTO, "winograd": ops.ALGO_AUTO, "direct": ops.ALGO_DIRECT, "winograd_w": ops.ALGO_WINO_W, "winograd_h2": ops.ALGO_WINO_H2}
+        names = {"auto": ops.ALGO_AUTO, "winograd": ops.ALGO_AUTO, "direct": ops.ALGO_DIRECT, "winograd_w": ops.ALGO_WINO_W, "winograd_h2": ops.ALGO_WINO_H2,
+                 "winograd_bf16x3": ops.ALGO_WINO_BF16X3}
         per_layer = {}
         if isinstance(conv_algo, dict):
             per_layer, conv_algo = conv_algo, conv_algo.get("*", "auto")
         if conv_algo not in names or any(v not in names for v in per_layer.values()):
-            raise ValueError("conv_algo must be 'auto', 'direct', 'winograd_w' or {layer name: one of these}")
+            raise ValueError("conv_algo must be 'auto', 'winograd_bf16x3', 'winograd_h2', 'winograd_w', 'direct' or {layer name: one of these}")
         known = set(L.name for L in self.layers)
         unknown = [k for k in per_layer if k != "*" and k not in known]
         if unknown:
@@ -399,7 +404,15 @@ class FlowNetModel:
         return np.concatenate(outs, axis=0)
 
     # ------------------------------------------------------------------ backward
-    def _workspace(self, nbytes):
+    def _workspace(self, nbytes, side=False):
+        """Scratch of the weight-gradient launches.  One block per stream, each allocated (and, when a later layer needs more,
+        re-allocated) while ITS stream is current: the caching allocator then hands a freed block only to later work of the same
+        stream, i.e. behind the kernels that may still be using it."""
+        if side:
+            if self._ws_side is None or self._ws_side.numel() * 4 < nbytes:
+                with torch.cuda.stream(self._side):
+                    self._ws_side = torch.empty((nbytes + 3) // 4, device=self.device, dtype=torch.float32)
+            return self._ws_side
         if self._ws is None or self._ws.numel() * 4 < nbytes:
             self._ws = torch.empty((nbytes + 3) // 4, device=self.device, dtype=torch.float32)
         return self._ws
@@ -411,18 +424,19 @@ class FlowNetModel:
         N, D, H, W = x.shape[:4]
         if (self.batch_wgrad and (L.k, L.cin, L.cout) == (3, 64, 64) and x2 is None and lddz is None and
                 N * D * H * W <= self.batch_wgrad_max_voxels and
-                (self.dtype != "float32" or self.conv_algo[L.name] in (ops.ALGO_AUTO, ops.ALGO_WINO_H2))):
+                (self.dtype != "float32" or self.conv_algo[L.name] in (ops.ALGO_AUTO, ops.ALGO_WINO_H2, ops.ALGO_WINO_BF16X3))):
             self._wg_pending.append((x, dz, L, bias))        # issued by _flush_wgrads() at the end of the gradient bucket
             return
-        ws = self._workspace(self.ops.wgrad_workspace_bytes(N, D, H, W, L.cin, L.cout, L.k))
+        nws = self.ops.wgrad_workspace_bytes(N, D, H, W, L.cin, L.cout, L.k)
         if not self.overlap_wgrad:
-            self.ops.conv3d_wgrad(x, dz, L.k, L.cin, L.cout, x2=x2, dw=L.gw, dbias=L.gb if bias else None, workspace=ws, lddz=lddz,
-                             dz_coff=dz_coff, algo=self.conv_algo[L.name])
+            self.ops.conv3d_wgrad(x, dz, L.k, L.cin, L.cout, x2=x2, dw=L.gw, dbias=L.gb if bias else None, workspace=self._workspace(nws),
+                             lddz=lddz, dz_coff=dz_coff, algo=self.conv_algo[L.name])
             return
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
         main = torch.cuda.current_stream()
-        self._side.wait_stream(main)                      # dz (and the workspace allocation) are ready
+        self._side.wait_stream(main)                      # dz is ready
+        ws = self._workspace(nws, side=True)
         with torch.cuda.stream(self._side):
             self.ops.conv3d_wgrad(x, dz, L.k, L.cin, L.cout, x2=x2, dw=L.gw, dbias=L.gb if bias else None, workspace=ws, lddz=lddz,
                              dz_coff=dz_coff, algo=self.conv_algo[L.name])
@@ -446,10 +460,10 @@ class FlowNetModel:
             with torch.cuda.stream(self._side) if side else contextlib.nullcontext():
                 if len(items) == 1:
                     x, dz, L, bias = items[0]
-                    ws = self._workspace(self.ops.wgrad_workspace_bytes(N, D, H, W, 64, 64, 3))
+                    ws = self._workspace(self.ops.wgrad_workspace_bytes(N, D, H, W, 64, 64, 3), side=side)
                     self.ops.conv3d_wgrad(x, dz, 3, 64, 64, dw=L.gw, dbias=L.gb if bias else None, workspace=ws, algo=algo)
                 else:
-                    ws = self._workspace(self.ops.wgrad_batch_workspace_bytes(len(items), N, D, H, W))
+                    ws = self._workspace(self.ops.wgrad_batch_workspace_bytes(len(items), N, D, H, W), side=side)
                     self.ops.conv3d_wgrad_batch([i[0] for i in items], [i[1] for i in items], [i[2].gw for i in items],
                                                 [i[2].gb if i[3] else None for i in items], workspace=ws, algo=algo)
             if side:

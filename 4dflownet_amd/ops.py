@@ -9,9 +9,12 @@ from ._lib import FdnError, check
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 # FDN_ALGO_*: per-call algorithm of the 64->64 3x3x3 entry points (AUTO = Winograd along W when W % 4 == 0, DIRECT = never)
-ALGO_AUTO, ALGO_DIRECT, ALGO_WINO_W, ALGO_WINO_H2 = 0, 1, 2, 3
+# ALGO_WINO_BF16X3: like AUTO, the F(4,3)xF(4,3) products on the bf16 matrix pipe (operands split exactly into 3 bf16 pieces, 6 terms, fp32 accumulation)
+ALGO_AUTO, ALGO_DIRECT, ALGO_WINO_W, ALGO_WINO_H2, ALGO_WINO_BF16X3 = 0, 1, 2, 3, 4
 LEAKY_ALPHA = 0.2
-CONV64_PACK_FLOATS = 261 * 64 * 64    # FDN_CONV64_PACK_FLOATS: direct stream (27 taps) + Winograd F(4,3) stream (54) + 2-D F(2,3)xF(4,3) stream (72)
+# FDN_CONV64_PACK_FLOATS (mirrored; _lib.load() checks fdn_version() against FDN_VERSION below): direct stream (27 taps) + Winograd F(4,3)
+# stream (54) + 2-D F(2,3)xF(4,3) stream (72) + 2-D F(4,3)xF(4,3) stream (108) + the same as three bf16 pieces per value (162 float-sized slots)
+CONV64_PACK_FLOATS = 423 * 64 * 64
 
 
 def _p(t, name="tensor", allow_none=False):
@@ -283,7 +286,8 @@ def pack_conv64_weights_batch(w_flat, w_offsets, packs, streams=None):
     return packs
 
 
-PACK_STREAM_ALL = 15
+PACK_STREAM_DIRECT, PACK_STREAM_WINO_W, PACK_STREAM_WINO_H2, PACK_STREAM_WINO_H4, PACK_STREAM_WINO_H4S = 1, 2, 4, 8, 16
+PACK_STREAM_ALL = 31
 ROLE_FWD, ROLE_DGRAD, ROLE_DGRAD_FUSED = 0, 1, 2
 
 

@@ -325,7 +325,8 @@ def roofline_obj(timer, kind, bf16, kernel, traffic_files):
             "traffic": traffic,
             "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)" if tfile else None, "traffic_source": tfile,
             "algorithmic_bytes_per_launch": alg, "launches_timed": n_launch, "avg_launch_ms": avg_ms,
-            "timing": "HIP events on the launch stream around every launch of the sampled timed steps (--event-every)",
+            "timing": "HIP events on the launch stream around every launch of --event-steps steps run right behind the timed region with every launch "
+                      "on ONE stream (FDN_OVERLAP_WGRAD=0 semantics: the timed steps overlap the weight gradients with the dgrad chain on a second stream)",
             "executed_gflop_per_launch": avg_exec / 1e9,
             # the direct 3x3x3 algorithm's FLOPs (221 184 per voxel) over the same launch time: what the contract calls
             # ALGORITHMIC work.  > peak when the kernel executes fewer multiplies than the direct algorithm (fp32: Winograd along W)
@@ -335,6 +336,24 @@ def roofline_obj(timer, kind, bf16, kernel, traffic_files):
                                       "2-D F(4,3)xF(4,3), a quarter of the direct algorithm's multiplies; wgrad: F(3,2) along D x F(3,4) along W, a third) = matrix-pipe "
                                       "utilisation; PMC SQ_VALU_MFMA_BUSY_CYCLES agrees (profiles/README.md).  algorithmic_* prices the same "
                                       "launches with the direct 3x3x3 FLOP count of SURVEY 8d and therefore exceeds the peak"}
+
+
+def event_pass(tc, batch, timer, steps):
+    """`steps` train steps with the weight gradients on the main stream and the LaunchTimer on; returns their mean wall time (ms)."""
+    ov = tc.model.overlap_wgrad
+    tc.model.overlap_wgrad = False
+    try:
+        tc.train_step(batch)
+        torch.cuda.synchronize()
+        timer.enabled = True
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tc.train_step(batch)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / max(steps, 1) * 1e3
+    finally:
+        timer.enabled = False
+        tc.model.overlap_wgrad = ov
 
 
 def timed_steps(step_fn, steps, warmup, parallel):
@@ -477,14 +496,13 @@ def secondary_runs(trainer, parallel, device, P, R, B, LB, HB, sustained_steps=3
         for _ in range(2):
             tc.train_step(batch)
         torch.cuda.synchronize()
-        timer.enabled = True
         steps = 5
         t0 = time.perf_counter()
         for _ in range(steps):
             tc.train_step(batch)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        timer.enabled = False
+        event_pass(tc, batch, timer, 3)
         timer.uninstall()
         f4 = fwd_flop_per_patch(tc.model.specs, P4, R4, LB)
         sec["cfg4_bf16"] = {"value": steps * B4 / dt, "unit": "patches/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
@@ -668,7 +686,8 @@ def main():
                     help="cfg2 = the headline workload (defaults above); cfg4 = patch 32, res x4, batch 4, bf16 (secondary metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
-    ap.add_argument("--event-every", type=int, default=4, help="bracket the conv launches with HIP events in every K-th timed step (1 = all)")
+    ap.add_argument("--event-steps", type=int, default=5,
+                    help="steps of the per-kernel pass behind the timed region: every 64->64 launch bracketed by HIP events, all launches on ONE stream")
     ap.add_argument("--sustained-steps", type=int, default=300, help="length of the secondary `sustained` run (N=1)")
     ap.add_argument("--single-allreduce", action="store_true",
                     help="N>1: ONE all-reduce of the whole gradient buffer after backward instead of the three buckets started inside it")
@@ -724,15 +743,16 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        # HIP events bracket every 64->64 launch of every `--event-every`-th timed step (default 4): 180 event records per step cost
-        # 0.4 ms of a 36 ms step, so the roofline figures sample the timed region instead of taxing all of it
-        timer.enabled = i % max(1, args.event_every) == 0
         tc.train_step(batch)
     torch.cuda.synchronize()
     dt_local = time.perf_counter() - t0               # this rank's own work is done (before the closing barrier)
     parallel.barrier()
     dt = time.perf_counter() - t0
-    timer.enabled = False
+    # The per-kernel pass, in steps of its own BEHIND the timed region: the product step runs the weight gradients on a second
+    # stream beside the dgrad chain (network.overlap_wgrad), and an event pair around a launch that shares the chip with another
+    # stream's kernel times neither.  Here everything is issued on one stream and every 64->64 launch is bracketed by HIP events
+    # on it; same kernels, same operands, same order within each stream as the timed steps.
+    per_kernel_ms = event_pass(tc, batch, timer, args.event_steps)
     timer.uninstall()
 
     dt = parallel.allreduce_sum_host([dt], op="max")[0]
@@ -767,6 +787,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step_one_stream": per_kernel_ms,          # the per-kernel pass (event records included): what the overlap buys is the difference
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

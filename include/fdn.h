@@ -52,15 +52,23 @@ extern "C" {
  *   FDN_ALGO_DIRECT : always the direct convolution (plain fp32 FMA chains over the 27 taps, no transform) -- for
  *                     parity-critical runs and for layers whose operands are too ill-conditioned for the transform;
  *   FDN_ALGO_WINO_W : Winograd along W only (the 1-D kernels), never the H transform;
- *   FDN_ALGO_WINO_H2: like AUTO, but never more than F(2,3) along H (round 4's kernels; a third of the error of F(4,3) x F(4,3)). */
+ *   FDN_ALGO_WINO_H2: like AUTO, but never more than F(2,3) along H (round 4's kernels; a third of the error of F(4,3) x F(4,3));
+ *   FDN_ALGO_WINO_BF16X3: like AUTO, but where AUTO takes F(4,3) x F(4,3) (forward, dgrad inner box) the Winograd-domain products run
+ *                     on the bf16 matrix pipe: both operands (fp32, transformed exactly as under AUTO) are split EXACTLY into three
+ *                     bf16 pieces v = hi + mid + lo, and the six cross terms hi.hi, mid.hi, lo.hi, hi.mid, mid.mid, hi.lo are
+ *                     accumulated in fp32 (a bf16 x bf16 product is exact in fp32; the three dropped terms are <= 2^-25 |u||v|, below
+ *                     the half ulp an fp32 multiply rounds away).  Inputs, outputs, transforms and accumulation stay fp32.  Every
+ *                     other grid and the weight gradient behave as under AUTO. */
 #define FDN_ALGO_AUTO 0
 #define FDN_ALGO_DIRECT 1
 #define FDN_ALGO_WINO_W 2
 #define FDN_ALGO_WINO_H2 3
+#define FDN_ALGO_WINO_BF16X3 4
+#define FDN_ALGO_LAST FDN_ALGO_WINO_BF16X3
 
 /* Version of this header; fdn_version() returns the version the library was built from.  A caller must see the two equal:
- * 140 -> 150 grew FDN_CONV64_PACK_FLOATS (a pack buffer sized by an older header is too small for this library). */
-#define FDN_VERSION 150
+ * 140 -> 150 and 150 -> 160 grew FDN_CONV64_PACK_FLOATS (a pack buffer sized by an older header is too small for this library). */
+#define FDN_VERSION 160
 int fdn_version(void);
 const char* fdn_last_error(void);
 
@@ -74,16 +82,17 @@ int fdn_input_features(const float* u, const float* v, const float* w, const flo
  * Cin/Cout swapped).  Each output is FDN_CONV64_PACK_FLOATS floats: the direct-convolution stream
  * (27 taps), the Winograd F(4,3)-along-W stream U = G g (9 (kd,kh) taps x 6 transform coordinates)
  * and the two 2-D streams U = Gh g Gw^T (3 kd taps x 4 x 6 coordinates for F(2,3) along H, 3 x 6 x 6
- * for F(4,3) along H); the conv entry points select among them by the extents (see FDN_ALGO_*).
+ * for F(4,3) along H), and the F(4,3) x F(4,3) stream once more as three bf16 pieces per value (FDN_ALGO_WINO_BF16X3:
+ * 162 * 4096 float-sized slots); the conv entry points select among them by the extents (see FDN_ALGO_*).
  * Either output may be NULL. */
-#define FDN_CONV64_PACK_FLOATS (261 * 64 * 64)
+#define FDN_CONV64_PACK_FLOATS (423 * 64 * 64)
 int fdn_pack_conv64_weights(const float* w, float* wp_fwd, float* wp_dgrad, void* stream);
 /* The same for n_layers kernels in ONE launch (after every optimizer step): layer i lives at
  * w_base + w_offsets[i] (w_offsets: DEVICE array of n_layers float offsets), its two streams at
  * packs + i * 2 * FDN_CONV64_PACK_FLOATS (forward stream first, dgrad stream second). */
 int fdn_pack_conv64_weights_batch(const float* w_base, const int64_t* w_offsets, int n_layers, float* packs,
                                   void* stream);
-/* A pack holds four streams and a given grid reads one or two of them.  fdn_conv64_pack_streams says which: the streams
+/* A pack holds five streams and a given grid reads one or two of them.  fdn_conv64_pack_streams says which: the streams
  * (FDN_PACK_STREAM_* bits) that fdn_conv3d_fwd (role FDN_ROLE_FWD, reads wp_fwd), fdn_conv3d_dgrad (FDN_ROLE_DGRAD) or
  * fdn_conv3d_dgrad_fused[_part] (FDN_ROLE_DGRAD_FUSED; both read wp_dgrad) read for a 64->64 layer on an (N,D,H,W) grid
  * under `algo` -- answered by the launcher's own selection code, so it cannot drift from it; negative = error code.
@@ -95,7 +104,8 @@ int fdn_pack_conv64_weights_batch(const float* w_base, const int64_t* w_offsets,
 #define FDN_PACK_STREAM_WINO_W 2
 #define FDN_PACK_STREAM_WINO_H2 4
 #define FDN_PACK_STREAM_WINO_H4 8
-#define FDN_PACK_STREAM_ALL 15
+#define FDN_PACK_STREAM_WINO_H4S 16 /* F(4,3) x F(4,3), three bf16 pieces per value (FDN_ALGO_WINO_BF16X3) */
+#define FDN_PACK_STREAM_ALL 31
 #define FDN_ROLE_FWD 0
 #define FDN_ROLE_DGRAD 1
 #define FDN_ROLE_DGRAD_FUSED 2

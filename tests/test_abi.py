@@ -21,7 +21,7 @@ def test_library_builds_and_exports_every_declared_symbol(fdn):
         assert hasattr(lib, name), "missing export %s" % name
     # the ctypes table covers exactly the declared API
     assert declared == set(fdn._lib.SIGNATURES), declared ^ set(fdn._lib.SIGNATURES)
-    assert fdn._lib.load().fdn_version() == 150          # == FDN_VERSION of include/fdn.h (the C link test below prints the header's)
+    assert fdn._lib.load().fdn_version() == 160 == fdn._lib.FDN_VERSION          # == FDN_VERSION of include/fdn.h (the C link test below prints the header's)
     # the product library carries no process-global switches (include/fdn.h: "no global mutable state"); the variant-forcing
     # hooks live in the test build only, which exports the full API as well
     exported = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
@@ -55,7 +55,7 @@ def test_header_is_plain_c_and_links_from_c(fdn, tmp_path):
                    '    /* every prototype is visible to C: take the address of a few */\n'
                    '    int (*f)(const float*, float*, float*, void*) = fdn_pack_conv64_weights;\n'
                    '    size_t (*g)(int, int, int, int, int, int, int) = fdn_conv3d_wgrad_workspace_bytes;\n'
-                   '    printf("%d %d %d %s\\n", fdn_version() == FDN_VERSION ? FDN_VERSION : -1, f != 0, (int)(g(8, 24, 24, 24, 64, 64, 3) > 0), FDN_CONV64_PACK_FLOATS == 261 * 4096 ? "ok" : "bad");\n'
+                   '    printf("%d %d %d %s\\n", fdn_version() == FDN_VERSION ? FDN_VERSION : -1, f != 0, (int)(g(8, 24, 24, 24, 64, 64, 3) > 0), FDN_CONV64_PACK_FLOATS == 423 * 4096 ? "ok" : "bad");\n'
                    '    /* an argument error comes back as a code + message, not as an exception */\n'
                    '    int rc = fdn_l2_sumsq(0, 0, 0, 0, 0);\n'
                    '    printf("%d %s\\n", rc, fdn_last_error());\n'
@@ -67,7 +67,7 @@ def test_header_is_plain_c_and_links_from_c(fdn, tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     lines = out.stdout.splitlines()
-    assert lines[0].split()[1:] == ["1", "1", "ok"] and int(lines[0].split()[0]) == 150
+    assert lines[0].split()[1:] == ["1", "1", "ok"] and int(lines[0].split()[0]) == 160
     assert lines[1].startswith("-1 ") and "fdn_l2_sumsq" in lines[1]
 
 

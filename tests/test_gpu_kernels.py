@@ -105,10 +105,12 @@ def test_conv64_fwd_wino2d(ops, fdn, shape, tile):
                 got = ops.conv3d_fwd(dev(x), dev(w), None if bias is None else dev(bias), act, 0.2,
                                      None if r is None else dev(r), algo=ops.ALGO_AUTO)
                 close(got, ref, name="conv64 fwd 2-D winograd act=%d" % act)
-                for algo in (ops.ALGO_WINO_H2, ops.ALGO_WINO_W, ops.ALGO_DIRECT):
+                for algo in (ops.ALGO_WINO_H2, ops.ALGO_WINO_W, ops.ALGO_DIRECT, ops.ALGO_WINO_BF16X3):
                     other = ops.conv3d_fwd(dev(x), dev(w), None if bias is None else dev(bias), act, 0.2,
                                            None if r is None else dev(r), algo=algo)
                     close(got, other.cpu().numpy(), name="2-D winograd vs algo %d" % algo)
+                    if algo == ops.ALGO_WINO_BF16X3:         # the bf16 x 3 products against the oracle itself (F(4,3) x F(4,3) grids; else = AUTO)
+                        close(other, ref, name="conv64 fwd 2-D winograd, bf16 x 3 products, act=%d" % act)
         finally:
             if lib is not None:
                 lib.fdn_debug_set_conv64_wino2d_tile(0)
@@ -181,6 +183,10 @@ def test_conv64_dgrad_fused_fold(ops, fdn, shape, layout):
                 ops.conv3d_dgrad_fused(dev(dz), wd, pad, out, skip=dev(skip), y_prev=dev(y), act=O.ACT_LEAKY, algo=ops.ALGO_WINO_H2)
                 ops.fold_halo_border([pad], out, dev(skip), dev(y), O.ACT_LEAKY)
                 close(out, O.act_bwd_from_output(dx + skip, y, O.ACT_LEAKY), name="fused dgrad+border, F(2,3) along H")
+                pad.fill_(float("nan")); out.fill_(float("nan"))  # and the F(4,3) x F(4,3) inner box with the bf16 x 3 products
+                ops.conv3d_dgrad_fused(dev(dz), wd, pad, out, skip=dev(skip), y_prev=dev(y), act=O.ACT_LEAKY, algo=ops.ALGO_WINO_BF16X3)
+                ops.fold_halo_border([pad], out, dev(skip), dev(y), O.ACT_LEAKY)
+                close(out, O.act_bwd_from_output(dx + skip, y, O.ACT_LEAKY), name="fused dgrad+border, bf16 x 3 products")
             # fan-in of three consumers chained through the output buffer (skip aliases out), mask on the last
             acc = torch.full((N, D, H, W, 64), float("nan"), device="cuda")
             pads = [torch.empty_like(pad) for _ in range(3)]
@@ -229,7 +235,8 @@ def test_conv64_wgrad_batch(ops, shape, nl):
 
 
 @pytest.mark.parametrize("shape,algo", [(sh, 0) for sh in [(1, 5, 8, 12), (2, 9, 2, 24), (1, 1, 2, 4), (3, 24, 24, 24), (1, 11, 14, 28), (1, 7, 12, 20), (1, 1, 4, 4)]] +
-                         [(sh, 3) for sh in [(1, 5, 8, 12), (3, 24, 24, 24)]])       # algo 3 = FDN_ALGO_WINO_H2 where AUTO takes F(4,3) along H
+                         [(sh, 3) for sh in [(1, 5, 8, 12), (3, 24, 24, 24)]] +      # algo 3 = FDN_ALGO_WINO_H2 where AUTO takes F(4,3) along H
+                         [(sh, 4) for sh in [(1, 5, 8, 12), (3, 24, 24, 24), (1, 7, 12, 20)]])   # algo 4 = FDN_ALGO_WINO_BF16X3: the same inner box with the bf16 x 3 products
 def test_conv64_dgrad_fused_one_launch_equals_two(ops, fdn, shape, algo):
     """The fused dgrad of the 2-D Winograd path is ONE launch (conv64_wino2d_shell_kernel: inner box on the 2-D body, shell faces behind
     it on the 1-D body).  It must be bit-identical to the same two bodies as two launches (test-build switch), and to the two `parts` a

@@ -36,13 +36,13 @@ def main():
         res = torch.randn(N, P, P, P, 64, device="cuda", generator=g)
         out = torch.empty_like(x)
         flop = 2.0 * 27 * 64 * 64 * N * P ** 3
-        for name, algo in (("2-D F(4,3)xF(4,3)", ops.ALGO_AUTO), ("2-D F(2,3)xF(4,3)", ops.ALGO_WINO_H2), ("1-D F(4,3)", ops.ALGO_WINO_W), ("direct", ops.ALGO_DIRECT)):
+        for name, algo in (("2-D F(4,3)xF(4,3)", ops.ALGO_AUTO), ("2-D F(4,3)^2 bf16x3", ops.ALGO_WINO_BF16X3), ("2-D F(2,3)xF(4,3)", ops.ALGO_WINO_H2), ("1-D F(4,3)", ops.ALGO_WINO_W), ("direct", ops.ALGO_DIRECT)):
             t = timeit(lambda: ops.conv3d_fwd(x, w, None, ops.ACT_RELU, wpack=wp, out=out, algo=algo))
             t2 = timeit(lambda: ops.conv3d_fwd(x, w, None, ops.ACT_LEAKY, residual=res, wpack=wp, out=out, algo=algo))
             print("fwd %-20s N=%d P=%d : %.3f ms (%.1f TF algorithmic)   +res+leaky %.3f ms" % (name, N, P, t, flop / t / 1e9, t2), flush=True)
         pad = torch.empty(N, P + 2, P + 2, P + 2, 64, device="cuda")
         dxo = torch.empty_like(x)
-        for name, algo in (("F(4,3)^2 inner + 1-D shell", ops.ALGO_AUTO), ("F(2,3)xF(4,3) inner + 1-D shell", ops.ALGO_WINO_H2), ("1-D F(4,3), one launch", ops.ALGO_WINO_W)):
+        for name, algo in (("F(4,3)^2 inner + 1-D shell", ops.ALGO_AUTO), ("F(4,3)^2 bf16x3 inner + 1-D shell", ops.ALGO_WINO_BF16X3), ("F(2,3)xF(4,3) inner + 1-D shell", ops.ALGO_WINO_H2), ("1-D F(4,3), one launch", ops.ALGO_WINO_W)):
             t = timeit(lambda: (ops.conv3d_dgrad_fused(x, wd, pad, dxo, skip=res, y_prev=out, act=ops.ACT_LEAKY, algo=algo),
                                 ops.fold_halo_border([pad], dxo, res, out, ops.ACT_LEAKY)))
             ti = timeit(lambda: ops.conv3d_dgrad_fused(x, wd, pad, dxo, skip=res, y_prev=out, act=ops.ACT_LEAKY, parts=1, algo=algo))
@@ -66,7 +66,8 @@ def main():
                 for bits, what in ((0, "full"), (4, "no staging"), (8, "no epilogue"), (1, "weights from one unit"), (13, "K loop only"), (128, "no XCD remap"), (16, "stages 2, 4 from own rows")):
                     lib.fdn_debug_set_conv64_wino2d_dbg(bits)
                     t = timeit(lambda: ops.conv3d_fwd(x, w, None, ops.ACT_RELU, wpack=wp, out=out))
-                    print("   2-D ablation %-22s: %.3f ms" % (what, t), flush=True)
+                    ts = timeit(lambda: ops.conv3d_fwd(x, w, None, ops.ACT_RELU, wpack=wp, out=out, algo=ops.ALGO_WINO_BF16X3))
+                    print("   2-D ablation %-22s: %.3f ms   bf16x3: %.3f ms" % (what, t, ts), flush=True)
                 lib.fdn_debug_set_conv64_wino2d_dbg(0)
                 for td, ch, cw in ((8, 2, 2), (8, 1, 4), (8, 4, 1), (16, 2, 1), (16, 1, 2), (12, 2, 1), (6, 2, 2), (4, 2, 2)):
                     lib.fdn_debug_set_conv64_wino2d_tile(td | ch << 8 | cw << 16)

@@ -1,0 +1,5 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 600 python tools/bench_wino2d.py --ablate 2>&1 | grep -v "2-D tile\|wgrad\|1-D\|direct\|F(2,3)" > gpurun_out/r6_bench_wino2d_b.txt 2>&1
+cat gpurun_out/r6_bench_wino2d_b.txt
