@@ -716,7 +716,7 @@ int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, 
         if (const int hm = (parts & 1) ? hm_for(IH, IW) : 0) {
             // round 4: the inner box (all 27 taps, fused-fold epilogue; 95 % / 91 % of the positions at 48^3 / 24^3) on the 2-D Winograd
             // body, the shell faces on the 1-D body (their single depth / height / width tap has nothing to transform along that axis)
-            if ((parts & 2) && !wface_direct && !fdn_conv64_split_dgrad) {
+            if ((parts & 2) && !wface_direct && !fdn_conv64_split_dgrad && !(split && hm == 4)) {      // (bf16 x 3: the inner box is a persistent launch of its own)
                 // both parts: ONE launch, the shell faces behind the inner box's workgroups (conv64_wino2d_shell_kernel, conv64_wino.hip)
                 if (probe) { *probe |= stream_bit(hm) | 2u; return FDN_OK; }
                 FdnWino2dPrepared inner;

@@ -157,7 +157,8 @@ int fdn_conv64_wino_launch_boxes(const float* x, const float* upack, const float
         Wino2Args a2;
         memcpy(&a2, inner->args, sizeof(a2));
         if ((size_t)inner->lds > lds) lds = (size_t)inner->lds;
-        const void* fn = a2.split ? (const void*)conv64_wino2d_shell_kernel<4, 2, true> : a2.hm == 4 ? (a2.mb == 1 ? (const void*)conv64_wino2d_shell_kernel<4, 1> : (const void*)conv64_wino2d_shell_kernel<4>)
+        FDN_REQUIRE(!a2.split, "conv64 (winograd): the bf16 x 3 inner box is a launch of its own");
+        const void* fn = a2.hm == 4 ? (a2.mb == 1 ? (const void*)conv64_wino2d_shell_kernel<4, 1> : (const void*)conv64_wino2d_shell_kernel<4>)
                                     : (const void*)conv64_wino2d_shell_kernel<2>;
         if (int rc = fdn_func_max_lds(fn, lds_max, "conv64_wino2d_shell")) return rc;
         int n2d = inner->blocks;

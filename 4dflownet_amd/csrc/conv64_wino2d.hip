@@ -37,6 +37,7 @@
 #include <string.h>
 
 #include "conv64_wino2d_kernel.h"
+#include "conv64_wino2d_pc_kernel.h"
 
 namespace {
 
@@ -49,6 +50,25 @@ template <bool FUSED, int HM, int MB = 2, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void conv64_wino2d_kernel(Wino2Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     conv64_wino2d_body<FUSED, HM, kW2RDB, kW2RDA, kW2Dep, MB, SPLIT>(p, (int)blockIdx.x, smem);
+}
+
+// FDN_ALGO_WINO_BF16X3: the producer / consumer kernel (conv64_wino2d_pc_kernel.h), one persistent workgroup of 512 threads per CU
+template <bool FUSED>
+__global__ __launch_bounds__(kPcThreads, 1) void conv64_wino2d_pc_kernel(Wino2Args p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    conv64_wino2d_pc_body<FUSED>(p, smem);
+}
+
+int device_cus() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int n = __atomic_load_n(&cus[dev], __ATOMIC_RELAXED);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        __atomic_store_n(&cus[dev], n, __ATOMIC_RELAXED);
+    }
+    return n;
 }
 
 #ifdef FDN_TEST_HOOKS
@@ -73,7 +93,10 @@ __global__ void pack_conv64_wino2d_kernel(const float* __restrict__ w, float* __
 }
 
 struct Wino2Plan { int td, ch, cw; double cost; };
-constexpr long long kW2HalfBelow = 0;                   // half-size tiles below this many full-size tiles (0: never)
+// half-size tiles below this many full-size tiles.  Measured (tools/bench_halftile.py, profiles/r6_halftile.txt; forward / fused dgrad, ms):
+// 108 full tiles 0.070 / 0.084 -> 0.045 / 0.070, 216 (8 x 24^3) 0.083 / 0.110 -> 0.074 / 0.108, 324 0.130 / 0.168 -> 0.113 / 0.150,
+// 432 0.139 / 0.189 -> 0.143 / 0.192 (two full workgroups on most CUs already), 1728 0.485 / 0.618 -> 0.520 / 0.668
+constexpr long long kW2HalfBelow = 400;
 
 // tile choice: every tile costs the MFMA time of 32 cells whatever its fill, plus the staging work of its rows and a fixed prologue /
 // epilogue; the launch ends with the busiest CU (2 co-resident workgroups per CU share the matrix pipe, so work per CU = its tiles).
@@ -130,6 +153,8 @@ int fdn_conv64_wino2d_prepare(const float* x, const float* upack2, const float* 
         const long long full = (long long)N * ((ebd + pl.td - 1) / pl.td) * ((ech + pl.ch - 1) / pl.ch) * ((ecw + pl.cw - 1) / pl.cw);
         if (full < kW2HalfBelow) mb = 1;
         if (fdn_conv64_wino2d_mb) mb = fdn_conv64_wino2d_mb;
+        else if (fdn_conv64_wino2d_tile)                // (test build: a forced tile decides by its own size)
+            mb = (fdn_conv64_wino2d_tile & 255) * ((fdn_conv64_wino2d_tile >> 8) & 255) * ((fdn_conv64_wino2d_tile >> 16) & 255) > 16 ? 2 : 1;
         if (mb == 1) pl = wino2d_plan(N, ebd, ech, ecw, 1);
     }
     if (fdn_conv64_wino2d_tile) {
@@ -165,8 +190,27 @@ int fdn_conv64_wino2d_launch(const float* x, const float* upack2, const float* b
     Wino2Args a;
     memcpy(&a, pr.args, sizeof(a));
     const long long blocks = pr.blocks;
-    const void* fn_split = fout ? (const void*)conv64_wino2d_kernel<true, 4, 2, true> : (const void*)conv64_wino2d_kernel<false, 4, 2, true>;
-    const void* fn = a.split ? fn_split : fout ? (hm == 4 ? (a.mb == 1 ? (const void*)conv64_wino2d_kernel<true, 4, 1> : (const void*)conv64_wino2d_kernel<true, 4>) : (const void*)conv64_wino2d_kernel<true, 2>)
+    if (a.split) {
+        // bf16 x 3 products: one persistent producer / consumer workgroup per CU walks the tiles
+        const void* fnp = fout ? (const void*)conv64_wino2d_pc_kernel<true> : (const void*)conv64_wino2d_pc_kernel<false>;
+        bool sync_variant = false;
+#ifdef FDN_TEST_HOOKS
+        sync_variant = fdn_conv64_wino2d_variant == 10;           // test build: the barrier-synchronous bf16 x 3 kernel (SPLIT body), for A/B
+        if (sync_variant) fnp = fout ? (const void*)conv64_wino2d_kernel<true, 4, 2, true> : (const void*)conv64_wino2d_kernel<false, 4, 2, true>;
+#endif
+        const int ldsp = sync_variant ? W2Geo<2, true>::lds : kPcLds;
+        if (int rc = fdn_func_max_lds(fnp, ldsp, "conv64_wino2d_pc")) return rc;
+        const int cus = device_cus();
+        const unsigned grid = sync_variant ? (unsigned)blocks : (unsigned)(blocks < cus ? blocks : cus);
+        void* kargs[] = {(void*)&a};
+        const hipError_t e = hipLaunchKernel(fnp, dim3(grid), dim3(sync_variant ? 256 : kPcThreads), kargs, ldsp, s);
+        if (e != hipSuccess) {
+            fdn_set_error("conv64_wino2d_pc_kernel: launch failed: %s", hipGetErrorString(e));
+            return FDN_ERR_HIP;
+        }
+        return FDN_OK;
+    }
+    const void* fn = fout ? (hm == 4 ? (a.mb == 1 ? (const void*)conv64_wino2d_kernel<true, 4, 1> : (const void*)conv64_wino2d_kernel<true, 4>) : (const void*)conv64_wino2d_kernel<true, 2>)
                           : (hm == 4 ? (a.mb == 1 ? (const void*)conv64_wino2d_kernel<false, 4, 1> : (const void*)conv64_wino2d_kernel<false, 4>) : (const void*)conv64_wino2d_kernel<false, 2>);
     int lds = pr.lds;
 #ifdef FDN_TEST_HOOKS

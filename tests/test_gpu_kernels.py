@@ -518,3 +518,34 @@ def test_winograd_kernels_equal_direct_kernels_on_random_shapes(ops, fdn):
             err, err2 = (a - r).abs().max().item() / scale, (a2 - r).abs().max().item() / scale
             assert err2 <= 1e-5, (name, "F(2,3) along H", (N, D, H, W, Wg), err2)
             assert err <= 1e-5, (name, "auto", (N, D, H, W, Wg), err)
+
+
+@pytest.mark.parametrize("shape", [(1, 5, 8, 12), (2, 24, 24, 24), (1, 7, 12, 20), (3, 4, 4, 4), (1, 19, 20, 12)])
+@pytest.mark.parametrize("mb", [1, 2])
+def test_conv64_wino2d_half_and_full_tiles(ops, fdn, shape, mb):
+    """F(4,3) x F(4,3) with half-size tiles (MB = 1: one 16-cell M-block per wave, the planner's choice below 400 full tiles) and with full
+    tiles (MB = 2), each forced through the test build: forward (all epilogues) and fused dgrad + border fold against the oracle."""
+    rng = np.random.default_rng(23)
+    N, D, H, W = shape
+    x = rng.normal(size=(N, D, H, W, 64)).astype(np.float32)
+    w = (rng.normal(size=(3, 3, 3, 64, 64)) * 0.05).astype(np.float32)
+    b = rng.normal(size=64).astype(np.float32)
+    res = rng.normal(size=(N, D, H, W, 64)).astype(np.float32)
+    y = rng.normal(size=(N, D, H, W, 64)).astype(np.float32)
+    dx = O.conv3d_dgrad(x.astype(np.float64), w.astype(np.float64), (N, D, H, W, 64))
+    with fdn._lib.test_build() as lib:
+        lib.fdn_debug_set_conv64_wino2d_mb(mb)
+        try:
+            for act, bias, r in [(O.ACT_RELU, b, None), (O.ACT_LEAKY, None, res), (O.ACT_NONE, None, None)]:
+                ref = O.conv3d_fwd(x.astype(np.float64), w.astype(np.float64), None if bias is None else bias.astype(np.float64),
+                                   act, 0.2, None if r is None else r.astype(np.float64))
+                got = ops.conv3d_fwd(dev(x), dev(w), None if bias is None else dev(bias), act, 0.2, None if r is None else dev(r))
+                close(got, ref, name="conv64 fwd MB=%d act=%d" % (mb, act))
+            _, wd = ops.pack_conv64_weights(dev(w))
+            pad = torch.full((N, D + 2, H + 2, W + 2, 64), float("nan"), device="cuda")
+            out = torch.full((N, D, H, W, 64), float("nan"), device="cuda")
+            ops.conv3d_dgrad_fused(dev(x), wd, pad, out, skip=dev(res), y_prev=dev(y), act=O.ACT_LEAKY)
+            ops.fold_halo_border([pad], out, dev(res), dev(y), O.ACT_LEAKY)
+            close(out, O.act_bwd_from_output(dx + res, y, O.ACT_LEAKY), name="fused dgrad+border MB=%d" % mb)
+        finally:
+            lib.fdn_debug_set_conv64_wino2d_mb(0)
