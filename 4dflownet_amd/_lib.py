@@ -42,6 +42,7 @@ SIGNATURES = {
     "fdn_l2_sumsq": (c_i, [c_fp, c_fp, c_i64, c_fp, c_fp]),
     "fdn_adam_step": (c_i, [c_fp] * 5 + [c_i64] + [c_f] * 5 + [c_fp, c_fp, c_fp]),
     "fdn_sum_partials": (c_i, [c_fp, c_i, c_fp, c_fp]),
+    "fdn_l2_sumsq_partials": (c_i, [c_fp, c_fp, c_i64, c_fp, c_fp]),
     "fdn_pack_conv64_weights_batch": (c_i, [c_fp, c_fp, c_i, c_fp, c_fp]),
     "fdn_conv64_pack_streams": (c_i, [c_i] * 6),
     "fdn_pack_conv64_weights_batch_streams": (c_i, [c_fp, c_fp, c_i, c_fp, c_i, c_i, c_fp]),

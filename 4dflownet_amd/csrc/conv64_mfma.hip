@@ -673,11 +673,32 @@ int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, 
     auto upack_hm = [&](int hm) { return hm == 4 ? (split ? upack2 + kWino2PackFloats + kWino44PackFloats : upack2 + kWino2PackFloats) : upack2; };
     auto stream_bit = [&](int hm) { return hm == 4 ? (split ? 16u : 8u) : 4u; };
     auto hm_arg = [&](int hm) { return hm == 4 && split ? 12 : hm; };
+    // Grids off the multiple-of-4 raster (patch sizes 10, 18, 22 are legal: README.md:83 of the reference): the F(4,3) x F(4,3) kernel takes
+    // the largest (h, w)-aligned box -- eh4 x ew4 of eh x ew, when that is most of the grid -- and the direct kernel the one or two
+    // remainder strips beside it (w in [ew4, ew) over all h; h in [eh4, eh) over the aligned w range) as regions of ONE more launch.
+    // Round 6 (tools/bench_small_grids.py, profiles/r6_small_grids.txt): at 8 x 22^3 the all-direct forward costs 0.186 ms, 2.4x the 24^3 grid's.
+    auto split_box = [&](int eh, int ew, int& eh4, int& ew4) {
+        eh4 = eh & ~3; ew4 = ew & ~3;
+        // (W % 4 == 0 grids have Winograd paths of their own; below ~24 K voxels the second launch costs more than the strips' multiplies:
+        // 8 x 10^3: forward 0.037 ms all direct, 0.071 split)
+        return wino2 && algo != FDN_ALGO_WINO_H2 && ew4 != ew && eh4 >= 4 && ew4 >= 4 && 2 * eh4 * ew4 >= eh * ew && (long long)N * ID * IH * IW >= 24576 &&
+               fdn_conv64_wino2d_ok(1, eh4, ew4, ID, IH, IW, 4);
+    };
     if (!(fout && zero_mode && off == -1 && fdn_conv64_shell_slabs)) {
         if (const int hm = fout ? 0 : hm_for(OH, OW)) {           // (a fused fold outside the slab path is the 1-D / direct kernels' business)
             if (probe) { *probe |= stream_bit(hm); return FDN_OK; }
             return fdn_conv64_wino2d_launch(x, upack_hm(hm), bias, residual, y, nullptr, nullptr, nullptr, N, ID, IH, IW, OD, OH, OW, 0, 0, 0,
                                             OD, OH, OW, off, zero_mode, act, alpha, hm_arg(hm), s);
+        }
+        int oh4, ow4;
+        if (!fout && split_box(OH, OW, oh4, ow4)) {
+            if (probe) { *probe |= stream_bit(4) | 1u; return FDN_OK; }
+            if (int rc = fdn_conv64_wino2d_launch(x, upack_hm(4), bias, residual, y, nullptr, nullptr, nullptr, N, ID, IH, IW, OD, OH, OW, 0, 0, 0,
+                                                  OD, oh4, ow4, off, zero_mode, act, alpha, hm_arg(4), s))
+                return rc;
+            const Box strips[2] = {{0, 0, ow4, OD, OH, OW - ow4, 0, 2, 0, 2, 0, 2}, {0, oh4, 0, OD, OH - oh4, ow4, 0, 2, 0, 2, 0, 2}};
+            const int first = OW > ow4 ? 0 : 1, count = (OW > ow4 ? 1 : 0) + (OH > oh4 ? 1 : 0);
+            return launch_boxes(a, strips + first, count, s);
         }
         if (wino && fdn_conv64_wino_ok(OD, OH, OW)) {
             if (probe) { *probe |= 2u; return FDN_OK; }
@@ -738,6 +759,20 @@ int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, 
                                                   count, off, zero_mode, act, alpha, s))
             return rc;
         return ((parts & 2) && wface_direct) ? launch_boxes(a, wfaces, 2, s) : FDN_OK;
+    }
+    int ih4, iw4;
+    if (split_box(IH, IW, ih4, iw4)) {
+        // the same split of the inner box [1, ID] x [1, IH] x [1, IW] (fused-fold epilogue in both kernels), the six shell slabs behind it
+        if (probe) { *probe |= stream_bit(4) | 1u; return FDN_OK; }
+        if (parts & 1) {
+            if (int rc = fdn_conv64_wino2d_launch(x, upack_hm(4), bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, 1, 1, 1, ID, ih4,
+                                                  iw4, off, zero_mode, act, alpha, hm_arg(4), s))
+                return rc;
+            const Box strips[2] = {{1, 1, 1 + iw4, ID, IH, IW - iw4, 0, 2, 0, 2, 0, 2}, {1, 1 + ih4, 1, ID, IH - ih4, iw4, 0, 2, 0, 2, 0, 2}};
+            const int first = IW > iw4 ? 0 : 1, count = (IW > iw4 ? 1 : 0) + (IH > ih4 ? 1 : 0);
+            if (int rc = launch_boxes(a, strips + first, count, s)) return rc;
+        }
+        return (parts & 2) ? launch_boxes(a, boxes + 1, 6, s) : FDN_OK;
     }
     if (probe) { *probe |= 1u; return FDN_OK; }
     if (parts == 3) return launch_boxes(a, boxes, 7, s);

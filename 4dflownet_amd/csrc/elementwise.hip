@@ -78,11 +78,16 @@ __device__ __forceinline__ void lerp_coeff(int o, float scale, int n, int& lo, i
 }
 
 // block = one output row (n, od, oh): the d / h interpolation coefficients are block-uniform; thread = one 16-B vector
-// (4 fp32 / 8 bf16 channels) of one output voxel, consecutive threads write consecutive vectors (32-bit index math only)
-template <typename T>
+// (4 fp32 / 8 bf16 channels) of one output voxel, consecutive threads write consecutive vectors (32-bit index math only).
+// STAGED (round 6): the four input rows (d0|d1, h0|h1) of the output row go through LDS once, as coalesced 16-B loads, and the
+// eight corner vectors of every output vector come from there -- the direct form asks the vector cache for eight 16-B loads per
+// 16 B written (1.8 GB of L1 traffic for the 226 MB of the cfg2 upsample: L1-bound at 0.078 ms, 2.9 TB/s written); same
+// arithmetic in the same order, bit-identical.  Rows too long for the LDS take the direct form.
+template <typename T, bool STAGED>
 __global__ __launch_bounds__(256) void upsample_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int D,
                                                             int H, int W, int CV, int R, float sd, float sh, float sw) {
     constexpr int E = FdnVec<T>::E;
+    extern __shared__ __attribute__((aligned(16))) float rowbuf[];      // STAGED: [4][W * CV] 16-B vectors
     const int OD = D * R, OH = H * R, OW = W * R;
     for (int row = blockIdx.x; row < N * OD * OH; row += gridDim.x) {
         const int oh = row % OH;
@@ -96,6 +101,17 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const T* __restrict__
         const T* r01 = x + (((int64_t)n * D + d0) * H + h1) * W * CV * E;
         const T* r10 = x + (((int64_t)n * D + d1) * H + h0) * W * CV * E;
         const T* r11 = x + (((int64_t)n * D + d1) * H + h1) * W * CV * E;
+        if constexpr (STAGED) {
+            const int nv = W * CV;
+            __syncthreads();                               // the previous row's corner reads are done
+            f32x4* dst = (f32x4*)rowbuf;
+            for (int i = threadIdx.x; i < nv; i += blockDim.x) {
+                const f32x4 a = ((const f32x4*)r00)[i], b = ((const f32x4*)r01)[i], c = ((const f32x4*)r10)[i], d = ((const f32x4*)r11)[i];
+                dst[i] = a; dst[nv + i] = b; dst[2 * nv + i] = c; dst[3 * nv + i] = d;
+            }
+            __syncthreads();
+            r00 = (const T*)rowbuf; r01 = r00 + nv * E; r10 = r01 + nv * E; r11 = r10 + nv * E;
+        }
         T* yr = y + (int64_t)row * OW * CV * E;
         for (int i = threadIdx.x; i < OW * CV; i += blockDim.x) {
             const int ow = i / CV, cv = i - ow * CV;
@@ -381,6 +397,22 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const 
     }
 }
 
+// The same per-block sums the Adam kernel leaves behind (identical blocking: block b covers the elements b * 256 + t + k * grid * 256),
+// for the steps that have no Adam step before them (first step, load_weights): FDN_ADAM_PARTIALS blocks stream the parameters at the
+// rate of the chip instead of one block at 9 GB/s (l2_sumsq_kernel: 1.87 ms for the 13.4 MB of cfg2)
+__global__ __launch_bounds__(256) void l2_sumsq_partials_kernel(const float* __restrict__ w, const uint8_t* __restrict__ isk, int64_t n,
+                                                                 float* __restrict__ sumsq) {
+    float ss = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        if (isk[i]) ss += w[i] * w[i];
+    __shared__ float red[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) sumsq[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // out[0] = sum of n partials, one block, fixed order (deterministic)
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
     __shared__ float red[4];
@@ -444,8 +476,16 @@ static int upsample_fwd_t(const T* x, T* y, int N, int D, int H, int W, int C, i
     FDN_REQUIRE(x && y && C % E == 0 && R >= 1 && N > 0 && D > 0 && H > 0 && W > 0, "fdn_upsample_trilinear_fwd: bad argument");
     const int64_t rows = (int64_t)N * D * R * H * R;
     FDN_REQUIRE(rows < (1ll << 31), "fdn_upsample_trilinear_fwd: too many rows");
-    hipLaunchKernelGGL(upsample_fwd_kernel<T>, dim3((unsigned)(rows < 262144 ? rows : 262144)), dim3(256), 0, (hipStream_t)stream,
-                       x, y, N, D, H, W, C / E, R, axis_scale(D, R), axis_scale(H, R), axis_scale(W, R));
+    const size_t lds = (size_t)4 * W * C * sizeof(T);
+    if (lds <= 64 * 1024) {
+        if (lds > 48 * 1024)
+            if (int rc = fdn_func_max_lds((const void*)upsample_fwd_kernel<T, true>, 64 * 1024, "upsample_fwd")) return rc;
+        hipLaunchKernelGGL((upsample_fwd_kernel<T, true>), dim3((unsigned)(rows < 262144 ? rows : 262144)), dim3(256), lds, (hipStream_t)stream,
+                           x, y, N, D, H, W, C / E, R, axis_scale(D, R), axis_scale(H, R), axis_scale(W, R));
+    } else {
+        hipLaunchKernelGGL((upsample_fwd_kernel<T, false>), dim3((unsigned)(rows < 262144 ? rows : 262144)), dim3(256), 0, (hipStream_t)stream,
+                           x, y, N, D, H, W, C / E, R, axis_scale(D, R), axis_scale(H, R), axis_scale(W, R));
+    }
     FDN_CHECK_LAUNCH("upsample_fwd_kernel");
     return FDN_OK;
 }
@@ -509,6 +549,13 @@ extern "C" int fdn_l2_sumsq(const float* w, const uint8_t* is_kernel, int64_t n,
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(l2_sumsq_kernel, dim3(1), dim3(1024), 0, s, w, is_kernel, n, out);
     FDN_CHECK_LAUNCH("l2_sumsq_kernel");
+    return FDN_OK;
+}
+
+extern "C" int fdn_l2_sumsq_partials(const float* w, const uint8_t* is_kernel, int64_t n, float* sumsq_partials, void* stream) {
+    FDN_REQUIRE(w && is_kernel && sumsq_partials && n > 0, "fdn_l2_sumsq_partials: bad argument");
+    hipLaunchKernelGGL(l2_sumsq_partials_kernel, dim3(FDN_ADAM_PARTIALS), dim3(256), 0, (hipStream_t)stream, w, is_kernel, n, sumsq_partials);
+    FDN_CHECK_LAUNCH("l2_sumsq_partials_kernel");
     return FDN_OK;
 }
 

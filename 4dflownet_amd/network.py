@@ -292,6 +292,9 @@ class FlowNetModel:
         if not any(a == ops.ALGO_AUTO for a in self.conv_algo.values()):
             return
         if W % 4:
+            h4, w4 = H & ~3, W & ~3
+            if h4 >= 4 and w4 >= 4 and 2 * h4 * w4 >= H * W and N * D * H * W >= 24576:   # (conv64_mfma.hip, split_box: the aligned box on F(4,3) x F(4,3), the strips direct)
+                return
             how = "the direct kernels (about 3x the time of the 2-D Winograd kernels)"
         elif H % 2:
             how = "the 1-D Winograd kernels (about 1.5x the time of the 2-D Winograd kernels)"

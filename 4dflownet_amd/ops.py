@@ -266,6 +266,14 @@ def adam_step(w, g, m, v, is_kernel, lr_t, b1, b2, eps, l2_grad_scale, l2_scale_
           "fdn_adam_step")
 
 
+def l2_sumsq_partials(w_flat, is_kernel, partials):
+    """ADAM_PARTIALS per-block sums of the kernel parameters' squares (what adam_step leaves behind), for parameters no Adam step has touched."""
+    if partials.numel() < ADAM_PARTIALS:
+        raise FdnError("l2_sumsq_partials: partials needs %d floats" % ADAM_PARTIALS)
+    check(_lib.load().fdn_l2_sumsq_partials(_p(w_flat), _p(is_kernel), w_flat.numel(), _p(partials), _stream()), "fdn_l2_sumsq_partials")
+    return partials
+
+
 def sum_partials(partials, out=None):
     if out is None:
         out = torch.empty((1,), device=partials.device, dtype=torch.float32)

@@ -118,10 +118,10 @@ class TrainerController:
 
     def calculate_regularizer_loss(self):
         """5e-7 * sum(kernel^2) as a 0-d device tensor (TrainerController.py:129-141)."""
-        if self._l2_version == self.model.weights_version:
-            ops.sum_partials(self._l2_partials, self._l2_buf)      # the Adam kernel already streamed the parameters
-        else:                                                      # first step, or weights were loaded / re-initialised
-            ops.l2_sumsq(self.model.flat_w, self.model.is_kernel, self._l2_buf)
+        if self._l2_version != self.model.weights_version:         # first step, or weights were loaded / re-initialised: stream them once
+            ops.l2_sumsq_partials(self.model.flat_w, self.model.is_kernel, self._l2_partials)
+            self._l2_version = self.model.weights_version
+        ops.sum_partials(self._l2_partials, self._l2_buf)          # (else the Adam kernel left the per-block sums behind)
         return self._l2_buf[0] * L2_LAMBDA
 
     def calculate_and_update_metrics(self, hires, predictions, mask, metric_set, want_grad):
@@ -249,6 +249,54 @@ class TrainerController:
         self.train_writer.flush()
         self.val_writer.flush()
 
+    # ------------------------------------------------------------------ input staging
+    def device_batches(self, dataset):
+        """Iterate `dataset` ONE BATCH AHEAD of the consumer: while step k computes, batch k + 1 is copied to the device on a copy stream
+        of its own -- non-blocking from the host loader's pinned ring (data.PatchHandler3D(..., pinned=True): a slot stays untouched
+        until two more batches were requested, which covers the copy in flight), staged by torch otherwise.  Batches that already live on
+        the device (DevicePatchHandler3D) pass through untouched.  What tf.data's prefetch-to-device does for the reference
+        (PatchHandler3D.py:26-35 ends in .prefetch); FDN_H2D_PREFETCH=0 yields the dataset's own batches (one blocking copy per tensor
+        inside train_step)."""
+        if os.environ.get("FDN_H2D_PREFETCH", "1") in ("", "0"):
+            yield from dataset
+            return
+        copy_stream = None
+
+        def upload(batch):
+            nonlocal copy_stream
+            if all(isinstance(a, torch.Tensor) and a.is_cuda for a in batch):
+                return batch, None
+            if copy_stream is None:
+                copy_stream = torch.cuda.Stream(device=self.device)
+            with torch.cuda.stream(copy_stream):
+                dev = []
+                for a in batch:
+                    t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+                    dev.append(t.to(device=self.device, dtype=torch.float32, non_blocking=True))
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+            return tuple(dev), ev
+
+        it = iter(dataset)
+        try:
+            nxt = upload(next(it))
+        except StopIteration:
+            return
+        while nxt is not None:
+            cur, ev = nxt
+            if ev is not None:
+                ev.synchronize()                           # `cur` has left its pinned slot (a copy-stream event: no wait for compute) before
+            try:                                           # the loader is asked for more -- the ring's lifetime contract, kept by construction
+                nxt = upload(next(it))                     # requested before the consumer gets `cur`: the copy runs beside its step
+            except StopIteration:
+                nxt = None
+            if ev is not None:
+                main = torch.cuda.current_stream()
+                main.wait_event(ev)
+                for t in cur:
+                    t.record_stream(main)                  # allocated under the copy stream, consumed on this one
+            yield cur
+
     # ------------------------------------------------------------------ training loop
     def train_network(self, trainset, valset, n_epoch, testset=None, verbose=True):
         """TrainerController.py:263-343.  trainset/valset: iterables of 11-tuples (PatchHandler3D datasets)."""
@@ -266,13 +314,13 @@ class TrainerController:
         for epoch in range(n_epoch):
             self.reset_metrics()
             start_loop = time.time()
-            for i, data_pairs in enumerate(trainset):
+            for i, data_pairs in enumerate(self.device_batches(trainset)):
                 self.train_step(data_pairs)
                 if verbose and is0:
                     print("\rEpoch %d Train batch %d/%d | loss: %.5f (%.1f %%) - %.1f secs" % (
                         epoch + 1, i + 1, total_batch_train, self.loss_metrics['train_loss'].result(),
                         self.loss_metrics['train_accuracy'].result(), time.time() - start_loop), end='')
-            for i, data_pairs in enumerate(valset):
+            for i, data_pairs in enumerate(self.device_batches(valset)):
                 self.test_step(data_pairs)
                 if verbose and is0:
                     print("\rEpoch %d Validation batch %d/%d | loss: %.5f (%.1f %%) - %.1f secs" % (

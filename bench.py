@@ -148,8 +148,8 @@ def executed_conv64_flop(N, D, H, W, dtype=None, algo=0):
     if (dtype is None or dtype == torch.float32) and algo != 1:
         if W % 4 == 0:
             taps = 13.5
-            if H % 2 == 0 and algo in (0, 3):
-                taps = 6.75 if H % 4 == 0 and algo == 0 else 9.0
+            if H % 2 == 0 and algo in (0, 3, 4):
+                taps = 6.75 if H % 4 == 0 and algo in (0, 4) else 9.0          # (algo 4 = FDN_ALGO_WINO_BF16X3: the same products, as bf16 x 3)
     return N * D * H * W * taps * 2.0 * 64 * 64
 
 
@@ -207,14 +207,14 @@ def pmc_live_passes(argv_tail):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pmc_traffic
     tmp = tempfile.mkdtemp(prefix="fdn_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", FDN_OVERLAP_WGRAD="0")      # one stream: a counter belongs to the one kernel that runs
     try:
         dirs = {}
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             dirs[ctr] = os.path.join(tmp, ctr)
             cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", dirs[ctr], "--", sys.executable,
-                   os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-secondary", "--steps", "2", "--warmup", "1"] + argv_tail
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=900)
+                   os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-secondary", "--no-pmc", "--event-steps", "0", "--steps", "2", "--warmup", "1"] + argv_tail
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
             if r.returncode != 0:
                 print("bench.py --pmc: the %s pass failed: %s" % (ctr, r.stderr[-300:]), file=sys.stderr)
                 return None
@@ -338,8 +338,21 @@ def roofline_obj(timer, kind, bf16, kernel, traffic_files):
                                       "launches with the direct 3x3x3 FLOP count of SURVEY 8d and therefore exceeds the peak"}
 
 
+def products_note(model, bf16):
+    """The arithmetic of the 64->64 contractions, in words (no reader should have to guess whether precision was traded)."""
+    if bf16:
+        return "bf16 activations x bf16 weights on v_mfma_f32_32x32x16_bf16, fp32 accumulation, fp32 parameters (BASELINE configs[3])"
+    algos = set(model.conv_algo[L.name] for L in model.layers if L.wp_f is not None)
+    if algos == {4}:
+        return ("FDN_ALGO_WINO_BF16X3: fp32 operands, transformed in fp32, each split EXACTLY into 3 bf16 pieces; 6 of the 9 cross terms on "
+                "v_mfma_f32_16x16x32_bf16 with fp32 accumulation (dropped terms <= 2^-25 |u||v|: below an fp32 multiply's rounding); weight gradients on fp32 MFMA")
+    return "exact fp32 products: v_mfma_f32_16x16x4_f32 / v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate)" + ("" if algos == {0} else "; conv_algo %s" % sorted(algos))
+
+
 def event_pass(tc, batch, timer, steps):
     """`steps` train steps with the weight gradients on the main stream and the LaunchTimer on; returns their mean wall time (ms)."""
+    if steps <= 0:
+        return None
     ov = tc.model.overlap_wgrad
     tc.model.overlap_wgrad = False
     try:
@@ -441,7 +454,7 @@ def secondary_runs(trainer, parallel, device, P, R, B, LB, HB, sustained_steps=3
         sec["cfg2_loader_fed"] = {"error": repr(e)}
     torch.cuda.empty_cache()
     # (1b) the same with the HOST loader (scripts/trainer.py under FDN_HOST_LOADER=1): PatchHandler3D, producer thread + worker pool
-    # + pinned staging ring, one blocking H2D copy per tensor; and the loader alone (what one rank's host side can supply)
+    # + pinned staging ring, TrainerController.device_batches (non-blocking H2D one batch ahead); and the loader alone (what one rank's host side can supply)
     try:
         data = importlib.import_module("4dflownet_amd.data")
         patch_index = importlib.import_module("4dflownet_amd.patch_index")
@@ -465,7 +478,7 @@ def secondary_runs(trainer, parallel, device, P, R, B, LB, HB, sustained_steps=3
         n_full = [0]
 
         def epoch_h():
-            for batch in ds:
+            for batch in tc.device_batches(ds):            # (what train_network does: batch k + 1 copied on a copy stream while step k runs)
                 if batch[0].shape[0] == B:
                     tc.train_step(batch)
                     n_full[0] += 1
@@ -479,7 +492,7 @@ def secondary_runs(trainer, parallel, device, P, R, B, LB, HB, sustained_steps=3
         sec["cfg2_host_loader_fed"] = {"value": n_full[0] * B / dt, "unit": "patches/s", "ms_per_step": dt / n_full[0] * 1e3, "steps": n_full[0],
                                        "loader_alone_patches_per_s": n_rows / dt_alone, "loader_threads": ds.n_parallel, "prefetch": ds.prefetch,
                                        "workload": "cfg2 train_step fed by the host loader data.PatchHandler3D (volumes cached in host memory, "
-                                                   "producer thread + %d worker threads, pinned staging ring, blocking H2D copy per tensor); "
+                                                   "producer thread + %d worker threads, pinned staging ring, batch k + 1 copied non-blocking on a copy stream while step k runs); "
                                                    "loader_alone = the same epoch without the train step" % ds.n_parallel}
         del tc, ds, ph
     except Exception as e:
@@ -691,8 +704,10 @@ def main():
     ap.add_argument("--sustained-steps", type=int, default=300, help="length of the secondary `sustained` run (N=1)")
     ap.add_argument("--single-allreduce", action="store_true",
                     help="N>1: ONE all-reduce of the whole gradient buffer after backward instead of the three buckets started inside it")
-    ap.add_argument("--pmc", action="store_true",
-                    help="N=1: measure roofline.traffic in this run (two extra rocprofv3 --pmc passes of 2 steps) instead of quoting profiles/")
+    ap.add_argument("--pmc", dest="pmc", action="store_true", default=None,
+                    help="N=1: measure roofline.traffic in this run (two extra rocprofv3 --pmc passes of 2 steps) instead of quoting profiles/ "
+                         "(default: on for the full default run when rocprofv3 is on the box, off with --no-secondary)")
+    ap.add_argument("--no-pmc", dest="pmc", action="store_false")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="launcher self-test: allow more ranks than GPUs (ranks share devices, gloo with host staging); not a scaling number")
     args = ap.parse_args()
@@ -767,10 +782,16 @@ def main():
     # rank 0 assembles the headline object BEFORE the N > 1 secondary legs run: those legs use point-to-point RCCL traffic that no
     # multi-GPU box has exercised yet, and a watchdog prints the headline (with the failure noted) rather than lose it to a hang
     line = None
+    if args.pmc is None:                               # the driver-facing default run measures its own traffic figure where the line is made
+        args.pmc = not args.no_secondary and world == 1
     if rank == 0 and args.pmc and world == 1:
         global PMC_LIVE
         tail = ["--config", args.config] if args.config != "cfg2" else []
-        PMC_LIVE = pmc_live_passes(tail)
+        try:
+            PMC_LIVE = pmc_live_passes(tail)
+        except Exception as e:                          # (a box without working counters must not cost the headline)
+            print("bench.py --pmc: %s: %s" % (type(e).__name__, str(e)[-200:]), file=sys.stderr)
+            PMC_LIVE = None
     if rank == 0:
         fwd_flop = fwd_flop_per_patch(tc.model.specs, P, R, LB)
         tr = CFG4_TRAFFIC if args.config == "cfg4" else ([] if bf16 else CFG2_TRAFFIC)
@@ -792,6 +813,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "bf16" if bf16 else "f32",
+            "products": products_note(tc.model, bf16),
             "data": "synthetic (SURVEY 8d: default_rng(1234+rank) inputs, Glorot-uniform default_rng(0) weights)",
             "config": {"workload": "%s train_step: patch_size=%d res_increase=%d batch=%d/GPU low_resblock=%d hi_resblock=%d %s"
                                    % (args.config, P, R, B, LB, HB, "bf16 activations, fp32 accumulation/parameters" if bf16 else "fp32"),

@@ -233,6 +233,9 @@ int fdn_adam_step(float* w, const float* g, float* m, float* v, const uint8_t* i
  * parameters again.  src/Network/TrainerController.py:129-141. */
 #define FDN_ADAM_PARTIALS 2048
 int fdn_sum_partials(const float* partials, int n, float* out, void* stream);
+/* The same FDN_ADAM_PARTIALS per-block sums for parameters no fdn_adam_step has touched yet (first step, after loading a
+ * checkpoint): the multi-block form of fdn_l2_sumsq, which needs no scratch and runs as ONE block.  Follow with fdn_sum_partials. */
+int fdn_l2_sumsq_partials(const float* w, const uint8_t* is_kernel, int64_t n, float* sumsq_partials, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * bf16 activation path (BASELINE.json configs[3]: patch 32, res x4, bf16).  The reference has no bf16

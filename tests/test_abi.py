@@ -167,7 +167,7 @@ def test_tracked_gpu_test_log_matches_the_tree():
 
 def test_pack_stream_query_follows_the_launchers_selection(fdn):
     """fdn_conv64_pack_streams runs the launcher's own selection in probe mode (no GPU needed): the streams named in include/fdn.h's
-    FDN_ALGO_* table.  Bits: 1 direct, 2 1-D Winograd, 4 F(2,3)xF(4,3), 8 F(4,3)xF(4,3)."""
+    FDN_ALGO_* table.  Bits: 1 direct, 2 1-D Winograd, 4 F(2,3)xF(4,3), 8 F(4,3)xF(4,3), 16 the same as three bf16 pieces."""
     q = fdn._lib.load().fdn_conv64_pack_streams
     FWD, DG, FUSED = 0, 1, 2
     AUTO, DIRECT, WINO_W, WINO_H2 = 0, 1, 2, 3
@@ -178,6 +178,9 @@ def test_pack_stream_query_follows_the_launchers_selection(fdn):
         assert q(*shp, DIRECT, FWD) == 1 and q(*shp, DIRECT, FUSED) == 1 and q(*shp, DIRECT, DG) == 1
     assert q(2, 8, 6, 8, AUTO, FWD) == 4                                      # H only even
     assert q(2, 9, 9, 12, AUTO, FWD) == 2 and q(2, 9, 9, 12, AUTO, FUSED) == 2   # odd H: 1-D Winograd
-    assert q(2, 10, 10, 10, AUTO, FWD) == 1 and q(2, 10, 10, 10, AUTO, FUSED) == 1   # W % 4 != 0: direct
+    assert q(8, 18, 18, 18, AUTO, FWD) == 8 | 1 and q(8, 18, 18, 18, AUTO, FUSED) == 8 | 1   # W % 4 != 0: the aligned 16 x 16 box on F(4,3) x F(4,3), the strips direct
+    assert q(2, 10, 10, 10, AUTO, FWD) == 1 and q(64, 10, 6, 6, AUTO, FUSED) == 1      # ... too few voxels / too small an aligned box for the split: direct
+    assert q(8, 18, 18, 18, WINO_H2, FWD) == 1 and q(8, 18, 18, 18, 4, FWD) == 16 | 1   # (FDN_ALGO_WINO_BF16X3 reads the bf16 x 3 stream)
+    assert q(8, 24, 24, 24, 4, FWD) == 16 and q(8, 24, 24, 24, 4, FUSED) == 16 | 2
     assert q(2, 10, 10, 10, AUTO, DG) == 8                                    # the padded grid is 12^3
     assert q(2, 10, 10, 10, 7, FWD) < 0 and q(0, 10, 10, 10, AUTO, FWD) < 0 and q(2, 10, 10, 10, AUTO, 3) < 0

@@ -481,6 +481,9 @@ def test_winograd_kernels_equal_direct_kernels_on_random_shapes(ops, fdn):
     rng = np.random.default_rng(2024)
     shapes = [(int(rng.integers(1, 4)), int(rng.integers(1, 21)), int(rng.integers(1, 21)), 4 * int(rng.integers(1, 9))) for _ in range(20)]
     shapes += [(1, 1, 1, 4), (2, 2, 19, 4), (1, 20, 1, 32), (1, 9, 9, 28)]
+    # round 6: grids off the multiple-of-4 raster -- the aligned box on F(4,3) x F(4,3), the remainder strips on the direct kernel (W % 4 != 0
+    # with any H; a w strip only, an h strip as well, odd H), and grids too small for the split (all direct)
+    shapes += [(30, 8, 10, 10), (8, 10, 18, 18), (6, 9, 22, 22), (40, 6, 9, 13), (200, 5, 5, 5), (2, 6, 8, 10), (1, 2, 12, 7), (1, 3, 6, 6), (5, 18, 18, 18)]
     for (N, D, H, W) in shapes:
         g = torch.Generator(device="cuda").manual_seed(N * 1000003 + D * 1009 + H * 31 + W)
         x = torch.randn((N, D, H, W, 64), device="cuda", generator=g)

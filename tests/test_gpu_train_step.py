@@ -49,21 +49,25 @@ def test_glorot_init_matches_oracle_seeded_init(fdn):
 
 
 def test_auto_algo_warns_once_when_a_grid_falls_off_the_winograd_kernels(fdn):
-    """FDN_ALGO_AUTO picks the 64->64 kernel by the extents; P = 18 (a legal reference patch size) has W % 4 != 0 -> the direct
-    kernels, ~3x slower: the model says so once per grid.  P = 16 stays silent."""
+    """FDN_ALGO_AUTO picks the 64->64 kernel by the extents and the model says so once per grid that lands on slower kernels -- and only
+    then: P = 18 (a legal reference patch size, W % 4 != 0) runs its aligned 16 x 16 box on F(4,3) x F(4,3) and two strips on the direct
+    kernel (round 6): silent, like P = 16; a 14 x 6 x 6 grid is too small for the split (all direct): warned."""
     import warnings
     net = __import__("importlib").import_module("4dflownet_amd.network")
     g = torch.Generator(device="cuda").manual_seed(0)
-    for P, expect in ((18, True), (16, False)):
+    for shp, expect in (((6, 18, 18, 18), False), ((6, 16, 16, 16), False), ((70, 14, 6, 6), True)):
         m = net.FlowNetModel(1, low_resblock=1, hi_resblock=0, seed=0)
-        x = [torch.rand((6, P, P, P, 1), device="cuda", generator=g) for _ in range(6)]
+        x = [torch.rand(shp + (1,), device="cuda", generator=g) for _ in range(6)]
         with warnings.catch_warnings(record=True) as w:
             warnings.simplefilter("always")
             m.forward(x); m.forward(x)
         hits = [i for i in w if issubclass(i.category, RuntimeWarning) and "W % 4 == 0" in str(i.message)]
         assert len(hits) == (1 if expect else 0), [str(i.message) for i in w]
         if expect:
-            assert "direct kernels" in str(hits[0].message) and "18x18x18" in str(hits[0].message)
+            assert "direct kernels" in str(hits[0].message) and "14x6x6" in str(hits[0].message)
+        # the library agrees with the python rule: which pack streams does this grid read?
+        need = fdn.ops.conv64_pack_streams(*shp, fdn.ops.ALGO_AUTO, fdn.ops.ROLE_FWD)
+        assert bool(need & fdn.ops.PACK_STREAM_WINO_H4) == (not expect), (shp, need)
 
 
 @pytest.mark.parametrize("P,R,LB,HB,B", [(6, 2, 1, 1, 2), (8, 1, 2, 1, 2), (4, 3, 0, 1, 1), (6, 2, 2, 0, 3)])
