@@ -459,19 +459,32 @@ __global__ void pack_conv64_kernel(const float* __restrict__ w, float* __restric
 // lies inside one stream (every stream is a multiple of 256 elements), so an unwanted stream costs an early exit
 __global__ void pack_conv64_batch_kernel(const float* __restrict__ w_base, const int64_t* __restrict__ w_offsets, float* __restrict__ packs,
                                          int sf, int sd) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over 261*64*64 packed elements per direction + the 108*64*64 values of the bf16 x 3 stream
-    const int st = idx < 27 * 64 * 64 ? 0 : idx < 81 * 64 * 64 ? 1 : idx < 153 * 64 * 64 ? 2 : idx < 261 * 64 * 64 ? 3 : 4;
-    if (!(((sf | sd) >> st) & 1) || idx >= 369 * 64 * 64) return;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over the 153*64*64 packed elements of the first three streams, then the 2 * 3*64*64 columns of the F(4,3) x F(4,3) streams
     const float* w = w_base + w_offsets[blockIdx.y];
     float* pf = packs + (size_t)blockIdx.y * 2 * FDN_CONV64_PACK_FLOATS;
     float* pd = pf + FDN_CONV64_PACK_FLOATS;
+    if (idx >= 153 * 64 * 64) {
+        // F(4,3) x F(4,3), fp32 and bf16 x 3: thread = (direction, kd, cin, cout) forms all 36 coordinates from one load of its 9 weights
+        const int c = idx - 153 * 64 * 64;
+        if (c >= 2 * 3 * 64 * 64) return;
+        const bool dg = c >= 3 * 64 * 64;
+        const int s = dg ? sd : sf;
+        if (!(s & 24)) return;
+        float* pk = dg ? pd : pf;
+        const int e = c - (dg ? 3 * 64 * 64 : 0);
+        // (thread order = the fp32 stream's element order inside a unit: consecutive lanes write consecutive floats)
+        const int o = e & 1023, nb = (e >> 10) & 3, kd = e >> 12;
+        fdn_pack_wino44_column(w, (s & 8) ? pk + 153 * 64 * 64 : nullptr, (s & 16) ? (uint16_t*)(pk + 261 * 64 * 64) : nullptr, kd,
+                               (o >> 6) * 4 + (o & 3), nb * 16 + ((o >> 2) & 15), dg);
+        return;
+    }
+    const int st = idx < 27 * 64 * 64 ? 0 : idx < 81 * 64 * 64 ? 1 : 2;
+    if (!(((sf | sd) >> st) & 1)) return;
     if (!((sf >> st) & 1)) pf = nullptr;
     if (!((sd >> st) & 1)) pd = nullptr;
     if (st == 0) fdn_pack_direct_one(w, pf, pd, idx);
     else if (st == 1) fdn_pack_wino_one(w, pf ? pf + 27 * 64 * 64 : nullptr, pd ? pd + 27 * 64 * 64 : nullptr, idx - 27 * 64 * 64);
-    else if (st == 2) fdn_pack_wino2d_one(w, pf ? pf + 81 * 64 * 64 : nullptr, pd ? pd + 81 * 64 * 64 : nullptr, idx - 81 * 64 * 64);
-    else if (st == 3) fdn_pack_wino44_one(w, pf ? pf + 153 * 64 * 64 : nullptr, pd ? pd + 153 * 64 * 64 : nullptr, idx - 153 * 64 * 64);
-    else fdn_pack_wino44s_one(w, pf ? (uint16_t*)(pf + 261 * 64 * 64) : nullptr, pd ? (uint16_t*)(pd + 261 * 64 * 64) : nullptr, idx - 261 * 64 * 64);
+    else fdn_pack_wino2d_one(w, pf ? pf + 81 * 64 * 64 : nullptr, pd ? pd + 81 * 64 * 64 : nullptr, idx - 81 * 64 * 64);
 }
 
 // pack = [direct stream, 27*64*64 floats | Winograd F(4,3) stream, 54*64*64 | 2-D F(2,3)xF(4,3) stream, 72*64*64 | 2-D F(4,3)xF(4,3)
@@ -500,7 +513,7 @@ extern "C" int fdn_pack_conv64_weights_batch_streams(const float* w_base, const 
     FDN_REQUIRE(!(streams_fwd & ~FDN_PACK_STREAM_ALL) && !(streams_dgrad & ~FDN_PACK_STREAM_ALL), "fdn_pack_conv64_weights_batch_streams: bad stream mask %d / %d",
                 streams_fwd, streams_dgrad);
     if (!(streams_fwd | streams_dgrad)) return FDN_OK;
-    hipLaunchKernelGGL(pack_conv64_batch_kernel, dim3((369 * 64 * 64 + 255) / 256, (unsigned)n_layers), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(pack_conv64_batch_kernel, dim3(((153 + 6) * 64 * 64 + 255) / 256, (unsigned)n_layers), dim3(256), 0, (hipStream_t)stream,
                        w_base, w_offsets, packs, streams_fwd, streams_dgrad);
     FDN_CHECK_LAUNCH("fdn_pack_conv64_weights_batch");
     return FDN_OK;

@@ -109,81 +109,64 @@ __device__ __forceinline__ void fdn_pack_wino2d_one(const float* __restrict__ w,
 // algorithm that is the same for every voxel (a fixed perturbation of the layer's kernel), and it should be half an ulp, not the three
 // or four of an fp32 fma chain over rounded constants.
 // layout [nb = cout/16][xh 0..5][kd][xw 0..5][g = cin/16][q][i][s], the 1-KB unit as in fdn_pack_wino2d_one; 108 * 64 * 64 floats.
-__device__ __forceinline__ void fdn_pack_wino44_one(const float* __restrict__ w, float* __restrict__ uf, float* __restrict__ ud, int idx) {
-    const int s = idx & 3;
-    const int i = (idx >> 2) & 15;
-    const int q = (idx >> 6) & 3;
-    const int g = (idx >> 8) & 3;
-    int rest = idx >> 10;                // ((nb*6 + xh)*3 + kd)*6 + xw
-    const int xw = rest % 6; rest /= 6;
-    const int kd = rest % 3; rest /= 3;
-    const int xh = rest % 6;
-    const int nb = rest / 6;
-    const int k = 16 * g + 4 * q + s;
-    const int cj = 16 * nb + i;
+// (fdn_pack_wino44_column below writes it.)
+
+// u = hi + mid + lo exactly, each piece the round-to-nearest-even bf16 of what the pieces before it leave.  Spelled on the bit pattern
+// (finite weights): every pack path rounds alike whatever conversion the compiler would pick for a (double ->) float -> bf16 chain.
+__device__ __forceinline__ uint16_t fdn_bf16_rne_bits(float x) {
+    const unsigned b = __builtin_bit_cast(unsigned, x);
+    return (uint16_t)((b + 0x7fffu + ((b >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ void fdn_split_bf16x3(float u, uint16_t& hi, uint16_t& mid, uint16_t& lo) {
+    hi = fdn_bf16_rne_bits(u);
+    const float r1 = u - __builtin_bit_cast(float, (unsigned)hi << 16);
+    mid = fdn_bf16_rne_bits(r1);
+    lo = fdn_bf16_rne_bits(r1 - __builtin_bit_cast(float, (unsigned)mid << 16));
+}
+
+// Both F(4,3) x F(4,3) streams for ONE (kd, cin k, cout cj) of one direction: the 9 (kh, kw) weights are loaded once and all 36 (xh, xw)
+// coordinates formed from them -- the per-element form above asks for 9 scattered 4-B loads per output, and the per-step re-pack
+// (30 layers x 2 directions after every optimizer step) was bound by exactly those load instructions (0.175 ms per cfg2 step).
+// Same expression, same order of the 9 terms as fdn_pack_wino44_one / fdn_pack_wino44s_one: bit-identical streams.
+// u44 / u44s: the layer-and-direction's fp32 stream / bf16 x 3 stream, or nullptr.  dgrad: taps flipped, channels transposed.
+// (NOT inlined: inlined into the single-layer and the batched pack kernel hipcc contracted the 9-term sums differently -- one fp32 value
+// in 1.3 million came out an ulp apart; as a function of its own both kernels run the same instructions)
+__device__ __attribute__((noinline)) static void fdn_pack_wino44_column(const float* __restrict__ w, float* __restrict__ u44, uint16_t* __restrict__ u44s,
+                                                                         int kd, int k, int cj, bool dgrad) {
     const double G[6][3] = {{64.0 / 81, 0.0, 0.0}, {-128.0 / 243, -32.0 / 81, -8.0 / 27}, {-128.0 / 243, 32.0 / 81, -8.0 / 27},
                             {32.0 / 243, 16.0 / 81, 8.0 / 27}, {32.0 / 243, -16.0 / 81, 8.0 / 27}, {0.0, 0.0, 1.0}};
-    if (uf) {
-        double v = 0.0;
+    double wv[3][3];
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
+    for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) v += G[xh][kh] * G[xw][t] * (double)w[(((kd * 3 + kh) * 3 + t) * 64 + k) * 64 + cj];
-        uf[idx] = (float)v;
-    }
-    if (ud) {
-        double v = 0.0;
+        for (int t = 0; t < 3; ++t) {
+            const int tap = (kd * 3 + kh) * 3 + t;
+            wv[kh][t] = (double)(dgrad ? w[((26 - tap) * 64 + cj) * 64 + k] : w[(tap * 64 + k) * 64 + cj]);
+        }
+    const int nb = cj >> 4, i = cj & 15;
+    // fp32 stream: [nb][xh][kd][xw][g = k/16][q][i][s], k = 16 g + 4 q + s;  bf16 x 3: [nb][xh][pass = k/32][kd][xw][piece][lane = 16 q' + i][j], k = 32 pass + 8 q' + j
+    const int o44 = (k >> 2) * 64 + i * 4 + (k & 3);
+    const int pass = k >> 5, o44s = ((k >> 3) & 3) * 128 + i * 8 + (k & 7);
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
+    for (int xh = 0; xh < 6; ++xh)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) v += G[xh][kh] * G[xw][t] * (double)w[((26 - ((kd * 3 + kh) * 3 + t)) * 64 + cj) * 64 + k];
-        ud[idx] = (float)v;
-    }
+        for (int xw = 0; xw < 6; ++xw) {
+            double v = 0.0;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) v += G[xh][kh] * G[xw][t] * wv[kh][t];
+            const float u = (float)v;
+            if (u44) u44[(size_t)(((nb * 6 + xh) * 3 + kd) * 6 + xw) * 1024 + o44] = u;
+            if (u44s) {
+                uint16_t* d = u44s + (size_t)((((nb * 6 + xh) * 2 + pass) * 3 + kd) * 6 + xw) * 1536 + o44s;
+                fdn_split_bf16x3(u, d[0], d[512], d[1024]);
+            }
+        }
 }
 
 // The F(4,3) x F(4,3) stream once more, for FDN_ALGO_WINO_BF16X3 (conv64_wino2d_kernel.h, SPLIT): the same U (double precision, rounded once
 // to fp32) split EXACTLY into three bf16 pieces u = hi + mid + lo, laid out as the row operand of v_mfma_f32_16x16x32_bf16:
 // [nb = cout/16][xh 0..5][pass = cin/32][kd][xw 0..5][piece][lane][8]: lane (i = lane & 15, q = lane >> 4), element j <-> cout 16 nb + i,
 // cin 32 pass + 8 q + j.  A wave's (stage, pass, kd, xw) step reads 3 KB: one 16-B load per lane and piece.
-// idx runs over the 108 * 64 * 64 values; the stream is 3 * 108 * 64 * 64 uint16_t = 162 * 64 * 64 float-sized slots.
-__device__ __forceinline__ void fdn_pack_wino44s_one(const float* __restrict__ w, uint16_t* __restrict__ uf, uint16_t* __restrict__ ud, int idx) {
-    const int j = idx & 7;
-    const int lane = (idx >> 3) & 63;
-    int rest = idx >> 9;                 // (((nb*6 + xh)*2 + pass)*3 + kd)*6 + xw
-    const int unit = rest;
-    const int xw = rest % 6; rest /= 6;
-    const int kd = rest % 3; rest /= 3;
-    const int pass = rest & 1; rest >>= 1;
-    const int xh = rest % 6;
-    const int nb = rest / 6;
-    const int k = 32 * pass + 8 * (lane >> 4) + j;
-    const int cj = 16 * nb + (lane & 15);
-    const double G[6][3] = {{64.0 / 81, 0.0, 0.0}, {-128.0 / 243, -32.0 / 81, -8.0 / 27}, {-128.0 / 243, 32.0 / 81, -8.0 / 27},
-                            {32.0 / 243, 16.0 / 81, 8.0 / 27}, {32.0 / 243, -16.0 / 81, 8.0 / 27}, {0.0, 0.0, 1.0}};
-    const size_t o = (size_t)unit * 1536 + lane * 8 + j;
-    auto put = [&](uint16_t* dst, float u) {
-        const __bf16 hi = (__bf16)u;
-        const float r1 = u - (float)hi;
-        const __bf16 mid = (__bf16)r1;
-        const __bf16 lo = (__bf16)(r1 - (float)mid);
-        dst[o] = __builtin_bit_cast(uint16_t, hi);
-        dst[o + 512] = __builtin_bit_cast(uint16_t, mid);
-        dst[o + 1024] = __builtin_bit_cast(uint16_t, lo);
-    };
-    if (uf) {
-        double v = 0.0;
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-            for (int t = 0; t < 3; ++t) v += G[xh][kh] * G[xw][t] * (double)w[(((kd * 3 + kh) * 3 + t) * 64 + k) * 64 + cj];
-        put(uf, (float)v);
-    }
-    if (ud) {
-        double v = 0.0;
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-            for (int t = 0; t < 3; ++t) v += G[xh][kh] * G[xw][t] * (double)w[((26 - ((kd * 3 + kh) * 3 + t)) * 64 + cj) * 64 + k];
-        put(ud, (float)v);
-    }
-}
+// The stream is 3 * 108 * 64 * 64 uint16_t = 162 * 64 * 64 float-sized slots (written by fdn_pack_wino44_column above).

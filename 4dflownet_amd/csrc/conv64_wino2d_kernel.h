@@ -54,25 +54,6 @@ template <int MB, bool SPLIT = false> struct W2Geo {
     static constexpr int plane = rows * row + 64;
     static constexpr int lds = 6 * plane + 96 * 4 + rows * 48;
 };
-typedef __bf16 fdn_bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 fdn_bf16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned fdn_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ unsigned fdn_pk_bf16(float a, float b) {       // two round-to-nearest-even bf16 in one dword (v_cvt_pk_bf16_f32)
-    const fdn_bf16x2 t = {(__bf16)a, (__bf16)b};
-    return __builtin_bit_cast(unsigned, t);
-}
-__device__ __forceinline__ f32x4 fdn_unpk_bf16(fdn_u32x2 h) {
-    return (f32x4){__builtin_bit_cast(float, h.x << 16), __builtin_bit_cast(float, h.x & 0xffff0000u),
-                   __builtin_bit_cast(float, h.y << 16), __builtin_bit_cast(float, h.y & 0xffff0000u)};
-}
-// v = hi + mid + lo exactly (the residual of a round-to-nearest is an fp32 number; the last one has at most 8 significant bits)
-__device__ __forceinline__ void fdn_split3(const f32x4 v, fdn_u32x2& hi, fdn_u32x2& mid, fdn_u32x2& lo) {
-    hi = (fdn_u32x2){fdn_pk_bf16(v.x, v.y), fdn_pk_bf16(v.z, v.w)};
-    f32x4 r = v - fdn_unpk_bf16(hi);
-    mid = (fdn_u32x2){fdn_pk_bf16(r.x, r.y), fdn_pk_bf16(r.z, r.w)};
-    r = r - fdn_unpk_bf16(mid);
-    lo = (fdn_u32x2){fdn_pk_bf16(r.x, r.y), fdn_pk_bf16(r.z, r.w)};
-}
 constexpr int kW2UnitS = 3072;              // bytes of one (stage, pass, kd, xw) step of a wave's split weight stream: 3 pieces x 64 lanes x 16 B
 constexpr int kW2UA = 3;                    // transform items per thread (<= 640 items = 40 rows x 16 chunks)
 constexpr int kW2RDB = 6;                   // weight-fragment ring depth

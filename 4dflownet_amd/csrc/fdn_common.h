@@ -67,6 +67,29 @@ template <> struct FdnVec<uint16_t> {
     }
 };
 
+// fp32 -> three bf16 pieces, v = hi + mid + lo EXACTLY (each piece the round-to-nearest-even bf16 of what the pieces before it leave: the
+// residual of a round-to-nearest is an fp32 number, the last one has at most 8 significant bits).  A bf16 x bf16 product is exact in fp32,
+// so the six cross terms hi.hi, mid.hi, lo.hi, hi.mid, mid.mid, hi.lo accumulated in fp32 on the bf16 matrix pipe reproduce the fp32
+// product to 2^-25 |u||v| (the three dropped terms) -- under the half ulp an fp32 multiply rounds away -- at 6/16 of the fp32-MFMA time.
+typedef __bf16 fdn_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 fdn_bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned fdn_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned fdn_pk_bf16(float a, float b) {       // two round-to-nearest-even bf16 in one dword (v_cvt_pk_bf16_f32)
+    const fdn_bf16x2 t = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, t);
+}
+__device__ __forceinline__ f32x4 fdn_unpk_bf16(fdn_u32x2 h) {
+    return (f32x4){__builtin_bit_cast(float, h.x << 16), __builtin_bit_cast(float, h.x & 0xffff0000u),
+                   __builtin_bit_cast(float, h.y << 16), __builtin_bit_cast(float, h.y & 0xffff0000u)};
+}
+__device__ __forceinline__ void fdn_split3(const f32x4 v, fdn_u32x2& hi, fdn_u32x2& mid, fdn_u32x2& lo) {
+    hi = (fdn_u32x2){fdn_pk_bf16(v.x, v.y), fdn_pk_bf16(v.z, v.w)};
+    f32x4 r = v - fdn_unpk_bf16(hi);
+    mid = (fdn_u32x2){fdn_pk_bf16(r.x, r.y), fdn_pk_bf16(r.z, r.w)};
+    r = r - fdn_unpk_bf16(mid);
+    lo = (fdn_u32x2){fdn_pk_bf16(r.x, r.y), fdn_pk_bf16(r.z, r.w)};
+}
+
 // Direct-to-LDS load (gfx950 `buffer_load_dwordx4 ... lds`): every lane reads 16 B at rsrc + voff + soff and the wave writes the
 // 64 x 16 B to LDS at lds + lane * 16 (lds is wave-uniform: it travels in M0).  Out-of-range lanes store zeros.  The compiler counts
 // it in vmcnt like any other vector-memory load.  (A __device__ function, not a lambda inside the kernel: the builtin does not exist

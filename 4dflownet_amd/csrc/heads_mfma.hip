@@ -50,20 +50,26 @@ __global__ __launch_bounds__(256, 2) void head_fwd_kernel(const T* __restrict__ 
     // bf16 storage: the chunk IS the v_mfma_f32_32x32x16_bf16 operand (k = 8 kh + s of 16-channel block g), and the fp32
     // weights enter as an exact-to-2^-17 bf16 pair w = hi + lo: two bf16 MFMAs per block (8 per M-tile, 32 cycles each)
     // instead of 32 fp32 MFMAs of 64 cycles -- the z-GEMM drops from the matrix-bound to the HBM-bound side.
+    // fp32 storage (round 6): the same bf16 pipe with EXACT splits -- x (as loaded) and w each in three bf16 pieces, six cross terms per
+    // 16-channel block, fp32 accumulation (fdn_common.h): 24 MFMAs of 32 cycles per M-tile instead of 32 fp32 MFMAs of 64 -- the
+    // z-GEMM over the tile's 600 halo voxels was 55 us of matrix time per launch at (8,48^3).  A lane's chunk c then holds cin
+    // 16 (c >> 1) + 8 kh + 4 (c & 1) + s, so that chunks 2G, 2G + 1 are the 8 consecutive channels of block G's operand.
     typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-    float wb[NCH][E];
-    bf16x8 wh[NCH], wl[NCH];
+    bf16x8 wh[E == 8 ? NCH : 1], wl[E == 8 ? NCH : 1];
+    bf16x8 w3[E == 4 ? 4 : 1][3];
 #pragma unroll
-    for (int g = 0; g < NCH; ++g)
+    for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int s = 0; s < E; ++s) {
-            const float wv = li < 27 ? w[li * 64 + 2 * E * g + E * kh + s] : 0.f;
+        for (int s = 0; s < 8; ++s) {
+            const float wv = li < 27 ? w[li * 64 + 16 * g + 8 * kh + s] : 0.f;     // (both storage types: block g, k = 8 kh + s)
+            const __bf16 h = (__bf16)wv;
             if constexpr (E == 8) {
-                const __bf16 h = (__bf16)wv;
                 wh[g][s] = h;
                 wl[g][s] = (__bf16)(wv - (float)h);
             } else {
-                wb[g][s] = wv;
+                const float r1 = wv - (float)h;
+                const __bf16 m = (__bf16)r1;
+                w3[g][0][s] = h; w3[g][1][s] = m; w3[g][2][s] = (__bf16)(r1 - (float)m);
             }
         }
     const float b0 = bias ? bias[0] : 0.f;
@@ -99,9 +105,9 @@ __global__ __launch_bounds__(256, 2) void head_fwd_kernel(const T* __restrict__ 
     auto load_tile = [&](const TileOrg& o, int k, u32x4 (&av)[NCH]) {
         const int zd = zpk[k] & 255, zh = (zpk[k] >> 8) & 255, zw = zpk[k] >> 16;
         const int qd = clampi(o.d + zd - 1, D - 1), qh = clampi(o.h + zh - 1, H - 1), qw = clampi(o.w + zw - 1, W - 1);
-        const T* xp = x + ((size_t)o.n * D * H * W + ((size_t)qd * H + qh) * W + qw) * 64 + kh * E;
+        const T* xp = x + ((size_t)o.n * D * H * W + ((size_t)qd * H + qh) * W + qw) * 64 + kh * 8;
 #pragma unroll
-        for (int g = 0; g < NCH; ++g) av[g] = *(const u32x4*)(xp + g * 2 * E);
+        for (int g = 0; g < NCH; ++g) av[g] = *(const u32x4*)(xp + (E == 8 ? g * 16 : (g >> 1) * 16 + (g & 1) * 4));
     };
     const int G = gridDim.x;
     // XCD-aware walk: workgroup ids are dealt round-robin to the 8 XCDs; within a generation of G tiles every XCD takes one
@@ -114,9 +120,20 @@ __global__ __launch_bounds__(256, 2) void head_fwd_kernel(const T* __restrict__ 
 #pragma unroll
         for (int g = 0; g < NCH; ++g) {
             if constexpr (E == 4) {
-                const f32x4 f = __builtin_bit_cast(f32x4, src[g]);     // (bit_cast of src[g][s] miscompiles: all four = element 0)
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f[s], wb[g][s], acc, 0, 0, 0);
+                if (g & 1) continue;                                   // chunks g, g + 1 = block g / 2
+                fdn_u32x2 h0, m0, l0, h1, m1, l1;
+                fdn_split3(__builtin_bit_cast(f32x4, src[g]), h0, m0, l0);
+                fdn_split3(__builtin_bit_cast(f32x4, src[g + 1]), h1, m1, l1);
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, (u32x4){h0.x, h0.y, h1.x, h1.y});
+                const bf16x8 am = __builtin_bit_cast(bf16x8, (u32x4){m0.x, m0.y, m1.x, m1.y});
+                const bf16x8 al = __builtin_bit_cast(bf16x8, (u32x4){l0.x, l0.y, l1.x, l1.y});
+                const int G = g >> 1;
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, w3[G][0], acc, 0, 0, 0);       // small terms first
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, w3[G][2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, w3[G][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, w3[G][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, w3[G][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, w3[G][0], acc, 0, 0, 0);
             } else {
                 const bf16x8 a = __builtin_bit_cast(bf16x8, src[g]);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wh[g], acc, 0, 0, 0);

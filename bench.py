@@ -784,14 +784,6 @@ def main():
     line = None
     if args.pmc is None:                               # the driver-facing default run measures its own traffic figure where the line is made
         args.pmc = not args.no_secondary and world == 1
-    if rank == 0 and args.pmc and world == 1:
-        global PMC_LIVE
-        tail = ["--config", args.config] if args.config != "cfg2" else []
-        try:
-            PMC_LIVE = pmc_live_passes(tail)
-        except Exception as e:                          # (a box without working counters must not cost the headline)
-            print("bench.py --pmc: %s: %s" % (type(e).__name__, str(e)[-200:]), file=sys.stderr)
-            PMC_LIVE = None
     if rank == 0:
         fwd_flop = fwd_flop_per_patch(tc.model.specs, P, R, LB)
         tr = CFG4_TRAFFIC if args.config == "cfg4" else ([] if bf16 else CFG2_TRAFFIC)
@@ -864,6 +856,25 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(P, R, LB, HB)
             except Exception as e:
                 line["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, str(e)[-300:]), "kind": "port", "value": None, "unit": "patches/s"}
+    if args.pmc and world == 1:
+        # roofline.traffic measured by THIS run: two rocprofv3 --pmc passes of the same command (2 steps each), behind every timed leg (a
+        # profiler child that has just left the device cost the next leg one 2.5-s step when the passes ran in front of them)
+        global PMC_LIVE
+        tail = ["--config", args.config] if args.config != "cfg2" else []
+        try:
+            PMC_LIVE = pmc_live_passes(tail)
+        except Exception as e:                          # (a box without working counters must not cost the line)
+            print("bench.py --pmc: %s: %s" % (type(e).__name__, str(e)[-200:]), file=sys.stderr)
+            PMC_LIVE = None
+        if PMC_LIVE is not None:
+            tr = CFG4_TRAFFIC if args.config == "cfg4" else ([] if bf16 else CFG2_TRAFFIC)
+            for key in ("roofline", "roofline_wgrad"):
+                obj = line.get(key)
+                if obj:
+                    traffic, tfile = pmc_traffic_bytes(tr, obj["kernel"].split(" ")[0])
+                    if tfile:
+                        obj["traffic"], obj["traffic_source"] = traffic, tfile
+                        obj["traffic_unit"] = "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)"
     print(json.dumps(line), flush=True)
     if parallel.is_dist():
         parallel.barrier()
