@@ -145,7 +145,6 @@ class FlowNetModel:
         assert off == n
         self.is_kernel = torch.tensor(is_kernel, device=self.device)
         self._w64_offsets = torch.tensor([L.w_off for L in self.layers if L.wp_f is not None], device=self.device, dtype=torch.int64)
-        self.set_conv_algo(conv_algo)
         self.weights_version = 0       # bumped by weights_changed(): lets the trainer know whether Adam's sum-of-squares is current
         self._ws = None
         self._ws_bias = None
@@ -163,6 +162,7 @@ class FlowNetModel:
         # per-kernel timing pass wants (bench.py takes its HIP-event pass that way, in steps of its own).
         self.overlap_wgrad = os.environ.get("FDN_OVERLAP_WGRAD", "1") not in ("", "0")
         self._ws_side = None           # the side stream's own workspace (allocated and re-allocated under that stream: see _workspace)
+        self.set_conv_algo(conv_algo)
         self._cache = None
         # Gradient buckets in the order backward() completes them: slices [lo, hi) of flat_g_ext that are final when the hi-res part
         # (heads + hi-res blocks, together with the trailing batch slot), the upper half of the low-res blocks and the rest are done.
@@ -198,6 +198,11 @@ class FlowNetModel:
         if unknown:
             raise ValueError("conv_algo: unknown layer(s) %s" % unknown)
         self.conv_algo = dict((L.name, names[per_layer.get(L.name, conv_algo)]) for L in self.layers)
+        # FDN_ALGO_WINO_BF16X3 runs persistent workgroups that hold every CU's registers and LDS for the whole launch: a weight-gradient
+        # launch on the second stream cannot share a CU with them and the two streams take turns badly (measured 28.9 ms one stream,
+        # 39.4 ms two at cfg2).  Models that use it keep everything on one stream unless FDN_OVERLAP_WGRAD says otherwise.
+        if ops.ALGO_WINO_BF16X3 in self.conv_algo.values() and "FDN_OVERLAP_WGRAD" not in os.environ and hasattr(self, "overlap_wgrad"):
+            self.overlap_wgrad = False
 
     # ------------------------------------------------------------------ parameters
     def glorot_uniform_init(self, seed=0):
