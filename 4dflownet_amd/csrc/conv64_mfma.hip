@@ -459,25 +459,11 @@ __global__ void pack_conv64_kernel(const float* __restrict__ w, float* __restric
 // lies inside one stream (every stream is a multiple of 256 elements), so an unwanted stream costs an early exit
 __global__ void pack_conv64_batch_kernel(const float* __restrict__ w_base, const int64_t* __restrict__ w_offsets, float* __restrict__ packs,
                                          int sf, int sd) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over the 153*64*64 packed elements of the first three streams, then the 2 * 3*64*64 columns of the F(4,3) x F(4,3) streams
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over the 153*64*64 packed elements of the first three streams
+    if (idx >= 153 * 64 * 64) return;
     const float* w = w_base + w_offsets[blockIdx.y];
     float* pf = packs + (size_t)blockIdx.y * 2 * FDN_CONV64_PACK_FLOATS;
     float* pd = pf + FDN_CONV64_PACK_FLOATS;
-    if (idx >= 153 * 64 * 64) {
-        // F(4,3) x F(4,3), fp32 and bf16 x 3: thread = (direction, kd, cin, cout) forms all 36 coordinates from one load of its 9 weights
-        const int c = idx - 153 * 64 * 64;
-        if (c >= 2 * 3 * 64 * 64) return;
-        const bool dg = c >= 3 * 64 * 64;
-        const int s = dg ? sd : sf;
-        if (!(s & 24)) return;
-        float* pk = dg ? pd : pf;
-        const int e = c - (dg ? 3 * 64 * 64 : 0);
-        // (thread order = the fp32 stream's element order inside a unit: consecutive lanes write consecutive floats)
-        const int o = e & 1023, nb = (e >> 10) & 3, kd = e >> 12;
-        fdn_pack_wino44_column(w, (s & 8) ? pk + 153 * 64 * 64 : nullptr, (s & 16) ? (uint16_t*)(pk + 261 * 64 * 64) : nullptr, kd,
-                               (o >> 6) * 4 + (o & 3), nb * 16 + ((o >> 2) & 15), dg);
-        return;
-    }
     const int st = idx < 27 * 64 * 64 ? 0 : idx < 81 * 64 * 64 ? 1 : 2;
     if (!(((sf | sd) >> st) & 1)) return;
     if (!((sf >> st) & 1)) pf = nullptr;
@@ -485,6 +471,32 @@ __global__ void pack_conv64_batch_kernel(const float* __restrict__ w_base, const
     if (st == 0) fdn_pack_direct_one(w, pf, pd, idx);
     else if (st == 1) fdn_pack_wino_one(w, pf ? pf + 27 * 64 * 64 : nullptr, pd ? pd + 27 * 64 * 64 : nullptr, idx - 27 * 64 * 64);
     else fdn_pack_wino2d_one(w, pf ? pf + 81 * 64 * 64 : nullptr, pd ? pd + 81 * 64 * 64 : nullptr, idx - 81 * 64 * 64);
+}
+
+// The two F(4,3) x F(4,3) streams (fp32: pack + 153*4096 floats; bf16 x 3: pack + 261*4096), for one layer (w_offsets == nullptr: w_base is
+// the kernel, packs = forward pack, packs_d = dgrad pack, either may be null) or for blockIdx.y = layer of the flat parameter buffer
+// (packs_d == nullptr: packs = [layer][fwd | dgrad][FDN_CONV64_PACK_FLOATS]).  Thread = (direction, kd, cin, cout): all 36 coordinates from
+// one load of its 9 weights, in the fp32 stream's element order (consecutive lanes write consecutive floats).  sf / sd: stream masks.
+__global__ void pack_conv64_wino44_kernel(const float* __restrict__ w_base, const int64_t* __restrict__ w_offsets, float* __restrict__ packs,
+                                          float* __restrict__ packs_d, int sf, int sd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= 2 * 3 * 64 * 64) return;
+    const bool dg = c >= 3 * 64 * 64;
+    const int s = dg ? sd : sf;
+    if (!(s & 24)) return;
+    const float* w = w_offsets ? w_base + w_offsets[blockIdx.y] : w_base;
+    float* pk = w_offsets ? packs + ((size_t)blockIdx.y * 2 + (dg ? 1 : 0)) * FDN_CONV64_PACK_FLOATS : (dg ? packs_d : packs);
+    if (!pk) return;
+    const int e = c - (dg ? 3 * 64 * 64 : 0);
+    const int o = e & 1023, nb = (e >> 10) & 3, kd = e >> 12;
+    fdn_pack_wino44_column(w, (s & 8) ? pk + 153 * 64 * 64 : nullptr, (s & 16) ? (uint16_t*)(pk + 261 * 64 * 64) : nullptr, kd,
+                           (o >> 6) * 4 + (o & 3), nb * 16 + ((o >> 2) & 15), dg);
+}
+
+int fdn_pack_conv64_wino44_launch(const float* w, float* wp_fwd, float* wp_dgrad, hipStream_t s) {
+    hipLaunchKernelGGL(pack_conv64_wino44_kernel, dim3((2 * 3 * 64 * 64 + 255) / 256, 1), dim3(256), 0, s, w, (const int64_t*)nullptr, wp_fwd, wp_dgrad, 24, 24);
+    FDN_CHECK_LAUNCH("pack_conv64_wino44_kernel");
+    return FDN_OK;
 }
 
 // pack = [direct stream, 27*64*64 floats | Winograd F(4,3) stream, 54*64*64 | 2-D F(2,3)xF(4,3) stream, 72*64*64 | 2-D F(4,3)xF(4,3)
@@ -503,8 +515,10 @@ extern "C" int fdn_pack_conv64_weights(const float* w, float* wp_fwd, float* wp_
     if (int rc = fdn_pack_conv64_wino_launch(w, wp_fwd ? wp_fwd + kDirectPackFloats : nullptr,
                                              wp_dgrad ? wp_dgrad + kDirectPackFloats : nullptr, (hipStream_t)stream))
         return rc;
-    return fdn_pack_conv64_wino2d_launch(w, wp_fwd ? wp_fwd + kDirectPackFloats + kWino1PackFloats : nullptr,
-                                         wp_dgrad ? wp_dgrad + kDirectPackFloats + kWino1PackFloats : nullptr, (hipStream_t)stream);
+    if (int rc = fdn_pack_conv64_wino2d_launch(w, wp_fwd ? wp_fwd + kDirectPackFloats + kWino1PackFloats : nullptr,
+                                               wp_dgrad ? wp_dgrad + kDirectPackFloats + kWino1PackFloats : nullptr, (hipStream_t)stream))
+        return rc;
+    return fdn_pack_conv64_wino44_launch(w, wp_fwd, wp_dgrad, (hipStream_t)stream);
 }
 
 extern "C" int fdn_pack_conv64_weights_batch_streams(const float* w_base, const int64_t* w_offsets, int n_layers, float* packs,
@@ -513,9 +527,16 @@ extern "C" int fdn_pack_conv64_weights_batch_streams(const float* w_base, const 
     FDN_REQUIRE(!(streams_fwd & ~FDN_PACK_STREAM_ALL) && !(streams_dgrad & ~FDN_PACK_STREAM_ALL), "fdn_pack_conv64_weights_batch_streams: bad stream mask %d / %d",
                 streams_fwd, streams_dgrad);
     if (!(streams_fwd | streams_dgrad)) return FDN_OK;
-    hipLaunchKernelGGL(pack_conv64_batch_kernel, dim3(((153 + 6) * 64 * 64 + 255) / 256, (unsigned)n_layers), dim3(256), 0, (hipStream_t)stream,
-                       w_base, w_offsets, packs, streams_fwd, streams_dgrad);
-    FDN_CHECK_LAUNCH("fdn_pack_conv64_weights_batch");
+    if ((streams_fwd | streams_dgrad) & 7) {
+        hipLaunchKernelGGL(pack_conv64_batch_kernel, dim3((153 * 64 * 64 + 255) / 256, (unsigned)n_layers), dim3(256), 0, (hipStream_t)stream,
+                           w_base, w_offsets, packs, streams_fwd, streams_dgrad);
+        FDN_CHECK_LAUNCH("fdn_pack_conv64_weights_batch");
+    }
+    if ((streams_fwd | streams_dgrad) & 24) {
+        hipLaunchKernelGGL(pack_conv64_wino44_kernel, dim3((2 * 3 * 64 * 64 + 255) / 256, (unsigned)n_layers), dim3(256), 0, (hipStream_t)stream,
+                           w_base, w_offsets, packs, (float*)nullptr, streams_fwd, streams_dgrad);
+        FDN_CHECK_LAUNCH("pack_conv64_wino44_kernel");
+    }
     return FDN_OK;
 }
 

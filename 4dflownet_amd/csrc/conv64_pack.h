@@ -129,10 +129,10 @@ __device__ __forceinline__ void fdn_split_bf16x3(float u, uint16_t& hi, uint16_t
 // (30 layers x 2 directions after every optimizer step) was bound by exactly those load instructions (0.175 ms per cfg2 step).
 // Same expression, same order of the 9 terms as fdn_pack_wino44_one / fdn_pack_wino44s_one: bit-identical streams.
 // u44 / u44s: the layer-and-direction's fp32 stream / bf16 x 3 stream, or nullptr.  dgrad: taps flipped, channels transposed.
-// (NOT inlined: inlined into the single-layer and the batched pack kernel hipcc contracted the 9-term sums differently -- one fp32 value
-// in 1.3 million came out an ulp apart; as a function of its own both kernels run the same instructions)
-__device__ __attribute__((noinline)) static void fdn_pack_wino44_column(const float* __restrict__ w, float* __restrict__ u44, uint16_t* __restrict__ u44s,
-                                                                         int kd, int k, int cj, bool dgrad) {
+// (Instantiated in ONE kernel, pack_conv64_wino44_kernel of conv64_mfma.hip, which both the single-layer and the batched pack launch:
+// inlined into two kernels hipcc contracted the 9-term sums differently -- one fp32 value in 1.3 million came out an ulp apart.)
+__device__ __forceinline__ void fdn_pack_wino44_column(const float* __restrict__ w, float* __restrict__ u44, uint16_t* __restrict__ u44s,
+                                                        int kd, int k, int cj, bool dgrad) {
     const double G[6][3] = {{64.0 / 81, 0.0, 0.0}, {-128.0 / 243, -32.0 / 81, -8.0 / 27}, {-128.0 / 243, 32.0 / 81, -8.0 / 27},
                             {32.0 / 243, 16.0 / 81, 8.0 / 27}, {32.0 / 243, -16.0 / 81, 8.0 / 27}, {0.0, 0.0, 1.0}};
     double wv[3][3];

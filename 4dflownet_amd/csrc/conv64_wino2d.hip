@@ -84,19 +84,10 @@ __global__ __launch_bounds__(256, 1) void conv64_wino2d_occ1_kernel(Wino2Args p)
 }
 #endif
 
-// the 2-D streams of one layer: [F(2,3) x F(4,3): 72 * 4096 floats | F(4,3) x F(4,3): 108 * 4096 | the same as three bf16 pieces per value: 162 * 4096 slots]
+// the F(2,3) x F(4,3) stream of one layer (72 * 4096 floats)
 __global__ void pack_conv64_wino2d_kernel(const float* __restrict__ w, float* __restrict__ uf, float* __restrict__ ud) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < 72 * 64 * 64) { fdn_pack_wino2d_one(w, uf, ud, idx); return; }
-    // both F(4,3) x F(4,3) streams: thread = (direction, kd, cin, cout) forms all 36 coordinates (the code of the batched launch, so the two agree bit for bit)
-    const int c = idx - 72 * 64 * 64;
-    if (c >= 2 * 3 * 64 * 64) return;
-    const bool dg = c >= 3 * 64 * 64;
-    float* pk = dg ? ud : uf;
-    if (!pk) return;
-    const int e = c - (dg ? 3 * 64 * 64 : 0);
-    const int o = e & 1023, nb = (e >> 10) & 3, kd = e >> 12;
-    fdn_pack_wino44_column(w, pk + 72 * 64 * 64, (uint16_t*)(pk + 180 * 64 * 64), kd, (o >> 6) * 4 + (o & 3), nb * 16 + ((o >> 2) & 15), dg);
+    if (idx < 72 * 64 * 64) fdn_pack_wino2d_one(w, uf, ud, idx);      // (the F(4,3) x F(4,3) streams: pack_conv64_wino44_kernel, conv64_mfma.hip)
 }
 
 struct Wino2Plan { int td, ch, cw; double cost; };
@@ -244,7 +235,7 @@ int fdn_conv64_wino2d_launch(const float* x, const float* upack2, const float* b
 }
 
 int fdn_pack_conv64_wino2d_launch(const float* w, float* uf, float* ud, hipStream_t s) {
-    hipLaunchKernelGGL(pack_conv64_wino2d_kernel, dim3(((72 + 6) * 64 * 64 + 255) / 256), dim3(256), 0, s, w, uf, ud);
+    hipLaunchKernelGGL(pack_conv64_wino2d_kernel, dim3((72 * 64 * 64 + 255) / 256), dim3(256), 0, s, w, uf, ud);
     FDN_CHECK_LAUNCH("pack_conv64_wino2d_kernel");
     return FDN_OK;
 }

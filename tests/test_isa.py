@@ -91,7 +91,7 @@ PRODUCT_KERNELS = {
     "wgrad64_wino_kernel<true>": "fdn_conv3d_wgrad 64->64, D even", "wgrad64_wino_batch_kernel<true>": "fdn_conv3d_wgrad_batch", "wgrad64_wino_kernel<false>": "... odd D, FDN_ALGO_WINO_W",
     "wgrad64_reduce_dep_kernel": "", "wgrad64_reduce_kernel": "", "wgrad64_pipe_kernel<4, 8>": "... W % 4 != 0, FDN_ALGO_DIRECT",
     "fold_halo_border_kernel": "fdn_fold_halo_border", "fold_halo_kernel": "fdn_fold_halo",
-    "pack_conv64_kernel": "fdn_pack_conv64_weights", "pack_conv64_wino_kernel": "", "pack_conv64_wino2d_kernel": "", "pack_conv64_batch_kernel": "fdn_pack_conv64_weights_batch",
+    "pack_conv64_kernel": "fdn_pack_conv64_weights", "pack_conv64_wino_kernel": "", "pack_conv64_wino2d_kernel": "", "pack_conv64_batch_kernel": "fdn_pack_conv64_weights_batch", "pack_conv64_wino44_kernel": "... the F(4,3) x F(4,3) streams, fp32 and bf16 x 3",
     "conv_cin3_fwd_mfma_kernel<T>": "fdn_conv3d_fwd 3->64", "wgrad_cin3_mfma_kernel<T>": "fdn_conv3d_wgrad 3->64", "wgrad_cin3_kernel<T>": "... odd W",
     "conv1x1_fwd_mfma_kernel<T>": "fdn_conv3d_fwd (64+64)->64 k1", "conv1x1_dgrad_mfma_kernel<T>": "fdn_conv1x1_dgrad", "wgrad_1x1_mfma_kernel<T>": "fdn_conv3d_wgrad k1",
     "head_fwd_kernel<T>": "fdn_conv3d_fwd 64->1", "head_dgrad_kernel<T>": "fdn_conv_cout1_dgrad_folded", "head_wgrad_kernel<T>": "fdn_conv3d_wgrad 64->1",

@@ -10,10 +10,15 @@ batch = tuple([f(-1, 1, (B, P, P, P, 1)) for _ in range(3)] + [f(0, 0.016, (B, P
               [f(-0.45, 0.45, (B, P * R, P * R, P * R, 1)) for _ in range(3)] + [np.full((B,), 1.5, np.float32), (rng.random((B, P * R, P * R, P * R)) < 0.12).astype(np.float32)])
 tc = trainer.TrainerController(P, R, quicksave_enable=False, low_resblock=LB, hi_resblock=HB)
 dev = tuple(tc.model._to_dev(a) for a in batch)
-for ov in (False, True, False, True):
-    tc.model.overlap_wgrad = ov
-    for _ in range(5): tc.train_step(dev)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(20): tc.train_step(dev)
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
-    print("overlap_wgrad=%s: %.3f ms/step" % (ov, dt * 1e3))
+res = {False: [], True: []}
+for rep in range(6):
+    for ov in ((False, True) if rep % 2 == 0 else (True, False)):       # alternate the order: clock / thermal drift must not pick the winner
+        tc.model.overlap_wgrad = ov
+        for _ in range(5): tc.train_step(dev)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(30): tc.train_step(dev)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 30
+        res[ov].append(dt * 1e3)
+        print("overlap_wgrad=%s: %.3f ms/step" % (ov, dt * 1e3), flush=True)
+for ov in (False, True):
+    print("overlap_wgrad=%s: mean %.3f ms/step, min %.3f, max %.3f over %d runs of 30 steps" % (ov, np.mean(res[ov]), min(res[ov]), max(res[ov]), len(res[ov])))
