@@ -162,6 +162,7 @@ class FlowNetModel:
         # per-kernel timing pass wants (bench.py takes its HIP-event pass that way, in steps of its own).
         self.overlap_wgrad = os.environ.get("FDN_OVERLAP_WGRAD", "1") not in ("", "0")
         self._ws_side = None           # the side stream's own workspace (allocated and re-allocated under that stream: see _workspace)
+        self._side_keep = []           # operands of side-stream launches, kept alive until the streams are joined
         self.set_conv_algo(conv_algo)
         self._cache = None
         # Gradient buckets in the order backward() completes them: slices [lo, hi) of flat_g_ext that are final when the hi-res part
@@ -448,9 +449,7 @@ class FlowNetModel:
         with torch.cuda.stream(self._side):
             self.ops.conv3d_wgrad(x, dz, L.k, L.cin, L.cout, x2=x2, dw=L.gw, dbias=L.gb if bias else None, workspace=ws, lddz=lddz,
                              dz_coff=dz_coff, algo=self.conv_algo[L.name])
-        for t in (x, dz, x2):                             # keep the caching allocator from recycling them too early
-            if t is not None:
-                t.record_stream(self._side)
+        self._side_keep.extend(t for t in (x, dz, x2) if t is not None)     # alive until the streams are joined (see _join_side)
 
     def _flush_wgrads(self):
         """Issue the collected weight gradients: layers of one grid and algorithm as one batched launch, a lone layer as before."""
@@ -476,7 +475,16 @@ class FlowNetModel:
                                                 [i[2].gb if i[3] else None for i in items], workspace=ws, algo=algo)
             if side:
                 for x, dz, _, _ in items:
-                    x.record_stream(self._side); dz.record_stream(self._side)
+                    self._side_keep.extend((x, dz))
+
+    def _join_side(self):
+        """The main stream waits for everything the side stream has been given; the operands of those launches may be freed after it.
+        (Holding references until the join instead of Tensor.record_stream: with record_stream the caching allocator could not reuse a
+        block until the side stream had passed its free point, took fresh device memory for the main stream meanwhile and never came
+        back -- 0.8 GB per step, 96 GB reserved after 120 cfg2 steps, and one 2.9-s step when it finally had to give the cache back.)"""
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+        self._side_keep.clear()
 
     def _pad_like(self, t):
         N, D, H, W, C = t.shape
@@ -519,8 +527,7 @@ class FlowNetModel:
         def bucket_done(k):
             self._flush_wgrads()                            # the batched weight gradients of this bucket's layers
             if grad_ready is not None and k < len(self.grad_buckets):
-                if self._side is not None:
-                    torch.cuda.current_stream().wait_stream(self._side)
+                self._join_side()
                 grad_ready(*self.grad_buckets[k])
         done = 0
         c = self._cache
@@ -604,8 +611,7 @@ class FlowNetModel:
             dz0 = self._dgrad_fold(dzz, second, None, x0, ACT_RELU)
             self._wgrad(c["phase"] if src == "p" else c["pc"], dz0, first)
         self._flush_wgrads()
-        if self._side is not None:
-            torch.cuda.current_stream().wait_stream(self._side)      # all weight gradients have landed in flat_g
+        self._join_side()                                            # all weight gradients have landed in flat_g
         while done < len(self.grad_buckets):
             bucket_done(done)
             done += 1

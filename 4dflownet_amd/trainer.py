@@ -268,11 +268,14 @@ class TrainerController:
                 return batch, None
             if copy_stream is None:
                 copy_stream = torch.cuda.Stream(device=self.device)
+            # destinations come from the consumer stream's pool (and go back to it): the copy stream first waits for what that stream has
+            # been given so far -- a recycled block may still be read by it -- which is at most the step before the one this batch feeds
+            src = [a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)) for a in batch]
+            dev = [torch.empty(t.shape, device=self.device, dtype=torch.float32) for t in src]
+            copy_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(copy_stream):
-                dev = []
-                for a in batch:
-                    t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
-                    dev.append(t.to(device=self.device, dtype=torch.float32, non_blocking=True))
+                for d, t in zip(dev, src):
+                    d.copy_(t, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(copy_stream)
             return tuple(dev), ev
@@ -291,10 +294,7 @@ class TrainerController:
             except StopIteration:
                 nxt = None
             if ev is not None:
-                main = torch.cuda.current_stream()
-                main.wait_event(ev)
-                for t in cur:
-                    t.record_stream(main)                  # allocated under the copy stream, consumed on this one
+                torch.cuda.current_stream().wait_event(ev)
             yield cur
 
     # ------------------------------------------------------------------ training loop
