@@ -527,8 +527,15 @@ class FlowNetModel:
         def bucket_done(k):
             self._flush_wgrads()                            # the batched weight gradients of this bucket's layers
             if grad_ready is not None and k < len(self.grad_buckets):
-                self._join_side()
-                grad_ready(*self.grad_buckets[k])
+                if self._side is not None and self.overlap_wgrad:
+                    # the bucket is complete once BOTH streams have run what they hold: the callback (the trainer starts the bucket's
+                    # all-reduce in it) is issued from the side stream after that stream has been made to wait for the main one, so the
+                    # collective is ordered behind both and the dgrad chain on the main stream does not stop for it
+                    self._side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(self._side):
+                        grad_ready(*self.grad_buckets[k])
+                else:
+                    grad_ready(*self.grad_buckets[k])
         done = 0
         c = self._cache
         if c is None:

@@ -1,6 +1,8 @@
 """One-off soak of the tile / region / XCD-order logic: Winograd kernels of the product library vs the direct MFMA kernels (test build) on many
 random shapes (the same comparison as tests/test_gpu_kernels.py::test_winograd_kernels_equal_direct_kernels_on_random_shapes).
-    python tools/soak_wino.py [count] [seed] [max_extent] [h4]      (h4: H a multiple of 4 as well -> the F(4,3) x F(4,3) kernel on every shape)"""
+    python tools/soak_wino.py [count] [seed] [max_extent] [h4|anyw|-] [auto|bf16x3]
+    h4: H a multiple of 4 as well -> the F(4,3) x F(4,3) kernel on every shape (half-size and full tiles); anyw: any W, N up to 40 -> grids off
+    the multiple-of-4 raster (aligned box + direct strips above 24 576 voxels, all direct below); bf16x3: FDN_ALGO_WINO_BF16X3 for forward / dgrad"""
 import importlib, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,11 +11,17 @@ count = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 mx = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 h4 = len(sys.argv) > 4 and sys.argv[4] == "h4"
+anyw = len(sys.argv) > 4 and sys.argv[4] == "anyw"
+algo = ops.ALGO_WINO_BF16X3 if len(sys.argv) > 5 and sys.argv[5] == "bf16x3" else ops.ALGO_AUTO
 rng = np.random.default_rng(seed)
 worst = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
 for k in range(count):
     N, D, H, W = int(rng.integers(1, 5)), int(rng.integers(1, mx + 1)), int(rng.integers(1, mx + 1)), 4 * int(rng.integers(1, mx // 4 + 1))
     if h4: H = 4 * int(rng.integers(1, mx // 4 + 1))
+    if anyw:
+        W = int(rng.integers(1, mx + 1))
+        N = int(rng.integers(1, 41))
+        while N > 1 and N * D * H * W > 120000: N //= 2
     if N * D * H * W > 120000: N = 1
     g = torch.Generator(device="cuda").manual_seed(k + 17 * seed)
     x = torch.randn((N, D, H, W, 64), device="cuda", generator=g); res = torch.randn((N, D, H, W, 64), device="cuda", generator=g)
@@ -22,14 +30,14 @@ for k in range(count):
     wf, wd = ops.pack_conv64_weights(w)
     Wg = max(1, W + 3 - int(rng.integers(0, 4)))
     xg = torch.randn((N, D, H, Wg, 64), device="cuda", generator=g); dzg = torch.randn((N, D, H, Wg, 64), device="cuda", generator=g)
-    def run():
-        y = ops.conv3d_fwd(x, w, b, ops.ACT_LEAKY, 0.2, res, wpack=wf)
+    def run(algo=ops.ALGO_AUTO):
+        y = ops.conv3d_fwd(x, w, b, ops.ACT_LEAKY, 0.2, res, wpack=wf, algo=algo)
         pad = torch.full((N, D + 2, H + 2, W + 2, 64), float("nan"), device="cuda"); out = torch.zeros_like(x)
-        ops.conv3d_dgrad_fused(dz, wd, pad, out, skip=res, y_prev=yfix, act=ops.ACT_LEAKY)
+        ops.conv3d_dgrad_fused(dz, wd, pad, out, skip=res, y_prev=yfix, act=ops.ACT_LEAKY, algo=algo)
         ops.fold_halo_border([pad], out, res, yfix, ops.ACT_LEAKY)
-        dw, _ = ops.conv3d_wgrad(xg, dzg, 3, 64, 64)
+        dw, _ = ops.conv3d_wgrad(xg, dzg, 3, 64, 64, algo=algo)
         return y, out, dw
-    got = run()
+    got = run(algo)
     with fdn._lib.test_build() as lib:
         lib.fdn_debug_set_conv64_mt(5); lib.fdn_debug_set_wgrad64_direct(1)
         try: ref = run()
@@ -38,4 +46,4 @@ for k in range(count):
         err = (a - r).abs().max().item() / max(r.abs().max().item(), 1e-30)
         if not (err <= 1e-5): print("MISMATCH", name, (N, D, H, W, Wg), err, flush=True)
         worst[name] = max(worst[name], err if err == err else 1e9)
-print("%d shapes, worst relative difference:" % count, worst)
+print("%d shapes (%s, %s), worst relative difference:" % (count, sys.argv[4] if len(sys.argv) > 4 else "-", "bf16x3" if algo == ops.ALGO_WINO_BF16X3 else "auto"), worst)
