@@ -193,7 +193,8 @@ extern "C" int fdn_conv3d_wgrad(const float* x, const float* x2, const float* dz
 }
 
 // Weight gradients of n_layers 64->64 3x3x3 layers that share one grid, in ONE launch (+ one reduction launch) where the kernel allows
-// it (W % 4 == 0, even D, FDN_ALGO_AUTO / _WINO_H2), else layer by layer through fdn_conv3d_wgrad's path: same results either way.
+// it (W % 4 == 0, even D, FDN_ALGO_AUTO / _WINO_H2), else layer by layer through fdn_conv3d_wgrad's path.  The batched kernel gives
+// every layer 64 / n_layers splits of the voxel sum where the single-layer launch uses 63: equal to fp32 rounding, not bit for bit.
 static bool wgrad_batchable(int n_layers, int D, int W, int algo) {
     return !fdn_wgrad64_force_direct && (W & 3) == 0 && fdn_wgrad64_wino_batch_ok(n_layers, D, algo);
 }

@@ -113,7 +113,7 @@ __device__ __forceinline__ unsigned fdn_lds_addr(const void* p) {
 }
 __device__ __forceinline__ void fdn_lds_dma16_untracked(fdn_i32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");      // (m0 is a reserved register: hipcc rewrites it before each of its own uses)
+                 :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() is a fence + s_barrier and hipcc drains EVERY counter in front of

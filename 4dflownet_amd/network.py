@@ -117,7 +117,10 @@ class FlowNetModel:
         off = 0
         n64 = sum(1 for _, k, ci, co, _ in self.specs if (k, ci, co) == (3, 64, 64))
         pack_elems = ops.CONV64_PACK_FLOATS if dtype == "float32" else 27 * 64 * 64
-        self._packs = torch.empty((n64, 2, pack_elems), device=self.device, dtype=self.act_dtype)
+        # (zero-filled: a pack holds five streams and only the ones the model's grids read are kept current -- _pack_streams below; the others
+        # stay zero, not garbage.  The packs are private to forward() / backward(): read L.wp_f / L.wp_d elsewhere only through
+        # _require_pack_streams, or re-pack everything with ops.pack_conv64_weights_batch(..., streams=None).)
+        self._packs = torch.zeros((n64, 2, pack_elems), device=self.device, dtype=self.act_dtype)
         i64 = 0
         for name, k, ci, co, ub in self.specs:
             L = _Layer()

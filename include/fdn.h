@@ -178,8 +178,9 @@ int fdn_conv1x1_dgrad(const float* dz, const float* w, const float* ya, const fl
 size_t fdn_conv3d_wgrad_workspace_bytes(int N, int D, int H, int W, int Cin, int Cout, int K);
 
 /* The weight gradients of n_layers 64->64 3x3x3 layers that share one (N, D, H, W) grid, as ONE launch + one reduction where the
- * Winograd kernel applies (W % 4 == 0, D even, algo AUTO / WINO_H2), else layer by layer: results identical to n_layers calls of
- * fdn_conv3d_wgrad.  x, dz, dw (and dbias, which may be NULL or hold NULL entries): HOST arrays of n_layers device pointers
+ * Winograd kernel applies (W % 4 == 0, D even, algo AUTO / WINO_H2 / WINO_BF16X3), else layer by layer.  Results equal n_layers calls
+ * of fdn_conv3d_wgrad to fp32 rounding, not bit for bit, where the batched kernel runs: it gives every layer 64 / n_layers splits of the
+ * voxel sum, the single-layer launch 63 (the layer-by-layer fall-back IS those calls).  x, dz, dw (and dbias, which may be NULL or hold NULL entries): HOST arrays of n_layers device pointers
  * (dz rows dense, 64 channels).  Why: at the low-res grid of cfg2 (8 x 24^3) a layer that has the chip to itself gives a workgroup
  * 4.6 tiles between its prologue and its output transform; batched, the ResBlock layers of one gradient bucket share the chip and
  * each workgroup walks n_layers times more tiles of its layer.  src/Network/TrainerController.py:223 (tape.gradient). */
