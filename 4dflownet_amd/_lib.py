@@ -28,6 +28,9 @@ SIGNATURES = {
     "fdn_conv_cout1_dgrad_folded": (c_i, [c_fp, c_fp, c_fp, c_i, c_f, c_fp, c_fp, c_fp, c_sz, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "fdn_fold_halo": (c_i, [c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_f, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "fdn_conv3d_dgrad_fused": (c_i, [c_fp] * 5 + [c_i, c_f, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "fdn_conv64_mask_ok": (c_i, [c_i] * 5),
+    "fdn_conv64_fwd_mask": (c_i, [c_fp] * 6 + [c_i] * 5 + [c_f, c_i, c_fp]),
+    "fdn_conv64_dgrad_fused_mask": (c_i, [c_fp] * 5 + [c_i, c_f, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "fdn_conv3d_dgrad_fused_part": (c_i, [c_fp] * 5 + [c_i, c_f, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "fdn_fold_halo_border": (c_i, [c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_f, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "fdn_conv1x1_dgrad": (c_i, [c_fp] * 6 + [c_i64, c_fp]),

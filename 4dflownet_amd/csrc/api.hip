@@ -125,6 +125,27 @@ extern "C" int fdn_conv3d_dgrad_fused(const float* dz, const float* wpack, float
                                 -1, 1, act, alpha, (hipStream_t)stream, 3, algo);
 }
 
+// 64->64 forward that also writes the sign mask of its output, and the fused dgrad that reads the mask instead of y_prev (conv64_wino2d_kernel.h)
+extern "C" int fdn_conv64_fwd_mask(const float* x, const float* wpack, const float* bias, const float* residual, float* y, uint16_t* y_mask,
+                                   int N, int D, int H, int W, int act, float alpha, int algo, void* stream) {
+    FDN_REQUIRE(x && wpack && y && y_mask, "fdn_conv64_fwd_mask: NULL argument");
+    FDN_REQUIRE(algo >= FDN_ALGO_AUTO && algo <= FDN_ALGO_LAST, "fdn_conv64_fwd_mask: bad algo %d", algo);
+    FDN_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && D <= 1020 && H <= 1020 && W <= 1020, "fdn_conv64_fwd_mask: bad dims");
+    FDN_REQUIRE(act >= FDN_ACT_NONE && act <= FDN_ACT_LEAKY, "fdn_conv64_fwd_mask: bad act %d", act);
+    return fdn_conv64_launch_ex(x, wpack, bias, residual, y, nullptr, nullptr, nullptr, N, D, H, W, D, H, W, 0, 0, act, alpha,
+                                (hipStream_t)stream, 3, algo, nullptr, y_mask, nullptr);
+}
+
+extern "C" int fdn_conv64_dgrad_fused_mask(const float* dz, const float* wpack, float* dxpad, const float* skip, const uint16_t* y_mask,
+                                           int act, float alpha, float* dz_prev, int N, int D, int H, int W, int algo, void* stream) {
+    FDN_REQUIRE(dz && wpack && dxpad && dz_prev && y_mask, "fdn_conv64_dgrad_fused_mask: NULL argument");
+    FDN_REQUIRE(algo >= FDN_ALGO_AUTO && algo <= FDN_ALGO_LAST, "fdn_conv64_dgrad_fused_mask: bad algo %d", algo);
+    FDN_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && D <= 1020 && H <= 1020 && W <= 1020, "fdn_conv64_dgrad_fused_mask: bad dims");
+    FDN_REQUIRE(act == FDN_ACT_RELU || act == FDN_ACT_LEAKY, "fdn_conv64_dgrad_fused_mask: a mask belongs to an activation (act %d)", act);
+    return fdn_conv64_launch_ex(dz, wpack, nullptr, nullptr, dxpad, skip, nullptr, dz_prev, N, D, H, W, D + 2, H + 2, W + 2,
+                                -1, 1, act, alpha, (hipStream_t)stream, 3, algo, nullptr, nullptr, y_mask);
+}
+
 extern "C" int fdn_conv3d_dgrad_fused_part(const float* dz, const float* wpack, float* dxpad, const float* skip,
                                            const float* y_prev, int act, float alpha, float* dz_prev, int N, int D, int H,
                                            int W, int parts, int algo, void* stream) {

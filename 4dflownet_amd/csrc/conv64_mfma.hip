@@ -560,6 +560,16 @@ extern "C" int fdn_conv64_pack_streams(int N, int D, int H, int W, int algo, int
     return rc ? rc : (int)m;
 }
 
+// 1: the forward and the fused dgrad of a 64->64 layer on this grid both run the plain F(4,3) x F(4,3) fp32-MFMA kernels, which write / read
+// sign masks (fdn_conv64_fwd_mask / fdn_conv64_dgrad_fused_mask); 0: they do not (the caller keeps y); < 0: error.  The launcher's own selection.
+extern "C" int fdn_conv64_mask_ok(int N, int D, int H, int W, int algo) {
+    const int f = fdn_conv64_pack_streams(N, D, H, W, algo, FDN_ROLE_FWD);
+    if (f < 0) return f;
+    const int d = fdn_conv64_pack_streams(N, D, H, W, algo, FDN_ROLE_DGRAD_FUSED);
+    if (d < 0) return d;
+    return f == FDN_PACK_STREAM_WINO_H4 && d == (FDN_PACK_STREAM_WINO_H4 | FDN_PACK_STREAM_WINO_W) ? 1 : 0;
+}
+
 // --------------------------------------------------------------------------------------------
 // host side: tile planning + launch
 // --------------------------------------------------------------------------------------------
@@ -678,7 +688,15 @@ FdnTile fdn_plan_tile(int N, int OD, int OH, int OW, int max_vox, int max_halo_r
 
 int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, const float* residual, float* y,
                          const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
-                         int OW, int off, int zero_mode, int act, float alpha, hipStream_t s, int parts, int algo, unsigned* probe) {
+                         int OW, int off, int zero_mode, int act, float alpha, hipStream_t s, int parts, int algo, unsigned* probe,
+                         uint16_t* ymask, const uint16_t* fmask) {
+    // ymask / fmask (sign masks, conv64_wino2d_kernel.h): only the plain F(4,3) x F(4,3) fp32-MFMA paths write / read them -- the forward
+    // over the whole grid, the fused dgrad as ONE launch; every other path refuses (the caller asks fdn_conv64_mask_ok first)
+    auto no_mask = [&](const char* what) {
+        if (!ymask && !fmask) return FDN_OK;
+        fdn_set_error("conv64: sign masks are not supported on this path (%s): ask fdn_conv64_mask_ok", what);
+        return FDN_ERR_UNSUPPORTED;
+    };
     // probe != nullptr: launch nothing, OR into *probe the streams of the pack this call would read (bit 0 direct, 1 1-D Winograd,
     // 2 F(2,3)xF(4,3), 3 F(4,3)xF(4,3), 4 the same as bf16 x 3) -- fdn_conv64_pack_streams; the selection below is the only statement of the rule.
     // staged rows are addressed with 32-bit byte offsets from the sample's first voxel (256 B per voxel)
@@ -721,12 +739,15 @@ int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, 
     if (!(fout && zero_mode && off == -1 && fdn_conv64_shell_slabs)) {
         if (const int hm = fout ? 0 : hm_for(OH, OW)) {           // (a fused fold outside the slab path is the 1-D / direct kernels' business)
             if (probe) { *probe |= stream_bit(hm); return FDN_OK; }
+            if (hm != 4 || split) if (int rc = no_mask("not the fp32 F(4,3) x F(4,3) forward")) return rc;
             return fdn_conv64_wino2d_launch(x, upack_hm(hm), bias, residual, y, nullptr, nullptr, nullptr, N, ID, IH, IW, OD, OH, OW, 0, 0, 0,
-                                            OD, OH, OW, off, zero_mode, act, alpha, hm_arg(hm), s);
+                                            OD, OH, OW, off, zero_mode, act, alpha, hm_arg(hm), s, ymask, nullptr);
         }
+        if (!probe) if (int rc = no_mask("forward off the F(4,3) x F(4,3) kernel")) return rc;
         int oh4, ow4;
         if (!fout && split_box(OH, OW, oh4, ow4)) {
             if (probe) { *probe |= stream_bit(4) | 1u; return FDN_OK; }
+            if (int rc = no_mask("aligned box + strips")) return rc;
             if (int rc = fdn_conv64_wino2d_launch(x, upack_hm(4), bias, residual, y, nullptr, nullptr, nullptr, N, ID, IH, IW, OD, OH, OW, 0, 0, 0,
                                                   OD, oh4, ow4, off, zero_mode, act, alpha, hm_arg(4), s))
                 return rc;
@@ -774,13 +795,15 @@ int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, 
             if ((parts & 2) && !wface_direct && !fdn_conv64_split_dgrad && !(split && hm == 4)) {      // (bf16 x 3: the inner box is a persistent launch of its own)
                 // both parts: ONE launch, the shell faces behind the inner box's workgroups (conv64_wino2d_shell_kernel, conv64_wino.hip)
                 if (probe) { *probe |= stream_bit(hm) | 2u; return FDN_OK; }
+                if (hm != 4) if (int rc = no_mask("not the fp32 F(4,3) x F(4,3) fused dgrad")) return rc;
                 FdnWino2dPrepared inner;
                 if (int rc = fdn_conv64_wino2d_prepare(x, upack_hm(hm), bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, 1, 1, 1, ID,
-                                                       IH, IW, off, zero_mode, act, alpha, hm_arg(hm), &inner))
+                                                       IH, IW, off, zero_mode, act, alpha, hm_arg(hm), &inner, nullptr, fmask))
                     return rc;
                 return fdn_conv64_wino_launch_boxes(x, upack, bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, wb + 1, count - 1,
                                                     off, zero_mode, act, alpha, s, &inner);
             }
+            if (!probe) if (int rc = no_mask("fused dgrad issued in parts")) return rc;
             if (probe) *probe |= stream_bit(hm);
             else if (int rc = fdn_conv64_wino2d_launch(x, upack_hm(hm), bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, 1, 1, 1, ID, IH,
                                                        IW, off, zero_mode, act, alpha, hm_arg(hm), s))
@@ -788,12 +811,14 @@ int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, 
             first = 1; count -= 1;
             if (count == 0) return FDN_OK;
         }
+        if (!probe) if (int rc = no_mask("1-D Winograd fused dgrad")) return rc;
         if (probe) { *probe |= 2u | (((parts & 2) && wface_direct) ? 1u : 0u); return FDN_OK; }
         if (int rc = fdn_conv64_wino_launch_boxes(x, upack, bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, wb + first,
                                                   count, off, zero_mode, act, alpha, s))
             return rc;
         return ((parts & 2) && wface_direct) ? launch_boxes(a, wfaces, 2, s) : FDN_OK;
     }
+    if (!probe) if (int rc = no_mask("fused dgrad off the Winograd kernels")) return rc;
     int ih4, iw4;
     if (split_box(IH, IW, ih4, iw4)) {
         // the same split of the inner box [1, ID] x [1, IH] x [1, IW] (fused-fold epilogue in both kernels), the six shell slabs behind it

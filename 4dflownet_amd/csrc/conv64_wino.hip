@@ -51,10 +51,10 @@ __global__ __launch_bounds__(256, 2) void conv64_wino_kernel(WinoArgs p) {
 // the 1-D body on the shell faces.  The faces are a few hundred short tiles; as a launch of their own they cost a launch gap and an
 // almost empty chip (0.069 ms at (8,48^3), 0.027 ms at (8,24^3)), here they are dispatched last and fill the inner launch's tail
 // (its last round of workgroup slots is a quarter empty at 48^3; at 24^3 the 432 inner tiles leave 80 of the 512 slots free).
-template <int HM, int MB = 2, bool SPLIT = false>
+template <int HM, int MB = 2, bool MASK = false>
 __global__ __launch_bounds__(256, 2) void conv64_wino2d_shell_kernel(Wino2Args p2, WinoArgs p1, int n2d) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if ((int)blockIdx.x < n2d) conv64_wino2d_body<true, HM, kW2RDB, kW2RDA, kW2Dep, MB, SPLIT>(p2, (int)blockIdx.x, smem);
+    if ((int)blockIdx.x < n2d) conv64_wino2d_body<true, HM, kW2RDB, kW2RDA, kW2Dep, MB, false, MASK>(p2, (int)blockIdx.x, smem);
     else conv64_wino_body<kWinoCS, true>(p1, (int)blockIdx.x - n2d, smem);
 }
 
@@ -158,7 +158,8 @@ int fdn_conv64_wino_launch_boxes(const float* x, const float* upack, const float
         memcpy(&a2, inner->args, sizeof(a2));
         if ((size_t)inner->lds > lds) lds = (size_t)inner->lds;
         FDN_REQUIRE(!a2.split, "conv64 (winograd): the bf16 x 3 inner box is a launch of its own");
-        const void* fn = a2.hm == 4 ? (a2.mb == 1 ? (const void*)conv64_wino2d_shell_kernel<4, 1> : (const void*)conv64_wino2d_shell_kernel<4>)
+        const void* fn = a2.fmask ? (a2.mb == 1 ? (const void*)conv64_wino2d_shell_kernel<4, 1, true> : (const void*)conv64_wino2d_shell_kernel<4, 2, true>)
+                       : a2.hm == 4 ? (a2.mb == 1 ? (const void*)conv64_wino2d_shell_kernel<4, 1> : (const void*)conv64_wino2d_shell_kernel<4>)
                                     : (const void*)conv64_wino2d_shell_kernel<2>;
         if (int rc = fdn_func_max_lds(fn, lds_max, "conv64_wino2d_shell")) return rc;
         int n2d = inner->blocks;

@@ -46,10 +46,10 @@ FDN_HOOK_VAR(int, fdn_conv64_wino2d_tile, 0);          // test build: force the 
 
 FDN_HOOK_VAR(int, fdn_conv64_wino2d_mb, 0);            // test build: force the M-blocks per wave (1 = half-size tiles, 2 = full; 0 = by the grid)
 
-template <bool FUSED, int HM, int MB = 2, bool SPLIT = false>
+template <bool FUSED, int HM, int MB = 2, bool SPLIT = false, bool MASK = false>
 __global__ __launch_bounds__(256, 2) void conv64_wino2d_kernel(Wino2Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    conv64_wino2d_body<FUSED, HM, kW2RDB, kW2RDA, kW2Dep, MB, SPLIT>(p, (int)blockIdx.x, smem);
+    conv64_wino2d_body<FUSED, HM, kW2RDB, kW2RDA, kW2Dep, MB, SPLIT, MASK>(p, (int)blockIdx.x, smem);
 }
 
 // FDN_ALGO_WINO_BF16X3: the producer / consumer kernel (conv64_wino2d_pc_kernel.h), one persistent workgroup of 512 threads per CU
@@ -130,15 +130,18 @@ static_assert(sizeof(Wino2Args) <= sizeof(FdnWino2dPrepared::args), "FdnWino2dPr
 int fdn_conv64_wino2d_prepare(const float* x, const float* upack2, const float* bias, const float* residual, float* y,
                               const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
                               int OW, int obd, int obh, int obw, int ebd, int ebh, int ebw, int off, int zero_mode, int act,
-                              float alpha, int hm_arg, FdnWino2dPrepared* out) {
+                              float alpha, int hm_arg, FdnWino2dPrepared* out, uint16_t* ymask, const uint16_t* fmask) {
     const int hm = hm_arg & 7;
     const bool split = (hm_arg & 8) != 0;               // F(4,3) x F(4,3) products as bf16 x 3 (upack2 = that stream)
     FDN_REQUIRE(!split || hm == 4, "conv64 (2-D winograd): the bf16 x 3 products exist for F(4,3) along H only");
     FDN_REQUIRE(fdn_conv64_wino2d_ok(ebd, ebh, ebw, ID, IH, IW, hm), "conv64 (2-D winograd, F(%d,3) along H): box %dx%dx%d of a %dx%dx%d grid is not supported",
                 hm, ebd, ebh, ebw, ID, IH, IW);
     FDN_REQUIRE(!fout || (zero_mode && off == -1 && obd == 1 && obh == 1 && obw == 1), "conv64 (2-D winograd): the fused fold belongs to the inner box of a padded dgrad");
+    FDN_REQUIRE(!(ymask || fmask) || (hm == 4 && !split && (fmask ? fout != nullptr : fout == nullptr)),
+                "conv64 (2-D winograd): sign masks belong to the F(4,3) x F(4,3) fp32-MFMA kernels (forward writes, fused dgrad reads)");
     Wino2Args a;
     a.x = x; a.up = upack2; a.bias = bias; a.res = residual; a.y = y; a.fskip = fskip; a.fy = fy; a.fout = fout;
+    a.ymask = ymask; a.fmask = fmask;
     a.N = N; a.ID = ID; a.IH = IH; a.IW = IW; a.OD = OD; a.OH = OH; a.OW = OW;
     a.off = off; a.zero_mode = zero_mode; a.act = act; a.alpha = alpha; a.dbg = fdn_conv64_wino2d_dbg;
     a.hm = hm; a.split = split ? 1 : 0;
@@ -179,11 +182,11 @@ int fdn_conv64_wino2d_prepare(const float* x, const float* upack2, const float* 
 int fdn_conv64_wino2d_launch(const float* x, const float* upack2, const float* bias, const float* residual, float* y,
                              const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
                              int OW, int obd, int obh, int obw, int ebd, int ebh, int ebw, int off, int zero_mode, int act,
-                             float alpha, int hm_arg, hipStream_t s) {
+                             float alpha, int hm_arg, hipStream_t s, uint16_t* ymask, const uint16_t* fmask) {
     const int hm = hm_arg & 7;
     FdnWino2dPrepared pr;
     if (int rc = fdn_conv64_wino2d_prepare(x, upack2, bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, obd, obh, obw, ebd,
-                                           ebh, ebw, off, zero_mode, act, alpha, hm_arg, &pr))
+                                           ebh, ebw, off, zero_mode, act, alpha, hm_arg, &pr, ymask, fmask))
         return rc;
     Wino2Args a;
     memcpy(&a, pr.args, sizeof(a));
@@ -208,7 +211,9 @@ int fdn_conv64_wino2d_launch(const float* x, const float* upack2, const float* b
         }
         return FDN_OK;
     }
-    const void* fn = fout ? (hm == 4 ? (a.mb == 1 ? (const void*)conv64_wino2d_kernel<true, 4, 1> : (const void*)conv64_wino2d_kernel<true, 4>) : (const void*)conv64_wino2d_kernel<true, 2>)
+    FDN_REQUIRE(!a.fmask, "conv64 (2-D winograd): the mask-reading fused dgrad is the one-launch form (inner box + shell)");
+    const void* fn = a.ymask ? (a.mb == 1 ? (const void*)conv64_wino2d_kernel<false, 4, 1, false, true> : (const void*)conv64_wino2d_kernel<false, 4, 2, false, true>)
+                   : fout ? (hm == 4 ? (a.mb == 1 ? (const void*)conv64_wino2d_kernel<true, 4, 1> : (const void*)conv64_wino2d_kernel<true, 4>) : (const void*)conv64_wino2d_kernel<true, 2>)
                           : (hm == 4 ? (a.mb == 1 ? (const void*)conv64_wino2d_kernel<false, 4, 1> : (const void*)conv64_wino2d_kernel<false, 4>) : (const void*)conv64_wino2d_kernel<false, 2>);
     int lds = pr.lds;
 #ifdef FDN_TEST_HOOKS

@@ -16,6 +16,13 @@ struct Wino2Args {
     const float* fskip;     // fused fold (dgrad mode): see conv64_args.h
     const float* fy;
     float* fout;
+    // Sign masks (round 6, the fp32 twin of conv64_args.h's): the activation gradient needs ONE BIT of the producer's output, and at the
+    // 48^3 grids an epilogue operand costs what streaming it at the HBM peak would take (0.022 of the 0.029 ms y costs a fused dgrad).
+    // Planar layout [cout / 16][voxel] of uint16_t words, bit b = (y[voxel][16 (cout / 16) + b] > 0): a wave owns one plane, a cell row's
+    // four voxels are four consecutive words -- ONE 8-B store (forward, MASK kernels: ymask) / load (fused dgrad: fmask instead of fy)
+    // per cell row and quarter-wave instead of four 16-B loads.  8 B per voxel beside the 256-B row.
+    uint16_t* ymask;
+    const uint16_t* fmask;
     int N, ID, IH, IW, OD, OH, OW;
     int off, zero_mode, act;
     float alpha;
@@ -73,7 +80,8 @@ constexpr unsigned kW2Big = 0x40000000u;    // "reads zero": any sum containing 
 // HM: output rows per cell = the F(HM,3) transform along H (NS = HM + 2 sequential stages, Y = HM x 4 voxels per cell)
 // MB: 16-cell M-blocks per wave (2 = the full tile; 1 = half-size tiles: each xw keeps TWO accumulators, even / odd k-steps, so that no
 // MFMA waits for its predecessor's result -- the sum over cin is split differently, equal to the full tile to fp32 rounding)
-template <bool FUSED, int HM = 2, int RDB = kW2RDB, int RDA = kW2RDA, int DEP = kW2Dep, int MB = 2, bool SPLIT = false>
+// MASK: the forward also writes the sign mask of its output (p.ymask) / the fused dgrad reads p.fmask instead of the rows of p.fy
+template <bool FUSED, int HM = 2, int RDB = kW2RDB, int RDA = kW2RDA, int DEP = kW2Dep, int MB = 2, bool SPLIT = false, bool MASK = false>
 __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int block_id, char* const smem) {
     constexpr int UA = kW2UA, SPT = 24;
     constexpr int kW2Plane = W2Geo<MB, SPLIT>::plane;       // (shadows the full-tile constants: every row / plane offset below is the variant's own)
@@ -594,14 +602,21 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
         // voxel: a surface voxel (or a cell outside the box) reads row 0 of the tensor, which nobody writes in this launch, and
         // discards it; value and destination are selected afterwards.
         int fi[2][HG][4];                     // voxel index into skip / y / dz_prev, or -1 (surface voxel, cell outside the box)
-        f32x4 sk[2][HG][4], ym[2][HG][4];
+        f32x4 sk[2][HG][4], ym[MASK ? 1 : 2][MASK ? 1 : HG][4];
+        fdn_u32x2 mw[2][HG];                  // MASK: the cell row's four sign words of this wave's 16 channels
+        const int q_f = HM == 2 ? q : (lane_e >> 4);
+        const size_t mplane = (size_t)(HM == 2 ? wave : wave_s) * ((size_t)p.N * p.ID * p.IH * p.IW);
         auto fload = [&](int g, int buf) {
             const int mb = g / GPB, h0 = (g % GPB) * HG;
             const int gf0 = mtab[32 + mb * 16 + c_e];
             const int hw = mtab[64 + mb * 16 + c_e];
             const int ph = hw & 0xffff, pw = hw >> 16;                    // padded coordinates of the cell's first voxel
 #pragma unroll
-            for (int hr = 0; hr < HG; ++hr)
+            for (int hr = 0; hr < HG; ++hr) {
+                if constexpr (MASK) {                                    // (the row's first voxel is a valid index wherever the cell has an interior depth)
+                    const int ri = (g0[mb] >= 0 && gf0 >= 0) ? gf0 + (h0 + hr) * p.IW : 0;
+                    mw[buf][hr] = *(const fdn_u32x2*)(p.fmask + mplane + ri);
+                }
 #pragma unroll
                 for (int wi = 0; wi < 4; ++wi) {
                     const int ih = ph + h0 + hr - 1, iw = pw + wi - 1;
@@ -609,8 +624,9 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
                     fi[buf][hr][wi] = in ? gf0 + (h0 + hr) * p.IW + wi : -1;
                     const size_t o = (size_t)((in ? fi[buf][hr][wi] : 0) & opmask) * 64 + cofs;
                     sk[buf][hr][wi] = p.fskip ? *(const f32x4*)(p.fskip + o) : (f32x4){0.f, 0.f, 0.f, 0.f};
-                    ym[buf][hr][wi] = p.fy ? *(const f32x4*)(p.fy + o) : (f32x4){1.f, 1.f, 1.f, 1.f};
+                    if constexpr (!MASK) ym[buf][hr][wi] = p.fy ? *(const f32x4*)(p.fy + o) : (f32x4){1.f, 1.f, 1.f, 1.f};
                 }
+            }
         };
         auto fstore = [&](int g, int buf) {
             const int mb = g / GPB, h0 = (g % GPB) * HG;
@@ -623,7 +639,12 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
                     const bool in = fi[buf][hr][wi] >= 0;
                     f32x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = in ? (z[e] + sk[buf][hr][wi][e]) * (ym[buf][hr][wi][e] > 0.f ? 1.f : slope) : z[e];
+                    for (int e = 0; e < 4; ++e) {
+                        bool pos;
+                        if constexpr (MASK) pos = (((wi < 2 ? mw[buf][hr].x : mw[buf][hr].y) >> (16 * (wi & 1) + 4 * q_f + e)) & 1u) != 0;
+                        else pos = ym[buf][hr][wi][e] > 0.f;
+                        v[e] = in ? (z[e] + sk[buf][hr][wi][e]) * (pos ? 1.f : slope) : z[e];
+                    }
                     float* dst = in ? p.fout + (size_t)fi[buf][hr][wi] * 64 + cofs : p.y + (size_t)(g0[mb] + (h0 + hr) * p.OW + wi) * 64 + cofs;
                     *(f32x4*)dst = v;
                 }
@@ -653,7 +674,8 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
             const int mb = g / GPB, h0 = (g % GPB) * HG, buf = g & 1;
             if (g0[mb] < 0) continue;
 #pragma unroll
-            for (int hr = 0; hr < HG; ++hr)
+            for (int hr = 0; hr < HG; ++hr) {
+                unsigned mlo = 0, mhi = 0;                                // MASK: this lane's 4 bits of the row's four voxels, at their place in the words
 #pragma unroll
                 for (int wi = 0; wi < 4; ++wi) {
                     f32x4 v = Y[h0 + hr][wi][mb] + bv;
@@ -661,7 +683,22 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], slope * v[e]);          // relu / leaky / none: slope in [0,1]
                     *(f32x4*)(p.y + (size_t)(g0[mb] + (h0 + hr) * p.OW + wi) * 64 + cofs) = v;
+                    if constexpr (MASK) {
+                        const unsigned nib = (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u);
+                        if (wi < 2) mlo |= nib << (16 * wi); else mhi |= nib << (16 * (wi - 2));
+                    }
                 }
+                if constexpr (MASK) {
+                    // the four quarter-waves (cout 4q .. 4q + 3 of the same cell: lanes c, c + 16, c + 32, c + 48) OR their nibbles into the
+                    // row's four 16-bit words; quarter 0 stores them (8 B, one plane per wave)
+                    const int q_m = HM == 2 ? q : (lane_e >> 4);
+                    mlo <<= 4 * q_m; mhi <<= 4 * q_m;
+                    mlo |= __shfl_xor(mlo, 16, 64); mhi |= __shfl_xor(mhi, 16, 64);
+                    mlo |= __shfl_xor(mlo, 32, 64); mhi |= __shfl_xor(mhi, 32, 64);
+                    if (q_m == 0)
+                        *(fdn_u32x2*)(p.ymask + (size_t)(HM == 2 ? wave : wave_s) * ((size_t)p.N * p.OD * p.OH * p.OW) + g0[mb] + (h0 + hr) * p.OW) = (fdn_u32x2){mlo, mhi};
+                }
+            }
         }
     }
 }

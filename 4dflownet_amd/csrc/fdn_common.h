@@ -196,7 +196,7 @@ int fdn_conv64_launch(const float* x, const float* wpack, const float* bias, con
 int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, const float* residual, float* y,
                          const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
                          int OW, int off, int zero_mode, int act, float alpha, hipStream_t s, int parts = 3,
-                         int algo = FDN_ALGO_AUTO, unsigned* probe = nullptr);
+                         int algo = FDN_ALGO_AUTO, unsigned* probe = nullptr, uint16_t* ymask = nullptr, const uint16_t* fmask = nullptr);
 // Winograd F(4,3)-along-W variant of the 64->64 conv (conv64_wino.hip): one output box with all 27 taps
 // output box + its non-zero (kd, kh) tap ranges.  wface = 1: the pair of w faces of a fused dgrad's shell (box = the (d,h) range of the
 // padded grid, ow = 0, ew = 4: one "group" per (d,h) position; see conv64_wino.hip)
@@ -217,15 +217,15 @@ int fdn_pack_conv64_wino_launch(const float* w, float* uf, float* ud, hipStream_
 bool fdn_conv64_wino2d_ok(int ebd, int ebh, int ebw, int ID, int IH, int IW, int hm);
 // A planned, not yet launched 2-D launch (the kernel's argument block, opaque outside conv64_wino2d_kernel.h): fdn_conv64_wino_launch_boxes
 // takes one as `inner` and issues it together with its own regions as ONE launch (conv64_wino2d_shell_kernel: the fused dgrad).
-struct FdnWino2dPrepared { alignas(8) unsigned char args[320]; int blocks; int lds; };
+struct FdnWino2dPrepared { alignas(8) unsigned char args[352]; int blocks; int lds; };
 int fdn_conv64_wino2d_prepare(const float* x, const float* upack2, const float* bias, const float* residual, float* y,
                               const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
                               int OW, int obd, int obh, int obw, int ebd, int ebh, int ebw, int off, int zero_mode, int act,
-                              float alpha, int hm, FdnWino2dPrepared* out);
+                              float alpha, int hm, FdnWino2dPrepared* out, uint16_t* ymask = nullptr, const uint16_t* fmask = nullptr);
 int fdn_conv64_wino2d_launch(const float* x, const float* upack2, const float* bias, const float* residual, float* y,
                              const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
                              int OW, int obd, int obh, int obw, int ebd, int ebh, int ebw, int off, int zero_mode, int act,
-                             float alpha, int hm, hipStream_t s);
+                             float alpha, int hm, hipStream_t s, uint16_t* ymask = nullptr, const uint16_t* fmask = nullptr);
 int fdn_pack_conv64_wino2d_launch(const float* w, float* uf, float* ud, hipStream_t s);
 int fdn_fold_halo_border_launch(const float* s0, const float* s1, const float* s2, int nsrc, const float* skip,
                                 const float* yprev, int act, float alpha, float* out, int N, int D, int H, int W,

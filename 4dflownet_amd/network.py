@@ -182,7 +182,8 @@ class FlowNetModel:
         self._pack_streams = [0, 0]
         # bf16 training: 64->64 layers write a sign mask beside their output and the fused dgrad reads it for act' instead of the output
         # (FDN_BF16_SIGN_MASK=0: read y, the round-4 behaviour -- same results bit for bit, for A/B timing)
-        self.sign_masks = os.environ.get("FDN_BF16_SIGN_MASK", "1") not in ("", "0")
+        self.sign_masks = os.environ.get("FDN_BF16_SIGN_MASK" if dtype == "bfloat16" else "FDN_SIGN_MASK", "1") not in ("", "0")
+        self._mask_ok_cache = {}
         self._pack_need_cache = {}
         self.glorot_uniform_init(seed)
 
@@ -339,11 +340,23 @@ class FlowNetModel:
             return self.ops.conv3d_fwd(x, L.w, L.b, act, ops.LEAKY_ALPHA, residual, None, L.wp_f, out, ldy, y_coff, mask=mask)
         return self.ops.conv3d_fwd(x, L.w, L.b, act, ops.LEAKY_ALPHA, residual, x2, L.wp_f, out, ldy, y_coff, algo=self.conv_algo[L.name])
 
+    def _mask_ok(self, x, L):
+        """fp32: do the forward and the fused dgrad of this grid write / read sign masks (the plain F(4,3) x F(4,3) kernels)?"""
+        key = (tuple(x.shape[:4]), self.conv_algo[L.name])
+        ok = self._mask_ok_cache.get(key)
+        if ok is None:
+            ok = self._mask_ok_cache[key] = ops.conv64_mask_ok(*key[0], key[1])
+        return ok
+
     def _conv_m(self, x, L, act, residual=None, want_mask=False):
-        """A 64->64 layer and, in bf16 training, the sign mask of its output (else None)."""
-        if want_mask and self.sign_masks and self.dtype == "bfloat16" and act != ACT_NONE:
-            mask = ops_bf16.new_sign_mask(x)
-            return self._conv(x, L, act, residual=residual, mask=mask), mask
+        """A 64->64 layer and, in training, the sign mask of its output (None where the kernels of the grid do not write one)."""
+        if want_mask and self.sign_masks and act != ACT_NONE:
+            if self.dtype == "bfloat16":
+                mask = ops_bf16.new_sign_mask(x)
+                return self._conv(x, L, act, residual=residual, mask=mask), mask
+            if self._mask_ok(x, L):
+                mask = ops.new_sign_mask(x)
+                return ops.conv3d_fwd(x, L.w, L.b, act, ops.LEAKY_ALPHA, residual, None, L.wp_f, algo=self.conv_algo[L.name], mask=mask), mask
         return self._conv(x, L, act, residual=residual), None
 
     def forward(self, inputs, training=False):
@@ -394,7 +407,7 @@ class FlowNetModel:
         heads = []
         gmasks = []                                         # bf16 training: sign masks of the three head activations (else None)
         for hidx in range(3):
-            g, m_g = self._conv_m(rb.t, Ls[li], ACT_RELU, want_mask=training)
+            g, m_g = self._conv_m(rb.t, Ls[li], ACT_RELU, want_mask=training and self.dtype == "bfloat16")   # (the fp32 head dgrad reads y's rows)
             self._conv(g, Ls[li + 1], ACT_NONE, out=pred, ldy=3, y_coff=hidx)
             heads.append(g)
             gmasks.append(m_g)
@@ -499,8 +512,9 @@ class FlowNetModel:
         the conv epilogue instead of y_prev itself."""
         out = torch.empty_like(dz)
         pad = self._pad_like(dz)
-        if mask is not None and y_prev is not None:
-            ops_bf16.conv3d_dgrad_fused(dz, L.wp_d, pad, out, skip=skip, y_prev=y_prev, act=act, mask=mask)
+        if mask is not None and y_prev is not None and (self.dtype == "bfloat16" or self._mask_ok(dz, L)):
+            self.ops.conv3d_dgrad_fused(dz, L.wp_d, pad, out, skip=skip, y_prev=y_prev, act=act, mask=mask,
+                                        **({} if self.dtype == "bfloat16" else {"algo": self.conv_algo[L.name]}))
             self.ops.fold_halo_border([pad], out, skip, y_prev, act)
             return out
         if self.overlap_shell and self.dtype == "float32":
@@ -573,8 +587,9 @@ class FlowNetModel:
             self._wgrad(rb.t, dz_g, L1, bias=False)
             pad = self._pad_like(rb.t)
             y_m, a_m = act_of(rb) if hidx == 2 else (None, ACT_NONE)
-            if y_m is not None and rb.mask is not None:
-                ops_bf16.conv3d_dgrad_fused(dz_g, L1.wp_d, pad, dz, skip=dz if hidx > 0 else None, y_prev=y_m, act=a_m, mask=rb.mask)
+            if y_m is not None and rb.mask is not None and (self.dtype == "bfloat16" or self._mask_ok(dz_g, L1)):
+                self.ops.conv3d_dgrad_fused(dz_g, L1.wp_d, pad, dz, skip=dz if hidx > 0 else None, y_prev=y_m, act=a_m, mask=rb.mask,
+                                            **({} if self.dtype == "bfloat16" else {"algo": self.conv_algo[L1.name]}))
             else:
                 self.ops.conv3d_dgrad_fused(dz_g, L1.wp_d, pad, dz, skip=dz if hidx > 0 else None, y_prev=y_m, act=a_m,
                                             algo=self.conv_algo[L1.name])

@@ -59,11 +59,41 @@ def pack_conv64_weights(w, wp_fwd=None, wp_dgrad=None, want_dgrad=True):
     return wp_fwd, wp_dgrad
 
 
+def conv64_mask_ok(N, D, H, W, algo=ALGO_AUTO):
+    """True when the 64->64 forward and fused dgrad of an (N,D,H,W) grid can write / read sign masks (fdn_conv64_mask_ok)."""
+    r = _lib.load().fdn_conv64_mask_ok(int(N), int(D), int(H), int(W), int(algo))
+    check(min(r, 0), "fdn_conv64_mask_ok")
+    return r == 1
+
+
+def new_sign_mask(y):
+    """Sign-mask buffer of an fp32 (N,D,H,W,64) tensor: four planes [cout / 16][voxel] of int16 words (include/fdn.h)."""
+    return torch.empty((4, y.shape[0] * y.shape[1] * y.shape[2] * y.shape[3]), device=y.device, dtype=torch.int16)
+
+
+def _pm(t, name="mask"):
+    if not t.is_cuda or t.dtype != torch.int16 or not t.is_contiguous():
+        raise FdnError("%s must be a contiguous int16 tensor on the GPU" % name)
+    return t.data_ptr()
+
+
 def conv3d_fwd(x, w, bias=None, act=ACT_NONE, alpha=LEAKY_ALPHA, residual=None, x2=None, wpack=None, out=None,
-               ldy=None, y_coff=0, algo=ALGO_AUTO):
-    """x (N,D,H,W,Cin[/2 if x2]); w Keras layout (K,K,K,Cin,Cout)."""
+               ldy=None, y_coff=0, algo=ALGO_AUTO, mask=None):
+    """x (N,D,H,W,Cin[/2 if x2]); w Keras layout (K,K,K,Cin,Cout).
+    mask (64->64 only, new_sign_mask(out), where conv64_mask_ok): also receives the sign mask of the output."""
     N, D, H, W = x.shape[:4]
     K, Cin, Cout = w.shape[0], w.shape[3], w.shape[4]
+    if mask is not None:
+        if (K, Cin, Cout) != (3, 64, 64) or x2 is not None or (ldy not in (None, 64)) or y_coff != 0 or mask.numel() != 4 * N * D * H * W:
+            raise FdnError("conv3d_fwd: a sign mask (4 x %d int16 words) belongs to a dense 64->64 3x3x3 layer" % (N * D * H * W))
+        if out is None:
+            out = torch.empty((N, D, H, W, 64), device=x.device, dtype=torch.float32)
+        if wpack is None:
+            wpack, _ = pack_conv64_weights(w, want_dgrad=False)
+        check(_lib.load().fdn_conv64_fwd_mask(_p(x, "x"), _p(wpack, "wpack"), _p(bias, allow_none=True), _p(residual, allow_none=True),
+                                              _p(out, "out"), _pm(mask), N, D, H, W, act, float(alpha), int(algo), _stream()),
+              "fdn_conv64_fwd_mask")
+        return out
     if out is None:
         out = torch.empty((N, D, H, W, Cout), device=x.device, dtype=torch.float32)
         ldy = Cout
@@ -126,11 +156,19 @@ DGRAD_INNER, DGRAD_SHELL = 1, 2
 
 
 def conv3d_dgrad_fused(dz, wpack_dgrad, dxpad, out, skip=None, y_prev=None, act=ACT_NONE, alpha=LEAKY_ALPHA, parts=3,
-                       algo=ALGO_AUTO):
+                       algo=ALGO_AUTO, mask=None):
     """64->64 dgrad; interior voxels of `out` are finished in the conv epilogue (skip may alias out), the rest lands
     in the padded scratch `dxpad` for fold_halo_border.  parts: DGRAD_INNER | DGRAD_SHELL -- the two pieces write disjoint
-    positions and may run on different streams."""
+    positions and may run on different streams.  mask: the sign mask the forward wrote beside y_prev (conv3d_fwd(mask=...)), read
+    instead of y_prev for act' (the one-launch form only)."""
     N, D, H, W = dz.shape[:4]
+    if mask is not None:
+        if parts != 3 or mask.numel() != 4 * N * D * H * W:
+            raise FdnError("conv3d_dgrad_fused: a sign mask needs the one-launch form and 4 x %d int16 words" % (N * D * H * W))
+        check(_lib.load().fdn_conv64_dgrad_fused_mask(_p(dz, "dz"), _p(wpack_dgrad, "wpack"), _p(dxpad, "dxpad"), _p(skip, allow_none=True),
+                                                      _pm(mask), act, float(alpha), _p(out, "out"), N, D, H, W, int(algo), _stream()),
+              "fdn_conv64_dgrad_fused_mask")
+        return out
     if parts == 3:
         check(_lib.load().fdn_conv3d_dgrad_fused(_p(dz, "dz"), _p(wpack_dgrad, "wpack"), _p(dxpad, "dxpad"),
                                                  _p(skip, allow_none=True), _p(y_prev, allow_none=True), act, float(alpha),

@@ -166,6 +166,18 @@ int fdn_conv3d_dgrad_fused_part(const float* dz, const float* wpack, float* dxpa
 int fdn_fold_halo_border(const float* dxpad0, const float* dxpad1, const float* dxpad2, int nsrc, const float* skip,
                          const float* y_prev, int act, float alpha, float* dz_prev, int N, int D, int H, int W,
                          void* stream);
+/* Sign masks for the activation gradient (training; the fp32 twin of the bf16 mode's).  act'(y) needs one bit of y, and at the large
+ * grids an epilogue operand costs the fused dgrad what streaming it from HBM costs: the forward of a 64->64 layer can write, beside y,
+ * the mask y_mask[c / 16][voxel] (uint16_t words, N*D*H*W per plane, 4 planes: bit b of word (p, v) = (y[v][16 p + b] > 0); 8 B per voxel)
+ * and the fused dgrad of its consumer read that instead of y_prev.  Only the plain F(4,3) x F(4,3) kernels do (H and W multiples of 4,
+ * FDN_ALGO_AUTO): fdn_conv64_mask_ok says 1 when BOTH entry points below are available for the grid, 0 when the caller must keep to
+ * fdn_conv3d_fwd / fdn_conv3d_dgrad_fused (they return FDN_ERR_UNSUPPORTED otherwise).  fdn_fold_halo_border still reads y_prev (surface
+ * voxels only).  Results are bit-identical to the y_prev forms.  src/Network/SR4DFlowNet.py:93-120 and their gradients. */
+int fdn_conv64_mask_ok(int N, int D, int H, int W, int algo);
+int fdn_conv64_fwd_mask(const float* x, const float* wpack, const float* bias, const float* residual, float* y, uint16_t* y_mask,
+                        int N, int D, int H, int W, int act, float alpha, int algo, void* stream);
+int fdn_conv64_dgrad_fused_mask(const float* dz, const float* wpack, float* dxpad, const float* skip, const uint16_t* y_mask,
+                                int act, float alpha, float* dz_prev, int N, int D, int H, int W, int algo, void* stream);
 
 /* 1x1x1 128->64 conv backward w.r.t. its two 64-channel inputs, fused with their ReLU masks:
  * dxa = (dz . W[0:64,:]^T) * (ya>0), dxb = (dz . W[64:128,:]^T) * (yb>0).  SR4DFlowNet.py:23-24. */

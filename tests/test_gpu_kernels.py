@@ -552,3 +552,46 @@ def test_conv64_wino2d_half_and_full_tiles(ops, fdn, shape, mb):
             close(out, O.act_bwd_from_output(dx + res, y, O.ACT_LEAKY), name="fused dgrad+border MB=%d" % mb)
         finally:
             lib.fdn_debug_set_conv64_wino2d_mb(0)
+
+
+@pytest.mark.parametrize("shape", [(1, 5, 8, 12), (2, 24, 24, 24), (1, 7, 12, 20), (3, 4, 4, 4)])
+@pytest.mark.parametrize("mb", [0, 1, 2])
+def test_fp32_sign_masks_replace_y_in_the_fused_dgrad(ops, fdn, shape, mb):
+    """Training forward of a 64->64 layer writes the sign mask of its output beside it (planar [cout / 16][voxel] int16 words); the fused
+    dgrad of its consumer reads the mask instead of y_prev.  The mask holds exactly (y > 0), the forward output is unchanged and the
+    fused dgrad is bit-identical to the y_prev form -- with the planner's tiles (mb = 0) and with half-size / full tiles forced."""
+    rng = np.random.default_rng(31)
+    N, D, H, W = shape
+    x = dev(rng.normal(size=(N, D, H, W, 64)).astype(np.float32))
+    w = dev((rng.normal(size=(3, 3, 3, 64, 64)) * 0.05).astype(np.float32))
+    res = dev(rng.normal(size=(N, D, H, W, 64)).astype(np.float32))
+    dz = dev(rng.normal(size=(N, D, H, W, 64)).astype(np.float32))
+    skip = dev(rng.normal(size=(N, D, H, W, 64)).astype(np.float32))
+    assert ops.conv64_mask_ok(N, D, H, W) and not ops.conv64_mask_ok(N, D, H, W + 2) and not ops.conv64_mask_ok(N, D, H, W, ops.ALGO_DIRECT)
+    wf, wd = ops.pack_conv64_weights(w)
+    with (fdn._lib.test_build() if mb else contextlib.nullcontext()) as lib:
+        if lib is not None:
+            lib.fdn_debug_set_conv64_wino2d_mb(mb)
+        try:
+            for act, r in ((O.ACT_LEAKY, res), (O.ACT_RELU, None)):
+                y0 = ops.conv3d_fwd(x, w, None, act, 0.2, r, wpack=wf)
+                mask = ops.new_sign_mask(y0)
+                mask.fill_(0x5a5a)
+                y1 = ops.conv3d_fwd(x, w, None, act, 0.2, r, wpack=wf, mask=mask)
+                assert torch.equal(y0, y1)
+                bits = (y0 > 0).view(N * D * H * W, 4, 16).to(torch.int32)
+                words = (bits << torch.arange(16, device="cuda", dtype=torch.int32)).sum(dim=2)          # (voxel, plane)
+                assert torch.equal(words.t().contiguous(), mask.to(torch.int32) & 0xffff)
+                pads, outs = [], []
+                for use_mask in (False, True):
+                    pad = torch.full((N, D + 2, H + 2, W + 2, 64), float("nan"), device="cuda")
+                    out = torch.full((N, D, H, W, 64), float("nan"), device="cuda")
+                    ops.conv3d_dgrad_fused(dz, wd, pad, out, skip=skip, y_prev=None if use_mask else y0, act=act, mask=mask if use_mask else None)
+                    pads.append(torch.nan_to_num(pad, nan=-7.0)); outs.append(torch.nan_to_num(out, nan=-7.0))
+                assert torch.equal(pads[0], pads[1]) and torch.equal(outs[0], outs[1])
+        finally:
+            if lib is not None:
+                lib.fdn_debug_set_conv64_wino2d_mb(0)
+    with pytest.raises(fdn.FdnError):                       # a grid off the F(4,3) x F(4,3) kernels refuses masks loudly
+        xs = torch.zeros((1, 4, 6, 6, 64), device="cuda")
+        ops.conv3d_fwd(xs, w, None, O.ACT_RELU, 0.2, None, wpack=wf, mask=ops.new_sign_mask(xs))

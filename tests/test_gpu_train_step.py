@@ -161,6 +161,28 @@ def test_wgrad_side_stream_gives_identical_gradients(fdn):
     assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
 
 
+@pytest.mark.parametrize("P,R,LB,HB,B", [(8, 2, 2, 1, 2), (12, 2, 1, 2, 1), (10, 2, 1, 1, 2)])
+def test_fp32_sign_masks_give_identical_gradients(fdn, P, R, LB, HB, B):
+    """fp32 training on grids the F(4,3) x F(4,3) kernels serve: the forward of a 64->64 layer writes the sign mask of its output and the
+    fused dgrad reads it instead of y (network._conv_m / _dgrad_fold).  Same gradient buffer bit for bit as reading y; on a grid off those
+    kernels (P = 10 low-res: W % 4 != 0) no mask is produced and nothing changes."""
+    batch = O.synthetic_batch(B, P, R, seed=19)
+    grads = []
+    for use_masks in (True, False):
+        tc, _ = make(fdn, P, R, LB, HB, seed=5)
+        tc.model.sign_masks = use_masks
+        inputs, hires, venc, mask = tc._unpack(batch)
+        pred = tc.model.forward(inputs, training=True)
+        if use_masks:
+            hm = tc.model._cache["hmasks"]
+            assert tc.model._cache["rb"].mask is not None                     # the high-res grid (P * R) is a multiple of 4 in all three
+            assert all(m is not None for m in hm) if P % 4 == 0 else (any(m is None for m in hm) and any(m is not None for m in hm))
+        out, dpred = fdn.ops.loss_metrics(pred, hires[0], hires[1], hires[2], mask)
+        grads.append(tc.model.backward(dpred).clone())
+        torch.cuda.synchronize()
+    assert torch.isfinite(grads[0]).all() and torch.equal(grads[0], grads[1])
+
+
 def test_batched_wgrad_gives_the_same_gradients(fdn):
     """batch_wgrad (default on): the 64->64 weight gradients of a gradient bucket's small-grid layers go out as ONE batched launch at
     the end of the bucket instead of one launch per layer.  Same products, a different split of the voxel sum: every layer's gradient

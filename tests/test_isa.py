@@ -75,16 +75,18 @@ def test_no_kernel_spills_or_uses_scratch(code_objects):
 # Every kernel of the PRODUCT library and the include/fdn.h entry point that reaches it.  Kernels only a fdn_debug_* switch can select
 # (the VALU thin-layer kernels, the cs4 direct layouts, the occupancy variants) are compiled into lib4dflow_hip_test.so only.
 PRODUCT_KERNELS = {
-    # conv64_wino2d_kernel<FUSED, HM, MB, SPLIT>, conv64_wino2d_shell_kernel<HM, MB, SPLIT>
-    "conv64_wino2d_kernel<false, 4, 2, false>": "fdn_conv3d_fwd / fdn_conv3d_dgrad, 64->64, H % 4 == 0 and W % 4 == 0 (F(4,3) x F(4,3))",
-    "conv64_wino2d_kernel<true, 4, 2, false>": "fdn_conv3d_dgrad_fused_part(FDN_DGRAD_INNER)",
+    # conv64_wino2d_kernel<FUSED, HM, MB, SPLIT, MASK>, conv64_wino2d_shell_kernel<HM, MB, MASK>
+    "conv64_wino2d_kernel<false, 4, 2, false, false>": "fdn_conv3d_fwd / fdn_conv3d_dgrad, 64->64, H % 4 == 0 and W % 4 == 0 (F(4,3) x F(4,3))",
+    "conv64_wino2d_kernel<true, 4, 2, false, false>": "fdn_conv3d_dgrad_fused_part(FDN_DGRAD_INNER)",
     "conv64_wino2d_shell_kernel<4, 2, false>": "fdn_conv3d_dgrad_fused",
-    "conv64_wino2d_kernel<false, 4, 1, false>": "... half-size tiles: grids whose full tiles leave CUs with one workgroup or none",
-    "conv64_wino2d_kernel<true, 4, 1, false>": "", "conv64_wino2d_shell_kernel<4, 1, false>": "",
+    "conv64_wino2d_kernel<false, 4, 1, false, false>": "... half-size tiles: grids whose full tiles leave CUs with one workgroup or none",
+    "conv64_wino2d_kernel<true, 4, 1, false, false>": "", "conv64_wino2d_shell_kernel<4, 1, false>": "",
+    "conv64_wino2d_kernel<false, 4, 2, false, true>": "fdn_conv64_fwd_mask (the forward + the sign mask of its output)", "conv64_wino2d_kernel<false, 4, 1, false, true>": "",
+    "conv64_wino2d_shell_kernel<4, 2, true>": "fdn_conv64_dgrad_fused_mask (act' from the sign mask)", "conv64_wino2d_shell_kernel<4, 1, true>": "",
     "conv64_wino2d_pc_kernel<false>": "... FDN_ALGO_WINO_BF16X3: the F(4,3) x F(4,3) products as bf16 x 3 on v_mfma_f32_16x16x32_bf16 (producer / consumer waves)",
     "conv64_wino2d_pc_kernel<true>": "",
-    "conv64_wino2d_kernel<false, 2, 2, false>": "... H even only, or FDN_ALGO_WINO_H2 (F(2,3) x F(4,3))",
-    "conv64_wino2d_kernel<true, 2, 2, false>": "", "conv64_wino2d_shell_kernel<2, 2, false>": "",
+    "conv64_wino2d_kernel<false, 2, 2, false, false>": "... H even only, or FDN_ALGO_WINO_H2 (F(2,3) x F(4,3))",
+    "conv64_wino2d_kernel<true, 2, 2, false, false>": "", "conv64_wino2d_shell_kernel<2, 2, false>": "",
     "conv64_wino_kernel<4, false>": "... odd H, FDN_ALGO_WINO_W (F(4,3) along W)", "conv64_wino_kernel<4, true>": "... + shell faces (FDN_DGRAD_SHELL)",
     "conv64_mfma_kernel<2, 1, 2, false>": "... W % 4 != 0, FDN_ALGO_DIRECT: the planner's three direct layouts", "conv64_mfma_kernel<2, 1, 2, true>": "",
     "conv64_mfma_kernel<1, 1, 2, false>": "", "conv64_mfma_kernel<1, 1, 2, true>": "", "conv64_mfma_kernel<1, 2, 2, false>": "", "conv64_mfma_kernel<1, 2, 2, true>": "",
@@ -120,7 +122,8 @@ def test_product_library_holds_only_reachable_kernels(code_objects):
 
 def test_hot_kernels_use_the_instructions_the_design_names(code_objects):
     asm = "\n".join(a for _, a in code_objects)
-    want = {"20conv64_wino2d_kernelILb0ELi4ELi2ELb0EE": "v_mfma_f32_16x16x4_f32", "20conv64_wino2d_kernelILb0ELi2ELi2ELb0EE": "v_mfma_f32_16x16x4_f32",
+    want = {"20conv64_wino2d_kernelILb0ELi4ELi2ELb0ELb0EE": "v_mfma_f32_16x16x4_f32", "20conv64_wino2d_kernelILb0ELi2ELi2ELb0ELb0EE": "v_mfma_f32_16x16x4_f32",
+            "20conv64_wino2d_kernelILb0ELi4ELi2ELb0ELb1EE": "ds_bpermute_b32",
             "23conv64_wino2d_pc_kernelILb0EE": "v_mfma_f32_16x16x32_bf16", "23conv64_wino2d_pc_kernelILb1EE": "v_cvt_pk_bf16_f32",
             "19wgrad64_wino_kernelILb1": "v_mfma_f32_32x32x2_f32",
             "18conv64_bf16_kernelILi8ELi2": "v_mfma_f32_32x32x16_bf16", "23wgrad64_bf16_dma_kernel": "ds_read_b64_tr_b16"}
