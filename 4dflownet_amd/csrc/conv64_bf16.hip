@@ -153,19 +153,23 @@ __device__ __forceinline__ void conv64_bf16_body(const Conv64BfArgs& p, const in
                     unsigned v = (unsigned)((qd * p.IH + qh) * p.IW + qw);
                     if (p.dbg & 4) v = (unsigned)(r & 255);  // ablation: real data, but always the same 32 KB (cache hits)
                     goff[u] = v * 128u + (unsigned)((S2 ? (pslot ^ (zh & 3)) : (chunk ^ f)) << 4);
+                    if (S2 && (p.dbg & 64)) goff[u] = v * 64u + (unsigned)((pslot ^ (zh & 3)) << 4);   // timing prototype: planar halves [2][N][DHW][32]
                 }
             }
         }
     }
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.x + (size_t)n * p.ID * p.IH * p.IW * 64), 0, (unsigned)(p.ID * p.IH * p.IW) * 128u, 0x00020000);
+    const bool planar = S2 && (p.dbg & 64);
+    const unsigned half_bytes = (unsigned)(p.N * p.ID * p.IH * p.IW) * 64u;
+    const __amdgpu_buffer_rsrc_t xrsrc = planar
+        ? __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)n * p.ID * p.IH * p.IW * 32), 0, half_bytes + (unsigned)(p.ID * p.IH * p.IW) * 64u, 0x00020000)
+        : __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)n * p.ID * p.IH * p.IW * 64), 0, (unsigned)(p.ID * p.IH * p.IW) * 128u, 0x00020000);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     auto stage_dma = [&](char* buf, int sl, int u0, int u1) {
 #pragma unroll
         for (int u = 0; u < NPL; ++u) {
             if (u < u0 || u >= u1) continue;
             if (u * 256 + wave_u * 64 >= nitems) continue;            // wave-uniform: the whole 1-KB piece lies past the (padded) image
-            fdn_lds_dma16(xrsrc, buf + (u * 256 + wave_u * 64) * 16, goff[u], sl * ROWB);
+            fdn_lds_dma16(xrsrc, buf + (u * 256 + wave_u * 64) * 16, goff[u], planar ? sl * (int)half_bytes : sl * ROWB);
         }
     };
     // GEN: register staging -- NP staged voxels x one 16-B chunk per thread, written to a padded / swizzled image by ds_write
