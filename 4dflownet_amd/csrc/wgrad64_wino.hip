@@ -57,6 +57,8 @@ constexpr int VBYTES = (WTH + 2) * WTG * GROWB;         // transformed x: 8 halo
 constexpr int ZBYTES = WTH * WTG * GROWB;               // transformed dz
 constexpr int WBUFB = VBYTES + ZBYTES;                  // 43 008 B; three buffers = 126 KB
 constexpr int kLocSlot = 5, kXSlot = 6, kZSlot = 13;      // pipeline slots: tile walk / raw x rows / raw dz rows of tile k+2
+constexpr int kLocSlotZ = 10;                             // ... the walk of the dz waves: the two waves of a SIMD (w, w + 4: one x wave, one dz wave) must
+                                                          // not sit in their ~50 scalar instructions at the same time -- the SIMD then issues no MFMA
 constexpr int XSCRATCH = 6 * 4096;                      // DEP: x chunks of the second plane, [chunk 6][x-thread 256] x 16 B, filled by LDS-DMA
 constexpr int ZSCRATCH = 2 * 3072;                      // DEP: dz chunks 2, 3 of the second plane, [2][dz-thread 192] x 16 B
 
@@ -342,7 +344,8 @@ __device__ __forceinline__ void wgrad64_wino_body(const WgWinoArgs& p, const int
             if (ROLE == 1 && s == 2) combine_z();
             if (ROLE == 0 && s < 2) write_v(s, nxt);
             if (ROLE == 1 && s >= 2 && s < 4) write_z(s - 2, nxt);
-            if (s == kLocSlot && !(FDN_DBG_BITS(p) & 32)) { advance(); locate(); }
+            if (ROLE == 0 && s == kLocSlot && !(FDN_DBG_BITS(p) & 32)) { advance(); locate(); }
+            if (ROLE == 1 && s == kLocSlotZ && !(FDN_DBG_BITS(p) & 32)) { advance(); locate(); }      // (wave 7 loads nothing: no walk)
             if (ROLE == 0 && s >= kXSlot && s < kXSlot + 6) load_x(s - kXSlot);
             if (ROLE == 1 && s >= kZSlot && s < kZSlot + 4) load_z(s - kZSlot);
             acc[b][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vp[(q + b) & 3].x, Zp[q & 1].x, acc[b][0], 0, 0, 0);
