@@ -82,6 +82,7 @@ DEBUG_SIGNATURES = {
     "fdn_debug_set_conv64_bf16_dbg": (c_i, [c_i]),
     "fdn_debug_set_conv64_bf16_mode2": (c_i, [c_i]),
     "fdn_debug_set_heads_mfma": (c_i, [c_i]),
+    "fdn_debug_set_upsample_bwd_hb": (c_i, [c_i]),
     "fdn_debug_set_wgrad64_direct": (c_i, [c_i]),
     "fdn_debug_set_conv64_wino_dbg": (c_i, [c_i]),
     "fdn_debug_set_conv64_wino_tile": (c_i, [c_i]),

@@ -155,92 +155,122 @@ __device__ __forceinline__ void axis_range(int i, float inv_scale, int m, int& o
     o1 = min(m - 1, (int)ceilf((float)(i + 1) * inv_scale) + 1);
 }
 
-// Adjoint of the trilinear upsample, block = one LOW-res row (n, d, h).  Phase A folds the (<= 2R+1)^2 high-res rows that
-// touch it (block-uniform weights wd * wh) into one high-res-wide row in LDS (coalesced 16-B reads of dy, every dy row is
-// read by the <= 4 low-res rows it touches -- L2 hits); phase B folds that row along w, applies act'(y_prev), stores.
-template <typename T>
+// Adjoint of the trilinear upsample, block = HB consecutive LOW-res rows (n, d, h0 .. h0 + HB - 1).  Phase A folds the high-res rows
+// that touch them (block-uniform weights wd * wh per low-res row) into HB high-res-wide rows in LDS: coalesced 16-B reads of dy, eight
+// rows requested before the first use, every loaded vector accumulated into all HB rows (weight 0 where it does not touch: exact).  A
+// high-res row touches two low-res rows per axis, so with HB = 1 (rounds 1-5) every dy row went through the vector cache four times
+// (1 GB of L2 -> L1 traffic for the 226 MB of cfg2: 0.071 ms); with HB = 2 it is three times.  Phase B folds each row along w, applies
+// act'(y_prev), stores.  Per low-res row the non-zero terms are added in the same order as before: bit-identical for every HB.
+template <typename T, int HB>
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ yprev,
                                                             int act, float alpha, T* __restrict__ dx, int N, int D,
                                                             int H, int W, int CV, int R, float sd, float sh, float sw) {
     constexpr int E = FdnVec<T>::E;
-    extern __shared__ __attribute__((aligned(16))) float rowbuf[];      // [OW][CV * E]
-    constexpr int kUpPairs = 32 * 32;                                   // <= 32 candidate rows per axis (host checks R)
+    extern __shared__ __attribute__((aligned(16))) float rowbuf[];      // [HB][OW][CV * E]
+    constexpr int kCandD = 32, kCandH = 64;                             // candidate rows per axis (host checks R and HB against them)
+    constexpr int kUpPairs = HB == 1 ? 1024 : 512;
     __shared__ int s_row[kUpPairs];
-    __shared__ float s_wgt[kUpPairs];
-    __shared__ int s_od[32], s_oh[32], s_nd, s_nh;
-    __shared__ float s_wd[32], s_wh[32];
+    __shared__ float s_wgt[kUpPairs * HB];
+    __shared__ int s_od[kCandD], s_oh[kCandH], s_nd, s_nh;
+    __shared__ float s_wd[kCandD], s_wh[kCandH * HB];
     const int OD = D * R, OH = H * R, OW = W * R;
     const int C = CV * E;
     const float isd = sd > 0.f ? 1.f / sd : 0.f, ish = sh > 0.f ? 1.f / sh : 0.f, isw = sw > 0.f ? 1.f / sw : 0.f;
-    // XCD-aware row order: block ids are dealt round-robin to the 8 XCDs; an XCD takes one contiguous run of low-res rows,
-    // so the high-res rows shared by neighbouring low-res rows are fetched into ITS L2 once (plain order: 3.8x dy from HBM)
-    const int nrows = N * D * H;
+    // XCD-aware block order: block ids are dealt round-robin to the 8 XCDs; an XCD takes one contiguous run of low-res row blocks,
+    // so the high-res rows shared by neighbouring blocks are fetched into ITS L2 once (plain order: 3.8x dy from HBM)
+    const int nhblk = (H + HB - 1) / HB;
+    const int nrows = N * D * nhblk;
     for (int it = blockIdx.x; it < nrows; it += gridDim.x) {
-        const int blk0 = it - (int)blockIdx.x, span = min((int)gridDim.x, nrows - blk0);     // rows of this sweep
+        const int blk0 = it - (int)blockIdx.x, span = min((int)gridDim.x, nrows - blk0);     // blocks of this sweep
         const int q = span >> 3, rem = span & 7, xc = blockIdx.x & 7;
         const int row = blk0 + xc * q + (xc < rem ? xc : rem) + ((int)blockIdx.x >> 3);
-        const int h = row % H;
-        const int t = row / H;
+        const int h0 = (row % nhblk) * HB;
+        const int nhb = min(HB, H - h0);
+        const int t = row / nhblk;
         const int d = t % D, n = t / D;
-        int od0, od1, oh0, oh1;
+        int od0, od1, oh0, oh1, tmp;
         axis_range(d, isd, OD, od0, od1);
-        axis_range(h, ish, OH, oh0, oh1);
+        axis_range(h0, ish, OH, oh0, tmp);
+        axis_range(h0 + nhb - 1, ish, OH, tmp, oh1);
         if (sd == 0.f) { od0 = 0; od1 = OD - 1; }
         if (sh == 0.f) { oh0 = 0; oh1 = OH - 1; }
-        __syncthreads();                                   // rowbuf and the pair list of the previous row fully consumed
-        // The high-res rows (od, oh) with a non-zero weight on this low-res row, as a compact block-uniform list: the fold below
-        // then has no data-dependent branch around its loads, which are requested four rows at a time before the first use
-        // (a `continue` per candidate row made every load its own round trip: 103 us for 280 MB at cfg2).
-        if (threadIdx.x < 64) {
-            // lanes 0..31: the depth candidates od0.., lanes 32..63: the height candidates oh0..; ballot + prefix count compacts the
-            // ones with a non-zero weight in index order (deterministic), wave 0 only
-            const int lane = threadIdx.x;
-            const bool dl = lane < 32;
-            const int c = dl ? od0 + lane : oh0 + (lane - 32);
-            float wgt = 0.f;
-            if (c <= (dl ? od1 : oh1)) wgt = dl ? axis_weight(c, d, sd, D) : axis_weight(c, h, sh, H);
-            const unsigned long long m = __ballot(wgt != 0.f);
-            const unsigned long long mine = dl ? (m & 0xffffffffull) : (m >> 32);
-            if (wgt != 0.f) {
-                const int pos = __popcll(mine & ((1ull << (lane & 31)) - 1ull));
-                if (dl) { s_od[pos] = c; s_wd[pos] = wgt; } else { s_oh[pos] = c; s_wh[pos] = wgt; }
+        __syncthreads();                                   // rowbuf and the pair list of the previous block fully consumed
+        // The high-res rows (od, oh) with a non-zero weight on one of these low-res rows, as a compact block-uniform list: the fold
+        // below then has no data-dependent branch around its loads (a `continue` per candidate row made every load its own round
+        // trip: 103 us for 280 MB at cfg2).  Wave 0: the depth candidates od0.. (lanes 0..31), wave 1: the height candidates oh0..;
+        // ballot + prefix count compacts the ones with a non-zero weight in index order (deterministic).
+        if (threadIdx.x < 128) {
+            const int lane = threadIdx.x & 63;
+            const bool dl = threadIdx.x < 64;
+            const int c = dl ? od0 + lane : oh0 + lane;
+            float wgt[HB];
+            bool any = false;
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+                wgt[hb] = 0.f;
+                if (dl) { if (hb == 0 && lane < kCandD && c <= od1) wgt[0] = axis_weight(c, d, sd, D); }
+                else if (hb < nhb && c <= oh1) wgt[hb] = axis_weight(c, h0 + hb, sh, H);
+                any = any || wgt[hb] != 0.f;
             }
-            if (lane == 0) { s_nd = __popcll(m & 0xffffffffull); s_nh = __popcll(m >> 32); }
+            const unsigned long long m = __ballot(any);
+            if (any) {
+                const int pos = __popcll(m & ((1ull << lane) - 1ull));
+                if (dl) { s_od[pos] = c; s_wd[pos] = wgt[0]; }
+                else {
+                    s_oh[pos] = c;
+#pragma unroll
+                    for (int hb = 0; hb < HB; ++hb) s_wh[pos * HB + hb] = wgt[hb];
+                }
+            }
+            if (lane == 0) { if (dl) s_nd = __popcll(m); else s_nh = __popcll(m); }
         }
         __syncthreads();
         const int nd_ = s_nd, nh_ = s_nh, npairs = nd_ * nh_;
         for (int k = threadIdx.x; k < npairs; k += blockDim.x) {
             const int a = k / nh_, b = k - a * nh_;
             s_row[k] = (n * OD + s_od[a]) * OH + s_oh[b];
-            s_wgt[k] = s_wd[a] * s_wh[b];
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) s_wgt[k * HB + hb] = s_wd[a] * s_wh[b * HB + hb];
         }
         __syncthreads();
+        constexpr int U = 8;                               // high-res rows requested before the first use (16 measured slower: 0.070 vs 0.057 ms at cfg2)
         for (int i = threadIdx.x; i < OW * CV; i += blockDim.x) {
-            float acc[E];
+            float acc[HB][E];
 #pragma unroll
-            for (int e = 0; e < E; ++e) acc[e] = 0.f;
-            for (int k0 = 0; k0 < npairs; k0 += 4) {
-                float g[4][E], wv[4];
+            for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int e = 0; e < E; ++e) acc[hb][e] = 0.f;
+            for (int k0 = 0; k0 < npairs; k0 += U) {
+                float g[U][E];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
                     const int k = min(k0 + u, npairs - 1);         // tail: re-read the last row with weight 0 (cache hit)
-                    wv[u] = k0 + u < npairs ? s_wgt[k] : 0.f;
                     FdnVec<T>::ld(dy + ((int64_t)s_row[k] * OW * CV + i) * E, g[u]);
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < U; ++u) {
+                    const int k = min(k0 + u, npairs - 1);
 #pragma unroll
-                    for (int e = 0; e < E; ++e) acc[e] += g[u][e] * wv[u];
+                    for (int hb = 0; hb < HB; ++hb) {
+                        const float wv = k0 + u < npairs ? s_wgt[k * HB + hb] : 0.f;
+#pragma unroll
+                        for (int e = 0; e < E; ++e) acc[hb][e] += g[u][e] * wv;
+                    }
+                }
             }
 #pragma unroll
-            for (int e = 0; e < E; ++e) rowbuf[i * E + e] = acc[e];
+            for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+                for (int e = 0; e < E; ++e) rowbuf[(hb * OW * CV + i) * E + e] = acc[hb][e];
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < W * CV; i += blockDim.x) {
+        for (int j = threadIdx.x; j < nhb * W * CV; j += blockDim.x) {
+            const int hb = j / (W * CV), i = j - hb * (W * CV);
             const int w = i / CV, cv = i - w * CV;
             int ow0, ow1;
             axis_range(w, isw, OW, ow0, ow1);
             if (sw == 0.f) { ow0 = 0; ow1 = OW - 1; }
+            const float* rb = rowbuf + hb * OW * C;
             float acc[E];
 #pragma unroll
             for (int e = 0; e < E; ++e) acc[e] = 0.f;
@@ -248,9 +278,9 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__
                 const float ww = axis_weight(ow, w, sw, W);
                 if (ww == 0.f) continue;
 #pragma unroll
-                for (int e = 0; e < E; ++e) acc[e] += rowbuf[ow * C + cv * E + e] * ww;
+                for (int e = 0; e < E; ++e) acc[e] += rb[ow * C + cv * E + e] * ww;
             }
-            const int64_t o = ((int64_t)row * W * CV + i) * E;
+            const int64_t o = ((((int64_t)n * D + d) * H + h0 + hb) * W * CV + i) * E;
             if (yprev) {
                 float yv[E];
                 FdnVec<T>::ld(yprev + o, yv);
@@ -489,26 +519,48 @@ static int upsample_fwd_t(const T* x, T* y, int N, int D, int H, int W, int C, i
     FDN_CHECK_LAUNCH("upsample_fwd_kernel");
     return FDN_OK;
 }
+FDN_HOOK_VAR(int, fdn_upsample_bwd_hb, 0);        // test / bench hook: low-res rows per block of upsample_bwd_kernel (0 = planner)
+#ifdef FDN_TEST_HOOKS
+extern "C" int fdn_debug_set_upsample_bwd_hb(int hb) { fdn_upsample_bwd_hb = hb; return FDN_OK; }
+#endif
 template <typename T>
 static int upsample_bwd_t(const T* dy, const T* y_prev, int act, float alpha, T* dx, int N, int D, int H, int W, int C, int R,
                           void* stream) {
     constexpr int E = 16 / (int)sizeof(T);
     FDN_REQUIRE(dy && dx && C % E == 0 && R >= 1 && N > 0 && D > 0 && H > 0 && W > 0, "fdn_upsample_trilinear_bwd: bad argument");
     const int64_t rows = (int64_t)N * D * H;
-    const size_t lds = (size_t)W * R * C * sizeof(float);
-    FDN_REQUIRE(rows * R * R < (1ll << 31) && lds <= 160 * 1024, "fdn_upsample_trilinear_bwd: row of %d x %d channels does not fit the LDS stage", W * R, C);
-    // the adjoint compacts the high-res rows that can touch a low-res row with 32 lanes per axis: a low-res row reaches
-    // 2 (OD-1)/(D-1) high-res rows (align_corners scale) + the rounding margin, which exceeds 2R+1 on short axes
-    auto span = [](int n, int r) { return n > 1 ? (2 * (n * r - 1) + (n - 2)) / (n - 1) + 3 : n * r; };
-    FDN_REQUIRE(span(D, R) <= 32 && span(H, R) <= 32, "fdn_upsample_trilinear_bwd: R = %d on a %d x %d grid needs %d / %d candidate rows per axis "
-                "(the adjoint keeps <= 32)", R, D, H, span(D, R), span(H, R));
-    const size_t lds_static = 9 * 1024;             // the kernel's static __shared__ tables (s_row, s_wgt, ...) share the 160 KB
-    FDN_REQUIRE(lds + lds_static <= 160 * 1024, "fdn_upsample_trilinear_bwd: row of %d x %d channels + the kernel's tables do not fit the LDS", W * R, C);
-    if (lds > 48 * 1024) {
-        if (int rc = fdn_func_max_lds((const void*)upsample_bwd_kernel<T>, 160 * 1024, "upsample_bwd")) return rc;
+    const size_t row_lds = (size_t)W * R * C * sizeof(float);
+    FDN_REQUIRE(rows * R * R < (1ll << 31) && row_lds <= 150 * 1024, "fdn_upsample_trilinear_bwd: row of %d x %d channels does not fit the LDS stage", W * R, C);
+    // the adjoint compacts the high-res rows that can touch a low-res row with 32 lanes along d: a low-res row reaches
+    // 2 (OD-1)/(D-1) high-res rows (align_corners scale) + the rounding margin, which exceeds 2R+1 on short axes; along h the HB rows of a
+    // block share 64 lanes
+    auto span = [](int n, int r, int hb) { return n > 1 ? ((hb + 1) * (n * r - 1) + (n - 2)) / (n - 1) + 3 : n * r; };
+    FDN_REQUIRE(span(D, R, 1) <= 32 && span(H, R, 1) <= 32, "fdn_upsample_trilinear_bwd: R = %d on a %d x %d grid needs %d / %d candidate rows per axis "
+                "(the adjoint keeps <= 32)", R, D, H, span(D, R, 1), span(H, R, 1));
+    // HB = 2 low-res rows per block where the LDS rows leave room for two workgroups per CU and the candidates fit the tables, else 1
+    // (measured, tools/bench_upsample.py --hb: fp32 (8,24^3) x2 0.062 / 0.057 / 0.087 ms with 1 / 2 / 4 rows -- four rows cost more
+    // occupancy than their L1 traffic saves; bf16 (4,32^3) x4 0.370 / 0.302)
+    auto fits = [&](int hb) { return hb * row_lds + 14 * 1024 <= 80 * 1024 && span(H, R, hb) <= 64 && span(D, R, 1) * span(H, R, hb) <= 512; };
+    int hb = fits(2) ? 2 : 1;
+    if (fdn_upsample_bwd_hb) {                                             // (test build: forced)
+        FDN_REQUIRE(fdn_upsample_bwd_hb == 1 || fits(fdn_upsample_bwd_hb), "fdn_upsample_trilinear_bwd: %d rows per block do not fit", fdn_upsample_bwd_hb);
+        hb = fdn_upsample_bwd_hb;
     }
-    hipLaunchKernelGGL(upsample_bwd_kernel<T>, dim3((unsigned)(rows < 65536 ? rows : 65536)), dim3(256), lds, (hipStream_t)stream, dy,
-                       y_prev, act, alpha, dx, N, D, H, W, C / E, R, axis_scale(D, R), axis_scale(H, R), axis_scale(W, R));
+    const size_t lds = (size_t)hb * row_lds;
+    const int64_t blocks = (int64_t)N * D * ((H + hb - 1) / hb);
+    const unsigned grid = (unsigned)(blocks < 65536 ? blocks : 65536);
+    const float sd = axis_scale(D, R), sh = axis_scale(H, R), sw = axis_scale(W, R);
+    auto launch = [&](auto tag) -> int {
+        constexpr int HB = decltype(tag)::value;
+        if (lds > 48 * 1024) {
+            if (int rc = fdn_func_max_lds((const void*)upsample_bwd_kernel<T, HB>, 150 * 1024, "upsample_bwd")) return rc;
+        }
+        hipLaunchKernelGGL((upsample_bwd_kernel<T, HB>), dim3(grid), dim3(256), lds, (hipStream_t)stream, dy, y_prev, act, alpha, dx, N, D, H, W,
+                           C / E, R, sd, sh, sw);
+        return FDN_OK;
+    };
+    FDN_REQUIRE(hb == 1 || hb == 2, "fdn_upsample_trilinear_bwd: %d rows per block", hb);
+    if (int rc = hb == 2 ? launch(std::integral_constant<int, 2>{}) : launch(std::integral_constant<int, 1>{})) return rc;
     FDN_CHECK_LAUNCH("upsample_bwd_kernel");
     return FDN_OK;
 }

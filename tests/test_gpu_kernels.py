@@ -371,6 +371,28 @@ def test_upsample(ops, R):
     close(ops.upsample_trilinear_bwd(dev(dy), R, dev(y), O.ACT_LEAKY, 0.2), O.act_bwd_from_output(refb, y, O.ACT_LEAKY), name="upsample bwd+mask")
 
 
+@pytest.mark.parametrize("shape,R", [((1, 3, 7, 5), 2), ((2, 1, 5, 4), 3), ((1, 4, 1, 3), 2), ((1, 6, 9, 8), 4), ((1, 3, 3, 2), 5)])
+def test_upsample_bwd_row_blocks(ops, fdn, shape, R):
+    """upsample_bwd_kernel folds the high-res rows of TWO low-res rows per block (round 6): odd H leaves a one-row block, an axis of
+    length 1 takes every high-res row; against the oracle, and one / two rows per block bit for bit (the same terms in the same order)."""
+    rng = np.random.default_rng(15)
+    N, D, H, W = shape
+    dy = rng.normal(size=(N, D * R, H * R, W * R, 64)).astype(np.float32)
+    y = rng.normal(size=(N, D, H, W, 64)).astype(np.float32)
+    refb = O.upsample_trilinear_bwd(dy.astype(np.float64), (D, H, W), R, f32_coeffs=True)
+    got = ops.upsample_trilinear_bwd(dev(dy), R, dev(y), O.ACT_LEAKY, 0.2)
+    close(got, O.act_bwd_from_output(refb, y, O.ACT_LEAKY), name="upsample bwd+mask")
+    with fdn._lib.test_build() as lib:
+        outs = []
+        try:
+            for hb in (1, 2):
+                lib.fdn_debug_set_upsample_bwd_hb(hb)
+                outs.append(ops.upsample_trilinear_bwd(dev(dy), R, dev(y), O.ACT_LEAKY, 0.2))
+        finally:
+            lib.fdn_debug_set_upsample_bwd_hb(0)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], got)
+
+
 def test_input_features_loss_metric(ops):
     B, P, R = 2, 6, 2
     batch = O.synthetic_batch(B, P, R, seed=11)

@@ -99,7 +99,7 @@ PRODUCT_KERNELS = {
     "head_fwd_kernel<T>": "fdn_conv3d_fwd 64->1", "head_dgrad_kernel<T>": "fdn_conv_cout1_dgrad_folded", "head_wgrad_kernel<T>": "fdn_conv3d_wgrad 64->1",
     "conv_cout1_dgrad_kernel": "fdn_conv3d_dgrad 64->1 (padded form)",
     "bias_grad_kernel<T>": "fdn_bias_grad", "reduce_partials_kernel": "", "sum_partials_kernel": "",
-    "upsample_fwd_kernel<T, true>": "fdn_upsample_trilinear_fwd (input rows staged through LDS)", "upsample_fwd_kernel<T, false>": "... rows too long for the LDS", "upsample_bwd_kernel<T>": "fdn_upsample_trilinear_bwd", "input_features_kernel<T>": "fdn_input_features",
+    "upsample_fwd_kernel<T, true>": "fdn_upsample_trilinear_fwd (input rows staged through LDS)", "upsample_fwd_kernel<T, false>": "... rows too long for the LDS", "upsample_bwd_kernel<T, 2>": "fdn_upsample_trilinear_bwd (two low-res rows per block)", "upsample_bwd_kernel<T, 1>": "... rows too long for two in the LDS", "input_features_kernel<T>": "fdn_input_features",
     "loss_main_kernel": "fdn_loss_metrics", "loss_finalize_kernel": "", "mask_sums_kernel": "", "l2_sumsq_kernel": "fdn_l2_sumsq", "l2_sumsq_partials_kernel": "fdn_l2_sumsq_partials", "adam_kernel": "fdn_adam_step",
     "gather_patches_kernel": "fdn_gather_patches",
     "conv64_bf16_kernel<8, 2>": "bf16 mode: fdn_conv64_fwd_bf16", "conv64_bf16_fused_kernel<8>": "fdn_conv64_dgrad_fused_bf16 (inner box + shell slabs, one launch)",

@@ -20,4 +20,13 @@ for dtype, N, P, R in (("f32", 8, 24, 2), ("bf16", 8, 24, 2), ("bf16", 4, 32, 4)
     tf = timeit(lambda: ops.upsample_trilinear_fwd(x, R, y))
     tb = timeit(lambda: ops.upsample_trilinear_bwd(dy, R, x, 2, 0.2, dx))
     gb = y.numel() * y.element_size() / 1e9
+    if "--hb" in sys.argv:
+        with fdn._lib.test_build() as lib:
+            for hb in (1, 2):
+                lib.fdn_debug_set_upsample_bwd_hb(hb)
+                try:
+                    print("   bwd with %d low-res rows per block: %.3f ms" % (hb, timeit(lambda: ops.upsample_trilinear_bwd(dy, R, x, 2, 0.2, dx))), flush=True)
+                except Exception as e:
+                    print("   bwd with %d rows per block: %s" % (hb, str(e)[:80]))
+            lib.fdn_debug_set_upsample_bwd_hb(0)
     print("%s N=%d %d^3 x%d: fwd %.3f ms (%.0f GB/s written)  bwd %.3f ms (%.0f GB/s read)" % (dtype, N, P, R, tf, gb / tf * 1e3, tb, gb / tb * 1e3), flush=True)
