@@ -152,8 +152,6 @@ class FlowNetModel:
         self._ws = None
         self._ws_bias = None
         self._side = None              # second HIP stream for the weight-gradient launches
-        self.overlap_shell = False     # dgrad shell slabs on a side stream: measured 38.6 -> 39.3 ms per cfg2 step (the two stream joins per
-                                       # layer cost more than the tail the slabs fill), so off
         # weight gradients of 64->64 layers on small grids are collected per gradient bucket and issued as ONE batched launch
         # (fdn_conv3d_wgrad_batch): at 8 x 24^3 a layer alone on the chip leaves a workgroup 4.6 tiles between prologue and output
         # transform.  The batch ends where the bucket does, so the data-parallel all-reduce of a bucket starts as early as before.
@@ -508,31 +506,14 @@ class FlowNetModel:
 
     def _dgrad_fold(self, dz, L, skip, y_prev, act, mask=None):
         """dz_prev = (MirrorPadGrad(Conv3DBackpropInput(dz)) + skip) * act'(y_prev) for a 64->64 layer: interior voxels
-        are finished by the conv epilogue, the surface by one small border kernel.  mask (bf16 mode): the sign mask of y_prev, read by
-        the conv epilogue instead of y_prev itself."""
+        are finished by the conv epilogue, the surface by one small border kernel.  mask: the sign mask of y_prev, read by the conv
+        epilogue instead of y_prev itself (bf16 mode; fp32 on the grids of the F(4,3) x F(4,3) kernels)."""
         out = torch.empty_like(dz)
         pad = self._pad_like(dz)
+        kw = {} if self.dtype == "bfloat16" else {"algo": self.conv_algo[L.name]}
         if mask is not None and y_prev is not None and (self.dtype == "bfloat16" or self._mask_ok(dz, L)):
-            self.ops.conv3d_dgrad_fused(dz, L.wp_d, pad, out, skip=skip, y_prev=y_prev, act=act, mask=mask,
-                                        **({} if self.dtype == "bfloat16" else {"algo": self.conv_algo[L.name]}))
-            self.ops.fold_halo_border([pad], out, skip, y_prev, act)
-            return out
-        if self.overlap_shell and self.dtype == "float32":
-            # the six 9-tap shell slabs (a short direct-conv launch) run on a second stream next to the Winograd launch of the
-            # inner box and fill its tail; both only read dz and write disjoint positions
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=self.device)
-            main = torch.cuda.current_stream()
-            self._side.wait_stream(main)
-            with torch.cuda.stream(self._side):
-                self.ops.conv3d_dgrad_fused(dz, L.wp_d, pad, out, parts=ops.DGRAD_SHELL, algo=self.conv_algo[L.name])
-            self.ops.conv3d_dgrad_fused(dz, L.wp_d, pad, out, skip=skip, y_prev=y_prev, act=act, parts=ops.DGRAD_INNER,
-                                        algo=self.conv_algo[L.name])
-            main.wait_stream(self._side)
-            for t in (dz, pad):
-                t.record_stream(self._side)
-        else:
-            self.ops.conv3d_dgrad_fused(dz, L.wp_d, pad, out, skip=skip, y_prev=y_prev, act=act, algo=self.conv_algo[L.name])
+            kw["mask"] = mask
+        self.ops.conv3d_dgrad_fused(dz, L.wp_d, pad, out, skip=skip, y_prev=y_prev, act=act, **kw)
         self.ops.fold_halo_border([pad], out, skip, y_prev, act)
         return out
 

@@ -94,7 +94,7 @@ class LaunchTimer:
                 # bf16 mode: ONE launch covers the inner box and the shell (conv64_bf16.hip); priced as algorithmic work
                 return bracket("conv", N * D * H * W, N * D * H * W * FLOP_PER_VOXEL_CONV64, lambda: dgf(dz, *a, **k))
             # fp32: ONE launch (conv64_wino2d_shell_kernel): the inner box on the 2-D Winograd body, the shell faces behind it on the 1-D
-            # body -- executed FLOPs = both; a caller-issued part (network.overlap_shell) is priced as that part alone
+            # body -- executed FLOPs = both; a caller-issued part is priced as that part alone
             parts = k.get("parts", 3)
             ex = (executed_conv64_flop(N, D, H, W, dz.dtype, k.get("algo", 0)) if parts & 1 else 0.0) + (executed_shell_flop(N, D, H, W) if parts & 2 else 0.0)
             return bracket("conv", N * D * H * W if parts & 1 else 0, ex, lambda: dgf(dz, *a, **k))

@@ -240,7 +240,7 @@ def test_conv64_wgrad_batch(ops, shape, nl):
 def test_conv64_dgrad_fused_one_launch_equals_two(ops, fdn, shape, algo):
     """The fused dgrad of the 2-D Winograd path is ONE launch (conv64_wino2d_shell_kernel: inner box on the 2-D body, shell faces behind
     it on the 1-D body).  It must be bit-identical to the same two bodies as two launches (test-build switch), and to the two `parts` a
-    caller may issue on its own (network.overlap_shell)."""
+    caller may issue on its own."""
     rng = np.random.default_rng(61)
     N, D, H, W = shape
     dz = dev(rng.normal(size=(N, D, H, W, 64)).astype(np.float32))
