@@ -72,9 +72,14 @@ meta = {"commit": head + ("+dirty" if dirty else ""), "lib_source_stamp": box_st
         "collected_by": "tools/collect_profiles.py %s" % tag}
 line = "# commit %s lib_source_stamp %s%s\n" % (meta["commit"], box_stamp, " STALE (tree at %s)" % tree_stamp[:16] if meta["stale"] else "")
 n = 0
+# only the files of the gpurun call that wrote the stamp (gpurun_out/ accumulates over calls: an older call's files were measured on other
+# sources and must not be re-labelled with this commit); files merged back from one call carry times within seconds of each other
+t_call = os.path.getmtime(stamp_file)
 for path in sorted(glob.glob(os.path.join(src, tag + "_*"))):
     name = os.path.basename(path)
     if name.endswith(("_prof_bench.log", "_source_stamp.txt", "_gputest.txt")) or os.path.isdir(path):
+        continue
+    if abs(os.path.getmtime(path) - t_call) > 600 and "--all" not in sys.argv:
         continue
     dst = os.path.join(ROOT, "profiles", name)
     if name.endswith(".json"):
