@@ -31,6 +31,7 @@ SIGNATURES = {
     "fdn_conv64_mask_ok": (c_i, [c_i] * 5),
     "fdn_conv64_fwd_mask": (c_i, [c_fp] * 6 + [c_i] * 5 + [c_f, c_i, c_fp]),
     "fdn_conv64_dgrad_fused_mask": (c_i, [c_fp] * 5 + [c_i, c_f, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "fdn_conv64_dgrad_fused_multi": (c_i, [c_fp, c_fp, c_i] + [c_fp] * 4 + [c_i, c_f, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "fdn_conv3d_dgrad_fused_part": (c_i, [c_fp] * 5 + [c_i, c_f, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "fdn_fold_halo_border": (c_i, [c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_f, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "fdn_conv1x1_dgrad": (c_i, [c_fp] * 6 + [c_i64, c_fp]),
@@ -103,7 +104,7 @@ class FdnError(RuntimeError):
     pass
 
 
-FDN_VERSION = 160    # include/fdn.h
+FDN_VERSION = 161    # include/fdn.h
 
 
 _product = None

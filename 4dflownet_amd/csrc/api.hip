@@ -34,7 +34,7 @@ FDN_HOOK_VAR(int, fdn_wgrad64_force_direct, 0);
 extern "C" int fdn_debug_set_wgrad64_direct(int on) { fdn_wgrad64_force_direct = on; return FDN_OK; }
 #endif
 
-extern "C" int fdn_version(void) { return FDN_VERSION; }   // 160: FDN_CONV64_PACK_FLOATS = 423 * 4096 (+ the bf16 x 3 stream), FDN_ALGO_WINO_BF16X3
+extern "C" int fdn_version(void) { return FDN_VERSION; }   // 161: fdn_conv64_dgrad_fused_multi; 160: FDN_CONV64_PACK_FLOATS = 423 * 4096 (+ the bf16 x 3 stream), FDN_ALGO_WINO_BF16X3
 extern "C" const char* fdn_last_error(void) { return g_err; }
 
 // small-channel kernels (small_convs.hip), templated on the activation storage type (float / uint16_t = bf16 bits)
@@ -144,6 +144,31 @@ extern "C" int fdn_conv64_dgrad_fused_mask(const float* dz, const float* wpack, 
     FDN_REQUIRE(act == FDN_ACT_RELU || act == FDN_ACT_LEAKY, "fdn_conv64_dgrad_fused_mask: a mask belongs to an activation (act %d)", act);
     return fdn_conv64_launch_ex(dz, wpack, nullptr, nullptr, dxpad, skip, nullptr, dz_prev, N, D, H, W, D + 2, H + 2, W + 2,
                                 -1, 1, act, alpha, (hipStream_t)stream, 3, algo, nullptr, nullptr, y_mask);
+}
+
+extern "C" int fdn_conv64_dgrad_fused_multi(const float* const* dz, const float* const* wpack, int nsrc, float* dxpad, const float* skip,
+                                            const float* y_prev, const uint16_t* y_mask, int act, float alpha, float* dz_prev, int N, int D,
+                                            int H, int W, int algo, void* stream) {
+    FDN_REQUIRE(dz && wpack && dxpad && dz_prev && nsrc >= 1 && nsrc <= 3, "fdn_conv64_dgrad_fused_multi: NULL argument or nsrc outside 1..3");
+    FDN_REQUIRE(algo >= FDN_ALGO_AUTO && algo <= FDN_ALGO_LAST, "fdn_conv64_dgrad_fused_multi: bad algo %d", algo);
+    FDN_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && D <= 1020 && H <= 1020 && W <= 1020, "fdn_conv64_dgrad_fused_multi: bad dims");
+    FDN_REQUIRE(act >= FDN_ACT_NONE && act <= FDN_ACT_LEAKY, "fdn_conv64_dgrad_fused_multi: bad act %d", act);
+    FDN_REQUIRE(!(y_mask && y_prev), "fdn_conv64_dgrad_fused_multi: y_prev OR its sign mask");
+    FDN_REQUIRE(!y_mask || act == FDN_ACT_RELU || act == FDN_ACT_LEAKY, "fdn_conv64_dgrad_fused_multi: a mask belongs to an activation (act %d)", act);
+    // the kernels address the further sources' weight streams as non-negative byte distances from source 0's: order by pack address
+    // (the sum over the sources is formed in that order)
+    int ord[3] = {0, 1, 2};
+    for (int i = 0; i < nsrc; ++i) FDN_REQUIRE(dz[i] && wpack[i], "fdn_conv64_dgrad_fused_multi: NULL pointer for source %d", i);
+    for (int i = 1; i < nsrc; ++i)
+        for (int j = i; j > 0 && wpack[ord[j]] < wpack[ord[j - 1]]; --j) { const int t = ord[j]; ord[j] = ord[j - 1]; ord[j - 1] = t; }
+    FdnExtraSrc ex{nsrc, nullptr, nullptr, 0, 0};
+    for (int i = 1; i < nsrc; ++i) {
+        const long long d = (long long)(wpack[ord[i]] - wpack[ord[0]]) * (long long)sizeof(float);
+        FDN_REQUIRE(d >= 0 && d < (1ll << 30), "fdn_conv64_dgrad_fused_multi: the packs of the sources must lie within 1 GiB of each other (one fdn_pack_conv64_weights_batch buffer)");
+        if (i == 1) { ex.x1 = dz[ord[1]]; ex.wd1 = (int)d; } else { ex.x2 = dz[ord[2]]; ex.wd2 = (int)d; }
+    }
+    return fdn_conv64_launch_ex(dz[ord[0]], wpack[ord[0]], nullptr, nullptr, dxpad, skip, y_prev, dz_prev, N, D, H, W, D + 2, H + 2, W + 2,
+                                -1, 1, act, alpha, (hipStream_t)stream, 3, algo, nullptr, nullptr, y_mask, nsrc > 1 ? &ex : nullptr);
 }
 
 extern "C" int fdn_conv3d_dgrad_fused_part(const float* dz, const float* wpack, float* dxpad, const float* skip,

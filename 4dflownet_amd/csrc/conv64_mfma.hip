@@ -689,10 +689,15 @@ FdnTile fdn_plan_tile(int N, int OD, int OH, int OW, int max_vox, int max_halo_r
 int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, const float* residual, float* y,
                          const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
                          int OW, int off, int zero_mode, int act, float alpha, hipStream_t s, int parts, int algo, unsigned* probe,
-                         uint16_t* ymask, const uint16_t* fmask) {
+                         uint16_t* ymask, const uint16_t* fmask, const FdnExtraSrc* extra) {
     // ymask / fmask (sign masks, conv64_wino2d_kernel.h): only the plain F(4,3) x F(4,3) fp32-MFMA paths write / read them -- the forward
     // over the whole grid, the fused dgrad as ONE launch; every other path refuses (the caller asks fdn_conv64_mask_ok first)
+    // extra (further sources of a fused dgrad, fdn_conv64_dgrad_fused_multi): the same rule -- the one-launch F(4,3) x F(4,3) / F(2,3) x F(4,3) form only
     auto no_mask = [&](const char* what) {
+        if (extra && extra->nsrc > 1) {
+            fdn_set_error("conv64: a multi-source fused dgrad is not supported on this path (%s): ask fdn_conv64_mask_ok", what);
+            return FDN_ERR_UNSUPPORTED;
+        }
         if (!ymask && !fmask) return FDN_OK;
         fdn_set_error("conv64: sign masks are not supported on this path (%s): ask fdn_conv64_mask_ok", what);
         return FDN_ERR_UNSUPPORTED;
@@ -798,10 +803,10 @@ int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, 
                 if (hm != 4) if (int rc = no_mask("not the fp32 F(4,3) x F(4,3) fused dgrad")) return rc;
                 FdnWino2dPrepared inner;
                 if (int rc = fdn_conv64_wino2d_prepare(x, upack_hm(hm), bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, 1, 1, 1, ID,
-                                                       IH, IW, off, zero_mode, act, alpha, hm_arg(hm), &inner, nullptr, fmask))
+                                                       IH, IW, off, zero_mode, act, alpha, hm_arg(hm), &inner, nullptr, fmask, extra))
                     return rc;
                 return fdn_conv64_wino_launch_boxes(x, upack, bias, residual, y, fskip, fy, fout, N, ID, IH, IW, OD, OH, OW, wb + 1, count - 1,
-                                                    off, zero_mode, act, alpha, s, &inner);
+                                                    off, zero_mode, act, alpha, s, &inner, extra);
             }
             if (!probe) if (int rc = no_mask("fused dgrad issued in parts")) return rc;
             if (probe) *probe |= stream_bit(hm);

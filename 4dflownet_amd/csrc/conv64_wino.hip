@@ -97,12 +97,18 @@ bool fdn_conv64_wino_ok(int ebd, int ebh, int ebw) { return ebd > 0 && ebh > 0 &
 int fdn_conv64_wino_launch_boxes(const float* x, const float* upack, const float* bias, const float* residual, float* y,
                                  const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
                                  int OW, const FdnWinoBox* boxes, int nbox, int off, int zero_mode, int act, float alpha,
-                                 hipStream_t s, const FdnWino2dPrepared* inner) {
+                                 hipStream_t s, const FdnWino2dPrepared* inner, const FdnExtraSrc* extra) {
     FDN_REQUIRE((long long)ID * IH * IW < (1ll << 24), "conv64 (winograd): a sample of %dx%dx%d voxels exceeds the 32-bit row addressing", ID, IH, IW);
     FDN_REQUIRE(nbox >= 1 && nbox <= 6, "conv64 (winograd): %d regions", nbox);
     constexpr int CS = kWinoCS, LROW = 256 / CS + 16, CH = 256 / CS / 16;
     WinoArgs a;
     a.x = x; a.up = upack; a.bias = bias; a.res = residual; a.y = y; a.fskip = fskip; a.fy = fy; a.fout = fout;
+    a.x1 = a.x2 = nullptr; a.wd1 = a.wd2 = 0; a.nsrc = 1; a.wspan = 0;
+    if (extra) {
+        FDN_REQUIRE(inner && fout && extra->nsrc >= 1 && extra->nsrc <= 3, "conv64 (winograd): further sources belong to the one-launch fused dgrad, 1..3 in all");
+        a.x1 = extra->x1; a.x2 = extra->x2; a.wd1 = extra->wd1; a.wd2 = extra->wd2; a.nsrc = extra->nsrc;
+        a.wspan = extra->nsrc > 2 ? extra->wd2 : (extra->nsrc > 1 ? extra->wd1 : 0);
+    }
     a.N = N; a.ID = ID; a.IH = IH; a.IW = IW; a.OD = OD; a.OH = OH; a.OW = OW;
     a.off = off; a.zero_mode = zero_mode; a.act = act; a.alpha = alpha; a.dbg = fdn_conv64_wino_dbg;
     a.nreg = 0;

@@ -130,7 +130,7 @@ static_assert(sizeof(Wino2Args) <= sizeof(FdnWino2dPrepared::args), "FdnWino2dPr
 int fdn_conv64_wino2d_prepare(const float* x, const float* upack2, const float* bias, const float* residual, float* y,
                               const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
                               int OW, int obd, int obh, int obw, int ebd, int ebh, int ebw, int off, int zero_mode, int act,
-                              float alpha, int hm_arg, FdnWino2dPrepared* out, uint16_t* ymask, const uint16_t* fmask) {
+                              float alpha, int hm_arg, FdnWino2dPrepared* out, uint16_t* ymask, const uint16_t* fmask, const FdnExtraSrc* extra) {
     const int hm = hm_arg & 7;
     const bool split = (hm_arg & 8) != 0;               // F(4,3) x F(4,3) products as bf16 x 3 (upack2 = that stream)
     FDN_REQUIRE(!split || hm == 4, "conv64 (2-D winograd): the bf16 x 3 products exist for F(4,3) along H only");
@@ -142,6 +142,12 @@ int fdn_conv64_wino2d_prepare(const float* x, const float* upack2, const float* 
     Wino2Args a;
     a.x = x; a.up = upack2; a.bias = bias; a.res = residual; a.y = y; a.fskip = fskip; a.fy = fy; a.fout = fout;
     a.ymask = ymask; a.fmask = fmask;
+    a.x1 = a.x2 = nullptr; a.wd1 = a.wd2 = 0; a.nsrc = 1; a.wspan = 0;
+    if (extra) {
+        FDN_REQUIRE(fout && !split && extra->nsrc >= 1 && extra->nsrc <= 3, "conv64 (2-D winograd): further sources belong to a fused dgrad (fp32-MFMA), 1..3 in all");
+        a.x1 = extra->x1; a.x2 = extra->x2; a.wd1 = extra->wd1; a.wd2 = extra->wd2; a.nsrc = extra->nsrc;
+        a.wspan = extra->nsrc > 2 ? extra->wd2 : (extra->nsrc > 1 ? extra->wd1 : 0);
+    }
     a.N = N; a.ID = ID; a.IH = IH; a.IW = IW; a.OD = OD; a.OH = OH; a.OW = OW;
     a.off = off; a.zero_mode = zero_mode; a.act = act; a.alpha = alpha; a.dbg = fdn_conv64_wino2d_dbg;
     a.hm = hm; a.split = split ? 1 : 0;
@@ -212,6 +218,7 @@ int fdn_conv64_wino2d_launch(const float* x, const float* upack2, const float* b
         return FDN_OK;
     }
     FDN_REQUIRE(!a.fmask, "conv64 (2-D winograd): the mask-reading fused dgrad is the one-launch form (inner box + shell)");
+    FDN_REQUIRE(a.nsrc == 1, "conv64 (2-D winograd): the multi-source fused dgrad is the one-launch form (inner box + shell)");
     const void* fn = a.ymask ? (a.mb == 1 ? (const void*)conv64_wino2d_kernel<false, 4, 1, false, true> : (const void*)conv64_wino2d_kernel<false, 4, 2, false, true>)
                    : fout ? (hm == 4 ? (a.mb == 1 ? (const void*)conv64_wino2d_kernel<true, 4, 1> : (const void*)conv64_wino2d_kernel<true, 4>) : (const void*)conv64_wino2d_kernel<true, 2>)
                           : (hm == 4 ? (a.mb == 1 ? (const void*)conv64_wino2d_kernel<false, 4, 1> : (const void*)conv64_wino2d_kernel<false, 4>) : (const void*)conv64_wino2d_kernel<false, 2>);

@@ -23,6 +23,13 @@ struct Wino2Args {
     // per cell row and quarter-wave instead of four 16-B loads.  8 B per voxel beside the 256-B row.
     uint16_t* ymask;
     const uint16_t* fmask;
+    // Multi-source fused dgrad (round 6): dz_prev = fold(sum_s conv_T(x_s, W_s)) for up to three layers that share their INPUT (the three
+    // heads' 64->64 convs read rb, SR4DFlowNet.py:39-46) -- the stage loop runs once per source over the same tile and accumulates into
+    // the same output registers: one epilogue, one skip / mask read, one set of stores instead of three chained launches.  Source s > 0:
+    // rows x1 / x2, weight stream at up + wd1 / wd2 bytes (the packs of one model lie in one buffer; the host orders the sources by address).
+    const float* x1;
+    const float* x2;
+    int wd1, wd2, nsrc, wspan;          // wspan: largest wd (the weight resource covers up + wspan + one stream)
     int N, ID, IH, IW, OD, OH, OW;
     int off, zero_mode, act;
     float alpha;
@@ -195,16 +202,17 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
     auto chunkb_now = [&]() { return HM == 2 ? chunkb_held : (unsigned)(tid_now() & 15) * 16u; };
     __syncthreads();                                          // mtab + ptab visible
     const unsigned sample_bytes = (unsigned)(p.ID * p.IH * p.IW) * 256u;
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+    __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.x + (size_t)n * p.ID * p.IH * p.IW * 64), 0, sample_bytes, 0x00020000);
+    int wsrc_off = 0;                                         // FUSED, source s > 0: byte distance of its weight stream from source 0's
 
     // weight stream: unit (1024 B) index = ((nb*NS + xh)*3 + kd)*24 + xw*4 + g
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.up, 0, NS * 18 * 64 * 64 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.up, 0, NS * 18 * 64 * 64 * 4 + (FUSED ? p.wspan : 0), 0x00020000);
     const int wvoff = wave * (NS * 72 * 1024) + lane * 16;
     const int bmul = (FDN_DBG_BITS(p) & 1) ? 0 : 1024;
     f32x4 A[SPLIT ? 1 : RDA][MB], B[SPLIT ? 1 : RDB];
     auto ldb = [&](int slot, int xh, int kd, int j) {
-        B[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, ((xh * 3 + kd) * 24 + j) * bmul, 0));
+        B[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, ((xh * 3 + kd) * 24 + j) * bmul + (FUSED ? wsrc_off : 0), 0));
     };
     auto lda = [&](int slot, int tapb, int j) {             // tapb: byte offset of the depth tap's rows
         const int o = tapb + (j >> 2) * kW2Plane + (j & 3) * 64;
@@ -277,10 +285,17 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) VS[pc][mb] = __builtin_bit_cast(fdn_bf16x8, *(const fdn_u32x4*)(smem + abase[mb < MB ? mb : 0] + o + pc * 64));
     };
+    const int nsrc = (FUSED && !SPLIT) ? p.nsrc : 1;
+#pragma unroll 1
+    for (int src = 0; src < nsrc; ++src) {
+    if (FUSED && src) {                                       // (scalar selects: no indexed kernel-argument access)
+        xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((src == 1 ? p.x1 : p.x2) + (size_t)n * p.ID * p.IH * p.IW * 64), 0, sample_bytes, 0x00020000);
+        wsrc_off = src == 1 ? p.wd1 : p.wd2;
+    }
 #pragma unroll 1
     for (int ss = 0; ss < NS * NPASS; ++ss) {
         const int xh = SPLIT ? ss >> 1 : ss;
-        if (ss) __syncthreads();                             // everyone finished reading the previous stage's planes
+        if (ss || src) __syncthreads();                      // everyone finished reading the previous stage's planes
         // a wave whose 64 items of a pass all lie past the tile's last item requests nothing in that pass (640 items: waves 2, 3 of pass 2)
         const int items_eff = ((FDN_DBG_BITS(p) & 4) ? 0 : p.items) - __builtin_amdgcn_readfirstlane(wave) * 64;
         if constexpr (SPLIT) {
@@ -573,6 +588,7 @@ __device__ __forceinline__ void conv64_wino2d_body(const Wino2Args& p, const int
                 for (int hr = 0; hr < HM; ++hr) Y[hr][wi][mb] += ch[hr] * t[wi];
         }
     }
+    }   // sources
 
     if (FDN_DBG_BITS(p) & 8) return;
     // ---- epilogue: lane = cell c of each M-block x cout 16w + 4q .. + 3; HM x 4 voxels per cell ----

@@ -39,6 +39,10 @@ struct WinoArgs {
     const float* fskip;     // fused fold (dgrad mode): see conv64_args.h
     const float* fy;
     float* fout;
+    // multi-source fused dgrad (conv64_wino2d_kernel.h, Wino2Args): the slice loop runs over CS x nsrc slices
+    const float* x1;
+    const float* x2;
+    int wd1, wd2, nsrc, wspan;
     int N, ID, IH, IW, OD, OH, OW;
     int off, zero_mode, act;
     float alpha;
@@ -183,12 +187,17 @@ __device__ __forceinline__ void conv64_wino_body(const WinoArgs& p, const int bl
     const unsigned sample_bytes = (unsigned)(p.ID * p.IH * p.IW) * 256u;
 
     // weight stream: unit (2048 B) index = half*216 + (tap*6 + xi)*4 + k-group-in-half
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.up, 0, 54 * 64 * 64 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.up, 0, 54 * 64 * 64 * 4 + (GEN ? p.wspan : 0), 0x00020000);
+    // GEN: the slice index runs over CS x nsrc (multi-source fused dgrad): slice sl_ of source sl_ / CS
+    const int nsl = GEN ? CS * p.nsrc : CS;
+    auto src_x = [&](int sl_) { return (!GEN || sl_ < CS) ? p.x : (sl_ < 2 * CS ? p.x1 : p.x2); };
+    auto src_wd = [&](int sl_) { return (!GEN || sl_ < CS) ? 0 : (sl_ < 2 * CS ? p.wd1 : p.wd2); };
     const int wvoff = (kh * 64 + wave_n * 32 + li) * 16;
     f32x4 A[RDA], B[RDB];
     const int bmul = (FDN_DBG_BITS(p) & 1) ? 0 : 2048;
     auto wsoff = [&](int sl_, int tap, int jj) -> int {      // jj = xi*KG + g within the tap
-        return ((((sl_ * KG) >> 2) * 216) + tap * 24 + ((sl_ * KG) & 3) + (jj / KG) * 4 + (jj % KG)) * bmul;
+        const int sc = GEN ? sl_ & (CS - 1) : sl_;           // slice within its source
+        return ((((sc * KG) >> 2) * 216) + tap * 24 + ((sc * KG) & 3) + (jj / KG) * 4 + (jj % KG)) * bmul + src_wd(sl_);
     };
     auto ldb = [&](int slot, int so) {
         B[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, so, 0));
@@ -205,11 +214,12 @@ __device__ __forceinline__ void conv64_wino_body(const WinoArgs& p, const int bl
         constexpr int NE = 2 * KG;
         auto jj_of = [](int e) { return (e < KG ? 0 : 5) * KG + (e % KG); };
 #pragma unroll 1
-        for (int sl = 0; sl < CS; ++sl) {
+        for (int sl = 0; sl < nsl; ++sl) {
             if (sl) __syncthreads();
             {
+                const int sc = sl & (CS - 1);
                 const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-                    (void*)(p.x + in_n * 64 + sl * (64 / CS)), 0, sample_bytes - sl * (256 / CS), 0x00020000);
+                    (void*)(src_x(sl) + in_n * 64 + sc * (64 / CS)), 0, sample_bytes - sc * (256 / CS), 0x00020000);
                 f32x4 xr[UA], xl[UA];
 #pragma unroll
                 for (int u = 0; u < UA; ++u) {
@@ -269,12 +279,13 @@ __device__ __forceinline__ void conv64_wino_body(const WinoArgs& p, const int bl
     }
 
 #pragma unroll 1
-    for (int sl = 0; sl < CS; ++sl) {
+    for (int sl = 0; sl < nsl; ++sl) {
         if (sl) __syncthreads();                             // everyone finished reading the previous slice
         // ---- stage + transform cin [sl*64/CS, (sl+1)*64/CS): all loads in flight before the first use ----
         {
+            const int sc = GEN ? sl & (CS - 1) : sl;
             const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)(p.x + in_n * 64 + sl * (64 / CS)), 0, sample_bytes - sl * (256 / CS), 0x00020000);
+                (void*)(src_x(sl) + in_n * 64 + sc * (64 / CS)), 0, sample_bytes - sc * (256 / CS), 0x00020000);
             f32x4 xv[UA][6];
             const int items_eff = (FDN_DBG_BITS(p) & 4) ? 0 : R.items;
 #pragma unroll
@@ -319,7 +330,7 @@ __device__ __forceinline__ void conv64_wino_body(const WinoArgs& p, const int bl
             }
 #pragma unroll
             for (int j = 0; j < RDA - 1; ++j) lda(j, 0, j);
-            const int sln = sl + 1 < CS ? sl + 1 : sl;       // harmless reload after the last slice
+            const int sln = sl + 1 < nsl ? sl + 1 : sl;      // harmless reload after the last slice
             int ta = ta0, tb = tb0, tapb = 0;
 #pragma unroll 1
             for (int it = 0; it < ntap9; ++it) {

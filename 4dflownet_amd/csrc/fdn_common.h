@@ -193,10 +193,15 @@ FdnTile fdn_plan_tile(int N, int OD, int OH, int OW, int max_vox, int max_halo_r
 int fdn_conv64_launch(const float* x, const float* wpack, const float* bias, const float* residual, float* y,
                       int N, int ID, int IH, int IW, int OD, int OH, int OW, int off, int zero_mode, int act,
                       float alpha, hipStream_t s, int algo = FDN_ALGO_AUTO);
+// Further sources of a multi-source fused dgrad (fdn_conv64_dgrad_fused_multi: dz_prev = fold(sum_s conv_T(dz_s, W_s))): rows and the byte
+// distance of the source's PACK from source 0's (>= 0: the caller orders the sources by pack address; every stream of a pack lies at
+// the same offset inside it, so one distance serves the 2-D and the 1-D kernel)
+struct FdnExtraSrc { int nsrc; const float* x1; const float* x2; int wd1, wd2; };
 int fdn_conv64_launch_ex(const float* x, const float* wpack, const float* bias, const float* residual, float* y,
                          const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
                          int OW, int off, int zero_mode, int act, float alpha, hipStream_t s, int parts = 3,
-                         int algo = FDN_ALGO_AUTO, unsigned* probe = nullptr, uint16_t* ymask = nullptr, const uint16_t* fmask = nullptr);
+                         int algo = FDN_ALGO_AUTO, unsigned* probe = nullptr, uint16_t* ymask = nullptr, const uint16_t* fmask = nullptr,
+                         const FdnExtraSrc* extra = nullptr);
 // Winograd F(4,3)-along-W variant of the 64->64 conv (conv64_wino.hip): one output box with all 27 taps
 // output box + its non-zero (kd, kh) tap ranges.  wface = 1: the pair of w faces of a fused dgrad's shell (box = the (d,h) range of the
 // padded grid, ow = 0, ew = 4: one "group" per (d,h) position; see conv64_wino.hip)
@@ -206,7 +211,7 @@ bool fdn_conv64_wino_ok(int ebd, int ebh, int ebw);
 int fdn_conv64_wino_launch_boxes(const float* x, const float* upack, const float* bias, const float* residual, float* y,
                                  const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
                                  int OW, const FdnWinoBox* boxes, int nbox, int off, int zero_mode, int act, float alpha,
-                                 hipStream_t s, const struct FdnWino2dPrepared* inner = nullptr);
+                                 hipStream_t s, const struct FdnWino2dPrepared* inner = nullptr, const FdnExtraSrc* extra = nullptr);
 int fdn_conv64_wino_launch(const float* x, const float* upack, const float* bias, const float* residual, float* y,
                            const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
                            int OW, int obd, int obh, int obw, int ebd, int ebh, int ebw, int off, int zero_mode, int act,
@@ -217,11 +222,12 @@ int fdn_pack_conv64_wino_launch(const float* w, float* uf, float* ud, hipStream_
 bool fdn_conv64_wino2d_ok(int ebd, int ebh, int ebw, int ID, int IH, int IW, int hm);
 // A planned, not yet launched 2-D launch (the kernel's argument block, opaque outside conv64_wino2d_kernel.h): fdn_conv64_wino_launch_boxes
 // takes one as `inner` and issues it together with its own regions as ONE launch (conv64_wino2d_shell_kernel: the fused dgrad).
-struct FdnWino2dPrepared { alignas(8) unsigned char args[352]; int blocks; int lds; };
+struct FdnWino2dPrepared { alignas(8) unsigned char args[384]; int blocks; int lds; };
 int fdn_conv64_wino2d_prepare(const float* x, const float* upack2, const float* bias, const float* residual, float* y,
                               const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
                               int OW, int obd, int obh, int obw, int ebd, int ebh, int ebw, int off, int zero_mode, int act,
-                              float alpha, int hm, FdnWino2dPrepared* out, uint16_t* ymask = nullptr, const uint16_t* fmask = nullptr);
+                              float alpha, int hm, FdnWino2dPrepared* out, uint16_t* ymask = nullptr, const uint16_t* fmask = nullptr,
+                              const FdnExtraSrc* extra = nullptr);
 int fdn_conv64_wino2d_launch(const float* x, const float* upack2, const float* bias, const float* residual, float* y,
                              const float* fskip, const float* fy, float* fout, int N, int ID, int IH, int IW, int OD, int OH,
                              int OW, int obd, int obh, int obw, int ebd, int ebh, int ebw, int off, int zero_mode, int act,

@@ -156,6 +156,9 @@ class FlowNetModel:
         # (fdn_conv3d_wgrad_batch): at 8 x 24^3 a layer alone on the chip leaves a workgroup 4.6 tiles between prologue and output
         # transform.  The batch ends where the bucket does, so the data-parallel all-reduce of a bucket starts as early as before.
         self.batch_wgrad = os.environ.get("FDN_BATCH_WGRAD", "1") not in ("", "0")
+        # the input gradients of the three heads' 64->64 convs (they all read the last ResBlock's output) as ONE multi-source launch
+        # (fp32; FDN_MULTI_DGRAD=0: three chained launches, equal to fp32 rounding)
+        self.multi_dgrad = os.environ.get("FDN_MULTI_DGRAD", "1") not in ("", "0")
         self.batch_wgrad_max_voxels = 1 << 18          # per launch; the 48^3 layers of cfg2 (8 x 110 592 voxels) fill the chip on their own
         self._wg_pending = []
         # weight gradients on a second HIP stream (they are leaves of the backward graph: they fill the tails of the dgrad launches and
@@ -550,6 +553,11 @@ class FlowNetModel:
         # apply act'(rb) on the last one, then one border fold over the three padded scratches
         dz = torch.empty_like(rb.t)
         pads = []
+        # fp32, grids of the F(4,3) x F(4,3) kernels: ONE multi-source launch forms the sum of the three input gradients in its registers
+        # (ops.conv3d_dgrad_fused_multi) instead of three chained launches that re-read and re-write the running sum
+        multi = (self.multi_dgrad and self.dtype == "float32" and len({self.conv_algo[Ls[li + 2 * h].name] for h in range(3)}) == 1
+                 and self._mask_ok(rb.t, Ls[li]))
+        dz_gs = []
         for hidx in range(3):
             L1, L2 = Ls[li], Ls[li + 1]
             g = c["heads"][hidx]
@@ -566,6 +574,11 @@ class FlowNetModel:
             del m_g, mk
             del g
             self._wgrad(rb.t, dz_g, L1, bias=False)
+            if multi:
+                dz_gs.append(dz_g)
+                del dz_g
+                li += 2
+                continue
             pad = self._pad_like(rb.t)
             y_m, a_m = act_of(rb) if hidx == 2 else (None, ACT_NONE)
             if y_m is not None and rb.mask is not None and (self.dtype == "bfloat16" or self._mask_ok(dz_g, L1)):
@@ -578,6 +591,13 @@ class FlowNetModel:
             del dz_g
             li += 2
         y_m, a_m = act_of(rb)
+        if multi:
+            pad = self._pad_like(rb.t)
+            use_mask = y_m is not None and rb.mask is not None
+            ops.conv3d_dgrad_fused_multi(dz_gs, [Ls[li - 6 + 2 * h].wp_d for h in range(3)], pad, dz, y_prev=None if use_mask else y_m, act=a_m,
+                                         mask=rb.mask if use_mask else None, algo=self.conv_algo[Ls[li - 6].name])
+            pads.append(pad)
+            del dz_gs
         self.ops.fold_halo_border(pads, dz, None, y_m, a_m)
         del pads, pad
         li = len(Ls) - 6

@@ -2,6 +2,8 @@
 
 Every function launches asynchronously on torch's current HIP stream and returns its output tensor(s).
 Tensors must be fp32, contiguous and on a ROCm device; anything else raises (no CPU path)."""
+import ctypes
+
 import torch
 
 from . import _lib
@@ -178,6 +180,24 @@ def conv3d_dgrad_fused(dz, wpack_dgrad, dxpad, out, skip=None, y_prev=None, act=
                                                       _p(skip, allow_none=True), _p(y_prev, allow_none=True), act, float(alpha),
                                                       _p(out, "out"), N, D, H, W, int(parts), int(algo), _stream()),
               "fdn_conv3d_dgrad_fused_part")
+    return out
+
+
+def conv3d_dgrad_fused_multi(dzs, wpacks_dgrad, dxpad, out, skip=None, y_prev=None, act=ACT_NONE, alpha=LEAKY_ALPHA, algo=ALGO_AUTO, mask=None):
+    """The fused dgrad of 1..3 64->64 layers that share their input, as ONE launch: out / dxpad receive what chained conv3d_dgrad_fused
+    calls (skip = the running sum) would leave, to fp32 rounding -- the sum over the sources is formed in the kernel's registers.  Only
+    where conv64_mask_ok(N, D, H, W, algo); the packs must be views of one pack buffer.  y_prev or mask (its sign mask) or neither."""
+    n = len(dzs)
+    N, D, H, W = dzs[0].shape[:4]
+    if not 1 <= n <= 3 or len(wpacks_dgrad) != n or any(tuple(t.shape) != tuple(dzs[0].shape) for t in dzs):
+        raise FdnError("conv3d_dgrad_fused_multi: 1..3 sources of one shape, one pack each")
+    if mask is not None and (y_prev is not None or mask.numel() != 4 * N * D * H * W):
+        raise FdnError("conv3d_dgrad_fused_multi: y_prev OR its sign mask of 4 x %d int16 words" % (N * D * H * W))
+    tz = (ctypes.c_void_p * n)(*[_p(t, "dz") for t in dzs])
+    tw = (ctypes.c_void_p * n)(*[_p(t, "wpack") for t in wpacks_dgrad])
+    check(_lib.load().fdn_conv64_dgrad_fused_multi(tz, tw, n, _p(dxpad, "dxpad"), _p(skip, allow_none=True), _p(y_prev, allow_none=True),
+                                                   None if mask is None else _pm(mask), act, float(alpha), _p(out, "out"), N, D, H, W, int(algo),
+                                                   _stream()), "fdn_conv64_dgrad_fused_multi")
     return out
 
 

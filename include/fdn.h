@@ -68,7 +68,7 @@ extern "C" {
 
 /* Version of this header; fdn_version() returns the version the library was built from.  A caller must see the two equal:
  * 140 -> 150 and 150 -> 160 grew FDN_CONV64_PACK_FLOATS (a pack buffer sized by an older header is too small for this library). */
-#define FDN_VERSION 160
+#define FDN_VERSION 161
 int fdn_version(void);
 const char* fdn_last_error(void);
 
@@ -178,6 +178,18 @@ int fdn_conv64_fwd_mask(const float* x, const float* wpack, const float* bias, c
                         int N, int D, int H, int W, int act, float alpha, int algo, void* stream);
 int fdn_conv64_dgrad_fused_mask(const float* dz, const float* wpack, float* dxpad, const float* skip, const uint16_t* y_mask,
                                 int act, float alpha, float* dz_prev, int N, int D, int H, int W, int algo, void* stream);
+/* Fused dgrad of up to three 64->64 layers that share their INPUT (the u, v, w heads' first convs all read the last ResBlock's output,
+ * src/Network/SR4DFlowNet.py:39-46; under tape.gradient their input gradients add up, TrainerController.py:223):
+ *   dz_prev = (MirrorPadGrad(sum_s Conv3DBackpropInput(dz[s], W_s)) + skip) * act'(y_prev)
+ * as ONE launch + one fdn_fold_halo_border instead of nsrc chained fdn_conv3d_dgrad_fused calls (each re-reading the running sum as
+ * `skip` and writing it back): the kernel walks the sources inside its tile and keeps the sum in its output registers.  dz / wpack:
+ * host arrays of nsrc (1..3) device pointers, wpack[s] = the dgrad pack of layer s; the packs must come from one
+ * fdn_pack_conv64_weights_batch buffer (within 1 GiB of each other).  y_prev or y_mask (fdn_conv64_fwd_mask's) or neither (act =
+ * FDN_ACT_NONE).  Available where fdn_conv64_mask_ok(N, D, H, W, algo) says 1 (FDN_ERR_UNSUPPORTED elsewhere: chain the single-source
+ * entry point).  Equal to the chained launches to fp32 rounding (the sum is formed in the Winograd domain, in pack-address order). */
+int fdn_conv64_dgrad_fused_multi(const float* const* dz, const float* const* wpack, int nsrc, float* dxpad, const float* skip,
+                                 const float* y_prev, const uint16_t* y_mask, int act, float alpha, float* dz_prev, int N, int D,
+                                 int H, int W, int algo, void* stream);
 
 /* 1x1x1 128->64 conv backward w.r.t. its two 64-channel inputs, fused with their ReLU masks:
  * dxa = (dz . W[0:64,:]^T) * (ya>0), dxb = (dz . W[64:128,:]^T) * (yb>0).  SR4DFlowNet.py:23-24. */

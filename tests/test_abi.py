@@ -21,7 +21,7 @@ def test_library_builds_and_exports_every_declared_symbol(fdn):
         assert hasattr(lib, name), "missing export %s" % name
     # the ctypes table covers exactly the declared API
     assert declared == set(fdn._lib.SIGNATURES), declared ^ set(fdn._lib.SIGNATURES)
-    assert fdn._lib.load().fdn_version() == 160 == fdn._lib.FDN_VERSION          # == FDN_VERSION of include/fdn.h (the C link test below prints the header's)
+    assert fdn._lib.load().fdn_version() == 161 == fdn._lib.FDN_VERSION          # == FDN_VERSION of include/fdn.h (the C link test below prints the header's)
     # the product library carries no process-global switches (include/fdn.h: "no global mutable state"); the variant-forcing
     # hooks live in the test build only, which exports the full API as well
     exported = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
@@ -67,7 +67,7 @@ def test_header_is_plain_c_and_links_from_c(fdn, tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     lines = out.stdout.splitlines()
-    assert lines[0].split()[1:] == ["1", "1", "ok"] and int(lines[0].split()[0]) == 160
+    assert lines[0].split()[1:] == ["1", "1", "ok"] and int(lines[0].split()[0]) == 161
     assert lines[1].startswith("-1 ") and "fdn_l2_sumsq" in lines[1]
 
 

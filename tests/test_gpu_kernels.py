@@ -617,3 +617,53 @@ def test_fp32_sign_masks_replace_y_in_the_fused_dgrad(ops, fdn, shape, mb):
     with pytest.raises(fdn.FdnError):                       # a grid off the F(4,3) x F(4,3) kernels refuses masks loudly
         xs = torch.zeros((1, 4, 6, 6, 64), device="cuda")
         ops.conv3d_fwd(xs, w, None, O.ACT_RELU, 0.2, None, wpack=wf, mask=ops.new_sign_mask(xs))
+
+
+@pytest.mark.parametrize("shape", [(1, 5, 8, 12), (2, 24, 24, 24), (1, 6, 4, 4), (3, 3, 12, 20)])
+@pytest.mark.parametrize("nsrc,use_mask,order", [(3, True, (0, 1, 2)), (3, False, (2, 0, 1)), (2, True, (1, 0)), (1, False, (0,))])
+def test_multi_source_fused_dgrad_equals_the_chained_launches(ops, fdn, shape, nsrc, use_mask, order):
+    """fdn_conv64_dgrad_fused_multi: dz_prev = fold(sum_s conv_T(dz_s, W_s)) in ONE launch (the three heads' 64->64 convs share their input).
+    Against the chained single-source launches (skip = the running sum) to fp32 rounding, and against the float64 oracle; the packs are
+    views of one buffer handed over in any order (the entry point orders them by address)."""
+    rng = np.random.default_rng(41)
+    N, D, H, W = shape
+    ws = [(rng.normal(size=(3, 3, 3, 64, 64)) * 0.05).astype(np.float32) for _ in range(nsrc)]
+    dzs = [rng.normal(size=(N, D, H, W, 64)).astype(np.float32) for _ in range(nsrc)]
+    y = rng.normal(size=(N, D, H, W, 64)).astype(np.float32)
+    skip = rng.normal(size=(N, D, H, W, 64)).astype(np.float32)
+    buf = torch.zeros((nsrc, 2, ops.CONV64_PACK_FLOATS), device="cuda")
+    for s in range(nsrc):
+        ops.pack_conv64_weights(dev(ws[s]), buf[order[s], 0], buf[order[s], 1])
+    packs = [buf[order[s], 1] for s in range(nsrc)]
+    ddz = [dev(z) for z in dzs]
+    ydev, sdev = dev(y), dev(skip)
+    mask = None
+    if use_mask:                                             # the mask of y, as the forward would have written it
+        bits = (ydev > 0).view(N * D * H * W, 4, 16).to(torch.int32)
+        mask = (bits << torch.arange(16, device="cuda", dtype=torch.int32)).sum(dim=2).t().contiguous()
+        mask = torch.where(mask >= 32768, mask - 65536, mask).to(torch.int16)
+    # chained reference: sources 0 .. n-2 linear with skip = running sum, the last applies act'
+    out_c = torch.zeros((N, D, H, W, 64), device="cuda")
+    pads_c = []
+    for s in range(nsrc):
+        pad = torch.full((N, D + 2, H + 2, W + 2, 64), float("nan"), device="cuda")
+        last = s == nsrc - 1
+        ops.conv3d_dgrad_fused(ddz[s], packs[s], pad, out_c, skip=(sdev if s == 0 else out_c), y_prev=ydev if last else None,
+                               act=O.ACT_LEAKY if last else O.ACT_NONE)
+        pads_c.append(pad)
+    ops.fold_halo_border(pads_c, out_c, sdev, ydev, O.ACT_LEAKY)
+    pad = torch.full((N, D + 2, H + 2, W + 2, 64), float("nan"), device="cuda")
+    out_m = torch.full((N, D, H, W, 64), float("nan"), device="cuda")
+    ops.conv3d_dgrad_fused_multi(ddz, packs, pad, out_m, skip=sdev, y_prev=None if use_mask else ydev, act=O.ACT_LEAKY, mask=mask)
+    ops.fold_halo_border([pad], out_m, sdev, ydev, O.ACT_LEAKY)
+    assert torch.isfinite(out_m).all()
+    scale = out_c.abs().max().item()
+    assert (out_m - out_c).abs().max().item() <= 2e-5 * scale
+    ref = sum(O.conv3d_dgrad(dzs[s].astype(np.float64), ws[s].astype(np.float64), (N, D, H, W, 64)) for s in range(nsrc))
+    ref = O.act_bwd_from_output(ref + skip, y, O.ACT_LEAKY)
+    close(out_m, ref, name="multi-source fused dgrad")
+    if nsrc == 1:                                             # one source: the single-source kernel's own arithmetic, bit for bit
+        assert torch.equal(out_m, out_c)
+    with pytest.raises(fdn.FdnError):                        # a grid off the F(4,3) x F(4,3) kernels refuses loudly
+        z = torch.zeros((1, 4, 6, 6, 64), device="cuda")
+        ops.conv3d_dgrad_fused_multi([z, z], packs[:1] * 2, torch.zeros((1, 6, 8, 8, 64), device="cuda"), torch.zeros_like(z))

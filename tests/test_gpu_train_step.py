@@ -370,3 +370,20 @@ def test_per_step_repack_writes_only_the_streams_in_use_and_widens_on_a_new_grid
     # the untouched streams of the narrowed model really are stale: only what the mask names is written
     stale = m._packs[:, 0, 27 * 4096:81 * 4096]           # forward packs, 1-D Winograd stream: never asked for
     assert not torch.equal(stale, full._packs[:, 0, 27 * 4096:81 * 4096])
+
+
+def test_multi_source_head_dgrad_gives_the_same_gradients(fdn):
+    """The input gradients of the three heads' 64->64 convs as ONE multi-source launch (default) vs three chained launches
+    (multi_dgrad = False): the same gradient buffer to fp32 rounding (the sum over the heads is formed in another order)."""
+    batch = O.synthetic_batch(2, 8, 2, seed=23)
+    grads = []
+    for multi in (True, False):
+        tc, _ = make(fdn, 8, 2, 2, 1, seed=7)
+        tc.model.multi_dgrad = multi
+        inputs, hires, venc, mask = tc._unpack(batch)
+        pred = tc.model.forward(inputs, training=True)
+        out, dpred = fdn.ops.loss_metrics(pred, hires[0], hires[1], hires[2], mask)
+        grads.append(tc.model.backward(dpred).clone())
+        torch.cuda.synchronize()
+    assert torch.isfinite(grads[0]).all() and not torch.equal(grads[0], grads[1])      # (the multi-source path really ran)
+    assert (grads[0] - grads[1]).abs().max().item() <= 2e-5 * grads[1].abs().max().item()
