@@ -57,6 +57,7 @@ SIGNATURES = {
     "fdn_conv64_dgrad_fused_bf16": (c_i, [c_fp] * 5 + [c_i, c_f, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "fdn_conv64_fwd_bf16_mask": (c_i, [c_fp] * 6 + [c_i] * 5 + [c_f, c_fp]),
     "fdn_conv64_dgrad_fused_bf16_mask": (c_i, [c_fp] * 6 + [c_i, c_f, c_fp, c_i, c_i, c_i, c_i, c_fp]),
+    "fdn_conv64_dgrad_fused_bf16_multi": (c_i, [c_fp, c_fp, c_i] + [c_fp] * 4 + [c_i, c_f, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "fdn_fold_halo_border_bf16": (c_i, [c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_f, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "fdn_input_features_bf16": (c_i, [c_fp] * 8 + [c_i64, c_fp]),
     "fdn_conv3d_fwd_bf16": (c_i, [c_fp] * 7 + [c_i] * 10 + [c_f, c_fp]),

@@ -303,6 +303,19 @@ extern "C" int fdn_conv64_dgrad_fused_bf16_mask(const uint16_t* dz, const uint16
                                   W + 2, -1, 1, act, alpha, (hipStream_t)stream, nullptr, y_mask);
 }
 
+extern "C" int fdn_conv64_dgrad_fused_bf16_multi(const uint16_t* const* dz, const uint16_t* const* wpack, int nsrc, float* dxpad,
+                                                 const uint16_t* skip, const uint16_t* y_prev, const uint16_t* y_mask, int act, float alpha,
+                                                 uint16_t* dz_prev, int N, int D, int H, int W, void* stream) {
+    FDN_REQUIRE(dz && wpack && dxpad && dz_prev && nsrc >= 1 && nsrc <= 3, "fdn_conv64_dgrad_fused_bf16_multi: NULL argument or nsrc outside 1..3");
+    FDN_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && D <= 1020 && H <= 1020 && W <= 1020, "fdn_conv64_dgrad_fused_bf16_multi: bad dims");
+    FDN_REQUIRE(act >= FDN_ACT_NONE && act <= FDN_ACT_LEAKY, "fdn_conv64_dgrad_fused_bf16_multi: bad act %d", act);
+    FDN_REQUIRE(!(y_mask && act == FDN_ACT_NONE), "fdn_conv64_dgrad_fused_bf16_multi: a sign mask needs act = RELU or LEAKY");
+    for (int i = 0; i < nsrc; ++i) FDN_REQUIRE(dz[i] && wpack[i], "fdn_conv64_dgrad_fused_bf16_multi: NULL pointer for source %d", i);
+    const FdnExtraSrcBf ex{nsrc, nsrc > 1 ? dz[1] : nullptr, nsrc > 2 ? dz[2] : nullptr, nsrc > 1 ? wpack[1] : nullptr, nsrc > 2 ? wpack[2] : nullptr};
+    return fdn_conv64_bf16_launch(dz[0], wpack[0], nullptr, nullptr, nullptr, dxpad, skip, y_prev, dz_prev, N, D, H, W, D + 2, H + 2,
+                                  W + 2, -1, 1, act, alpha, (hipStream_t)stream, nullptr, y_mask, nsrc > 1 ? &ex : nullptr);
+}
+
 extern "C" int fdn_conv64_dgrad_fused_bf16(const uint16_t* dz, const uint16_t* wpack, float* dxpad, const uint16_t* skip,
                                            const uint16_t* y_prev, int act, float alpha, uint16_t* dz_prev, int N, int D,
                                            int H, int W, void* stream) {

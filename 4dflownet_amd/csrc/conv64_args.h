@@ -68,6 +68,13 @@ struct Conv64BfArgs {
     // 16-B load per lane and plane instead of two 16-B loads -- at (4,128^3) an epilogue operand costs what streaming its 1.07 GB costs
     uint16_t* ymask;
     const uint16_t* fmask;
+    // multi-source fused dgrad (round 6; the fp32 twin is Wino2Args'): dz_prev = fold(sum_s conv_T(x_s, W_s)) for up to three layers that
+    // share their input -- the slice loop of the one-launch fused kernel runs over 2 (MODE 2) resp. 4 (MODE 0) slices x nsrc sources
+    const uint16_t* x1;
+    const uint16_t* x2;
+    const uint16_t* wp1;
+    const uint16_t* wp2;
+    int nsrc;
     int N, ID, IH, IW, OD, OH, OW;
     int off, zero_mode;
     int act;

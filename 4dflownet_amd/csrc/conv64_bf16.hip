@@ -160,11 +160,19 @@ __device__ __forceinline__ void conv64_bf16_body(const Conv64BfArgs& p, const in
     }
     const bool planar = S2 && (p.dbg & 64);
     const unsigned half_bytes = (unsigned)(p.N * p.ID * p.IH * p.IW) * 64u;
-    const __amdgpu_buffer_rsrc_t xrsrc = planar
-        ? __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)n * p.ID * p.IH * p.IW * 32), 0, half_bytes + (unsigned)(p.ID * p.IH * p.IW) * 64u, 0x00020000)
-        : __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)n * p.ID * p.IH * p.IW * 64), 0, (unsigned)(p.ID * p.IH * p.IW) * 128u, 0x00020000);
+    // multi-source fused dgrad (MODE 2 / MODE 0 of the one-launch form): the rows / weights of source `src` (scalar selects)
+    const int nsrc = p.fout ? p.nsrc : 1;
+    // (loaded once, unconditionally: a conditional load per branch gets merged into ONE load through a selected ADDRESS, which forces the
+    // whole argument block into scratch memory)
+    const uint16_t* const xs0 = p.x; const uint16_t* const xs1 = p.x1; const uint16_t* const xs2 = p.x2;
+    const uint16_t* const ws0 = p.wp; const uint16_t* const ws1 = p.wp1; const uint16_t* const ws2 = p.wp2;
+    auto x_of = [&](int src) { return src == 0 ? xs0 : (src == 1 ? xs1 : xs2); };
+    auto wp_of = [&](int src) { return src == 0 ? ws0 : (src == 1 ? ws1 : ws2); };
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    auto stage_dma = [&](char* buf, int sl, int u0, int u1) {
+    auto stage_dma = [&](char* buf, int sl, int u0, int u1, int src = 0) {
+        const __amdgpu_buffer_rsrc_t xrsrc = planar
+            ? __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)n * p.ID * p.IH * p.IW * 32), 0, half_bytes + (unsigned)(p.ID * p.IH * p.IW) * 64u, 0x00020000)
+            : __builtin_amdgcn_make_buffer_rsrc((void*)(x_of(src) + (size_t)n * p.ID * p.IH * p.IW * 64), 0, (unsigned)(p.ID * p.IH * p.IW) * 128u, 0x00020000);
 #pragma unroll
         for (int u = 0; u < NPL; ++u) {
             if (u < u0 || u >= u1) continue;
@@ -201,14 +209,15 @@ __device__ __forceinline__ void conv64_bf16_body(const Conv64BfArgs& p, const in
             }
         }
     }
-    const uint16_t* xchunk = p.x + chunk * 8;
+    const int xchunk_off = chunk * 8;
     // staged in two halves of NP/2 voxels that share four registers (half 0: loaded at step 0, written at step 3; half 1: steps 4, 7)
     constexpr int NH = NP / 2;
     u32x4 sv[GEN ? NH : 1];
-    auto stage_load = [&](int sl, int half) {       // unconditional loads (clamped address), zero selection afterwards
+    auto stage_load = [&](int vs, int half) {       // unconditional loads (clamped address), zero selection afterwards; vs = 4 * source + slice
         if (!GEN) return;
+        const uint16_t* xchunk = x_of(vs >> 2) + xchunk_off;
 #pragma unroll
-        for (int u = 0; u < NH; ++u) sv[u] = *(const u32x4*)(xchunk + (size_t)(gv[half * NH + u] & 0x7fffffff) * 64 + sl * 16);
+        for (int u = 0; u < NH; ++u) sv[u] = *(const u32x4*)(xchunk + (size_t)(gv[half * NH + u] & 0x7fffffff) * 64 + (vs & 3) * 16);
     };
     auto stage_write = [&](char* buf, int half) {
         if (!GEN) return;
@@ -223,9 +232,10 @@ __device__ __forceinline__ void conv64_bf16_body(const Conv64BfArgs& p, const in
 
     // ---- weight fragments: stream [slice 4][b*3+c][a][kh][cout row 64] x 16 B, two register sets, two steps ahead ----
     const int wstride = (p.dbg & 1) ? 0 : 1;
-    const u32x4* wbase = (const u32x4*)p.wp + kh * 64 + wn * 32 + j;
+    const int wlane = kh * 64 + wn * 32 + j;
     u32x4 wq[3][3];                       // three register sets: weights THREE steps ahead (see fast_slice)
-    auto load_w = [&](u32x4 (&dst)[3], int sl, int tb, int tc) {
+    auto load_w = [&](u32x4 (&dst)[3], int sl, int tb, int tc, int src = 0) {
+        const u32x4* wbase = (const u32x4*)wp_of(src) + wlane;
         const int bc = tb * 3 + tc;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -322,19 +332,19 @@ __device__ __forceinline__ void conv64_bf16_body(const Conv64BfArgs& p, const in
         // summation order as the four-slice kernel (cin group outermost), so the variants stay bit-identical; weights three steps
         // ahead across the slice boundary; the second slice replaces the first in the same buffer between two barriers
 #pragma unroll 1
-        for (int sl = 0; sl < 2; ++sl) {
+        for (int vs = 0; vs < 2 * nsrc; ++vs) {               // slice vs & 1 of source vs >> 1
 #pragma unroll
             for (int it = 0; it < 18; ++it) {
                 const int k2 = it / 9, bc = it % 9;
                 kstep(std::true_type{}, smem, bc / 3, bc % 3, wq[it % 3], k2);
-                // step it + 3 of the stream of 36 steps: 16-cin group n / 9, tap n % 9
-                const int nx = it + 3, slx = sl + nx / 18, itx = nx % 18;
-                if (slx < 2) load_w(wq[it % 3], slx * 2 + itx / 9, tb0 + (itx % 9) / 3, tc0 + (itx % 9) % 3);
+                // step it + 3 of the stream of 36 steps per source: 16-cin group n / 9, tap n % 9 (running into the next source's stream)
+                const int nx = it + 3, vsx = vs + nx / 18, itx = nx % 18;
+                if (vsx < 2 * nsrc) load_w(wq[it % 3], (vsx & 1) * 2 + itx / 9, tb0 + (itx % 9) / 3, tc0 + (itx % 9) % 3, vsx >> 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (sl == 0) {
-                __syncthreads();                          // every wave is done reading slice 0
-                stage_dma(smem, 1, 0, NPL);
+            if (vs + 1 < 2 * nsrc) {
+                __syncthreads();                          // every wave is done reading this slice
+                stage_dma(smem, (vs + 1) & 1, 0, NPL, (vs + 1) >> 1);
                 __syncthreads();                          // (the compiler drains the LDS-DMA queue in front of the barrier)
             }
         }
@@ -343,11 +353,12 @@ __device__ __forceinline__ void conv64_bf16_body(const Conv64BfArgs& p, const in
         // slice's voxels are loaded behind step 0's weight refill and written to the other buffer at step 7.  No branch
         // sits between a load and its use, so every wait is a counted vmcnt.  A slice has an odd number of steps, so the
         // register set of step `it` alternates from slice to slice (PAR); all four slices are straight-line code.
-        auto fast_slice = [&](auto prefetchc, auto parc, int sl) {
+        auto fast_slice = [&](auto prefetchc, auto parc, int sl) {   // sl = 4 * source + slice
             constexpr bool PREFETCH = decltype(prefetchc)::value;
             (void)parc;
             const char* cur = smem + (sl & 1) * bufB;
             char* nxt = smem + ((sl + 1) & 1) * bufB;
+            const int src_n = min((sl + 1) >> 2, nsrc - 1);      // source of the next slice (past the last one: a harmless re-read)
 #pragma unroll
             for (int it = 0; it < 9; ++it) {
                 // A wave's vector-memory operations return in order (vmcnt), so the wait for a weight fragment also waits for every
@@ -355,11 +366,11 @@ __device__ __forceinline__ void conv64_bf16_body(const Conv64BfArgs& p, const in
                 // loads ~70 MFMAs to come back before the first wait that covers them.
                 kstep(std::true_type{}, cur, it / 3, it % 3, wq[it % 3]);
                 if (PREFETCH || it < 6)
-                    load_w(wq[it % 3], sl + (it + 3) / 9, tb0 + ((it + 3) % 9) / 3, tc0 + ((it + 3) % 9) % 3);
+                    load_w(wq[it % 3], sl + (it + 3) / 9, tb0 + ((it + 3) % 9) / 3, tc0 + ((it + 3) % 9) % 3, it < 6 ? sl >> 2 : src_n);
                 // the next slice goes straight from memory into the other buffer, in two bursts (VMEM operations return in order: a burst
                 // sits in front of the weight fragments requested after it)
-                if (PREFETCH && it == 0) stage_dma(nxt, (sl + 1) & 3, 0, NPL / 2);
-                if (PREFETCH && it == 4) stage_dma(nxt, (sl + 1) & 3, NPL / 2, NPL);
+                if (PREFETCH && it == 0) stage_dma(nxt, (sl + 1) & 3, 0, NPL / 2, src_n);
+                if (PREFETCH && it == 4) stage_dma(nxt, (sl + 1) & 3, NPL / 2, NPL, src_n);
                 // keep every step's loads inside the step: under register pressure the scheduler otherwise sinks the
                 // weight refills down to their first use, i.e. prefetch distance 0
                 __builtin_amdgcn_sched_barrier(0);
@@ -367,25 +378,26 @@ __device__ __forceinline__ void conv64_bf16_body(const Conv64BfArgs& p, const in
             __syncthreads();
         };
 #pragma unroll 1
-        for (int sl = 0; sl < 4; sl += 2) {
+        for (int sl = 0; sl < 4 * nsrc; sl += 2) {
             fast_slice(std::true_type{}, std::integral_constant<int, 0>{}, sl);
             fast_slice(std::true_type{}, std::integral_constant<int, 1>{}, sl + 1);
         }
     } else {
 #pragma unroll 1
-        for (int sl = 0; sl < 4; ++sl) {
-            const char* cur = smem + (sl & 1) * bufB;
-            char* nxt = smem + ((sl + 1) & 1) * bufB;
+        for (int vs = 0; vs < 4 * nsrc; ++vs) {              // slice vs & 3 of source vs >> 2
+            const char* cur = smem + (vs & 1) * bufB;
+            char* nxt = smem + ((vs + 1) & 1) * bufB;
+            const bool more = vs + 1 < 4 * nsrc;
             // shell slabs / ragged tiles: rolled loop, predicated planes and taps, weights loaded in step
-            if (sl < 3) { stage_load(sl + 1, 0); stage_write(nxt, 0); stage_load(sl + 1, 1); }
+            if (more) { stage_load(vs + 1, 0); stage_write(nxt, 0); stage_load(vs + 1, 1); }
 #pragma unroll 1
             for (int it = 0; it < nb * nc; ++it) {
                 const int db = it / nc, dc = it - db * nc;
                 u32x4 w3[3] = {};
-                load_w(w3, sl, tb0 + db, tc0 + dc);
+                load_w(w3, vs & 3, tb0 + db, tc0 + dc, vs >> 2);
                 kstep(std::false_type{}, cur, db, dc, w3);
             }
-            if (sl < 3) stage_write(nxt, 1);
+            if (more) stage_write(nxt, 1);
             __syncthreads();
         }
     }
@@ -763,9 +775,14 @@ int launch_boxes(Conv64BfArgs& a, const Box* boxes, int nbox, hipStream_t s) {
 int fdn_conv64_bf16_launch(const uint16_t* x, const uint16_t* wpack, const float* bias, const uint16_t* residual, uint16_t* y,
                            float* ypad, const uint16_t* fskip, const uint16_t* fy, uint16_t* fout, int N, int ID, int IH,
                            int IW, int OD, int OH, int OW, int off, int zero_mode, int act, float alpha, hipStream_t s,
-                           uint16_t* ymask, const uint16_t* fmask) {
+                           uint16_t* ymask, const uint16_t* fmask, const FdnExtraSrcBf* extra) {
     Conv64BfArgs a;
     a.x = x; a.wp = wpack; a.bias = bias; a.res = residual; a.y = y; a.ypad = ypad;
+    a.x1 = a.x2 = a.wp1 = a.wp2 = nullptr; a.nsrc = 1;
+    if (extra && extra->nsrc > 1) {
+        FDN_REQUIRE(fout && zero_mode && off == -1 && extra->nsrc <= 3, "conv64 (bf16): further sources belong to a fused dgrad, 1..3 in all");
+        a.x1 = extra->x1; a.x2 = extra->x2; a.wp1 = extra->wp1; a.wp2 = extra->wp2; a.nsrc = extra->nsrc;
+    }
     a.fskip = fskip; a.fy = fmask ? nullptr : fy; a.fout = fout;
     a.ymask = ymask; a.fmask = fmask;
     a.N = N; a.ID = ID; a.IH = IH; a.IW = IW; a.OD = OD; a.OH = OH; a.OW = OW;

@@ -250,10 +250,12 @@ int fdn_wgrad64_wino_batch_launch(const float* const* x, const float* const* dz,
 int fdn_wgrad64_reduce_launch(const float* partial, float* dw, int S, hipStream_t s);
 
 // bf16 activation path (conv64_bf16.hip)
+// further sources of a multi-source fused dgrad in bf16 mode (fdn_conv64_dgrad_fused_bf16_multi): rows and packs of sources 1, 2
+struct FdnExtraSrcBf { int nsrc; const uint16_t* x1; const uint16_t* x2; const uint16_t* wp1; const uint16_t* wp2; };
 int fdn_conv64_bf16_launch(const uint16_t* x, const uint16_t* wpack, const float* bias, const uint16_t* residual, uint16_t* y,
                            float* ypad, const uint16_t* fskip, const uint16_t* fy, uint16_t* fout, int N, int ID, int IH,
                            int IW, int OD, int OH, int OW, int off, int zero_mode, int act, float alpha, hipStream_t s,
-                           uint16_t* ymask = nullptr, const uint16_t* fmask = nullptr);
+                           uint16_t* ymask = nullptr, const uint16_t* fmask = nullptr, const struct FdnExtraSrcBf* extra = nullptr);
 int fdn_fold_halo_border_bf16_launch(const float* s0, const float* s1, const float* s2, int nsrc, const uint16_t* skip,
                                      const uint16_t* yprev, int act, float alpha, uint16_t* out, int N, int D, int H, int W,
                                      hipStream_t s);

@@ -157,7 +157,7 @@ class FlowNetModel:
         # transform.  The batch ends where the bucket does, so the data-parallel all-reduce of a bucket starts as early as before.
         self.batch_wgrad = os.environ.get("FDN_BATCH_WGRAD", "1") not in ("", "0")
         # the input gradients of the three heads' 64->64 convs (they all read the last ResBlock's output) as ONE multi-source launch
-        # (fp32; FDN_MULTI_DGRAD=0: three chained launches, equal to fp32 rounding)
+        # (FDN_MULTI_DGRAD=0: three chained launches; equal to fp32 rounding in fp32, bf16 roundings of the partial sums apart in bf16 mode)
         self.multi_dgrad = os.environ.get("FDN_MULTI_DGRAD", "1") not in ("", "0")
         self.batch_wgrad_max_voxels = 1 << 18          # per launch; the 48^3 layers of cfg2 (8 x 110 592 voxels) fill the chip on their own
         self._wg_pending = []
@@ -553,10 +553,10 @@ class FlowNetModel:
         # apply act'(rb) on the last one, then one border fold over the three padded scratches
         dz = torch.empty_like(rb.t)
         pads = []
-        # fp32, grids of the F(4,3) x F(4,3) kernels: ONE multi-source launch forms the sum of the three input gradients in its registers
-        # (ops.conv3d_dgrad_fused_multi) instead of three chained launches that re-read and re-write the running sum
-        multi = (self.multi_dgrad and self.dtype == "float32" and len({self.conv_algo[Ls[li + 2 * h].name] for h in range(3)}) == 1
-                 and self._mask_ok(rb.t, Ls[li]))
+        # ONE multi-source launch forms the sum of the three input gradients in its registers (ops.conv3d_dgrad_fused_multi; fp32: on the
+        # grids of the F(4,3) x F(4,3) kernels) instead of three chained launches that re-read and re-write the running sum
+        multi = self.multi_dgrad and (self.dtype == "bfloat16" or (len({self.conv_algo[Ls[li + 2 * h].name] for h in range(3)}) == 1
+                                                                   and self._mask_ok(rb.t, Ls[li])))
         dz_gs = []
         for hidx in range(3):
             L1, L2 = Ls[li], Ls[li + 1]
@@ -594,8 +594,8 @@ class FlowNetModel:
         if multi:
             pad = self._pad_like(rb.t)
             use_mask = y_m is not None and rb.mask is not None
-            ops.conv3d_dgrad_fused_multi(dz_gs, [Ls[li - 6 + 2 * h].wp_d for h in range(3)], pad, dz, y_prev=None if use_mask else y_m, act=a_m,
-                                         mask=rb.mask if use_mask else None, algo=self.conv_algo[Ls[li - 6].name])
+            self.ops.conv3d_dgrad_fused_multi(dz_gs, [Ls[li - 6 + 2 * h].wp_d for h in range(3)], pad, dz, y_prev=None if use_mask else y_m, act=a_m,
+                                              mask=rb.mask if use_mask else None, algo=self.conv_algo[Ls[li - 6].name])
             pads.append(pad)
             del dz_gs
         self.ops.fold_halo_border(pads, dz, None, y_m, a_m)

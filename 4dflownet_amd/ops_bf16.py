@@ -141,6 +141,24 @@ def conv3d_dgrad_fused(dz, wpack_dgrad, dxpad, out, skip=None, y_prev=None, act=
 conv64_dgrad_fused = conv3d_dgrad_fused
 
 
+def conv3d_dgrad_fused_multi(dzs, wpacks_dgrad, dxpad, out, skip=None, y_prev=None, act=ACT_NONE, alpha=LEAKY_ALPHA, algo=0, mask=None):
+    """The fused dgrad of 1..3 64->64 layers that share their input, as ONE launch (ops.conv3d_dgrad_fused_multi for bf16 activations): the
+    sum over the sources stays in the fp32 accumulators (the chained launches round the running sum to bf16 after every source)."""
+    import ctypes
+    n = len(dzs)
+    N, D, H, W = dzs[0].shape[:4]
+    if not 1 <= n <= 3 or len(wpacks_dgrad) != n or any(tuple(t.shape) != tuple(dzs[0].shape) for t in dzs):
+        raise FdnError("conv3d_dgrad_fused_multi: 1..3 sources of one shape, one pack each")
+    if mask is not None and mask.numel() != N * D * H * W * 4:
+        raise FdnError("conv3d_dgrad_fused_multi: mask needs %d int16 words" % (N * D * H * W * 4))
+    tz = (ctypes.c_void_p * n)(*[_pb(t, "dz") for t in dzs])
+    tw = (ctypes.c_void_p * n)(*[_pb(t, "wpack") for t in wpacks_dgrad])
+    check(_lib.load().fdn_conv64_dgrad_fused_bf16_multi(tz, tw, n, _pf(dxpad, "dxpad"), _pb(skip, allow_none=True), _pb(y_prev, allow_none=True),
+                                                        _pm(mask, allow_none=True), act, float(alpha), _pb(out, "out"), N, D, H, W, _stream()),
+          "fdn_conv64_dgrad_fused_bf16_multi")
+    return out
+
+
 def fold_halo_border(dxpads, out, skip=None, y_prev=None, act=ACT_NONE, alpha=LEAKY_ALPHA):
     N, D, H, W = out.shape[:4]
     ptrs = [_pf(t) for t in dxpads] + [None] * (3 - len(dxpads))

@@ -301,6 +301,13 @@ int fdn_conv64_fwd_bf16_mask(const uint16_t* x, const uint16_t* wpack, const flo
 int fdn_conv64_dgrad_fused_bf16_mask(const uint16_t* dz, const uint16_t* wpack, float* dxpad, const uint16_t* skip,
                                      const uint16_t* y_prev, const uint16_t* y_mask, int act, float alpha,
                                      uint16_t* dz_prev, int N, int D, int H, int W, void* stream);
+/* fdn_conv64_dgrad_fused_multi for bf16 activations: the fused dgrad of up to three 64->64 layers that share their input as ONE launch
+ * (+ one fdn_fold_halo_border_bf16), the sum over the sources kept in the fp32 accumulators -- the chained launches round the running sum
+ * to bf16 after every source, so this form is the more accurate one (it differs from the chain by bf16 roundings of the partial sums).
+ * Every grid (all kernel variants of the bf16 path walk the sources).  y_prev or y_mask or neither. */
+int fdn_conv64_dgrad_fused_bf16_multi(const uint16_t* const* dz, const uint16_t* const* wpack, int nsrc, float* dxpad,
+                                      const uint16_t* skip, const uint16_t* y_prev, const uint16_t* y_mask, int act, float alpha,
+                                      uint16_t* dz_prev, int N, int D, int H, int W, void* stream);
 
 /* The remaining entry points of the path in bf16 storage: same contracts as the fp32 functions of the same
  * name.  Parameters, parameter gradients, the 64->1 heads' output (the prediction, `y` of Cout=1) and its

@@ -114,6 +114,49 @@ def test_conv64_dgrad_fused_bf16(bops, fdn, shape, mt):
                 lib.fdn_debug_set_conv64_bf16_mode2(1)
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 8, 8), (1, 5, 7, 9), (1, 10, 12, 16), (1, 16, 16, 16), (3, 24, 24, 24), (1, 3, 20, 11)])
+@pytest.mark.parametrize("mt,nsrc,use_mask", [(0, 3, True), (0, 2, False), (8, 3, False), (20, 3, True), (52, 3, True), (4, 2, True), (0, 1, False)])
+def test_multi_source_fused_dgrad_bf16(bops, fdn, shape, mt, nsrc, use_mask):
+    """fdn_conv64_dgrad_fused_bf16_multi: dz_prev = fold(sum_s conv_T(dz_s, W_s)) as ONE launch, the sum kept in the fp32 accumulators of every
+    kernel variant (two-slice MODE 2 + shell slabs in one launch, the four-slice FAST kernel, the general body).  Against the float64
+    oracle within the bf16 bound; one source is bit-identical to the single-source entry point."""
+    rng = np.random.default_rng(12)
+    N, D, H, W = shape
+    dzs = [rb(rng.normal(size=(N, D, H, W, 64))) for _ in range(nsrc)]
+    ws = [(rng.normal(size=(3, 3, 3, 64, 64)) * 0.05).astype(np.float32) for _ in range(nsrc)]
+    y = rb(rng.normal(size=(N, D, H, W, 64)))
+    skip = rb(rng.normal(size=(N, D, H, W, 64)))
+    dx = sum(O.conv3d_dgrad(dzs[s], rb(ws[s]), (N, D, H, W, 64)) for s in range(nsrc))
+    packs = [bops.pack_conv64_weights(dev(w))[1] for w in ws]
+    ydev = devb(y)
+    mask = None
+    if use_mask:
+        bits = (ydev.float() > 0).view(N, D, H, W, 4, 16).to(torch.int32)
+        mask = (bits << torch.arange(16, device="cuda", dtype=torch.int32)).sum(dim=-1)
+        mask = torch.where(mask >= 32768, mask - 65536, mask).to(torch.int16).contiguous()
+    with variant_lib(fdn, mt) as lib:
+        if lib is not None:
+            lib.fdn_debug_set_conv64_bf16_mt(mt & 31)
+            lib.fdn_debug_set_conv64_bf16_mode2(0 if mt & 32 else 1)
+        try:
+            pad = torch.full((N, D + 2, H + 2, W + 2, 64), float("nan"), device="cuda")
+            out = torch.full((N, D, H, W, 64), float("nan"), device="cuda", dtype=torch.bfloat16)
+            bops.conv3d_dgrad_fused_multi([devb(z) for z in dzs], packs, pad, out, skip=devb(skip), y_prev=None if use_mask else ydev,
+                                          act=O.ACT_LEAKY, mask=mask)
+            bops.fold_halo_border([pad], out, devb(skip), ydev, O.ACT_LEAKY)
+            close_bf16(out, O.act_bwd_from_output(dx + skip, y, O.ACT_LEAKY), name="bf16 multi-source fused dgrad+border")
+            if nsrc == 1:
+                pad1 = torch.full((N, D + 2, H + 2, W + 2, 64), float("nan"), device="cuda")
+                out1 = torch.full((N, D, H, W, 64), float("nan"), device="cuda", dtype=torch.bfloat16)
+                bops.conv64_dgrad_fused(devb(dzs[0]), packs[0], pad1, out1, skip=devb(skip), y_prev=ydev, act=O.ACT_LEAKY)
+                bops.fold_halo_border([pad1], out1, devb(skip), ydev, O.ACT_LEAKY)
+                assert torch.equal(out, out1)
+        finally:
+            if lib is not None:
+                lib.fdn_debug_set_conv64_bf16_mt(0)
+                lib.fdn_debug_set_conv64_bf16_mode2(1)
+
+
 @pytest.mark.parametrize("variant", [0, 1])      # 0 = planner (the LDS-DMA kernel below 4 GB), 1 = the register-staged kernel (the >= 4 GB fallback)
 @pytest.mark.parametrize("shape", [(2, 8, 8, 8), (1, 5, 7, 9), (1, 10, 12, 16), (3, 4, 4, 2), (2, 16, 16, 16), (1, 1, 1, 1),
                                    (1, 3, 20, 11), (1, 17, 9, 12), (2, 33, 8, 24)])

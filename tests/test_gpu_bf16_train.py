@@ -164,3 +164,21 @@ def test_bf16_training_with_sign_masks_is_bit_identical_to_reading_y(fdn, P, R, 
         ws.append((tc.model.flat_w.clone(), torch.stack([l.float().reshape(-1) for l in losses])))
     assert torch.isfinite(ws[0][0]).all()
     assert torch.equal(ws[0][1], ws[1][1]) and torch.equal(ws[0][0], ws[1][0])
+
+
+def test_bf16_multi_source_head_dgrad_matches_the_chained_launches(fdn):
+    """bf16 mode: the three heads' input gradients as ONE multi-source launch (default; the sum over the heads stays in fp32 accumulators)
+    vs three chained launches that round the running sum to bf16 each time: the gradient buffers agree to bf16 noise."""
+    batch = O.synthetic_batch(2, 8, 2, seed=43)
+    grads = []
+    for multi in (True, False):
+        tc, _ = make(8, 2, 2, 1, seed=5, dtype="bfloat16")
+        tc.model.multi_dgrad = multi
+        inputs, hires, venc, mask = tc._unpack(batch)
+        pred = tc.model.forward(inputs, training=True)
+        out, dpred = fdn.ops.loss_metrics(pred, hires[0], hires[1], hires[2], mask)
+        grads.append(tc.model.backward(dpred).clone())
+        torch.cuda.synchronize()
+    assert torch.isfinite(grads[0]).all() and not torch.equal(grads[0], grads[1])      # (the multi-source path really ran)
+    rel = ((grads[0] - grads[1]).double().norm() / grads[1].double().norm()).item()
+    assert rel <= 1e-2, rel
