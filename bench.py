@@ -107,6 +107,23 @@ class LaunchTimer:
             f = 1.0 if x.dtype != torch.float32 or W % 4 or k.get("algo", 0) == 1 else (1.0 / 3 if D % 2 == 0 and k.get("algo", 0) == 0 else 0.5)
             return bracket("wgrad", N * D * H * W, f * N * D * H * W * FLOP_PER_VOXEL_CONV64, lambda: wg(x, dz, K, Cin, Cout, *a, **k))
 
+        dgm = getattr(ops, "conv3d_dgrad_fused_multi", None)
+        self._orig["conv3d_dgrad_fused_multi"] = dgm
+
+        def conv3d_dgrad_fused_multi(dzs, *a, **k):
+            # ONE launch over len(dzs) sources (the three heads' 64->64 convs share their input): priced as that many layers' work
+            if not self.enabled:
+                return dgm(dzs, *a, **k)
+            N, D, H, W = shp(dzs[0])
+            n = len(dzs)
+            if dzs[0].dtype != torch.float32:
+                return bracket("conv", n * N * D * H * W, n * N * D * H * W * FLOP_PER_VOXEL_CONV64, lambda: dgm(dzs, *a, **k))
+            ex = n * (executed_conv64_flop(N, D, H, W, dzs[0].dtype, k.get("algo", 0)) + executed_shell_flop(N, D, H, W))
+            return bracket("conv", n * N * D * H * W, ex, lambda: dgm(dzs, *a, **k))
+
+        if dgm is not None:
+            ops.conv3d_dgrad_fused_multi = conv3d_dgrad_fused_multi
+
         wgb = getattr(ops, "conv3d_wgrad_batch", None)
         self._orig["conv3d_wgrad_batch"] = wgb
 
