@@ -71,7 +71,9 @@ __device__ __forceinline__ void ld_bf16x16(const uint16_t* src, float (&z)[16]) 
 // (a __device__ body + thin __global__ wrappers: conv64_bf16_fused_kernel below runs the MODE 2 body on the inner box of a fused dgrad
 // and the MODE 0 body on its shell slabs in ONE launch.  block / total: this part's workgroup id and count; xcd_remap: the ids are the
 // hardware's own (dealt round-robin to the XCDs), so the XCD-aware order applies.)
-template <int MT, int MODE>
+// MULTI: the multi-source fused dgrad (p.nsrc sources); false = one source, every source loop folds away at compile time (the single-source
+// kernels are round 5's instruction for instruction: with a run-time source count the two-slice forward ran 7 % slower, r6 kernel traces)
+template <int MT, int MODE, bool MULTI = false>
 __device__ __forceinline__ void conv64_bf16_body(const Conv64BfArgs& p, const int block, const int total, const bool xcd_remap, char* const smem) {
     constexpr bool FAST = MODE != 0, S2 = MODE == 2;
     constexpr bool GEN = !FAST;
@@ -161,13 +163,13 @@ __device__ __forceinline__ void conv64_bf16_body(const Conv64BfArgs& p, const in
     const bool planar = S2 && (p.dbg & 64);
     const unsigned half_bytes = (unsigned)(p.N * p.ID * p.IH * p.IW) * 64u;
     // multi-source fused dgrad (MODE 2 / MODE 0 of the one-launch form): the rows / weights of source `src` (scalar selects)
-    const int nsrc = p.fout ? p.nsrc : 1;
+    const int nsrc = MULTI ? p.nsrc : 1;
     // (loaded once, unconditionally: a conditional load per branch gets merged into ONE load through a selected ADDRESS, which forces the
     // whole argument block into scratch memory)
     const uint16_t* const xs0 = p.x; const uint16_t* const xs1 = p.x1; const uint16_t* const xs2 = p.x2;
     const uint16_t* const ws0 = p.wp; const uint16_t* const ws1 = p.wp1; const uint16_t* const ws2 = p.wp2;
-    auto x_of = [&](int src) { return src == 0 ? xs0 : (src == 1 ? xs1 : xs2); };
-    auto wp_of = [&](int src) { return src == 0 ? ws0 : (src == 1 ? ws1 : ws2); };
+    auto x_of = [&](int src) { return (!MULTI || src == 0) ? xs0 : (src == 1 ? xs1 : xs2); };
+    auto wp_of = [&](int src) { return (!MULTI || src == 0) ? ws0 : (src == 1 ? ws1 : ws2); };
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     auto stage_dma = [&](char* buf, int sl, int u0, int u1, int src = 0) {
         const __amdgpu_buffer_rsrc_t xrsrc = planar
@@ -477,20 +479,20 @@ __device__ __forceinline__ void conv64_bf16_body(const Conv64BfArgs& p, const in
     }
 }
 
-template <int MT, int MODE>
+template <int MT, int MODE, bool MULTI = false>
 __global__ __launch_bounds__(256, 2) void conv64_bf16_kernel(Conv64BfArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    conv64_bf16_body<MT, MODE>(p, (int)blockIdx.x, (int)gridDim.x, true, smem);
+    conv64_bf16_body<MT, MODE, MULTI>(p, (int)blockIdx.x, (int)gridDim.x, true, smem);
 }
 
 // Fused dgrad as ONE launch (round 5, the fp32 path's conv64_wino2d_shell_kernel idea): workgroups [0, n2) run the MODE 2 body on the
 // inner box, the rest the general body on the six shell slabs.  As a launch of their own the slabs -- 1.6 % of the inner box's work at
 // 128^3 -- cost 0.126 ms on an almost empty chip; dispatched last they fill the inner launch's tail.
-template <int MT>
+template <int MT, bool MULTI = false>
 __global__ __launch_bounds__(256, 2) void conv64_bf16_fused_kernel(Conv64BfArgs p2, Conv64BfArgs p0, int n2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if ((int)blockIdx.x < n2) conv64_bf16_body<MT, 2>(p2, (int)blockIdx.x, n2, true, smem);
-    else conv64_bf16_body<MT, 0>(p0, (int)blockIdx.x - n2, (int)gridDim.x - n2, false, smem);
+    if ((int)blockIdx.x < n2) conv64_bf16_body<MT, 2, MULTI>(p2, (int)blockIdx.x, n2, true, smem);
+    else conv64_bf16_body<MT, 0, MULTI>(p0, (int)blockIdx.x - n2, (int)gridDim.x - n2, false, smem);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -662,11 +664,12 @@ Plan best_plan(int N, const Box& bx, int mt, int max_rows, int max_lrows, bool t
     return best;
 }
 
-template <int MT, int MODE>
+template <int MT, int MODE, bool MULTI = false>
 int launch_regions(Conv64BfArgs& a, hipStream_t s) {
+    if (!MULTI && a.nsrc > 1) return launch_regions<MT, MODE, true>(a, s);
     using C = Conv64BfCfg<MT>;
     if (a.nreg == 0) return FDN_OK;
-    if (int rc = fdn_func_max_lds((const void*)conv64_bf16_kernel<MT, MODE>, C::LDS_BUDGET, "conv64_bf16")) return rc;
+    if (int rc = fdn_func_max_lds((const void*)conv64_bf16_kernel<MT, MODE, MULTI>, C::LDS_BUDGET, "conv64_bf16")) return rc;
     int blocks = 0, max_lrows = 0;
     for (int i = 0; i < a.nreg; ++i) {
         Conv64Region& r = a.reg[i];
@@ -676,7 +679,7 @@ int launch_regions(Conv64BfArgs& a, hipStream_t s) {
     }
     // every region's mtab sits behind ITS two buffers; size the allocation for the largest region
     const size_t lds = (size_t)max_lrows * 64 + C::MCAP * 4;          // two buffers of 32-B rows, or (MODE 2) one of 64-B rows
-    hipLaunchKernelGGL((conv64_bf16_kernel<MT, MODE>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv64_bf16_kernel<MT, MODE, MULTI>), dim3((unsigned)blocks), dim3(256), lds, s, a);
     FDN_CHECK_LAUNCH("conv64_bf16_kernel");
     return FDN_OK;
 }
@@ -746,8 +749,14 @@ int launch_bf16(Conv64BfArgs& a, const Box* boxes, int nbox, hipStream_t s) {
             r.first_block = n0; n0 += a.N * r.ntd * r.nth * r.ntw;
             if (r.lrows_p > max0) max0 = r.lrows_p;
         }
-        if (int rc = fdn_func_max_lds((const void*)conv64_bf16_fused_kernel<MT>, C::LDS_BUDGET, "conv64_bf16_fused")) return rc;
         const size_t lds = (size_t)(max2 > max0 ? max2 : max0) * 64 + C::MCAP * 4;
+        if (a.nsrc > 1) {
+            if (int rc = fdn_func_max_lds((const void*)conv64_bf16_fused_kernel<MT, true>, C::LDS_BUDGET, "conv64_bf16_fused")) return rc;
+            hipLaunchKernelGGL((conv64_bf16_fused_kernel<MT, true>), dim3((unsigned)(n2 + n0)), dim3(256), lds, s, fast2, slow, n2);
+            FDN_CHECK_LAUNCH("conv64_bf16_fused_kernel");
+            return FDN_OK;
+        }
+        if (int rc = fdn_func_max_lds((const void*)conv64_bf16_fused_kernel<MT>, C::LDS_BUDGET, "conv64_bf16_fused")) return rc;
         hipLaunchKernelGGL((conv64_bf16_fused_kernel<MT>), dim3((unsigned)(n2 + n0)), dim3(256), lds, s, fast2, slow, n2);
         FDN_CHECK_LAUNCH("conv64_bf16_fused_kernel");
         return FDN_OK;

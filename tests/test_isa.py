@@ -102,9 +102,14 @@ PRODUCT_KERNELS = {
     "upsample_fwd_kernel<T, true>": "fdn_upsample_trilinear_fwd (input rows staged through LDS)", "upsample_fwd_kernel<T, false>": "... rows too long for the LDS", "upsample_bwd_kernel<T, 2>": "fdn_upsample_trilinear_bwd (two low-res rows per block)", "upsample_bwd_kernel<T, 1>": "... rows too long for two in the LDS", "input_features_kernel<T>": "fdn_input_features",
     "loss_main_kernel": "fdn_loss_metrics", "loss_finalize_kernel": "", "mask_sums_kernel": "", "l2_sumsq_kernel": "fdn_l2_sumsq", "l2_sumsq_partials_kernel": "fdn_l2_sumsq_partials", "adam_kernel": "fdn_adam_step",
     "gather_patches_kernel": "fdn_gather_patches",
-    "conv64_bf16_kernel<8, 2>": "bf16 mode: fdn_conv64_fwd_bf16", "conv64_bf16_fused_kernel<8>": "fdn_conv64_dgrad_fused_bf16 (inner box + shell slabs, one launch)",
-    "conv64_bf16_fused_kernel<4>": "", "conv64_bf16_kernel<8, 1>": "", "conv64_bf16_kernel<8, 0>": "",
-    "conv64_bf16_kernel<4, 2>": "", "conv64_bf16_kernel<4, 1>": "", "conv64_bf16_kernel<4, 0>": "", "pack_conv64_bf16_kernel": "", "fold_halo_border_bf16_kernel": "",
+    # conv64_bf16_kernel<MT, MODE, MULTI>, conv64_bf16_fused_kernel<MT, MULTI> (MULTI: fdn_conv64_dgrad_fused_bf16_multi)
+    "conv64_bf16_kernel<8, 2, false>": "bf16 mode: fdn_conv64_fwd_bf16", "conv64_bf16_fused_kernel<8, false>": "fdn_conv64_dgrad_fused_bf16 (inner box + shell slabs, one launch)",
+    "conv64_bf16_fused_kernel<4, false>": "", "conv64_bf16_kernel<8, 1, false>": "", "conv64_bf16_kernel<8, 0, false>": "",
+    "conv64_bf16_kernel<4, 2, false>": "", "conv64_bf16_kernel<4, 1, false>": "", "conv64_bf16_kernel<4, 0, false>": "",
+    "conv64_bf16_fused_kernel<8, true>": "fdn_conv64_dgrad_fused_bf16_multi", "conv64_bf16_fused_kernel<4, true>": "",
+    "conv64_bf16_kernel<8, 2, true>": "... on grids whose fused dgrad is issued in parts", "conv64_bf16_kernel<8, 1, true>": "", "conv64_bf16_kernel<8, 0, true>": "",
+    "conv64_bf16_kernel<4, 2, true>": "", "conv64_bf16_kernel<4, 1, true>": "", "conv64_bf16_kernel<4, 0, true>": "",
+    "pack_conv64_bf16_kernel": "", "fold_halo_border_bf16_kernel": "",
     "wgrad64_bf16_dma_kernel": "fdn_conv3d_wgrad_bf16", "wgrad64_bf16_kernel": "... tensors of 4 GB and more",
     "wgrad64_bf16_dma_batch_kernel": "fdn_conv3d_wgrad_bf16_batch", "wgrad64_reduce_batch_kernel": "",
 }
