@@ -12,7 +12,7 @@ for leg in range(2):
     for _ in range(5): tc.train_step(batch)
     torch.cuda.synchronize()
     st0 = torch.cuda.memory_stats()
-    n = 120
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 120
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
     host = []
     evs[0].record()
