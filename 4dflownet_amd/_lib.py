@@ -26,6 +26,7 @@ SIGNATURES = {
     "fdn_conv3d_fwd": (c_i, [c_fp] * 7 + [c_i] * 10 + [c_f, c_i, c_fp]),
     "fdn_conv3d_dgrad": (c_i, [c_fp] * 4 + [c_i] * 10 + [c_fp]),
     "fdn_conv_cout1_dgrad_folded": (c_i, [c_fp, c_fp, c_fp, c_i, c_f, c_fp, c_fp, c_fp, c_sz, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "fdn_conv_cout1_dgrad_folded_mask": (c_i, [c_fp, c_fp, c_fp, c_i, c_f, c_fp, c_fp, c_fp, c_sz, c_i, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "fdn_fold_halo": (c_i, [c_fp, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_f, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "fdn_conv3d_dgrad_fused": (c_i, [c_fp] * 5 + [c_i, c_f, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "fdn_conv64_mask_ok": (c_i, [c_i] * 5),

@@ -345,6 +345,14 @@ extern "C" int fdn_conv_cout1_dgrad_folded(const float* dz, const float* w, cons
                                                      N, D, H, W, lddz, dz_coff, (hipStream_t)stream);
 }
 
+extern "C" int fdn_conv_cout1_dgrad_folded_mask(const float* dz, const float* w, const uint16_t* y_mask, int act, float alpha,
+                                                float* dz_prev, float* dbias_prev, void* workspace, size_t workspace_bytes, int N,
+                                                int D, int H, int W, int lddz, int dz_coff, void* stream) {
+    FDN_REQUIRE(y_mask && (act == FDN_ACT_RELU || act == FDN_ACT_LEAKY), "fdn_conv_cout1_dgrad_folded_mask: a sign mask and act = RELU or LEAKY");
+    return fdn_conv_cout1_dgrad_folded_launch<float>(dz, w, nullptr, act, alpha, dz_prev, dbias_prev, workspace, workspace_bytes,
+                                                     N, D, H, W, lddz, dz_coff, (hipStream_t)stream, y_mask);
+}
+
 // ---- bf16 activation path: the thin layers and the generic conv entry points ----
 extern "C" int fdn_conv1x1_dgrad_bf16(const uint16_t* dz, const float* w, const uint16_t* ya, const uint16_t* yb,
                                       uint16_t* dxa, uint16_t* dxb, int64_t nvox, void* stream) {

@@ -343,7 +343,21 @@ __global__ __launch_bounds__(256, 2) void head_dgrad_kernel(const float* __restr
             // their latency hides behind the fold arithmetic and the MFMAs (loaded one by one next to their stores they serialised
             // into 32 round trips per M-tile: 192 us per launch at (8,48^3) against 59 us without the mask)
             float ym[2][16];
+            // fp32 storage with a sign mask (conv64_wino2d_kernel.h: planar [cout / 16][voxel] words, grids with W % 4 == 0): the lane's
+            // channel 32 m + li is bit li & 15 of plane 2 m + (li >> 4); the four voxels of a register row are four consecutive words --
+            // eight 8-B loads instead of the 32 rows above (7 MB instead of 226 MB per (8,48^3) launch)
+            fdn_u32x2 ymw[VROW ? 2 : 1][VROW ? 4 : 1];
             if constexpr (VROW) {
+                if (ymask) {
+                    const int pw = min(o.w + 4 * kh, W - 4), ph0 = o.h + 4 * (mt & 1);
+                    const size_t nv = (size_t)N * D * H * W;
+                    const size_t plane = (size_t)o.n * D * H * W + (size_t)min(gd, D - 1) * H * W;
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr)
+                            ymw[m][rr] = *(const fdn_u32x2*)(ymask + (size_t)(2 * m + (li >> 4)) * nv + plane + (size_t)min(ph0 + rr, H - 1) * W + pw);
+                } else
                 if (yprev) {
                     const int pw = o.w + 4 * kh, ph0 = o.h + 4 * (mt & 1);
                     const size_t plane = (size_t)o.n * D * H * W + (size_t)min(gd, D - 1) * H * W;
@@ -470,7 +484,8 @@ __global__ __launch_bounds__(256, 2) void head_dgrad_kernel(const float* __restr
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
                         float v = acc[m][r];
-                        if (yprev) v *= ym[m][r] > 0.f ? 1.f : slope;
+                        if (ymask) v *= ((ymw[m][r >> 2][(r & 3) >> 1] >> (16 * (r & 1) + (li & 15))) & 1u) ? 1.f : slope;
+                        else if (yprev) v *= ym[m][r] > 0.f ? 1.f : slope;
                         if (in2) {
                             fdn_st1(out + e + 32 * m, v);
                             bsum[m][0] += v;
@@ -547,7 +562,7 @@ int fdn_head_dgrad_launch(const float* dz, const float* w, const T* y_prev, int 
                           int D, int H, int W, int lddz, int dz_coff, hipStream_t s, const uint16_t* ymask) {
     const int ntd = (D + H_TD - 1) / H_TD, nth = (H + H_TH - 1) / H_TH, ntw = (W + H_TW - 1) / H_TW;
     hipLaunchKernelGGL(head_dgrad_kernel<T>, dim3((unsigned)fdn_head_dgrad_blocks(N, D, H, W)), dim3(256), 0, s, dz, w, y_prev, act,
-                       alpha, dz_prev, bpart, N, D, H, W, ntd, nth, ntw, lddz, dz_coff, sizeof(T) == 2 ? ymask : nullptr);
+                       alpha, dz_prev, bpart, N, D, H, W, ntd, nth, ntw, lddz, dz_coff, ymask);
     FDN_CHECK_LAUNCH("head_dgrad_kernel");
     return FDN_OK;
 }

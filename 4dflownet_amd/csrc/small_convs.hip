@@ -697,6 +697,7 @@ int fdn_conv_cout1_dgrad_folded_launch(const float* dz, const float* w, const T*
                                        float* dbias_prev, void* workspace, size_t workspace_bytes, int N, int D, int H, int W,
                                        int lddz, int dz_coff, hipStream_t s, const uint16_t* ymask) {
     FDN_REQUIRE(dz && w && dz_prev && N > 0 && D > 0 && H > 0 && W > 0, "fdn_conv_cout1_dgrad_folded: bad argument");
+    FDN_REQUIRE(!(ymask && sizeof(T) == 4) || (W % 4 == 0 && fdn_heads_use_mfma), "fdn_conv_cout1_dgrad_folded: the fp32 sign mask (planar words) needs W %% 4 == 0");
 #ifdef FDN_TEST_HOOKS
     if (!fdn_heads_use_mfma) {
         FDN_REQUIRE(W <= 4096, "fdn_conv_cout1_dgrad_folded: W too large for the row stage");

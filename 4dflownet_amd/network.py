@@ -408,7 +408,7 @@ class FlowNetModel:
         heads = []
         gmasks = []                                         # bf16 training: sign masks of the three head activations (else None)
         for hidx in range(3):
-            g, m_g = self._conv_m(rb.t, Ls[li], ACT_RELU, want_mask=training and self.dtype == "bfloat16")   # (the fp32 head dgrad reads y's rows)
+            g, m_g = self._conv_m(rb.t, Ls[li], ACT_RELU, want_mask=training)
             self._conv(g, Ls[li + 1], ACT_NONE, out=pred, ldy=3, y_coff=hidx)
             heads.append(g)
             gmasks.append(m_g)

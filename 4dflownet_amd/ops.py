@@ -126,15 +126,23 @@ def conv3d_dgrad(dz, w, wpack_dgrad=None, out=None, lddz=None, dz_coff=0, spatia
 
 
 def conv_cout1_dgrad_folded(dz, w, spatial, y_prev=None, act=ACT_NONE, alpha=LEAKY_ALPHA, lddz=1, dz_coff=0, out=None,
-                            dbias_prev=None, workspace=None):
+                            dbias_prev=None, workspace=None, mask=None):
     """64->1 head dgrad + halo fold + act'(y_prev) in one kernel.  Returns (N,D,H,W,64).  With dbias_prev (64 floats) it
-    also emits the producing layer's bias gradient (sum of the result over voxels); needs a >= 512 KB workspace."""
+    also emits the producing layer's bias gradient (sum of the result over voxels); needs a >= 512 KB workspace.
+    mask: the sign mask conv3d_fwd(mask=...) wrote beside y_prev (W % 4 == 0), read instead of y_prev's rows."""
     N, D, H, W = spatial
     if out is None:
         out = torch.empty((N, D, H, W, 64), device=dz.device, dtype=torch.float32)
     if dbias_prev is not None and workspace is None:
         workspace = torch.empty(2048 * 64, device=dz.device, dtype=torch.float32)
     wsb = 0 if workspace is None else workspace.numel() * workspace.element_size()
+    if mask is not None:
+        if mask.numel() != 4 * N * D * H * W:
+            raise FdnError("conv_cout1_dgrad_folded: a sign mask of 4 x %d int16 words expected" % (N * D * H * W))
+        check(_lib.load().fdn_conv_cout1_dgrad_folded_mask(_p(dz, "dz"), _p(w, "w"), _pm(mask), act, float(alpha), _p(out),
+                                                           _p(dbias_prev, allow_none=True), _p(workspace, allow_none=True), wsb,
+                                                           N, D, H, W, lddz, dz_coff, _stream()), "fdn_conv_cout1_dgrad_folded_mask")
+        return out
     check(_lib.load().fdn_conv_cout1_dgrad_folded(_p(dz, "dz"), _p(w, "w"), _p(y_prev, allow_none=True), act, float(alpha),
                                                   _p(out), _p(dbias_prev, allow_none=True), _p(workspace, allow_none=True), wsb,
                                                   N, D, H, W, lddz, dz_coff, _stream()), "fdn_conv_cout1_dgrad_folded")

@@ -140,6 +140,11 @@ int fdn_conv3d_dgrad(const float* dz, const float* w, const float* wpack, float*
 int fdn_conv_cout1_dgrad_folded(const float* dz, const float* w, const float* y_prev, int act, float alpha,
                                 float* dz_prev, float* dbias_prev, void* workspace, size_t workspace_bytes, int N,
                                 int D, int H, int W, int lddz, int dz_coff, void* stream);
+/* ... reading the producer's sign mask (fdn_conv64_fwd_mask: planar [cout / 16][voxel] words; W % 4 == 0) instead of y_prev: eight 8-B loads
+ * per 16 voxels and lane instead of 32 rows, 7 MB instead of 226 MB per (8,48^3) launch.  Bit-identical to the y_prev form. */
+int fdn_conv_cout1_dgrad_folded_mask(const float* dz, const float* w, const uint16_t* y_mask, int act, float alpha,
+                                     float* dz_prev, float* dbias_prev, void* workspace, size_t workspace_bytes, int N,
+                                     int D, int H, int W, int lddz, int dz_coff, void* stream);
 
 /* MirrorPadGrad + gradient fan-in + activation gradient in one pass:
  * dz_prev[i] = (sum_s sum_{P: clamp(P)=i} dxpad_s[P] + skip[i]) * act'(y_prev[i]).

@@ -667,3 +667,23 @@ def test_multi_source_fused_dgrad_equals_the_chained_launches(ops, fdn, shape, n
     with pytest.raises(fdn.FdnError):                        # a grid off the F(4,3) x F(4,3) kernels refuses loudly
         z = torch.zeros((1, 4, 6, 6, 64), device="cuda")
         ops.conv3d_dgrad_fused_multi([z, z], packs[:1] * 2, torch.zeros((1, 6, 8, 8, 64), device="cuda"), torch.zeros_like(z))
+
+
+@pytest.mark.parametrize("shape", [(1, 5, 8, 12), (2, 24, 24, 24), (1, 3, 7, 4), (2, 9, 5, 20)])
+def test_fp32_sign_mask_replaces_y_in_the_head_dgrad(ops, shape):
+    """fdn_conv_cout1_dgrad_folded_mask: the 64->1 head dgrad reads the producer's planar sign mask (eight 8-B loads per 16 voxels and lane)
+    instead of y's rows: dz_prev and the producer's bias gradient bit for bit (ragged tiles in d and h included; W % 4 == 0)."""
+    rng = np.random.default_rng(77)
+    N, D, H, W = shape
+    y = dev(rng.normal(size=(N, D, H, W, 64)).astype(np.float32))
+    w = dev((rng.normal(size=(3, 3, 3, 64, 1)) * 0.1).astype(np.float32))
+    dpred = dev(rng.normal(size=(N, D, H, W, 3)).astype(np.float32))
+    bits = (y > 0).view(N * D * H * W, 4, 16).to(torch.int32)
+    mask = (bits << torch.arange(16, device="cuda", dtype=torch.int32)).sum(dim=2).t().contiguous()
+    mask = torch.where(mask >= 32768, mask - 65536, mask).to(torch.int16)
+    for coff in (0, 2):
+        db0, db1 = torch.zeros(64, device="cuda"), torch.zeros(64, device="cuda")
+        a = ops.conv_cout1_dgrad_folded(dpred, w, (N, D, H, W), y, O.ACT_RELU, lddz=3, dz_coff=coff, dbias_prev=db0)
+        b = ops.conv_cout1_dgrad_folded(dpred, w, (N, D, H, W), None, O.ACT_RELU, lddz=3, dz_coff=coff, dbias_prev=db1, mask=mask)
+        assert torch.equal(a, b) and torch.equal(db0, db1)
+        assert 0.2 < (a == 0).float().mean().item() < 0.8          # (the ReLU mask really bit)

@@ -22,6 +22,12 @@ for v in (3, 1, 3, 1):
     print("head fwd (xcd walk %s) %.1f us" % ("off" if v & 2 else "on", timeit(lambda: ops.conv3d_fwd(g, w, b, ops.ACT_NONE, out=pred, ldy=3, y_coff=1))))
 print("head dgrad (folded, + act', + bias grad of the producer) %.1f us" % timeit(
     lambda: ops.conv_cout1_dgrad_folded(dpred, w, (N, P, P, P), g, ops.ACT_RELU, lddz=3, dz_coff=1, dbias_prev=gb, workspace=wsb)))
+bits = (g > 0).view(N * P * P * P, 4, 16).to(torch.int32)
+mask = (bits << torch.arange(16, device="cuda", dtype=torch.int32)).sum(dim=2).t().contiguous()
+mask = torch.where(mask >= 32768, mask - 65536, mask).to(torch.int16)
+del bits
+print("head dgrad with the producer's sign mask instead of y (+ bias grad) %.1f us" % timeit(
+    lambda: ops.conv_cout1_dgrad_folded(dpred, w, (N, P, P, P), None, ops.ACT_RELU, lddz=3, dz_coff=1, dbias_prev=gb, workspace=wsb, mask=mask)))
 print("head wgrad (+reduce) %.1f us" % timeit(lambda: ops.conv3d_wgrad(g, dpred, 3, 64, 1, dw=dw, workspace=ws, lddz=3, dz_coff=1)))
 print("head dgrad without the act' mask (no y_prev loads) %.1f us" % timeit(
     lambda: ops.conv_cout1_dgrad_folded(dpred, w, (N, P, P, P), None, ops.ACT_NONE, lddz=3, dz_coff=1)))
