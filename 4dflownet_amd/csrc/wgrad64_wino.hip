@@ -460,7 +460,7 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_batch_kernel(WgWinoBatch 
 bool wgrad64_wino_dep_ok(int D) { return D >= 2 && (D & 1) == 0; }
 int wgrad64_wino_splits(int N, int D, int H, int W, bool dep) {
     const long long ntiles = (long long)N * (dep ? D / 2 : D) * ((H + WTH - 1) / WTH) * ((W + WTW - 1) / WTW);
-    long long S = dep ? 63 : 85;       // 4 * 63 = 252 / 3 * 85 = 255 workgroups: one (8 waves, 126-150 KB of LDS) per CU
+    long long S = dep ? 64 : 85;       // 4 * 64 = 256 / 3 * 85 = 255 workgroups: one (8 waves, 126-150 KB of LDS) per CU
     if (ntiles < S) S = ntiles > 0 ? ntiles : 1;
     return (int)S;
 }
