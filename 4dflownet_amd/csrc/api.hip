@@ -247,7 +247,12 @@ static bool wgrad_batchable(int n_layers, int D, int W, int algo) {
 extern "C" size_t fdn_conv3d_wgrad_batch_workspace_bytes(int n_layers, int N, int D, int H, int W) {
     if (n_layers <= 0 || N <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
     const size_t one = fdn_conv3d_wgrad_workspace_bytes(N, D, H, W, 64, 64, 3);
-    const size_t all = wgrad_batchable(n_layers, D, W, FDN_ALGO_AUTO) ? fdn_wgrad64_wino_batch_workspace_bytes(n_layers, N, D, H, W) : 0;
+    size_t all = 0;                       // (the batch may go out in chunks of fewer layers with more splits each: fdn_conv3d_wgrad_batch)
+    if (wgrad_batchable(n_layers, D, W, FDN_ALGO_AUTO))
+        for (int c = 2; c <= n_layers; ++c) {
+            const size_t b = fdn_wgrad64_wino_batch_workspace_bytes(c, N, D, H, W);
+            if (b > all) all = b;
+        }
     return all > one ? all : one;
 }
 extern "C" int fdn_conv3d_wgrad_batch(const float* const* x, const float* const* dz, float* const* dw, float* const* dbias, int n_layers,
@@ -262,7 +267,17 @@ extern "C" int fdn_conv3d_wgrad_batch(const float* const* x, const float* const*
     }
     hipStream_t s = (hipStream_t)stream;
     if (wgrad_batchable(n_layers, D, W, algo)) {
-        if (int rc = fdn_wgrad64_wino_batch_launch(x, dz, dw, n_layers, workspace, workspace_bytes, N, D, H, W, s)) return rc;
+        // The batched kernel gives every layer 64 / n splits x 4 coordinates: n = 11 fills 220 of the 256 CUs.  Such a batch goes out in
+        // chunks that fill the chip (>= 63 of 64 split slots: 1, 2, 3, 4, 7, 8, 9, 16 layers), a batch at >= 15/16 as it is.
+        auto fill64 = [](int c) { return (64 / c) * c; };
+        for (int i0 = 0; i0 < n_layers;) {
+            const int rem = n_layers - i0;
+            int c = rem;
+            if (fill64(rem) < 60) { c = rem - 1; while (c > 1 && fill64(c) < 63) --c; }
+            if (c >= 2) { if (int rc = fdn_wgrad64_wino_batch_launch(x + i0, dz + i0, dw + i0, c, workspace, workspace_bytes, N, D, H, W, s)) return rc; }
+            else if (int rc = fdn_conv3d_wgrad(x[i0], nullptr, dz[i0], dw[i0], nullptr, workspace, workspace_bytes, N, D, H, W, 64, 64, 3, 64, 0, algo, stream)) return rc;
+            i0 += c;
+        }
     } else {
         for (int i = 0; i < n_layers; ++i) {
             FDN_REQUIRE(x[i] && dz[i] && dw[i], "fdn_conv3d_wgrad_batch: NULL pointer for layer %d", i);

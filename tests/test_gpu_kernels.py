@@ -202,7 +202,7 @@ def test_conv64_dgrad_fused_fold(ops, fdn, shape, layout):
                 lib.fdn_debug_set_conv64_wface_direct(0)
 
 
-@pytest.mark.parametrize("shape,nl", [((2, 8, 12, 16), 3), ((8, 24, 24, 24), 8), ((1, 2, 5, 4), 2), ((2, 6, 6, 8), 11), ((1, 7, 6, 8), 3), ((1, 4, 6, 10), 2)])
+@pytest.mark.parametrize("shape,nl", [((2, 8, 12, 16), 3), ((8, 24, 24, 24), 8), ((1, 2, 5, 4), 2), ((2, 6, 6, 8), 11), ((1, 7, 6, 8), 3), ((1, 4, 6, 10), 2), ((4, 24, 24, 24), 11), ((2, 12, 12, 24), 14)])
 def test_conv64_wgrad_batch(ops, shape, nl):
     """fdn_conv3d_wgrad_batch: the weight (and bias) gradients of nl layers of one grid in ONE launch == the float64 oracle, and == nl
     calls of fdn_conv3d_wgrad (different split of the voxel sum: equal to fp32 rounding; the fall-back shapes -- odd D, W % 4 != 0 --
