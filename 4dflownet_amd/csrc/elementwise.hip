@@ -364,13 +364,16 @@ __global__ __launch_bounds__(256) void loss_main_kernel(const float* __restrict_
     }
 }
 
-__global__ void loss_finalize_kernel(const float* __restrict__ scratch, float* __restrict__ out, int N, int nblk) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    const float sm = scratch[n * 8 + 0], snf = scratch[n * 8 + 1];
+// one wave per sample: lane t sums the partials of blocks t, t + 64, ..., then a shuffle tree -- a fixed order, so the reported loss /
+// metric stays run-to-run identical (one THREAD per sample walked the 256 partials as a chain of dependent loads: 24 us)
+__global__ __launch_bounds__(64) void loss_finalize_kernel(const float* __restrict__ scratch, float* __restrict__ out, int N, int nblk) {
+    const int n = blockIdx.x;
     const float* part = scratch + (size_t)N * 8 + (size_t)n * nblk * 3;
     float sf = 0.f, sn = 0.f, sr = 0.f;
-    for (int b = 0; b < nblk; ++b) { sf += part[b * 3]; sn += part[b * 3 + 1]; sr += part[b * 3 + 2]; }
+    for (int b = threadIdx.x; b < nblk; b += 64) { sf += part[b * 3]; sn += part[b * 3 + 1]; sr += part[b * 3 + 2]; }
+    for (int o = 32; o > 0; o >>= 1) { sf += __shfl_down(sf, o, 64); sn += __shfl_down(sn, o, 64); sr += __shfl_down(sr, o, 64); }
+    if (threadIdx.x) return;
+    const float sm = scratch[n * 8 + 0], snf = scratch[n * 8 + 1];
     out[n * 4 + 0] = sf / (sm + 1.f) + sn / (snf + 1.f);
     out[n * 4 + 1] = sr / (sm + 1.f) * 100.f;
     out[n * 4 + 2] = sm;
@@ -587,11 +590,12 @@ extern "C" int fdn_loss_metrics(const float* pred, const float* uh, const float*
     hipError_t e = hipMemsetAsync(scratch, 0, (size_t)N * 8 * sizeof(float), s);
     if (e != hipSuccess) { fdn_set_error("fdn_loss_metrics: memset: %s", hipGetErrorString(e)); return FDN_ERR_HIP; }
     const int gx = grid_for(V, FDN_LOSS_BLOCKS);
-    hipLaunchKernelGGL(mask_sums_kernel, dim3(gx, N), dim3(256), 0, s, mask, scratch, V);
+    // (16 blocks per sample: with 256 the 2 x 256 x N atomics on 2 N words took longer than reading the mask -- 29 us at cfg2)
+    hipLaunchKernelGGL(mask_sums_kernel, dim3(gx < 16 ? gx : 16, N), dim3(256), 0, s, mask, scratch, V);
     FDN_CHECK_LAUNCH("mask_sums_kernel");
     hipLaunchKernelGGL(loss_main_kernel, dim3(gx, N), dim3(256), 0, s, pred, uh, vh, wh, mask, scratch, dpred, V);
     FDN_CHECK_LAUNCH("loss_main_kernel");
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3((N + 63) / 64), dim3(64), 0, s, (const float*)scratch, out, N, gx);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(N), dim3(64), 0, s, (const float*)scratch, out, N, gx);
     FDN_CHECK_LAUNCH("loss_finalize_kernel");
     return FDN_OK;
 }
