@@ -184,3 +184,21 @@ def test_pack_stream_query_follows_the_launchers_selection(fdn):
     assert q(8, 24, 24, 24, 4, FWD) == 16 and q(8, 24, 24, 24, 4, FUSED) == 16 | 2
     assert q(2, 10, 10, 10, AUTO, DG) == 8                                    # the padded grid is 12^3
     assert q(2, 10, 10, 10, 7, FWD) < 0 and q(0, 10, 10, 10, AUTO, FWD) < 0 and q(2, 10, 10, 10, AUTO, 3) < 0
+
+
+def test_mask_query_and_multi_source_argument_checks_need_no_gpu(fdn):
+    """fdn_conv64_mask_ok answers from the launcher's selection (no GPU needed); fdn_conv64_dgrad_fused_multi refuses bad source counts and
+    packs that do not lie in one buffer before it touches the device (the pointers here are never dereferenced)."""
+    import ctypes
+    lib = fdn._lib.load()
+    ok = lib.fdn_conv64_mask_ok
+    assert ok(8, 24, 24, 24, 0) == 1 and ok(8, 48, 48, 48, 0) == 1 and ok(1, 5, 8, 12, 0) == 1
+    assert ok(8, 18, 18, 18, 0) == 0 and ok(2, 9, 9, 12, 0) == 0 and ok(8, 24, 24, 24, 1) == 0 and ok(8, 24, 24, 24, 4) == 0
+    assert ok(0, 24, 24, 24, 0) < 0
+    fake = lambda *a: (ctypes.c_void_p * len(a))(*a)
+    multi = lib.fdn_conv64_dgrad_fused_multi
+    err = lambda: lib.fdn_last_error().decode()
+    args = (0x1000, None, None, None, 2, 0.2, 0x2000, 2, 8, 8, 8, 0, None)
+    assert multi(fake(0x10000, 0x20000), fake(0x30000, 0x40000), 4, *args) != 0 and "1..3" in err()
+    assert multi(fake(0x10000, 0x20000), fake(0x30000, 0x30000 + (1 << 31)), 2, *args) != 0 and "1 GiB" in err()
+    assert multi(fake(0x10000, None), fake(0x30000, 0x40000), 2, *args) != 0 and "source 1" in err()
